@@ -1,0 +1,1266 @@
+/* TEST INFRASTRUCTURE — NOT PRODUCT CODE.  See pwicp_oracle.h for scope and provenance.
+ *
+ * Plain C99, single-threaded, compiled with -O2 -ffp-contract=off (no FMA contraction:
+ * every float/double operation below rounds exactly once, as the MSVC x64 /O2 build of the
+ * reference does).  Citations "R.cpp", "C.cpp", "S.cpp" are src/Registration.cpp,
+ * src/CommonFunc.cpp, src/Segmentation.cpp of the reference; "PCL:" cites PCL 1.8.1.
+ */
+#include "pwicp_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+void orc_free(void* p) { free(p); }
+
+/* =====================================================================================
+ * KD-tree — FLANN KDTreeSingleIndex semantics (PCL: kdtree/impl/kdtree_flann.hpp builds
+ * flann::KDTreeSingleIndexParams(15); metric flann::L2_Simple<float>: result = 0;
+ * result += diff*diff for x, y, z in that order, all in float; exact search, eps = 0).
+ * The result of an exact search is the argmin of that float expression; FLANN's tie order
+ * is traversal dependent, so ties are canonicalised to the LOWEST index here.
+ * ===================================================================================== */
+#define KD_LEAF 15
+
+typedef struct {
+    int   left, right;      /* child node ids, -1 for leaf */
+    int   lo, hi;           /* leaf: range in perm */
+    int   dim;
+    float divlow, divhigh;
+} kd_node;
+
+struct orc_kdtree {
+    int      n;
+    float*   pts;           /* reordered copy, 4 floats per point (FLANN reorder = true) */
+    int*     perm;          /* reordered position -> original index */
+    kd_node* nodes;
+    int      n_nodes, cap_nodes;
+    float    bmin[3], bmax[3];
+};
+
+static inline float l2_simple(const float* a, const float* b)
+{
+    float r = 0.0f, d;
+    d = a[0] - b[0]; r += d * d;
+    d = a[1] - b[1]; r += d * d;
+    d = a[2] - b[2]; r += d * d;
+    return r;
+}
+
+static int kd_new_node(orc_kdtree* t)
+{
+    if (t->n_nodes == t->cap_nodes) {
+        t->cap_nodes = t->cap_nodes ? 2 * t->cap_nodes : 1024;
+        t->nodes = (kd_node*)realloc(t->nodes, sizeof(kd_node) * (size_t)t->cap_nodes);
+    }
+    return t->n_nodes++;
+}
+
+/* src: original points (stride 4); perm[lo,hi) indices into src */
+static int kd_build_rec(orc_kdtree* t, const float* src, int* perm, int lo, int hi)
+{
+    int id = kd_new_node(t);
+    int cnt = hi - lo;
+    float mn[3], mx[3];
+    for (int d = 0; d < 3; ++d) { mn[d] = FLT_MAX; mx[d] = -FLT_MAX; }
+    for (int i = lo; i < hi; ++i) {
+        const float* p = src + 4 * (size_t)perm[i];
+        for (int d = 0; d < 3; ++d) {
+            if (p[d] < mn[d]) mn[d] = p[d];
+            if (p[d] > mx[d]) mx[d] = p[d];
+        }
+    }
+    int dim = 0;
+    float span = mx[0] - mn[0];
+    for (int d = 1; d < 3; ++d)
+        if (mx[d] - mn[d] > span) { span = mx[d] - mn[d]; dim = d; }
+    if (cnt <= KD_LEAF || !(span > 0.0f)) {
+        kd_node* nd = &t->nodes[id];
+        nd->left = nd->right = -1; nd->lo = lo; nd->hi = hi; nd->dim = 0;
+        nd->divlow = nd->divhigh = 0.0f;
+        return id;
+    }
+    float cut = (mn[dim] + mx[dim]) * 0.5f;
+    /* three-way partition: [lo,l1) < cut, [l1,l2) == cut, [l2,hi) > cut */
+    int l1 = lo, l2, i = lo, j = hi - 1;
+    while (i <= j) {
+        float v = src[4 * (size_t)perm[i] + dim];
+        if (v < cut) { ++i; }
+        else { int tmp = perm[i]; perm[i] = perm[j]; perm[j] = tmp; --j; }
+    }
+    l1 = i;
+    i = l1; j = hi - 1;
+    while (i <= j) {
+        float v = src[4 * (size_t)perm[i] + dim];
+        if (v <= cut) { ++i; }
+        else { int tmp = perm[i]; perm[i] = perm[j]; perm[j] = tmp; --j; }
+    }
+    l2 = i;
+    int mid = lo + cnt / 2, split;
+    if (l1 > mid) split = l1; else if (l2 < mid) split = l2; else split = mid;
+    if (split == lo) split = lo + 1;
+    if (split == hi) split = hi - 1;
+    float dl = -FLT_MAX, dh = FLT_MAX;
+    for (int k = lo; k < split; ++k) { float v = src[4 * (size_t)perm[k] + dim]; if (v > dl) dl = v; }
+    for (int k = split; k < hi; ++k) { float v = src[4 * (size_t)perm[k] + dim]; if (v < dh) dh = v; }
+    int L = kd_build_rec(t, src, perm, lo, split);
+    int R = kd_build_rec(t, src, perm, split, hi);
+    kd_node* nd = &t->nodes[id];
+    nd->left = L; nd->right = R; nd->lo = lo; nd->hi = hi; nd->dim = dim;
+    nd->divlow = dl; nd->divhigh = dh;
+    return id;
+}
+
+orc_kdtree* orc_kdtree_build(const float* pts4, int n)
+{
+    orc_kdtree* t = (orc_kdtree*)calloc(1, sizeof(orc_kdtree));
+    t->n = n;
+    t->perm = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    t->pts = (float*)malloc(sizeof(float) * 4 * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; ++i) t->perm[i] = i;
+    for (int d = 0; d < 3; ++d) { t->bmin[d] = FLT_MAX; t->bmax[d] = -FLT_MAX; }
+    for (int i = 0; i < n; ++i)
+        for (int d = 0; d < 3; ++d) {
+            float v = pts4[4 * (size_t)i + d];
+            if (v < t->bmin[d]) t->bmin[d] = v;
+            if (v > t->bmax[d]) t->bmax[d] = v;
+        }
+    if (n > 0) kd_build_rec(t, pts4, t->perm, 0, n);
+    for (int i = 0; i < n; ++i) memcpy(t->pts + 4 * (size_t)i, pts4 + 4 * (size_t)t->perm[i], 16);
+    return t;
+}
+
+void orc_kdtree_free(orc_kdtree* t)
+{
+    if (!t) return;
+    free(t->perm); free(t->pts); free(t->nodes); free(t);
+}
+
+/* k-NN result set: sorted ascending by (d2, idx) */
+typedef struct { int k, cnt; int* idx; float* d2; } kd_result;
+
+static inline int kd_better(float d2, int idx, float bd2, int bidx)
+{
+    return d2 < bd2 || (d2 == bd2 && idx < bidx);
+}
+
+static inline void kd_insert(kd_result* r, float d2, int idx)
+{
+    if (r->cnt == r->k && !kd_better(d2, idx, r->d2[r->k - 1], r->idx[r->k - 1])) return;
+    int pos = r->cnt < r->k ? r->cnt : r->k - 1;
+    while (pos > 0 && kd_better(d2, idx, r->d2[pos - 1], r->idx[pos - 1])) {
+        r->d2[pos] = r->d2[pos - 1]; r->idx[pos] = r->idx[pos - 1]; --pos;
+    }
+    r->d2[pos] = d2; r->idx[pos] = idx;
+    if (r->cnt < r->k) r->cnt++;
+}
+
+static void kd_search_rec(const orc_kdtree* t, int id, const float* q, kd_result* r,
+                          double mindist, double* dists)
+{
+    const kd_node* nd = &t->nodes[id];
+    if (nd->left < 0) {
+        for (int i = nd->lo; i < nd->hi; ++i)
+            kd_insert(r, l2_simple(q, t->pts + 4 * (size_t)i), t->perm[i]);
+        return;
+    }
+    int dim = nd->dim;
+    double val = q[dim];
+    double diff1 = val - (double)nd->divlow, diff2 = val - (double)nd->divhigh;
+    int best, other; double cut;
+    if (diff1 + diff2 < 0) { best = nd->left; other = nd->right; cut = diff2 * diff2; }
+    else                   { best = nd->right; other = nd->left; cut = diff1 * diff1; }
+    kd_search_rec(t, best, q, r, mindist, dists);
+    double dst = dists[dim];
+    double md = mindist + cut - dst;
+    dists[dim] = cut;
+    /* visit when the (real) lower bound could still tie with the current worst float d2 */
+    if (r->cnt < r->k || md * (1.0 - 1e-6) <= (double)r->d2[r->k - 1])
+        kd_search_rec(t, other, q, r, md, dists);
+    dists[dim] = dst;
+}
+
+void orc_kdtree_knn(const orc_kdtree* t, const float* q3, int k, int* idx, float* d2)
+{
+    kd_result r; r.k = k; r.cnt = 0; r.idx = idx; r.d2 = d2;
+    for (int i = 0; i < k; ++i) { idx[i] = -1; d2[i] = FLT_MAX; }
+    if (t->n == 0) return;
+    double dists[3], md = 0.0;
+    for (int d = 0; d < 3; ++d) {
+        double v = q3[d]; dists[d] = 0.0;
+        if (v < t->bmin[d]) { double e = v - t->bmin[d]; dists[d] = e * e; }
+        if (v > t->bmax[d]) { double e = v - t->bmax[d]; dists[d] = e * e; }
+        md += dists[d];
+    }
+    kd_search_rec(t, 0, q3, &r, md, dists);
+}
+
+void orc_kdtree_nn1(const orc_kdtree* t, const float* qry4, int nq, int* idx, float* d2)
+{
+    for (int i = 0; i < nq; ++i) orc_kdtree_knn(t, qry4 + 4 * (size_t)i, 1, idx + i, d2 + i);
+}
+
+/* PCL: registration/impl/correspondence_estimation.hpp determineCorrespondences():
+ * initCompute() (re)builds the target tree; for every source point nearestKSearch(p, 1);
+ * kept unless d2 > max_dist^2 (= DBL_MAX^2 = inf here, i.e. always kept);
+ * Correspondence.distance is the SQUARED float distance.   (R.cpp:737-747, 1293-1297,
+ * 597-601; C.cpp:269-273) */
+void orc_determine_correspondences(const float* tgt4, int nt, const float* src4, int ns,
+                                   int* idx, float* d2)
+{
+    orc_kdtree* t = orc_kdtree_build(tgt4, nt);
+    orc_kdtree_nn1(t, src4, ns, idx, d2);
+    orc_kdtree_free(t);
+}
+
+/* =====================================================================================
+ * small dense helpers
+ * ===================================================================================== */
+
+/* cyclic Jacobi for a symmetric 3x3 in double; eigenvalues ascending, V columns */
+static void jacobi3(const double Ain[9], double w[3], double V[9])
+{
+    double A[3][3], U[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) { A[i][j] = Ain[3 * i + j]; U[i][j] = (i == j) ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        double diag = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
+        if (off <= 1e-300 || off <= 1e-18 * diag) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (A[p][q] == 0.0) continue;
+                double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+                for (int k = 0; k < 3; ++k) {
+                    double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    double ukp = U[k][p], ukq = U[k][q];
+                    U[k][p] = c * ukp - s * ukq; U[k][q] = s * ukp + c * ukq;
+                }
+            }
+    }
+    int ord[3] = {0, 1, 2};
+    double ev[3] = {A[0][0], A[1][1], A[2][2]};
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2 - i; ++j)
+            if (ev[ord[j]] > ev[ord[j + 1]]) { int tmp = ord[j]; ord[j] = ord[j + 1]; ord[j + 1] = tmp; }
+    for (int c = 0; c < 3; ++c) {
+        w[c] = ev[ord[c]];
+        for (int r = 0; r < 3; ++r) V[3 * r + c] = U[r][ord[c]];
+    }
+}
+
+/* inverse of a 6x6 (double) by LU with partial pivoting (Eigen: MatrixBase::inverse() for
+ * sizes > 4 = PartialPivLU(m).inverse(), i.e. solve against the identity). returns 0 if a
+ * zero pivot is met. */
+static int inv6(const double* Ain, double* inv)
+{
+    double A[6][6]; int piv[6];
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) A[i][j] = Ain[6 * i + j];
+    for (int i = 0; i < 6; ++i) piv[i] = i;
+    for (int k = 0; k < 6; ++k) {
+        int p = k; double best = fabs(A[k][k]);
+        for (int i = k + 1; i < 6; ++i) if (fabs(A[i][k]) > best) { best = fabs(A[i][k]); p = i; }
+        if (best == 0.0) return 0;
+        if (p != k) {
+            for (int j = 0; j < 6; ++j) { double tmp = A[k][j]; A[k][j] = A[p][j]; A[p][j] = tmp; }
+            int tp = piv[k]; piv[k] = piv[p]; piv[p] = tp;
+        }
+        for (int i = k + 1; i < 6; ++i) {
+            A[i][k] = A[i][k] / A[k][k];
+            for (int j = k + 1; j < 6; ++j) A[i][j] = A[i][j] - A[i][k] * A[k][j];
+        }
+    }
+    for (int c = 0; c < 6; ++c) {
+        double y[6];
+        for (int i = 0; i < 6; ++i) {
+            double s = (piv[i] == c) ? 1.0 : 0.0;
+            for (int j = 0; j < i; ++j) s = s - A[i][j] * y[j];
+            y[i] = s;
+        }
+        for (int i = 5; i >= 0; --i) {
+            double s = y[i];
+            for (int j = i + 1; j < 6; ++j) s = s - A[i][j] * inv[6 * j + c];
+            inv[6 * i + c] = s / A[i][i];
+        }
+    }
+    return 1;
+}
+
+/* Eigen Matrix4f * Matrix4f (coefficient-based lazy product: k = 0..3 in order, float) */
+void orc_mat4_mul(const float* A, const float* B, float* C)
+{
+    float R[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float s = A[4 * i + 0] * B[0 + j];
+            s = s + A[4 * i + 1] * B[4 + j];
+            s = s + A[4 * i + 2] * B[8 + j];
+            s = s + A[4 * i + 3] * B[12 + j];
+            R[4 * i + j] = s;
+        }
+    memcpy(C, R, sizeof(R));
+}
+
+/* PCL: common/impl/transforms.hpp transformPointCloud(): per point, float,
+ * x' = ((m00*x + m01*y) + m02*z) + m03    (R.cpp:943-954, 293-294) */
+void orc_transform_points(float* p4, int n, const float* T)
+{
+    for (int i = 0; i < n; ++i) {
+        float* p = p4 + 4 * (size_t)i;
+        float x = p[0], y = p[1], z = p[2];
+        p[0] = T[0] * x + T[1] * y + T[2] * z + T[3];
+        p[1] = T[4] * x + T[5] * y + T[6] * z + T[7];
+        p[2] = T[8] * x + T[9] * y + T[10] * z + T[11];
+    }
+}
+
+/* =====================================================================================
+ * per-patch statistics
+ * ===================================================================================== */
+
+/* PCL: common/impl/eigen.hpp computeRoots2 / computeRoots / eigen33 (Scalar = float) */
+static void pcl_compute_roots2(float b, float c, float* roots)
+{
+    roots[0] = 0.0f;
+    float d = (float)((double)(b * b) - 4.0 * (double)c);
+    if (d < 0.0f) d = 0.0f;
+    float sd = sqrtf(d);
+    roots[2] = 0.5f * (b + sd);
+    roots[1] = 0.5f * (b - sd);
+}
+
+/* float trig: evaluated in double and rounded once (== correctly rounded float result
+ * except for ~2^-29 double-rounding cases); keeps CPU oracle and GPU bit-compatible */
+static inline float f_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
+static inline float f_cos(float x) { return (float)cos((double)x); }
+static inline float f_sin(float x) { return (float)sin((double)x); }
+
+static void pcl_compute_roots(const float m[9], float* roots)
+{
+    float c0 = m[0] * m[4] * m[8] + 2.0f * m[1] * m[2] * m[5] - m[0] * m[5] * m[5]
+             - m[4] * m[2] * m[2] - m[8] * m[1] * m[1];
+    float c1 = m[0] * m[4] - m[1] * m[1] + m[0] * m[8] - m[2] * m[2] + m[4] * m[8] - m[5] * m[5];
+    float c2 = m[0] + m[4] + m[8];
+    if (fabsf(c0) < FLT_EPSILON) {
+        pcl_compute_roots2(c2, c1, roots);
+        return;
+    }
+    const float s_inv3 = (float)(1.0 / 3.0);
+    const float s_sqrt3 = sqrtf(3.0f);
+    float c2_over_3 = c2 * s_inv3;
+    float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+    if (a_over_3 > 0.0f) a_over_3 = 0.0f;
+    float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
+    float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+    if (q > 0.0f) q = 0.0f;
+    float rho = sqrtf(-a_over_3);
+    float theta = f_atan2(sqrtf(-q), half_b) * s_inv3;
+    float cos_theta = f_cos(theta);
+    float sin_theta = f_sin(theta);
+    roots[0] = c2_over_3 + 2.0f * rho * cos_theta;
+    roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+    roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+    float tmp;
+    if (roots[0] >= roots[1]) { tmp = roots[0]; roots[0] = roots[1]; roots[1] = tmp; }
+    if (roots[1] >= roots[2]) {
+        tmp = roots[1]; roots[1] = roots[2]; roots[2] = tmp;
+        if (roots[0] >= roots[1]) { tmp = roots[0]; roots[0] = roots[1]; roots[1] = tmp; }
+    }
+    if (roots[0] <= 0.0f) pcl_compute_roots2(c2, c1, roots);
+}
+
+static inline void cross3f(const float* a, const float* b, float* c)
+{
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+/* smallest eigenpair of a symmetric PSD 3x3 (float) */
+static void pcl_eigen33_smallest(const float mat[9], float* eigenvalue, float* vec)
+{
+    float scale = 0.0f;
+    for (int i = 0; i < 9; ++i) if (fabsf(mat[i]) > scale) scale = fabsf(mat[i]);
+    if (scale <= FLT_MIN) scale = 1.0f;
+    float s[9];
+    for (int i = 0; i < 9; ++i) s[i] = mat[i] / scale;
+    float ev[3];
+    pcl_compute_roots(s, ev);
+    *eigenvalue = ev[0] * scale;
+    s[0] -= ev[0]; s[4] -= ev[0]; s[8] -= ev[0];
+    float v1[3], v2[3], v3[3];
+    cross3f(s + 0, s + 3, v1);
+    cross3f(s + 0, s + 6, v2);
+    cross3f(s + 3, s + 6, v3);
+    float l1 = v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2];
+    float l2 = v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2];
+    float l3 = v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2];
+    const float* v; float l;
+    if (l1 >= l2 && l1 >= l3) { v = v1; l = l1; }
+    else if (l2 >= l1 && l2 >= l3) { v = v2; l = l2; }
+    else { v = v3; l = l3; }
+    float sl = sqrtf(l);
+    vec[0] = v[0] / sl; vec[1] = v[1] / sl; vec[2] = v[2] / sl;
+}
+
+/* PCL: common/impl/centroid.hpp computeMeanAndCovarianceMatrix (float, dense cloud):
+ * single pass, nine float running sums in storage order, all divided by n,
+ * cov = E[pp^T] - mu mu^T.   features/normal_3d.h computePointNormal/solvePlaneParameters. */
+static int pcl_compute_point_normal(const float* p4, int n, float* nrm)
+{
+    if (n < 3) return 0;
+    float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
+    for (int i = 0; i < n; ++i) {
+        const float* p = p4 + 4 * (size_t)i;
+        a0 += p[0] * p[0]; a1 += p[0] * p[1]; a2 += p[0] * p[2];
+        a3 += p[1] * p[1]; a4 += p[1] * p[2]; a5 += p[2] * p[2];
+        a6 += p[0]; a7 += p[1]; a8 += p[2];
+    }
+    float fn = (float)n;
+    a0 /= fn; a1 /= fn; a2 /= fn; a3 /= fn; a4 /= fn; a5 /= fn; a6 /= fn; a7 /= fn; a8 /= fn;
+    float cov[9];
+    cov[0] = a0 - a6 * a6; cov[1] = a1 - a6 * a7; cov[2] = a2 - a6 * a8;
+    cov[4] = a3 - a7 * a7; cov[5] = a4 - a7 * a8; cov[8] = a5 - a8 * a8;
+    cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
+    float ev;
+    pcl_eigen33_smallest(cov, &ev, nrm);
+    return 1;
+}
+
+/* C.cpp:284-333 calPatchNormal.  The fallback branch (|‖n‖-1| >= 1e-5, in practice only a
+ * NaN normal from a degenerate covariance) recomputes the normal from the demeaned
+ * covariance (Eigen JacobiSVD there; symmetric Jacobi here — same subspace). */
+int orc_cal_patch_normal(const float* p4, int n, float* nx, float* ny, float* nz)
+{
+    float nrm[3];
+    if (n > 4 && pcl_compute_point_normal(p4, n, nrm)) {
+        float nLen = sqrtf(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+        if (fabs((double)nLen - 1.0) < 1e-5) { *nx = nrm[0]; *ny = nrm[1]; *nz = nrm[2]; return 1; }
+        /* C.cpp:303-326 */
+        float mean[3] = {0, 0, 0};
+        for (int i = 0; i < n; ++i) for (int d = 0; d < 3; ++d) mean[d] += p4[4 * (size_t)i + d];
+        for (int d = 0; d < 3; ++d) mean[d] /= (float)n;
+        double S[9] = {0};
+        for (int i = 0; i < n; ++i) {
+            float dx = p4[4 * (size_t)i] - mean[0], dy = p4[4 * (size_t)i + 1] - mean[1],
+                  dz = p4[4 * (size_t)i + 2] - mean[2];
+            S[0] += (double)dx * dx; S[1] += (double)dx * dy; S[2] += (double)dx * dz;
+            S[4] += (double)dy * dy; S[5] += (double)dy * dz; S[8] += (double)dz * dz;
+        }
+        double C[9];
+        for (int i = 0; i < 9; ++i) C[i] = (double)((float)S[i] / (float)n);
+        C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
+        double w[3], V[9];
+        jacobi3(C, w, V);
+        *nx = (float)V[0]; *ny = (float)V[3]; *nz = (float)V[6];
+        float nLen2 = sqrtf(*nx * *nx + *ny * *ny + *nz * *nz);
+        return fabs((double)nLen2 - 1.0) < 1e-5 ? 1 : 0;
+    }
+    *nx = 0; *ny = 0; *nz = 1;
+    return 0;
+}
+
+/* PCL: common/impl/pca.hpp initCompute(): float centroid (compute3DCentroid), demean,
+ * alpha = D D^T (Matrix3f), SelfAdjointEigenSolver, eigenvectors descending -> col(2) is
+ * the plane normal.  The 3x3 product order inside Eigen's GEMM is not observable; the
+ * scatter is accumulated in double from the float demeaned coordinates and rounded to
+ * float once.  Returns plane (a,b,c,d) as used by C.cpp:341-346 / S.cpp:204-209. */
+static void pca_plane(const float* p4, int n, float* abcd)
+{
+    float c[3] = {0, 0, 0};
+    for (int i = 0; i < n; ++i) { c[0] += p4[4 * (size_t)i]; c[1] += p4[4 * (size_t)i + 1]; c[2] += p4[4 * (size_t)i + 2]; }
+    c[0] /= (float)n; c[1] /= (float)n; c[2] /= (float)n;
+    double S[9] = {0};
+    for (int i = 0; i < n; ++i) {
+        float dx = p4[4 * (size_t)i] - c[0], dy = p4[4 * (size_t)i + 1] - c[1], dz = p4[4 * (size_t)i + 2] - c[2];
+        S[0] += (double)dx * dx; S[1] += (double)dx * dy; S[2] += (double)dx * dz;
+        S[4] += (double)dy * dy; S[5] += (double)dy * dz; S[8] += (double)dz * dz;
+    }
+    double A[9];
+    for (int i = 0; i < 9; ++i) A[i] = (double)(float)S[i];
+    A[3] = A[1]; A[6] = A[2]; A[7] = A[5];
+    double w[3], V[9];
+    jacobi3(A, w, V);
+    float a = (float)V[0], b = (float)V[3], cc = (float)V[6];
+    abcd[0] = a; abcd[1] = b; abcd[2] = cc;
+    abcd[3] = -((a * c[0] + b * c[1]) + cc * c[2]);
+}
+
+/* PCL: sample_consensus/model_types / common/distances: pointToPlaneDistance =
+ * |a*x + b*y + c*z + d| evaluated in float */
+static inline double pt2plane(const float* p, const float* abcd)
+{
+    float s = abcd[0] * p[0] + abcd[1] * p[1] + abcd[2] * p[2] + abcd[3];
+    return (double)fabsf(s);
+}
+
+/* C.cpp:336-354 */
+float orc_cal_patch_std(const float* p4, int n)
+{
+    float abcd[4];
+    pca_plane(p4, n, abcd);
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) { double d = pt2plane(p4 + 4 * (size_t)i, abcd); s += d * d; }
+    return (float)sqrt(s / (double)(n - 1));
+}
+
+/* S.cpp:195-228 */
+int orc_patch_refinement(const float* p4, int n, double sigma_mul, unsigned char* keep)
+{
+    float abcd[4];
+    pca_plane(p4, n, abcd);
+    double* dist = (double*)malloc(sizeof(double) * (size_t)n);
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) { dist[i] = pt2plane(p4 + 4 * (size_t)i, abcd); s += dist[i] * dist[i]; }
+    s = sqrt(s / (double)n);
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) { keep[i] = fabs(dist[i]) < fabs(sigma_mul * s); cnt += keep[i]; }
+    free(dist);
+    return cnt;
+}
+
+/* S.cpp:231-257 */
+void orc_cal_patch_feature(const float* p4, int n, float* variation, float* planarity, float* linearity)
+{
+    float m[3] = {0, 0, 0};
+    for (int i = 0; i < n; ++i) { m[0] += p4[4 * (size_t)i]; m[1] += p4[4 * (size_t)i + 1]; m[2] += p4[4 * (size_t)i + 2]; }
+    m[0] /= (float)n; m[1] /= (float)n; m[2] /= (float)n;
+    double S[9] = {0};
+    for (int i = 0; i < n; ++i) {
+        float dx = p4[4 * (size_t)i] - m[0], dy = p4[4 * (size_t)i + 1] - m[1], dz = p4[4 * (size_t)i + 2] - m[2];
+        S[0] += (double)dx * dx; S[1] += (double)dx * dy; S[2] += (double)dx * dz;
+        S[4] += (double)dy * dy; S[5] += (double)dy * dz; S[8] += (double)dz * dz;
+    }
+    double C[9];
+    for (int i = 0; i < 9; ++i) C[i] = (double)((float)S[i] / (float)n);
+    C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
+    double w[3], V[9];
+    jacobi3(C, w, V);
+    float e[3] = {(float)fabs(w[0]), (float)fabs(w[1]), (float)fabs(w[2])};
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2 - i; ++j)
+            if (e[j] < e[j + 1]) { float t = e[j]; e[j] = e[j + 1]; e[j + 1] = t; }
+    float E1 = e[0], E2 = e[1], E3 = e[2];
+    *variation = E3 / (E1 + E2 + E3);
+    *planarity = (E2 - E3) / E1;
+    *linearity = (E1 - E2) / E1;
+}
+
+/* S.cpp:260-303 : float centroid (pcl::compute3DCentroid), 6 extremal points in the order
+ * Xmax, Xmin, Ymax, Ymin, Zmax, Zmin; strict compares -> first point wins ties;
+ * initial values +-DBL_MAX cast to float = +-inf */
+void orc_cal_patch_ct_bp(const float* p4, int n, float* ct4, float* bp4)
+{
+    float c[3] = {0, 0, 0};
+    for (int i = 0; i < n; ++i) { c[0] += p4[4 * (size_t)i]; c[1] += p4[4 * (size_t)i + 1]; c[2] += p4[4 * (size_t)i + 2]; }
+    ct4[0] = c[0] / (float)n; ct4[1] = c[1] / (float)n; ct4[2] = c[2] / (float)n; ct4[3] = 1.0f;
+    float inf = INFINITY;
+    float init[6][4] = {{-inf, 0, 0, 1}, {inf, 0, 0, 1}, {0, -inf, 0, 1}, {0, inf, 0, 1}, {0, 0, -inf, 1}, {0, 0, inf, 1}};
+    memcpy(bp4, init, sizeof(init));
+    for (int i = 0; i < n; ++i) {
+        const float* p = p4 + 4 * (size_t)i;
+        if (p[0] > bp4[0])      { memcpy(bp4 + 0, p, 12); }
+        if (p[0] < bp4[4])      { memcpy(bp4 + 4, p, 12); }
+        if (p[1] > bp4[8 + 1])  { memcpy(bp4 + 8, p, 12); }
+        if (p[1] < bp4[12 + 1]) { memcpy(bp4 + 12, p, 12); }
+        if (p[2] > bp4[16 + 2]) { memcpy(bp4 + 16, p, 12); }
+        if (p[2] < bp4[20 + 2]) { memcpy(bp4 + 20, p, 12); }
+    }
+}
+
+/* S.cpp:97-150 (patch extraction, refinement, selection) + S.cpp:306-321 (sigma_BP, sigma_CT) */
+int orc_select_patches(const float* cloud4, int n, const int* labels, int nsv,
+                       float** pat4_o, int** off_o, int** src_o,
+                       float** ct4_o, float** bp4_o, float** bpstd_o, float** ctstd_o)
+{
+    const int minPtNum = 20;   /* C.h:42 */
+    int* cnt = (int*)calloc((size_t)nsv + 1, sizeof(int));
+    for (int i = 0; i < n; ++i) cnt[labels[i] + 1]++;
+    for (int s = 0; s < nsv; ++s) cnt[s + 1] += cnt[s];
+    int* fill = (int*)malloc(sizeof(int) * (size_t)(nsv > 0 ? nsv : 1));
+    memcpy(fill, cnt, sizeof(int) * (size_t)nsv);
+    int* order = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; ++i) order[fill[labels[i]]++] = i;    /* S.cpp:99-103: point order */
+
+    float* pat4 = (float*)malloc(sizeof(float) * 4 * (size_t)(n > 0 ? n : 1));
+    int* src = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    int* off = (int*)malloc(sizeof(int) * ((size_t)nsv + 1));
+    float* ct4 = (float*)malloc(sizeof(float) * 4 * (size_t)(nsv > 0 ? nsv : 1));
+    float* bp4 = (float*)malloc(sizeof(float) * 24 * (size_t)(nsv > 0 ? nsv : 1));
+    float* bpstd = (float*)malloc(sizeof(float) * (size_t)(nsv > 0 ? nsv : 1));
+    float* ctstd = (float*)malloc(sizeof(float) * (size_t)(nsv > 0 ? nsv : 1));
+    int maxsz = 0;
+    for (int s = 0; s < nsv; ++s) if (cnt[s + 1] - cnt[s] > maxsz) maxsz = cnt[s + 1] - cnt[s];
+    float* tmp = (float*)malloc(sizeof(float) * 4 * (size_t)(maxsz > 0 ? maxsz : 1));
+    unsigned char* keep = (unsigned char*)malloc((size_t)(maxsz > 0 ? maxsz : 1));
+
+    int np = 0, w = 0;
+    off[0] = 0;
+    for (int s = 0; s < nsv; ++s) {
+        int sz = cnt[s + 1] - cnt[s];
+        if (sz < minPtNum) continue;                                   /* S.cpp:109 */
+        for (int k = 0; k < sz; ++k) memcpy(tmp + 4 * (size_t)k, cloud4 + 4 * (size_t)order[cnt[s] + k], 16);
+        int kept = orc_patch_refinement(tmp, sz, 2.0, keep);          /* S.cpp:116 */
+        if (kept < minPtNum) continue;                                 /* S.cpp:119 */
+        int w0 = w;
+        for (int k = 0; k < sz; ++k)
+            if (keep[k]) {
+                memcpy(pat4 + 4 * (size_t)w, tmp + 4 * (size_t)k, 16);
+                pat4[4 * (size_t)w + 3] = 1.0f;
+                src[w] = order[cnt[s] + k];
+                ++w;
+            }
+        float variation, planarity, linearity;
+        orc_cal_patch_feature(pat4 + 4 * (size_t)w0, kept, &variation, &planarity, &linearity);
+        if (variation > 0.02f || planarity < 0.25f) { w = w0; continue; }   /* S.cpp:127 */
+        orc_cal_patch_ct_bp(pat4 + 4 * (size_t)w0, kept, ct4 + 4 * (size_t)np, bp4 + 24 * (size_t)np);
+        float sd = orc_cal_patch_std(pat4 + 4 * (size_t)w0, kept);    /* S.cpp:315 */
+        bpstd[np] = sd;
+        ctstd[np] = sd / (float)kept;                                  /* S.cpp:317-319 (sigma/N) */
+        ++np;
+        off[np] = w;
+    }
+    free(cnt); free(fill); free(order); free(tmp); free(keep);
+    *pat4_o = pat4; *off_o = off; *src_o = src; *ct4_o = ct4; *bp4_o = bp4; *bpstd_o = bpstd; *ctstd_o = ctstd;
+    return np;
+}
+
+/* =====================================================================================
+ * inner ICP
+ * ===================================================================================== */
+
+/* PCL: registration/impl/transformation_estimation_lm.hpp-style constructTransformationMatrix
+ * of TransformationEstimationPointToPlaneLLS: R = Rz(gamma) Ry(beta) Rx(alpha), double trig,
+ * cast to float */
+static void construct_T(double alpha, double beta, double gamma, double tx, double ty, double tz, float* T)
+{
+    double ca = cos(alpha), sa = sin(alpha), cb = cos(beta), sb = sin(beta), cg = cos(gamma), sg = sin(gamma);
+    T[0] = (float)(cg * cb);
+    T[1] = (float)(-sg * ca + cg * sb * sa);
+    T[2] = (float)(sg * sa + cg * sb * ca);
+    T[4] = (float)(sg * cb);
+    T[5] = (float)(cg * ca + sg * sb * sa);
+    T[6] = (float)(-cg * sa + sg * sb * ca);
+    T[8] = (float)(-sb);
+    T[9] = (float)(cb * sa);
+    T[10] = (float)(cb * ca);
+    T[3] = (float)tx; T[7] = (float)ty; T[11] = (float)tz;
+    T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
+}
+
+/* PCL: registration/impl/transformation_estimation_point_to_plane_lls.hpp
+ * estimateRigidTransformation(): a,b,c and d are FLOAT expressions widened to double;
+ * products n*n are float products; sums in double, correspondence order. */
+void orc_p2p_lls(const float* src4, const float* tgt4, const float* tgt_n4, const int* match, int ns,
+                 double* ATA, double* ATb, double* x, float* T16)
+{
+    double A[36], b6[6];
+    memset(A, 0, sizeof(A)); memset(b6, 0, sizeof(b6));
+    for (int i = 0; i < ns; ++i) {
+        const float* s = src4 + 4 * (size_t)i;
+        const float* t = tgt4 + 4 * (size_t)match[i];
+        const float* nn = tgt_n4 + 4 * (size_t)match[i];
+        float sx = s[0], sy = s[1], sz = s[2], dx = t[0], dy = t[1], dz = t[2], nx = nn[0], ny = nn[1], nz = nn[2];
+        if (!isfinite(sx) || !isfinite(sy) || !isfinite(sz) || !isfinite(dx) || !isfinite(dy) || !isfinite(dz) ||
+            !isfinite(nx) || !isfinite(ny) || !isfinite(nz)) continue;
+        double a = (double)(nz * sy - ny * sz);
+        double b = (double)(nx * sz - nz * sx);
+        double c = (double)(ny * sx - nx * sy);
+        A[0] += a * a;  A[1] += a * b;  A[2] += a * c;  A[3] += a * nx;  A[4] += a * ny;  A[5] += a * nz;
+        A[7] += b * b;  A[8] += b * c;  A[9] += b * nx; A[10] += b * ny; A[11] += b * nz;
+        A[14] += c * c; A[15] += c * nx; A[16] += c * ny; A[17] += c * nz;
+        A[21] += (double)(nx * nx); A[22] += (double)(nx * ny); A[23] += (double)(nx * nz);
+        A[28] += (double)(ny * ny); A[29] += (double)(ny * nz);
+        A[35] += (double)(nz * nz);
+        double d = (double)(nx * dx + ny * dy + nz * dz - nx * sx - ny * sy - nz * sz);
+        b6[0] += a * d; b6[1] += b * d; b6[2] += c * d; b6[3] += nx * d; b6[4] += ny * d; b6[5] += nz * d;
+    }
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < i; ++j) A[6 * i + j] = A[6 * j + i];
+    double inv[36];
+    if (!inv6(A, inv)) for (int i = 0; i < 36; ++i) inv[i] = NAN;
+    double xx[6];
+    for (int i = 0; i < 6; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < 6; ++j) s += inv[6 * i + j] * b6[j];
+        xx[i] = s;
+    }
+    construct_T(xx[0], xx[1], xx[2], xx[3], xx[4], xx[5], T16);
+    if (ATA) memcpy(ATA, A, sizeof(A));
+    if (ATb) memcpy(ATb, b6, sizeof(b6));
+    if (x) memcpy(x, xx, sizeof(xx));
+}
+
+/* R.cpp:1255-1269 -> PCL: registration/impl/icp.hpp computeTransformation() with
+ * TransformationEpsilon 1e-8, EuclideanFitnessEpsilon euclid_eps, MaximumIterations 100,
+ * no rejectors, corr_dist_threshold = sqrt(DBL_MAX); convergence per
+ * registration/impl/default_convergence_criteria.hpp hasConverged(). */
+int orc_p2p_icp(const float* tgt4, const float* tgt_n4, int nt, const float* src4_in, const float* src_n4_in,
+                int ns, double euclid_eps, float* Tfinal, long long* n_corr_total)
+{
+    const int max_iterations = 100;
+    const double rot_thr = 1.0 - 1e-8, trans_thr = 1e-8, mse_abs = 1e-12, mse_rel = euclid_eps;
+    float* src = (float*)malloc(sizeof(float) * 4 * (size_t)(ns > 0 ? ns : 1));
+    float* srn = (float*)malloc(sizeof(float) * 4 * (size_t)(ns > 0 ? ns : 1));
+    int* match = (int*)malloc(sizeof(int) * (size_t)(ns > 0 ? ns : 1));
+    float* d2 = (float*)malloc(sizeof(float) * (size_t)(ns > 0 ? ns : 1));
+    memcpy(src, src4_in, sizeof(float) * 4 * (size_t)ns);
+    memcpy(srn, src_n4_in, sizeof(float) * 4 * (size_t)ns);
+    float final[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    orc_kdtree* tree = orc_kdtree_build(tgt4, nt);     /* tree built once per align() */
+    int iters = 0;
+    double prev_mse = DBL_MAX;
+    for (;;) {
+        orc_kdtree_nn1(tree, src, ns, match, d2);
+        if (n_corr_total) *n_corr_total += ns;
+        if (ns < 3) break;                              /* min_number_correspondences_ = 3 */
+        float T[16];
+        orc_p2p_lls(src, tgt4, tgt_n4, match, ns, NULL, NULL, NULL, T);
+        /* transformPointCloudWithNormals: points and normals, float */
+        for (int i = 0; i < ns; ++i) {
+            float* p = src + 4 * (size_t)i; float* q = srn + 4 * (size_t)i;
+            float x = p[0], y = p[1], z = p[2];
+            p[0] = T[0] * x + T[1] * y + T[2] * z + T[3];
+            p[1] = T[4] * x + T[5] * y + T[6] * z + T[7];
+            p[2] = T[8] * x + T[9] * y + T[10] * z + T[11];
+            float u = q[0], v = q[1], w = q[2];
+            q[0] = T[0] * u + T[1] * v + T[2] * w;
+            q[1] = T[4] * u + T[5] * v + T[6] * w;
+            q[2] = T[8] * u + T[9] * v + T[10] * w;
+        }
+        orc_mat4_mul(T, final, final);
+        ++iters;
+        /* hasConverged() */
+        if (iters >= max_iterations) break;
+        double cos_angle = 0.5 * (double)(T[0] + T[5] + T[10] - 1.0f);
+        double translation_sqr = (double)(T[3] * T[3] + T[7] * T[7] + T[11] * T[11]);
+        if (cos_angle >= rot_thr && translation_sqr <= trans_thr) break;
+        double mse = 0.0;
+        for (int i = 0; i < ns; ++i) mse += (double)d2[i];
+        mse /= (double)ns;
+        if (fabs(mse - prev_mse) < mse_abs) break;
+        if (fabs(mse - prev_mse) / prev_mse < mse_rel) break;
+        prev_mse = mse;
+    }
+    orc_kdtree_free(tree);
+    memcpy(Tfinal, final, sizeof(final));
+    free(src); free(srn); free(match); free(d2);
+    return iters;
+}
+
+/* R.cpp:1273-1343 calTransParaVCM */
+void orc_cal_trans_para_vcm(const float* tgt4, const float* tgt_n4, int nt, const float* srcs4, int ns, double* VCM)
+{
+    int* match = (int*)malloc(sizeof(int) * (size_t)(ns > 0 ? ns : 1));
+    float* d2 = (float*)malloc(sizeof(float) * (size_t)(ns > 0 ? ns : 1));
+    orc_determine_correspondences(tgt4, nt, srcs4, ns, match, d2);          /* R.cpp:1293-1297 */
+    double* A = (double*)malloc(sizeof(double) * 6 * (size_t)(ns > 0 ? ns : 1));
+    double* L = (double*)malloc(sizeof(double) * (size_t)(ns > 0 ? ns : 1));
+    for (int i = 0; i < ns; ++i) {                                         /* R.cpp:1300-1318 */
+        int j = match[i];
+        double Qx = srcs4[4 * (size_t)i], Qy = srcs4[4 * (size_t)i + 1], Qz = srcs4[4 * (size_t)i + 2];
+        double Px = tgt4[4 * (size_t)j], Py = tgt4[4 * (size_t)j + 1], Pz = tgt4[4 * (size_t)j + 2];
+        double Nx = tgt_n4[4 * (size_t)j], Ny = tgt_n4[4 * (size_t)j + 1], Nz = tgt_n4[4 * (size_t)j + 2];
+        double* a = A + 6 * (size_t)i;
+        a[0] = Nz * Qy - Ny * Qz; a[1] = Nx * Qz - Nz * Qx; a[2] = Ny * Qx - Nx * Qy;
+        a[3] = Nx; a[4] = Ny; a[5] = Nz;
+        L[i] = Nx * (Px - Qx) + Ny * (Py - Qy) + Nz * (Pz - Qz);
+    }
+    double ATA[36], ATL[6];
+    memset(ATA, 0, sizeof(ATA)); memset(ATL, 0, sizeof(ATL));
+    for (int i = 0; i < ns; ++i) {
+        const double* a = A + 6 * (size_t)i;
+        for (int r = 0; r < 6; ++r) { for (int c = 0; c < 6; ++c) ATA[6 * r + c] += a[r] * a[c]; ATL[r] += a[r] * L[i]; }
+    }
+    double Q[36];
+    if (!inv6(ATA, Q)) for (int i = 0; i < 36; ++i) Q[i] = NAN;           /* R.cpp:1328 */
+    double X[6];
+    for (int r = 0; r < 6; ++r) { double s = 0; for (int c = 0; c < 6; ++c) s += Q[6 * r + c] * ATL[c]; X[r] = s; }
+    double vtpv = 0.0;                                                     /* R.cpp:1330-1333 */
+    for (int i = 0; i < ns; ++i) {
+        const double* a = A + 6 * (size_t)i;
+        double v = 0; for (int c = 0; c < 6; ++c) v += a[c] * X[c];
+        v -= L[i];
+        vtpv += v * v;
+    }
+    double STD0 = sqrt(vtpv / (double)(ns - 6));
+    for (int i = 0; i < 36; ++i) VCM[i] = STD0 * STD0 * Q[i];
+    free(match); free(d2); free(A); free(L);
+}
+
+/* =====================================================================================
+ * helpers
+ * ===================================================================================== */
+
+/* C.cpp:145-170: quicksort, first element as pivot.  (The reference recurses on both
+ * sides; the smaller side is recursed first here to bound stack depth — same comparisons,
+ * same result.) */
+static int quick_sort_once(double* a, int low, int high)
+{
+    double pivot = a[low];
+    int i = low, j = high;
+    while (i < j) {
+        while (a[j] >= pivot && i < j) j--;
+        a[i] = a[j];
+        while (a[i] <= pivot && i < j) i++;
+        a[j] = a[i];
+    }
+    a[i] = pivot;
+    return i;
+}
+static void quick_sort(double* a, int low, int high)
+{
+    while (low < high) {
+        int p = quick_sort_once(a, low, high);
+        if (p - low < high - p) { quick_sort(a, low, p - 1); low = p + 1; }
+        else { quick_sort(a, p + 1, high); high = p - 1; }
+    }
+}
+
+/* C.cpp:266-281: target = cloud1, source = cloud2; sqrt is the float overload
+ * (std::sqrt(float)) widened to double; element a[int(n * percentile)] (C.cpp:174-179) */
+static double percentile_from_d2(const float* d2, int n, float percentile)
+{
+    double* a = (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; ++i) a[i] = (double)sqrtf(d2[i]);
+    quick_sort(a, 0, n - 1);
+    int leftnum = (int)((float)n * percentile);
+    double r = a[leftnum];
+    free(a);
+    return r;
+}
+
+double orc_percentile_dist(const float* c1, int n1, const float* c2, int n2, float percentile)
+{
+    int* idx = (int*)malloc(sizeof(int) * (size_t)(n2 > 0 ? n2 : 1));
+    float* d2 = (float*)malloc(sizeof(float) * (size_t)(n2 > 0 ? n2 : 1));
+    orc_determine_correspondences(c1, n1, c2, n2, idx, d2);
+    double r = percentile_from_d2(d2, n2, percentile);
+    free(idx); free(d2);
+    return r;
+}
+
+/* R.cpp:593-614 */
+float orc_overlap_ratio(const float* c1, int n1, const float* c2, int n2, float DTinit)
+{
+    int* idx = (int*)malloc(sizeof(int) * (size_t)(n2 > 0 ? n2 : 1));
+    float* d2 = (float*)malloc(sizeof(float) * (size_t)(n2 > 0 ? n2 : 1));
+    orc_determine_correspondences(c1, n1, c2, n2, idx, d2);
+    int under = 0;
+    for (int i = 0; i < n2; ++i) if (sqrtf(d2[i]) < DTinit) under++;
+    free(idx); free(d2);
+    return (float)under / (float)n2;
+}
+
+/* PCL: octree/impl/octree_pointcloud.hpp defineBoundingBox() + getKeyBitSize(), then
+ * getBoundingBox() (R.cpp:881-886).  Result order: minx,miny,minz,maxx,maxy,maxz. */
+void orc_octree_bbox(const float* c4, int n, double resolution, double* bb)
+{
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = 0; i < n; ++i)
+        for (int d = 0; d < 3; ++d) {
+            float v = c4[4 * (size_t)i + d];
+            if (v < mn[d]) mn[d] = v;
+            if (v > mx[d]) mx[d] = v;
+        }
+    float minValue = FLT_EPSILON * 512.0f;
+    double lo[3], hi[3];
+    for (int d = 0; d < 3; ++d) { lo[d] = mn[d]; hi[d] = (double)(mx[d] + minValue); }
+    const float eps = FLT_EPSILON;
+    unsigned int mk[3];
+    for (int d = 0; d < 3; ++d) mk[d] = (unsigned int)ceil((hi[d] - lo[d] - eps) / resolution);
+    unsigned int max_voxels = mk[0];
+    if (mk[1] > max_voxels) max_voxels = mk[1];
+    if (mk[2] > max_voxels) max_voxels = mk[2];
+    if (max_voxels < 2) max_voxels = 2;
+    unsigned int depth = (unsigned int)ceil(log((double)max_voxels) / log(2.0) - eps);
+    if (depth > 32) depth = 32;
+    double side = (double)(1u << depth) * resolution;
+    for (int d = 0; d < 3; ++d) {
+        double over = (side - (hi[d] - lo[d])) / 2.0;
+        if (over > eps) { lo[d] -= over; hi[d] += over; }
+    }
+    bb[0] = lo[0]; bb[1] = lo[1]; bb[2] = lo[2]; bb[3] = hi[0]; bb[4] = hi[1]; bb[5] = hi[2];
+}
+
+/* C.cpp:410-419 (Eigen float: T*corner with w = 1, then norm of the 3-vector difference) */
+float orc_bb_corner_change(const double* bb, const float* T)
+{
+    float r = 0.0f;
+    for (int k = 0; k < 2; ++k) {
+        float c[3] = {(float)bb[3 * k + 0], (float)bb[3 * k + 1], (float)bb[3 * k + 2]};
+        float t[3];
+        for (int i = 0; i < 3; ++i)
+            t[i] = T[4 * i] * c[0] + T[4 * i + 1] * c[1] + T[4 * i + 2] * c[2] + T[4 * i + 3] * 1.0f;
+        float dx = t[0] - c[0], dy = t[1] - c[1], dz = t[2] - c[2];
+        float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+        if (nrm > r) r = nrm;
+    }
+    return r;
+}
+
+/* C.cpp:385-407 (asin of a float argument is the float overload) */
+void orc_matrix2angle(const float* T, float* ang)
+{
+    double ax, ay, az;
+    if (T[8] == 1 || T[8] == -1) {
+        az = 0;
+        double dlta = (double)atan2f(T[1], T[2]);
+        if (T[8] == -1) { ay = M_PI / 2; ax = az + dlta; }
+        else { ay = -M_PI / 2; ax = -az + dlta; }
+    } else {
+        ay = (double)(-asinf(T[8]));
+        ax = atan2((double)T[9] / cos(ay), (double)T[10] / cos(ay));
+        az = atan2((double)T[4] / cos(ay), (double)T[0] / cos(ay));
+    }
+    ang[0] = (float)ax; ang[1] = (float)ay; ang[2] = (float)az;
+}
+
+/* =====================================================================================
+ * preprocessing
+ * ===================================================================================== */
+typedef struct { unsigned int idx; int pt; } vg_entry;
+static int vg_cmp(const void* a, const void* b)
+{
+    const vg_entry* x = (const vg_entry*)a; const vg_entry* y = (const vg_entry*)b;
+    if (x->idx != y->idx) return x->idx < y->idx ? -1 : 1;
+    return x->pt < y->pt ? -1 : (x->pt > y->pt);     /* std::sort is unstable in the reference;
+                                                        point order inside a voxel is made
+                                                        deterministic (input order) here */
+}
+
+/* PCL: filters/impl/voxel_grid.hpp applyFilter() (downsample_all_data_, no field filter,
+ * min_points_per_voxel_ = 0): ijk = floor(p * inverse_leaf) - min_b; linear index
+ * i + j*dx + k*dx*dy; output = float centroid per occupied voxel in ascending index order.
+ * (C.cpp:429-434) */
+int orc_voxel_grid(const float* in4, int n, float leaf, float* out4)
+{
+    if (n <= 0) return 0;
+    float inv = 1.0f / leaf;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = 0; i < n; ++i)
+        for (int d = 0; d < 3; ++d) {
+            float v = in4[4 * (size_t)i + d];
+            if (v < mn[d]) mn[d] = v;
+            if (v > mx[d]) mx[d] = v;
+        }
+    int minb[3], maxb[3], divb[3];
+    for (int d = 0; d < 3; ++d) {
+        minb[d] = (int)floorf(mn[d] * inv);
+        maxb[d] = (int)floorf(mx[d] * inv);
+        divb[d] = maxb[d] - minb[d] + 1;
+    }
+    int mul[3] = {1, divb[0], divb[0] * divb[1]};
+    vg_entry* e = (vg_entry*)malloc(sizeof(vg_entry) * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const float* p = in4 + 4 * (size_t)i;
+        int ijk0 = (int)(floorf(p[0] * inv) - (float)minb[0]);
+        int ijk1 = (int)(floorf(p[1] * inv) - (float)minb[1]);
+        int ijk2 = (int)(floorf(p[2] * inv) - (float)minb[2]);
+        e[i].idx = (unsigned int)(ijk0 * mul[0] + ijk1 * mul[1] + ijk2 * mul[2]);
+        e[i].pt = i;
+    }
+    qsort(e, (size_t)n, sizeof(vg_entry), vg_cmp);
+    int m = 0, i = 0;
+    while (i < n) {
+        int j = i;
+        float c[3] = {0, 0, 0};
+        while (j < n && e[j].idx == e[i].idx) {
+            const float* p = in4 + 4 * (size_t)e[j].pt;
+            c[0] += p[0]; c[1] += p[1]; c[2] += p[2];
+            ++j;
+        }
+        float cntf = (float)(j - i);
+        out4[4 * (size_t)m] = c[0] / cntf; out4[4 * (size_t)m + 1] = c[1] / cntf; out4[4 * (size_t)m + 2] = c[2] / cntf;
+        out4[4 * (size_t)m + 3] = 1.0f;
+        ++m; i = j;
+    }
+    free(e);
+    return m;
+}
+
+/* PCL: filters/impl/statistical_outlier_removal.hpp applyFilterIndices(): mean distance to
+ * the mean_k nearest OTHER points (searches mean_k+1, skips result 0), global mean and
+ * sample stddev of those means, keep d <= mean + std_mul*stddev.  (C.cpp:442-452) */
+int orc_sor_filter(const float* in4, int n, int mean_k, double std_mul, float* out4)
+{
+    if (n <= 0) return 0;
+    orc_kdtree* t = orc_kdtree_build(in4, n);
+    float* dist = (float*)malloc(sizeof(float) * (size_t)n);
+    int* nn_i = (int*)malloc(sizeof(int) * (size_t)(mean_k + 1));
+    float* nn_d = (float*)malloc(sizeof(float) * (size_t)(mean_k + 1));
+    int valid = 0;
+    for (int i = 0; i < n; ++i) {
+        orc_kdtree_knn(t, in4 + 4 * (size_t)i, mean_k + 1, nn_i, nn_d);
+        double s = 0.0;
+        for (int k = 1; k < mean_k + 1; ++k) s += (double)sqrtf(nn_d[k]);
+        dist[i] = (float)(s / mean_k);
+        valid++;
+    }
+    double sum = 0, sq = 0;
+    for (int i = 0; i < n; ++i) { sum += dist[i]; sq += (double)(dist[i] * dist[i]); }
+    double mean = sum / (double)valid;
+    double var = (sq - sum * sum / (double)valid) / ((double)valid - 1);
+    double thr = mean + std_mul * sqrt(var);
+    int m = 0;
+    for (int i = 0; i < n; ++i)
+        if (!((double)dist[i] > thr)) { memcpy(out4 + 4 * (size_t)m, in4 + 4 * (size_t)i, 16); ++m; }
+    orc_kdtree_free(t); free(dist); free(nn_i); free(nn_d);
+    return m;
+}
+
+/* C.cpp:239-263 */
+float orc_pc_resolution(const float* c4, int n)
+{
+    orc_kdtree* t = orc_kdtree_build(c4, n);
+    float res = 0.0f; int cnt = 0; int ii[2]; float dd[2];
+    for (int i = 0; i < n; ++i) {
+        orc_kdtree_knn(t, c4 + 4 * (size_t)i, 2, ii, dd);
+        if (ii[1] < 0) { orc_kdtree_free(t); return 0.0f; }
+        res += sqrtf(dd[1]); ++cnt;
+    }
+    orc_kdtree_free(t);
+    if (cnt) res /= (float)cnt;
+    return res;
+}
+
+/* =====================================================================================
+ * the outer loop: R.cpp:618-700 (after patch generation) and R.cpp:704-972
+ * ===================================================================================== */
+int orc_piecewise_icp_loop(const float* cloud1, int n1, float* cloud2, int n2,
+                           const float* pat1, const int* off1, int m1, const float* ct1, const float* bp1,
+                           float* pat2, const int* off2, int m2, float* ct2, float* bp2, orc_loop_io* io)
+{
+    (void)bp1;
+    io->status = 0; io->n_outer = 0; io->n_corr = 0; io->t_loop_s = 0; io->t_inner_s = 0; io->n_inner_total = 0;
+    for (int i = 0; i < 16; ++i) io->T16[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    for (int i = 0; i < 36; ++i) io->VCM[i] = 0.0;
+
+    /* R.cpp:626-631 */
+    float DTinit = io->DTinit;
+    if (!io->isManualDTinit) {
+        double Dist75 = orc_percentile_dist(cloud1, n1, cloud2, n2, 0.75f);
+        DTinit = (float)(Dist75 * 3.0);
+    }
+    float currDT = DTinit;
+    float SVRes1 = io->SVRes1, SVRes2 = io->SVRes2;
+    const float DTmin = io->DTmin;
+
+    /* R.cpp:660-664: sigma_BP / sigma_CT per patch (S.cpp:306-321) */
+    float* CTstd1 = (float*)malloc(sizeof(float) * (size_t)(m1 > 0 ? m1 : 1));
+    float* BPstd2 = (float*)malloc(sizeof(float) * (size_t)(m2 > 0 ? m2 : 1));
+    for (int i = 0; i < m1; ++i) {
+        int np = off1[i + 1] - off1[i];
+        CTstd1[i] = orc_cal_patch_std(pat1 + 4 * (size_t)off1[i], np) / (float)np;
+    }
+    for (int i = 0; i < m2; ++i) BPstd2[i] = orc_cal_patch_std(pat2 + 4 * (size_t)off2[i], off2[i + 1] - off2[i]);
+
+    /* hoisted (result-neutral) target-side caches, used when !faithful_cost */
+    float* nrm1 = (float*)malloc(sizeof(float) * 4 * (size_t)(m1 > 0 ? m1 : 1));
+    unsigned char* nrm1_ok = (unsigned char*)malloc((size_t)(m1 > 0 ? m1 : 1));
+    for (int i = 0; i < m1; ++i) {
+        float a, b, c;
+        nrm1_ok[i] = (unsigned char)orc_cal_patch_normal(pat1 + 4 * (size_t)off1[i], off1[i + 1] - off1[i], &a, &b, &c);
+        nrm1[4 * i] = a; nrm1[4 * i + 1] = b; nrm1[4 * i + 2] = c; nrm1[4 * i + 3] = 0;
+    }
+    orc_kdtree* tree_ct1 = io->faithful_cost ? NULL : orc_kdtree_build(ct1, m1);
+    orc_kdtree* tree_c1 = io->faithful_cost ? NULL : orc_kdtree_build(cloud1, n1);
+
+    int nbp2 = 6 * m2;
+    int* mCT = (int*)malloc(sizeof(int) * (size_t)(m2 > 0 ? m2 : 1));
+    float* dCT = (float*)malloc(sizeof(float) * (size_t)(m2 > 0 ? m2 : 1));
+    int* mBP = (int*)malloc(sizeof(int) * (size_t)(nbp2 > 0 ? nbp2 : 1));
+    float* dBP = (float*)malloc(sizeof(float) * (size_t)(nbp2 > 0 ? nbp2 : 1));
+    float* LoDet = (float*)malloc(sizeof(float) * (size_t)(m2 > 0 ? m2 : 1));
+    float* P2PlCT = (float*)malloc(sizeof(float) * (size_t)(m2 > 0 ? m2 : 1));
+    float* P2PtCT = (float*)malloc(sizeof(float) * (size_t)(m2 > 0 ? m2 : 1));
+    float* P2PlBP = (float*)malloc(sizeof(float) * (size_t)(nbp2 > 0 ? nbp2 : 1));
+    float* ct1n = (float*)malloc(sizeof(float) * 4 * (size_t)(m1 > 0 ? m1 : 1));
+    float* ct2n = (float*)malloc(sizeof(float) * 4 * (size_t)(m2 > 0 ? m2 : 1));
+    float* stCT = (float*)malloc(sizeof(float) * 4 * (size_t)(m2 > 0 ? m2 : 1));
+    float* stN = (float*)malloc(sizeof(float) * 4 * (size_t)(m2 > 0 ? m2 : 1));
+    int tot2 = off2[m2];
+    float* stPC = (float*)malloc(sizeof(float) * 4 * (size_t)(tot2 > 0 ? tot2 : 1));
+    int* tmp_i = (int*)malloc(sizeof(int) * (size_t)(tot2 > 0 ? tot2 : 1));
+    float* tmp_d = (float*)malloc(sizeof(float) * (size_t)(tot2 > 0 ? tot2 : 1));
+
+    int stage2 = 0, stage3 = 0;       /* g_toStage2 / g_toStage3, R.cpp:623-624 */
+    float BB1 = 0.0f, BB2 = 0.0f;     /* R.cpp:672-673 */
+    io->DTseries[0] = currDT;
+
+    double t0 = now_s();
+    while (!stage3) {                 /* R.cpp:680 */
+        int k = io->n_outer;
+        if (k >= ORC_MAX_OUTER) break;
+        /* ---------------- PwICP_singleIteration, R.cpp:704-972 ------------------------ */
+        if (currDT <= DTmin) currDT = DTmin;                                   /* 724-725 */
+        if (4 > m2) { io->status = 1; break; }                                 /* 728-731 */
+
+        /* (1) 737-747: the reference builds the CT1 tree twice */
+        if (io->faithful_cost) {
+            orc_determine_correspondences(ct1, m1, ct2, m2, mCT, dCT);
+            orc_determine_correspondences(ct1, m1, bp2, nbp2, mBP, dBP);
+        } else {
+            orc_kdtree_nn1(tree_ct1, ct2, m2, mCT, dCT);
+            orc_kdtree_nn1(tree_ct1, bp2, nbp2, mBP, dBP);
+        }
+        io->n_corr += (long long)m2 + nbp2;
+
+        /* (2) 750-769 */
+        float maxLoD = DTmin * 2.0f, minLoD = DTmin;
+        float LoDet_min = FLT_MAX, LoDet_max = -FLT_MAX;
+        for (int i = 0; i < m2; ++i) {
+            float s1 = CTstd1[mCT[i]], s2 = BPstd2[i];
+            float LoD = (float)(1.96 * (double)sqrtf(s1 * s1 + s2 * s2));
+            if (LoD > maxLoD) LoD = maxLoD; else if (LoD < minLoD) LoD = minLoD;
+            LoDet[i] = LoD;
+            if (LoD < LoDet_min) LoDet_min = LoD;
+            if (LoD > LoDet_max) LoDet_max = LoD;
+        }
+
+        /* (3) 774-812: point-to-plane distances; calPatchNormal on the matched TARGET patch */
+        for (int i = 0; i < m2; ++i) {
+            int j = mCT[i]; float nx, ny, nz; int ok;
+            if (io->faithful_cost) ok = orc_cal_patch_normal(pat1 + 4 * (size_t)off1[j], off1[j + 1] - off1[j], &nx, &ny, &nz);
+            else { ok = nrm1_ok[j]; nx = nrm1[4 * j]; ny = nrm1[4 * j + 1]; nz = nrm1[4 * j + 2]; }
+            float res;
+            if (ok) {
+                float dx = ct1[4 * j] - ct2[4 * i], dy = ct1[4 * j + 1] - ct2[4 * i + 1], dz = ct1[4 * j + 2] - ct2[4 * i + 2];
+                res = fabsf(dx * nx + dy * ny + dz * nz);
+            } else res = sqrtf(dCT[i]);
+            P2PlCT[i] = res;
+            P2PtCT[i] = sqrtf(dCT[i]);
+        }
+        for (int i = 0; i < nbp2; ++i) {
+            int j = mBP[i]; float nx, ny, nz; int ok;
+            if (io->faithful_cost) ok = orc_cal_patch_normal(pat1 + 4 * (size_t)off1[j], off1[j + 1] - off1[j], &nx, &ny, &nz);
+            else { ok = nrm1_ok[j]; nx = nrm1[4 * j]; ny = nrm1[4 * j + 1]; nz = nrm1[4 * j + 2]; }
+            float res;
+            if (ok) {
+                float dx = ct1[4 * j] - bp2[4 * i], dy = ct1[4 * j + 1] - bp2[4 * i + 1], dz = ct1[4 * j + 2] - bp2[4 * i + 2];
+                res = fabsf(dx * nx + dy * ny + dz * nz);
+            } else res = sqrtf(dBP[i]);
+            P2PlBP[i] = res;
+        }
+
+        /* (4) 815-871 ; generateCentroidCloudWithPatchNormals C.cpp:357-382 */
+        float DTctct = currDT + 1 * (SVRes1 + SVRes2);
+        for (int i = 0; i < m1; ++i) {
+            int np = off1[i + 1] - off1[i]; float nx = 0, ny = 0, nz = 1;
+            int ok;
+            if (io->faithful_cost) ok = (np > 6) && orc_cal_patch_normal(pat1 + 4 * (size_t)off1[i], np, &nx, &ny, &nz);
+            else { ok = (np > 6) && nrm1_ok[i]; nx = nrm1[4 * i]; ny = nrm1[4 * i + 1]; nz = nrm1[4 * i + 2]; }
+            if (!ok) { nx = 0; ny = 0; nz = 1; }
+            ct1n[4 * i] = nx; ct1n[4 * i + 1] = ny; ct1n[4 * i + 2] = nz; ct1n[4 * i + 3] = 0;
+        }
+        for (int i = 0; i < m2; ++i) {
+            int np = off2[i + 1] - off2[i]; float nx = 0, ny = 0, nz = 1;
+            int ok = (np > 6) && orc_cal_patch_normal(pat2 + 4 * (size_t)off2[i], np, &nx, &ny, &nz);
+            if (!ok) { nx = 0; ny = 0; nz = 1; }
+            ct2n[4 * i] = nx; ct2n[4 * i + 1] = ny; ct2n[4 * i + 2] = nz; ct2n[4 * i + 3] = 0;
+        }
+        int ns = 0, nsp = 0;
+        for (int i = 0; i < m2; ++i) {
+            int BPpass = 1;
+            for (int kk = 0; kk < 6; ++kk) {
+                if (currDT <= LoDet[i]) { if (LoDet[i] < P2PlBP[6 * i + kk]) BPpass = 0; }
+                else { if (currDT < P2PlBP[6 * i + kk]) BPpass = 0; }
+            }
+            int CTpass = 1;
+            if (currDT <= LoDet[i]) { if (LoDet[i] < P2PlCT[i]) CTpass = 0; }
+            else { if (currDT < P2PlCT[i]) CTpass = 0; }
+            if (CTpass && BPpass && (P2PtCT[i] < DTctct)) {
+                int np = off2[i + 1] - off2[i];
+                memcpy(stPC + 4 * (size_t)nsp, pat2 + 4 * (size_t)off2[i], sizeof(float) * 4 * (size_t)np);
+                nsp += np;
+                memcpy(stCT + 4 * (size_t)ns, ct2 + 4 * (size_t)i, 16);
+                memcpy(stN + 4 * (size_t)ns, ct2n + 4 * (size_t)i, 16);
+                ++ns;
+            }
+        }
+        io->n_stable[k] = ns; io->n_stable_pts[k] = nsp; io->LoDmin[k] = LoDet_min;
+        if (4 > ns) { io->status = 2; break; }                                /* 864-867 */
+
+        /* (5) 875-877 */
+        float Tk[16];
+        double ti0 = now_s();
+        int n_in = orc_p2p_icp(ct1, ct1n, m1, stCT, stN, ns, 1e-6, Tk, &io->n_corr);
+        if (io->faithful_cost) { orc_kdtree* extra = orc_kdtree_build(ct1, m1); orc_kdtree_free(extra); } /* Registration::initCompute tree */
+        io->t_inner_s += now_s() - ti0;
+        io->n_inner[k] = n_in; io->n_inner_total += n_in;
+        memcpy(io->Tk[k], Tk, sizeof(Tk));
+
+        /* (6) 881-888 */
+        double bb[6];
+        orc_octree_bbox(cloud2, n2, (double)(io->Res2 * 2), bb);
+        float maxBB = orc_bb_corner_change(bb, Tk);
+        io->maxBB[k] = maxBB;
+
+        /* (7) 891-935 */
+        io->d75[k] = -1.0;
+        if (!stage2 && maxBB < minLoD) stage2 = 1;
+        else if (currDT == LoDet_min) stage3 = 1;
+        if (!stage2) {
+            double Dist75;
+            if (io->faithful_cost) Dist75 = orc_percentile_dist(cloud1, n1, stPC, nsp, 0.75f);
+            else { orc_kdtree_nn1(tree_c1, stPC, nsp, tmp_i, tmp_d); Dist75 = percentile_from_d2(tmp_d, nsp, 0.75f); }
+            io->n_corr += nsp;
+            io->d75[k] = Dist75;
+            if ((double)currDT > Dist75) currDT = (float)Dist75; else stage2 = 1;
+            if (currDT <= LoDet_min) currDT = LoDet_min;
+            BB2 = BB1; BB1 = maxBB;
+        }
+        if (stage2 && !stage3) {
+            float upperBound = 0.8f, lowerBound = 0.5f;
+            float alpha = fabsf(BB1 / BB2);
+            if (isnan(alpha) || isinf(alpha)) currDT = currDT * upperBound;
+            else if (alpha < lowerBound) currDT = currDT * lowerBound;
+            else if (alpha > upperBound) currDT = currDT * upperBound;
+            else currDT = currDT * alpha;
+            if (currDT <= LoDet_min) currDT = LoDet_min;
+            BB2 = BB1; BB1 = maxBB;
+        }
+
+        /* (8) 943-954 */
+        orc_transform_points(cloud2, n2, Tk);
+        orc_transform_points(ct2, m2, Tk);
+        orc_transform_points(bp2, nbp2, Tk);
+        orc_transform_points(pat2, tot2, Tk);
+
+        /* (9) 958-961: stable centroids BEFORE the update (copied at 868) */
+        if (stage3) {
+            orc_cal_trans_para_vcm(ct1, ct1n, m1, stCT, ns, io->VCM);
+            io->n_corr += ns;
+        }
+        /* ---------------- back in Piecewise_ICP, R.cpp:687-689 ------------------------ */
+        orc_mat4_mul(Tk, io->T16, io->T16);
+        io->n_outer = k + 1;
+        io->DTseries[k + 1] = currDT;
+    }
+    io->t_loop_s = now_s() - t0;
+
+    orc_kdtree_free(tree_ct1); orc_kdtree_free(tree_c1);
+    free(CTstd1); free(BPstd2); free(nrm1); free(nrm1_ok); free(mCT); free(dCT); free(mBP); free(dBP);
+    free(LoDet); free(P2PlCT); free(P2PtCT); free(P2PlBP); free(ct1n); free(ct2n); free(stCT); free(stN);
+    free(stPC); free(tmp_i); free(tmp_d);
+    return io->status;
+}
