@@ -1,0 +1,187 @@
+/*
+ * pwicp.h — C ABI of libpwicp.so: the MI355X-native (HIP, gfx950) implementation of the
+ * Piecewise-ICP fine-registration loop.
+ *
+ * This is the drop-in boundary for the hot path of yihui4d/Piecewise-ICP.  Every entry point
+ * names the reference interface it replaces (file:line in the reference tree; R = src/
+ * Registration.cpp, C = src/CommonFunc.cpp, S = src/Segmentation.cpp, R.h/S.h/C.h = include/).
+ * Plain pointers and sizes only — no PCL, Eigen or torch types.  The PCL-typed C++ facade
+ * with the reference's own signatures (Registration.h) lives in include/pwicp/ and forwards
+ * here.
+ *
+ * Conventions
+ *  - point arrays are pcl::PointXYZ-compatible: 16 bytes per point, floats x,y,z,pad;
+ *    "xyz4" below.  Normals likewise (nx,ny,nz,pad).
+ *  - all pointers are HOST pointers unless the name says `_dev`; a pwicp_pair keeps its data
+ *    resident in HBM between calls.
+ *  - 4x4 matrices are row-major float[16]; 6x6 VCM is row-major double[36]
+ *    (parameter order Rx,Ry,Rz,tx,ty,tz as R.cpp:1286).
+ *  - functions return PWICP_OK (0) or a negative pwicp_status; pwicp_last_error() gives text.
+ *    Nothing in this library calls exit() (the reference does: R.cpp:728-731, 864-867).
+ *  - there is NO CPU fallback: every compute entry point fails with PWICP_E_NO_DEVICE when no
+ *    HIP device is usable.
+ */
+#ifndef PWICP_H
+#define PWICP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PWICP_API __attribute__((visibility("default")))
+
+typedef enum {
+    PWICP_OK = 0,
+    PWICP_E_NO_DEVICE = -1,       /* no usable HIP device / HIP runtime error */
+    PWICP_E_INVALID = -2,         /* bad argument (null pointer, negative size, non-finite input) */
+    PWICP_E_TOO_FEW_PATCHES = -3, /* < 4 source patches            (R.cpp:728-731) */
+    PWICP_E_TOO_FEW_STABLE = -4,  /* < 4 stable patches            (R.cpp:864-867) */
+    PWICP_E_NOMEM = -5,
+    PWICP_E_INTERNAL = -6
+} pwicp_status;
+
+typedef struct pwicp_context pwicp_context;   /* one per GPU / per thread; replaces the reference's
+                                                 module globals g_toStage2/3, g_isVis (R.cpp:11-14) */
+typedef struct pwicp_pair pwicp_pair;         /* one target/source pair resident in HBM */
+
+/* ---- context ------------------------------------------------------------------------------ */
+PWICP_API int         pwicp_create(pwicp_context** ctx, int device_id);
+PWICP_API void        pwicp_destroy(pwicp_context* ctx);
+PWICP_API const char* pwicp_last_error(const pwicp_context* ctx);
+PWICP_API const char* pwicp_version(void);
+/* number of visible HIP devices (0 when none / no runtime) */
+PWICP_API int         pwicp_device_count(void);
+
+/* ---- building blocks (each replaces one reference / PCL call site) ------------------------- */
+
+/* Exact 1-NN of every query in the target set; all correspondences kept.
+ * Replaces pcl::registration::CorrespondenceEstimation<PointXYZ,PointXYZ>::
+ * determineCorrespondences(corr, DBL_MAX) as called at R.cpp:737-747, 1293-1297, 597-601 and
+ * C.cpp:269-273: index_match[i] = argmin_j of the FLOAT expression ((dx*dx)+dy*dy)+dz*dz,
+ * sq_distance[i] = that float value (pcl::Correspondence::distance is the squared distance).
+ * Ties resolve to the lowest target index. */
+PWICP_API int pwicp_nn_search(pwicp_context* ctx, const float* target_xyz4, int n_target,
+                              const float* query_xyz4, int n_query,
+                              int32_t* index_match, float* sq_distance);
+
+/* p-th percentile of the 1-NN distances cloud2 -> cloud1: element int(n*percentile) of the
+ * ascending sqrt(float d2) list.  Replaces calPercentileDistBetween2PC (C.cpp:266-281 with
+ * C.cpp:145-179; decl C.h). */
+PWICP_API int pwicp_percentile_dist(pwicp_context* ctx, const float* cloud1_xyz4, int n1,
+                                    const float* cloud2_xyz4, int n2, float percentile,
+                                    double* dist_out);
+
+/* Fraction of cloud2 points whose 1-NN distance to cloud1 is < DTinit.
+ * Replaces calOverlapRatioByC2Cdist (R.cpp:593-614; decl R.h:116-129). */
+PWICP_API int pwicp_overlap_ratio(pwicp_context* ctx, const float* cloud1_xyz4, int n1,
+                                  const float* cloud2_xyz4, int n2, float DTinit, float* ratio_out);
+
+/* Patch plane normals: for patch i (points patch_xyz4[offsets[i]..offsets[i+1])) the smallest
+ * eigenvector of the float single-pass covariance.  Replaces calPatchNormal (C.cpp:284-333 ->
+ * pcl::computePointNormal) for all patches at once, i.e. the normal part of
+ * generateCentroidCloudWithPatchNormals (C.cpp:357-382).  ok[i] = calPatchNormal's return value;
+ * on failure the normal is (0,0,1). */
+PWICP_API int pwicp_patch_normals(pwicp_context* ctx, const float* patch_xyz4, const int32_t* offsets,
+                                  int n_patches, float* normals4, uint8_t* ok);
+
+/* Patch extraction, 2-sigma refinement, selection, centroids, boundary points, sigmas from a
+ * supervoxel labelling.  Replaces the body of PatchGenerationAndRefinement after the
+ * segmentation call (S.cpp:97-150: PatchRefinement S.cpp:195-228, calPatchFeature S.cpp:231-257,
+ * calPatchCTandBP S.cpp:260-303) plus calBPandCTSTD / calPatchSTD (S.cpp:306-321, C.cpp:336-354).
+ * Two-call protocol: call with patch_xyz4 == NULL to get *n_patches and *n_patch_points, then
+ * with buffers: patch_xyz4 [n_patch_points*4], offsets [n_patches+1], src_index [n_patch_points]
+ * (may be NULL), centroid_xyz4 [n_patches*4], boundary_xyz4 [n_patches*24] (order Xmax,Xmin,
+ * Ymax,Ymin,Zmax,Zmin), std_bp, std_ct [n_patches]. */
+PWICP_API int pwicp_select_patches(pwicp_context* ctx, const float* cloud_xyz4, int n,
+                                   const int32_t* labels, int n_supervoxels,
+                                   int* n_patches, int* n_patch_points,
+                                   float* patch_xyz4, int32_t* offsets, int32_t* src_index,
+                                   float* centroid_xyz4, float* boundary_xyz4,
+                                   float* std_bp, float* std_ct);
+
+/* Point-to-plane ICP between centroid clouds with normals.  Replaces P2PICPwithPatchNormal
+ * (R.cpp:1255-1269; decl R.h:213-214) = pcl::IterativeClosestPointWithNormals<PointNormal,
+ * PointNormal>::align with TransformationEpsilon 1e-8, EuclideanFitnessEpsilon euclid_eps,
+ * MaximumIterations 100 (TransformationEstimationPointToPlaneLLS + DefaultConvergenceCriteria).
+ * T16: final transformation; n_iterations (optional). */
+PWICP_API int pwicp_p2p_icp(pwicp_context* ctx, const float* target_xyz4, const float* target_normal4,
+                            int n_target, const float* source_xyz4, const float* source_normal4,
+                            int n_source, double euclid_eps, float* T16, int* n_iterations);
+
+/* Variance-covariance matrix of the 6 transformation parameters.  Replaces calTransParaVCM
+ * (R.cpp:1273-1343; decl R.h:227-229). */
+PWICP_API int pwicp_trans_para_vcm(pwicp_context* ctx, const float* target_xyz4,
+                                   const float* target_normal4, int n_target,
+                                   const float* source_stable_xyz4, int n_source, double* VCM36);
+
+/* ---- the loop: Piecewise_ICP (R.cpp:618-700; decl R.h:149-153) ------------------------------ */
+#define PWICP_MAX_OUTER 256
+
+typedef struct {
+    float Res1, Res2;            /* average point spacing of cloud1 / cloud2            */
+    float SVRes1, SVRes2;        /* patch (supervoxel) size actually used (R.cpp:635-640) */
+    int   isManualDTinit;        /* 0: DTinit = 3 * p75 dense NN distance (R.cpp:627-630)  */
+    float DTinit, DTmin;
+} pwicp_params;
+
+typedef struct {
+    int    status;                        /* pwicp_status of the run                         */
+    int    n_outer;                       /* outer (Piecewise-ICP) iterations                */
+    float  T16[16];                       /* accumulated transMat (R.cpp:687)                */
+    double VCM[36];                       /* R.cpp:958-961                                   */
+    float  DTseries[PWICP_MAX_OUTER + 1]; /* R.cpp:675-676, 688                              */
+    int    n_inner[PWICP_MAX_OUTER];      /* inner ICP iterations per outer iteration        */
+    int    n_stable[PWICP_MAX_OUTER];     /* stable source patches                           */
+    int    n_stable_pts[PWICP_MAX_OUTER]; /* points of the stable patches (|stablePC2|)      */
+    float  LoDmin[PWICP_MAX_OUTER];
+    float  maxBB[PWICP_MAX_OUTER];
+    double d75[PWICP_MAX_OUTER];          /* Stage-1 percentile distance, -1 if not computed */
+    float  Tk[PWICP_MAX_OUTER][16];       /* per-iteration transMatICP                       */
+    long long n_corr;                     /* completed 1-NN queries inside the loop */
+    long long n_corr_dense;               /* of which dense Stage-1 queries                  */
+    long long n_inner_total;
+    double t_loop_ms;                     /* host wall time of the loop                      */
+    double t_dense_nn_ms;                 /* HIP-event time of the dense NN kernel launches  */
+    int    n_dense_nn_launches;
+    double t_inner_ms;                    /* HIP-event time of the inner-ICP launches        */
+    double dense_kbar;                    /* mean target points examined per dense query     */
+} pwicp_result;
+
+/* Uploads both clouds and their supervoxel labellings, runs patch selection/statistics and builds
+ * the static target-side search structures in HBM.  Everything PatchGenerationAndRefinement
+ * (S.cpp:11-192) produces after the segmentation call + calBPandCTSTD (R.cpp:660-664). */
+PWICP_API int pwicp_pair_create(pwicp_context* ctx,
+                                const float* cloud1_xyz4, int n1, const int32_t* labels1, int nsv1,
+                                const float* cloud2_xyz4, int n2, const int32_t* labels2, int nsv2,
+                                const pwicp_params* params, pwicp_pair** pair);
+/* Same, from already selected patches (the arrays pwicp_select_patches returns). */
+PWICP_API int pwicp_pair_create_from_patches(pwicp_context* ctx,
+                                const float* cloud1_xyz4, int n1,
+                                const float* patch1_xyz4, const int32_t* off1, int m1,
+                                const float* cloud2_xyz4, int n2,
+                                const float* patch2_xyz4, const int32_t* off2, int m2,
+                                const pwicp_params* params, pwicp_pair** pair);
+PWICP_API void pwicp_pair_destroy(pwicp_pair* pair);
+PWICP_API int  pwicp_pair_num_patches(const pwicp_pair* pair, int* m1, int* m2);
+/* Restores the source-side arrays to their uploaded state (the loop transforms them in place,
+ * R.cpp:943-954) so the same pair can be registered again. Device-to-device copies only. */
+PWICP_API int pwicp_pair_reset(pwicp_pair* pair);
+/* The while-loop of Piecewise_ICP (R.cpp:680-694) = repeated PwICP_singleIteration
+ * (R.cpp:704-972; decl R.h:181-188), entirely on the device. */
+PWICP_API int pwicp_pair_run(pwicp_pair* pair, pwicp_result* result);
+/* Copies the current (transformed) source cloud back: cloud2 after the loop (R.cpp:943-945). */
+PWICP_API int pwicp_pair_download_source(pwicp_pair* pair, float* cloud2_xyz4);
+
+/* ---- one dense NN launch on resident data, for roofline measurement (bench.py) --------------- */
+/* Runs the dense 1-NN kernel for all source patch points of `pair` against cloud1 `n_launches`
+ * times on the pair's stream and returns the mean HIP-event time per launch, the number of queries
+ * per launch, and Kbar (mean target points in the 27-cell stencil of a query). */
+PWICP_API int pwicp_pair_bench_dense_nn(pwicp_pair* pair, int n_launches, double* ms_per_launch,
+                                        long long* n_queries, double* kbar, double* cell_edge);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PWICP_H */

@@ -1,0 +1,111 @@
+// Shared host-side definitions for libpwicp.so (HIP, gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pwicp.h"
+
+// All translation units are compiled with -ffp-contract=off: every float/double operation
+// rounds once, so the decision-relevant arithmetic (squared distances, point-to-plane
+// distances, thresholds, covariance sums) is bit-identical to the reference's x64 SSE2 build.
+
+struct pwicp_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int n_cu = 256;
+    void set_err(const char* where, hipError_t e) {
+        char buf[512];
+        snprintf(buf, sizeof(buf), "%s: %s", where, hipGetErrorString(e));
+        err = buf;
+    }
+    void set_err(const char* msg) { err = msg; }
+};
+
+#define PW_STR2(x) #x
+#define PW_STR(x) PW_STR2(x)
+#define HIPCHK(ctx, expr)                                                   \
+    do {                                                                    \
+        hipError_t e__ = (expr);                                            \
+        if (e__ != hipSuccess) {                                            \
+            (ctx)->set_err(__FILE__ ":" PW_STR(__LINE__) " " #expr, e__);   \
+            return PWICP_E_NO_DEVICE;                                       \
+        }                                                                   \
+    } while (0)
+#define PWCHK(expr)                        \
+    do {                                   \
+        int s__ = (expr);                  \
+        if (s__ != PWICP_OK) return s__;   \
+    } while (0)
+
+// Device buffer with explicit lifetime (no exceptions across the C ABI).
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    // grows only; contents are NOT preserved
+    hipError_t reserve(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+};
+
+static inline int div_up(long long a, int b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------------
+// Uniform-grid search structure over a static point set (device resident).
+// Points are bucketed by cell with a counting sort; a cell row along x is contiguous in memory,
+// so the 3 x-neighbour cells of a stencil row are ONE contiguous range of points.
+// ---------------------------------------------------------------------------------------------
+struct GridDesc {
+    float ox, oy, oz;        // origin = min corner of the bounding box
+    float h, inv_h;          // cell edge
+    float slack;             // bound on |computed cell boundary - true boundary| (rounding)
+    int nx, ny, nz;
+    int n;                   // number of points
+    const int* cell_start;   // nx*ny*nz + 1 entries
+    const float4* pts;       // sorted by cell; w = __int_as_float(original index)
+};
+
+struct Grid {
+    GridDesc d{};
+    DevBuf<int> cell_start;
+    DevBuf<float4> pts;
+    double kbar27 = 0.0;     // mean #points in the 27-cell stencil around an occupied cell, point weighted
+};
+
+// grid.hip
+int pw_grid_build(pwicp_context* ctx, const float4* d_pts, int n, float cell_edge, Grid* g);
+// exact 1-NN of d_q[0..nq) ; d_idx may be null; d_examined (optional) accumulates #points examined
+int pw_nn_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_q, int nq, int* d_idx, float* d_d2,
+                 unsigned long long* d_examined);
+// dense NN over the points of the listed patches: query i in [0, n_pts) belongs to stable patch j with
+// d_soff[j] <= i < d_soff[j+1]; its point is pat[off[list[j]] + i - soff[j]]
+int pw_nn_patches_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pat, const int* d_off,
+                         const int* d_list, const int* d_soff, int n_list, int n_pts, float* d_d2,
+                         unsigned long long* d_examined);
+// k-th smallest (0-based) of n non-negative floats; result written to d_out[0]; scratch >= 3*2048+8 uints
+int pw_select_kth_launch(pwicp_context* ctx, const float* d_vals, int n, int k, unsigned* d_scratch, float* d_out);
+// count of values with sqrtf(v) < thr  -> d_count[0]
+int pw_count_below_launch(pwicp_context* ctx, const float* d_d2, int n, float thr, unsigned* d_count);
+// exclusive scan in place of n ints (n may be large); d_tmp >= div_up(n,4096)+1 ints
+int pw_exclusive_scan(pwicp_context* ctx, int* d_data, long long n, DevBuf<int>* tmp);

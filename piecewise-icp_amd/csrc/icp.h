@@ -1,0 +1,27 @@
+// Inner ICP / VCM device work buffers and launch wrappers (icp.hip).
+#pragma once
+#include "common.h"
+
+struct IcpState {
+    float T[16];        // last incremental transformation (row-major)
+    float Tfinal[16];   // accumulated final transformation
+    int iters;
+    int done;
+    int reason;         // 1 max iterations, 2 transform epsilon, 3 abs MSE, 4 rel MSE
+    int pad;
+    double prev_mse;
+};
+
+struct IcpWork {
+    DevBuf<float4> src, srcn;      // working source centroids + normals (transformed in place)
+    DevBuf<int> match;
+    DevBuf<double> partials;
+    DevBuf<IcpState> state;
+    DevBuf<double> qx, vcm;
+    int reserve(pwicp_context* ctx, int ns_max);
+};
+
+int pw_icp_run(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w, int ns,
+               double euclid_eps, float* T16, int* iters_out);
+int pw_vcm_run(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
+               const float4* d_src, int ns, double* VCM36);

@@ -1,0 +1,294 @@
+// Inner point-to-plane ICP and the variance-covariance matrix on the device.
+//
+// Reference: P2PICPwithPatchNormal src/Registration.cpp:1255-1269 (= pcl::IterativeClosestPointWithNormals::
+// align: correspondence search, TransformationEstimationPointToPlaneLLS, transformPointCloudWithNormals,
+// DefaultConvergenceCriteria) and calTransParaVCM Registration.cpp:1273-1343.
+//
+// One inner iteration = two launches on one stream, no host round trip:
+//   k_icp_accum  (grid over the S stable centroids): applies the previous incremental transform to the
+//                working source (points + normals), exact 1-NN in the target-centroid grid, forms the row
+//                [a b c nx ny nz | d] in float exactly as PCL does, widens to double and reduces the 21+6
+//                sums (+ sum of d2 for the MSE test) with wave shuffles -> LDS -> one partial per block;
+//   k_icp_solve  (one wave): fixed-order sum of the block partials, 6x6 LU inverse, x = inv*ATb,
+//                Rz*Ry*Rx matrix in double -> float, final = T*final, convergence tests, done flag.
+// Launches after convergence are no-ops (done flag), so iterations are enqueued in small batches.
+#include "common.h"
+#include "devmath.h"
+#include "icp.h"
+#include "nn_device.h"
+
+using namespace pwdev;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kNSums = 28;    // 21 ATA (upper triangle) + 6 ATb + 1 sum(d2)
+
+__device__ __forceinline__ void block_reduce_store(double* v, int nv, double* __restrict__ partial_out) {
+    __shared__ double sh[kBlock / 64][kNSums];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = 0; k < nv; ++k) {
+        double x = v[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+        if (lane == 0) sh[wave][k] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < nv) {
+        double s = sh[0][threadIdx.x];
+        for (int w = 1; w < kBlock / 64; ++w) s += sh[w][threadIdx.x];
+        partial_out[threadIdx.x] = s;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_icp_accum(GridDesc g, const float4* __restrict__ tgt,
+                                                      const float4* __restrict__ tgt_n, float4* __restrict__ src,
+                                                      float4* __restrict__ srcn, int ns, const IcpState* st,
+                                                      double* __restrict__ partials) {
+    if (st->done) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[kNSums];
+#pragma unroll
+    for (int k = 0; k < kNSums; ++k) v[k] = 0.0;
+    if (i < ns) {
+        float4 p = src[i], nrm = srcn[i];
+        if (st->iters > 0) {       // transformPointCloudWithNormals with the previous estimate
+            p = xform_point(st->T, p);
+            nrm = xform_normal(st->T, nrm);
+            src[i] = p;
+            srcn[i] = nrm;
+        }
+        unsigned ex;
+        NNBest b = nn_query(g, p.x, p.y, p.z, ex);
+        const float4 t = tgt[b.idx], n = tgt_n[b.idx];
+        const float sx = p.x, sy = p.y, sz = p.z, dx = t.x, dy = t.y, dz = t.z, nx = n.x, ny = n.y, nz = n.z;
+        const double a = (double)(nz * sy - ny * sz);
+        const double bb = (double)(nx * sz - nz * sx);
+        const double c = (double)(ny * sx - nx * sy);
+        v[0] = a * a;   v[1] = a * bb;  v[2] = a * c;   v[3] = a * nx;  v[4] = a * ny;  v[5] = a * nz;
+        v[6] = bb * bb; v[7] = bb * c;  v[8] = bb * nx; v[9] = bb * ny; v[10] = bb * nz;
+        v[11] = c * c;  v[12] = c * nx; v[13] = c * ny; v[14] = c * nz;
+        v[15] = (double)(nx * nx); v[16] = (double)(nx * ny); v[17] = (double)(nx * nz);
+        v[18] = (double)(ny * ny); v[19] = (double)(ny * nz);
+        v[20] = (double)(nz * nz);
+        const double d = (double)(nx * dx + ny * dy + nz * dz - nx * sx - ny * sy - nz * sz);
+        v[21] = a * d; v[22] = bb * d; v[23] = c * d; v[24] = nx * d; v[25] = ny * d; v[26] = nz * d;
+        v[27] = (double)b.d2;
+    }
+    block_reduce_store(v, kNSums, partials + (size_t)blockIdx.x * kNSums);
+}
+
+__device__ inline void construct_T(const double* x, float* T) {
+    const double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cg = cos(x[2]), sg = sin(x[2]);
+    T[0] = (float)(cg * cb);
+    T[1] = (float)(-sg * ca + cg * sb * sa);
+    T[2] = (float)(sg * sa + cg * sb * ca);
+    T[4] = (float)(sg * cb);
+    T[5] = (float)(cg * ca + sg * sb * sa);
+    T[6] = (float)(-cg * sa + sg * sb * ca);
+    T[8] = (float)(-sb);
+    T[9] = (float)(cb * sa);
+    T[10] = (float)(cb * ca);
+    T[3] = (float)x[3]; T[7] = (float)x[4]; T[11] = (float)x[5];
+    T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
+}
+
+__global__ void __launch_bounds__(64) k_icp_solve(IcpState* st, const double* __restrict__ partials, int nblocks,
+                                                  int ns, double mse_rel) {
+    if (st->done) return;
+    __shared__ double sums[kNSums];
+    if (threadIdx.x < kNSums) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * kNSums + threadIdx.x];
+        sums[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double A[36];
+    const int map[21][2] = {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {1, 1}, {1, 2}, {1, 3}, {1, 4}, {1, 5},
+                            {2, 2}, {2, 3}, {2, 4}, {2, 5}, {3, 3}, {3, 4}, {3, 5}, {4, 4}, {4, 5}, {5, 5}};
+    for (int k = 0; k < 21; ++k) {
+        A[6 * map[k][0] + map[k][1]] = sums[k];
+        A[6 * map[k][1] + map[k][0]] = sums[k];
+    }
+    double inv[36], x[6];
+    if (!inv6(A, inv))
+        for (int k = 0; k < 36; ++k) inv[k] = NAN;
+    for (int r = 0; r < 6; ++r) {
+        double s = 0.0;
+        for (int c = 0; c < 6; ++c) s += inv[6 * r + c] * sums[21 + c];
+        x[r] = s;
+    }
+    float T[16];
+    construct_T(x, T);
+    for (int k = 0; k < 16; ++k) st->T[k] = T[k];
+    mat4_mul(T, st->Tfinal, st->Tfinal);
+    const int iters = st->iters + 1;
+    st->iters = iters;
+    // pcl::registration::DefaultConvergenceCriteria<float>::hasConverged()
+    if (iters >= 100) { st->done = 1; st->reason = 1; return; }
+    const double cos_angle = 0.5 * (double)(T[0] + T[5] + T[10] - 1.0f);
+    const double translation_sqr = (double)(T[3] * T[3] + T[7] * T[7] + T[11] * T[11]);
+    if (cos_angle >= 1.0 - 1e-8 && translation_sqr <= 1e-8) { st->done = 1; st->reason = 2; return; }
+    const double mse = sums[27] / (double)ns;
+    if (fabs(mse - st->prev_mse) < 1e-12) { st->done = 1; st->reason = 3; return; }
+    if (fabs(mse - st->prev_mse) / st->prev_mse < mse_rel) { st->done = 1; st->reason = 4; return; }
+    st->prev_mse = mse;
+}
+
+__global__ void k_icp_init(IcpState* st) {
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 16; ++k) {
+            st->T[k] = (k % 5 == 0) ? 1.f : 0.f;
+            st->Tfinal[k] = (k % 5 == 0) ? 1.f : 0.f;
+        }
+        st->iters = 0; st->done = 0; st->reason = 0; st->pad = 0;
+        st->prev_mse = 1.7976931348623157e308;   // std::numeric_limits<double>::max()
+    }
+}
+
+// ---- VCM (R.cpp:1273-1343) ------------------------------------------------------------------------------
+constexpr int kVSums = 27;    // 21 ATA + 6 ATL
+
+__device__ __forceinline__ void vcm_row(float4 q, float4 p, float4 n, double* a, double* L) {
+    const double Qx = q.x, Qy = q.y, Qz = q.z, Px = p.x, Py = p.y, Pz = p.z, Nx = n.x, Ny = n.y, Nz = n.z;
+    a[0] = Nz * Qy - Ny * Qz;
+    a[1] = Nx * Qz - Nz * Qx;
+    a[2] = Ny * Qx - Nx * Qy;
+    a[3] = Nx; a[4] = Ny; a[5] = Nz;
+    *L = Nx * (Px - Qx) + Ny * (Py - Qy) + Nz * (Pz - Qz);
+}
+
+__global__ void __launch_bounds__(kBlock) k_vcm_accum(GridDesc g, const float4* __restrict__ tgt,
+                                                      const float4* __restrict__ tgt_n,
+                                                      const float4* __restrict__ src, int ns, int* __restrict__ match,
+                                                      double* __restrict__ partials) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[kNSums];
+#pragma unroll
+    for (int k = 0; k < kNSums; ++k) v[k] = 0.0;
+    if (i < ns) {
+        float4 q = src[i];
+        unsigned ex;
+        NNBest b = nn_query(g, q.x, q.y, q.z, ex);
+        match[i] = b.idx;
+        double a[6], L;
+        vcm_row(q, tgt[b.idx], tgt_n[b.idx], a, &L);
+        int k = 0;
+        for (int r = 0; r < 6; ++r)
+            for (int c = r; c < 6; ++c) v[k++] = a[r] * a[c];
+        for (int r = 0; r < 6; ++r) v[21 + r] = a[r] * L;
+    }
+    block_reduce_store(v, kVSums, partials + (size_t)blockIdx.x * kNSums);
+}
+
+// out: Q[36], X[6]
+__global__ void __launch_bounds__(64) k_vcm_solve(const double* __restrict__ partials, int nblocks, double* __restrict__ QX) {
+    __shared__ double sums[kVSums];
+    if (threadIdx.x < kVSums) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * kNSums + threadIdx.x];
+        sums[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double A[36];
+    int k = 0;
+    for (int r = 0; r < 6; ++r)
+        for (int c = r; c < 6; ++c) { A[6 * r + c] = sums[k]; A[6 * c + r] = sums[k]; ++k; }
+    double Q[36];
+    if (!inv6(A, Q))
+        for (int i = 0; i < 36; ++i) Q[i] = NAN;
+    for (int i = 0; i < 36; ++i) QX[i] = Q[i];
+    for (int r = 0; r < 6; ++r) {
+        double s = 0;
+        for (int c = 0; c < 6; ++c) s += Q[6 * r + c] * sums[21 + c];
+        QX[36 + r] = s;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_vcm_resid(const float4* __restrict__ tgt, const float4* __restrict__ tgt_n,
+                                                      const float4* __restrict__ src, int ns,
+                                                      const int* __restrict__ match, const double* __restrict__ QX,
+                                                      double* __restrict__ partials) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[kNSums];
+    v[0] = 0.0;
+    if (i < ns) {
+        double a[6], L;
+        vcm_row(src[i], tgt[match[i]], tgt_n[match[i]], a, &L);
+        double r = 0;
+        for (int c = 0; c < 6; ++c) r += a[c] * QX[36 + c];
+        r -= L;
+        v[0] = r * r;
+    }
+    block_reduce_store(v, 1, partials + (size_t)blockIdx.x * kNSums);
+}
+
+__global__ void __launch_bounds__(64) k_vcm_final(const double* __restrict__ partials, int nblocks, int ns,
+                                                  const double* __restrict__ QX, double* __restrict__ vcm) {
+    if (threadIdx.x != 0) return;
+    double vtpv = 0.0;
+    for (int b = 0; b < nblocks; ++b) vtpv += partials[(size_t)b * kNSums];
+    const double STD0 = sqrt(vtpv / (double)(ns - 6));
+    for (int i = 0; i < 36; ++i) vcm[i] = STD0 * STD0 * QX[i];
+}
+
+}  // namespace
+
+// ==========================================================================================================
+int IcpWork::reserve(pwicp_context* ctx, int ns_max) {
+    int nb = div_up(std::max(ns_max, 1), kBlock);
+    HIPCHK(ctx, src.reserve((size_t)std::max(ns_max, 1)));
+    HIPCHK(ctx, srcn.reserve((size_t)std::max(ns_max, 1)));
+    HIPCHK(ctx, match.reserve((size_t)std::max(ns_max, 1)));
+    HIPCHK(ctx, partials.reserve((size_t)nb * kNSums));
+    HIPCHK(ctx, state.reserve(1));
+    HIPCHK(ctx, qx.reserve(48));
+    HIPCHK(ctx, vcm.reserve(36));
+    return PWICP_OK;
+}
+
+// d_src / d_srcn: working copies (modified in place). Returns final T and the iteration count.
+int pw_icp_run(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w, int ns,
+               double euclid_eps, float* T16, int* iters_out) {
+    for (int k = 0; k < 16; ++k) T16[k] = (k % 5 == 0) ? 1.f : 0.f;
+    if (iters_out) *iters_out = 0;
+    if (ns < 3 || g.n <= 0) return PWICP_OK;      // min_number_correspondences_ = 3: no update
+    const int nb = div_up(ns, kBlock);
+    hipLaunchKernelGGL(k_icp_init, dim3(1), dim3(64), 0, ctx->stream, w->state.p);
+    IcpState h;
+    const int batch = 4;
+    for (int done_iters = 0; done_iters < 100;) {
+        for (int k = 0; k < batch; ++k) {
+            hipLaunchKernelGGL(k_icp_accum, dim3(nb), dim3(kBlock), 0, ctx->stream, g, d_tgt, d_tgt_n, w->src.p,
+                               w->srcn.p, ns, w->state.p, w->partials.p);
+            hipLaunchKernelGGL(k_icp_solve, dim3(1), dim3(64), 0, ctx->stream, w->state.p, w->partials.p, nb, ns,
+                               euclid_eps);
+        }
+        HIPCHK(ctx, hipMemcpyAsync(&h, w->state.p, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        done_iters = h.iters;
+        if (h.done) break;
+    }
+    HIPCHK(ctx, hipGetLastError());
+    memcpy(T16, h.Tfinal, sizeof(h.Tfinal));
+    if (iters_out) *iters_out = h.iters;
+    return PWICP_OK;
+}
+
+int pw_vcm_run(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
+               const float4* d_src, int ns, double* VCM36) {
+    if (ns <= 0) { for (int i = 0; i < 36; ++i) VCM36[i] = NAN; return PWICP_OK; }
+    const int nb = div_up(ns, kBlock);
+    hipLaunchKernelGGL(k_vcm_accum, dim3(nb), dim3(kBlock), 0, ctx->stream, g, d_tgt, d_tgt_n, d_src, ns, w->match.p,
+                       w->partials.p);
+    hipLaunchKernelGGL(k_vcm_solve, dim3(1), dim3(64), 0, ctx->stream, w->partials.p, nb, w->qx.p);
+    hipLaunchKernelGGL(k_vcm_resid, dim3(nb), dim3(kBlock), 0, ctx->stream, d_tgt, d_tgt_n, d_src, ns, w->match.p,
+                       w->qx.p, w->partials.p);
+    hipLaunchKernelGGL(k_vcm_final, dim3(1), dim3(64), 0, ctx->stream, w->partials.p, nb, ns, w->qx.p, w->vcm.p);
+    HIPCHK(ctx, hipMemcpyAsync(VCM36, w->vcm.p, 36 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipGetLastError());
+    return PWICP_OK;
+}

@@ -1,0 +1,673 @@
+// pwicp_pair_*: one target/source pair resident in HBM and the Piecewise-ICP outer loop.
+//
+// Reference: Piecewise_ICP src/Registration.cpp:618-700 (loop 680-694) and PwICP_singleIteration
+// Registration.cpp:704-972.  Device residency: clouds, patches (CSR), centroids, boundary points, normals,
+// sigmas and both search grids are uploaded/built once (pwicp_pair_create); per outer iteration only a few
+// scalars (stable counts, LoD_min, the 4x4 of the inner ICP, the p75 distance) come back to the host, which
+// runs the reference's distance-threshold schedule (Registration.cpp:891-935) verbatim.
+#include <chrono>
+#include <cmath>
+#include <new>
+
+#include "common.h"
+#include "devmath.h"
+#include "icp.h"
+#include "nn_device.h"
+#include "patch.h"
+
+using namespace pwdev;
+
+struct Mat4 {
+    float m[16];
+};
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ unsigned f2ord_dev(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+inline float ord2f_host(unsigned u) {
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// scal layout (unsigned words): [0] LoDmin bits, [1] LoDmax bits, [2] n stable, [3] n stable points,
+//                               [4..6] bbox min (ordered), [7..9] bbox max (ordered)
+
+// Steps (2)-(4) of PwICP_singleIteration for one source patch per lane (R.cpp:750-862).
+__global__ void __launch_bounds__(kBlock) k_classify(
+    int m2, const int* __restrict__ mCT, const float* __restrict__ dCT, const int* __restrict__ mBP,
+    const float* __restrict__ dBP, const float* __restrict__ ctstd1, const float* __restrict__ bpstd2,
+    const float4* __restrict__ nrm1, const float4* __restrict__ ct1, const float4* __restrict__ ct2,
+    const float4* __restrict__ bp2, float currDT, float DTmin, float DTctct, int* __restrict__ stable,
+    unsigned* __restrict__ scal) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float lod_min = INFINITY, lod_max = 0.0f;
+    if (i < m2) {
+        // (2) level of detection, R.cpp:756-766
+        const float maxLoD = DTmin * 2.0f, minLoD = DTmin;
+        const int j = mCT[i];
+        const float s1 = ctstd1[j], s2 = bpstd2[i];
+        float LoD = (float)(1.96 * (double)sqrtf(s1 * s1 + s2 * s2));
+        if (LoD > maxLoD) LoD = maxLoD; else if (LoD < minLoD) LoD = minLoD;
+        lod_min = LoD; lod_max = LoD;
+        // (3) point-to-plane distances with the matched TARGET patch normal, R.cpp:781-812
+        const float4 q = ct2[i];
+        float4 n = nrm1[j], t = ct1[j];
+        float resCT;
+        if (n.w != 0.0f) {
+            const float dx = t.x - q.x, dy = t.y - q.y, dz = t.z - q.z;
+            resCT = fabsf(dx * n.x + dy * n.y + dz * n.z);
+        } else resCT = sqrtf(dCT[i]);
+        const float p2pt = sqrtf(dCT[i]);
+        // (4) R.cpp:826-862; `thr < dist` fails, exactly the reference's comparisons
+        const float thr = (currDT <= LoD) ? LoD : currDT;
+        bool pass = !(thr < resCT);
+        for (int k = 0; k < 6; ++k) {
+            const int jb = mBP[6 * i + k];
+            const float4 b = bp2[6 * i + k];
+            n = nrm1[jb]; t = ct1[jb];
+            float res;
+            if (n.w != 0.0f) {
+                const float dx = t.x - b.x, dy = t.y - b.y, dz = t.z - b.z;
+                res = fabsf(dx * n.x + dy * n.y + dz * n.z);
+            } else res = sqrtf(dBP[6 * i + k]);
+            if (thr < res) pass = false;
+        }
+        stable[i] = (pass && (p2pt < DTctct)) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lod_min = fminf(lod_min, __shfl_xor(lod_min, o));
+        lod_max = fmaxf(lod_max, __shfl_xor(lod_max, o));
+    }
+    if ((threadIdx.x & 63) == 0 && lod_max > 0.0f) {
+        atomicMin(&scal[0], __float_as_uint(lod_min));   // positive floats order like their bit patterns
+        atomicMax(&scal[1], __float_as_uint(lod_max));
+    }
+}
+
+// Order-preserving compaction of the stable patches (single block): list, point prefix, stable centroids with
+// normals (generateCentroidCloudWithPatchNormals semantics: (0,0,1) unless > 6 points and a valid normal).
+__global__ void __launch_bounds__(1024) k_compact(int m2, const int* __restrict__ stable, const int* __restrict__ off2,
+                                                  const float4* __restrict__ ct2, const float4* __restrict__ nrm2,
+                                                  int* __restrict__ list, int* __restrict__ soff,
+                                                  float4* __restrict__ stCT, float4* __restrict__ stN,
+                                                  float4* __restrict__ wsrc, float4* __restrict__ wsrcn,
+                                                  unsigned* __restrict__ scal) {
+    __shared__ int sh[1024];
+    __shared__ int carry_n, carry_p;
+    if (threadIdx.x == 0) { carry_n = 0; carry_p = 0; }
+    __syncthreads();
+    for (int base = 0; base < m2; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int f = (i < m2) ? stable[i] : 0;
+        const int sz = f ? (off2[i + 1] - off2[i]) : 0;
+        // scan of flags
+        sh[threadIdx.x] = f;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            int t = (threadIdx.x >= o) ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const int pos = carry_n + sh[threadIdx.x] - f;
+        const int tot_n = sh[1023];
+        __syncthreads();
+        // scan of sizes
+        sh[threadIdx.x] = sz;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            int t = (threadIdx.x >= o) ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const int ppos = carry_p + sh[threadIdx.x] - sz;
+        const int tot_p = sh[1023];
+        if (f) {
+            list[pos] = i;
+            soff[pos] = ppos;
+            const float4 c = ct2[i];
+            float4 n = nrm2[i];
+            const int np = off2[i + 1] - off2[i];
+            if (!(np > 6 && n.w != 0.0f)) n = make_float4(0.f, 0.f, 1.f, 0.f);
+            n.w = 0.f;
+            stCT[pos] = c; stN[pos] = n;
+            wsrc[pos] = c; wsrcn[pos] = n;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { carry_n += tot_n; carry_p += tot_p; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        soff[carry_n] = carry_p;
+        scal[2] = (unsigned)carry_n;
+        scal[3] = (unsigned)carry_p;
+    }
+}
+
+// target centroids with normals for the ICP / VCM (C.cpp:357-382)
+__global__ void k_with_norm(int m, const int* __restrict__ off, const float4* __restrict__ nrm,
+                            float4* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    float4 n = nrm[i];
+    if (!((off[i + 1] - off[i]) > 6 && n.w != 0.0f)) n = make_float4(0.f, 0.f, 1.f, 0.f);
+    n.w = 0.f;
+    out[i] = n;
+}
+
+__global__ void __launch_bounds__(kBlock) k_transform(float4* __restrict__ p, int n, Mat4 T) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = xform_point(T.m, p[i]);
+}
+
+// transform + bounding box of the result (for the next iteration's octree box, R.cpp:881-886)
+__global__ void __launch_bounds__(kBlock) k_transform_bbox(float4* __restrict__ p, int n, Mat4 T, int apply,
+                                                           unsigned* __restrict__ scal) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float4 v = p[i];
+        if (apply) { v = xform_point(T.m, v); p[i] = v; }
+        mn[0] = fminf(mn[0], v.x); mx[0] = fmaxf(mx[0], v.x);
+        mn[1] = fminf(mn[1], v.y); mx[1] = fmaxf(mx[1], v.y);
+        mn[2] = fminf(mn[2], v.z); mx[2] = fmaxf(mx[2], v.z);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            mn[d] = fminf(mn[d], __shfl_xor(mn[d], o));
+            mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], o));
+        }
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            atomicMin(&scal[4 + d], f2ord_dev(mn[d]));
+            atomicMax(&scal[7 + d], f2ord_dev(mx[d]));
+        }
+}
+
+__global__ void k_iota_list(int* list, int* soff, const int* __restrict__ off, int m) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) { list[i] = i; soff[i] = off[i]; }
+    if (i == m) soff[m] = off[m];
+}
+
+// ---- host-side scalar pieces of the reference's control logic --------------------------------------------
+// pcl::octree::OctreePointCloud::defineBoundingBox + getKeyBitSize, from the tight
+// float min/max of the cloud.  resolution = double(Res2 * 2)  (R.cpp:882)
+void octree_bbox(const float* mn, const float* mx, double resolution, double* bb) {
+    const float minValue = FLT_EPSILON * 512.0f;
+    const float eps = FLT_EPSILON;
+    double lo[3], hi[3];
+    for (int d = 0; d < 3; ++d) { lo[d] = mn[d]; hi[d] = (double)(mx[d] + minValue); }
+    unsigned mk = 2;
+    for (int d = 0; d < 3; ++d) {
+        unsigned k = (unsigned)std::ceil((hi[d] - lo[d] - eps) / resolution);
+        if (k > mk) mk = k;
+    }
+    unsigned depth = (unsigned)std::ceil(std::log((double)mk) / std::log(2.0) - eps);
+    if (depth > 32) depth = 32;
+    const double side = (double)(1u << depth) * resolution;
+    for (int d = 0; d < 3; ++d) {
+        const double over = (side - (hi[d] - lo[d])) / 2.0;
+        if (over > eps) { lo[d] -= over; hi[d] += over; }
+    }
+    bb[0] = lo[0]; bb[1] = lo[1]; bb[2] = lo[2]; bb[3] = hi[0]; bb[4] = hi[1]; bb[5] = hi[2];
+}
+
+// calBoundingBoxCornerChange, C.cpp:410-419
+float bb_corner_change(const double* bb, const float* T) {
+    float r = 0.f;
+    for (int k = 0; k < 2; ++k) {
+        const float c[3] = {(float)bb[3 * k], (float)bb[3 * k + 1], (float)bb[3 * k + 2]};
+        float t[3];
+        for (int i = 0; i < 3; ++i) t[i] = T[4 * i] * c[0] + T[4 * i + 1] * c[1] + T[4 * i + 2] * c[2] + T[4 * i + 3] * 1.0f;
+        const float dx = t[0] - c[0], dy = t[1] - c[1], dz = t[2] - c[2];
+        const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+        if (nrm > r) r = nrm;
+    }
+    return r;
+}
+
+}  // namespace
+
+// ==========================================================================================================
+struct pwicp_pair {
+    pwicp_context* ctx = nullptr;
+    pwicp_params prm{};
+    // target (static)
+    int n1 = 0;
+    DevBuf<float4> cloud1;
+    Grid g_c1, g_ct1;
+    PatchSet P1;
+    DevBuf<float4> nrm1;    // calPatchNormal per target patch, w = ok
+    DevBuf<float4> ct1n;    // normals of CTcloud1_withNorm
+    // source (transformed in place by the loop) + pristine copies for reset
+    int n2 = 0;
+    DevBuf<float4> cloud2, cloud2_0;
+    PatchSet P2;
+    DevBuf<float4> pat2_0, ct2_0, bp2_0;
+    DevBuf<float4> nrm2;
+    // per-iteration work
+    DevBuf<int> mCT, mBP, stable, list, soff;
+    DevBuf<float> dCT, dBP, d2dense;
+    DevBuf<float4> stCT, stN;
+    IcpWork icp;
+    DevBuf<unsigned> scal, sel_scratch;
+    DevBuf<float> sel_out;
+    DevBuf<unsigned long long> examined;
+    std::vector<hipEvent_t> ev;
+    ~pwicp_pair() {
+        for (auto e : ev) (void)hipEventDestroy(e);
+    }
+    hipEvent_t event(size_t i) {
+        while (ev.size() <= i) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            ev.push_back(e);
+        }
+        return ev[i];
+    }
+};
+
+namespace {
+
+int finish_create(pwicp_pair* pr) {
+    pwicp_context* ctx = pr->ctx;
+    const int m1 = pr->P1.m, m2 = pr->P2.m;
+    // static target side: patch normals, centroid normals, grids
+    HIPCHK(ctx, pr->nrm1.reserve((size_t)std::max(m1, 1)));
+    HIPCHK(ctx, pr->ct1n.reserve((size_t)std::max(m1, 1)));
+    PWCHK(pw_patch_normals_launch(ctx, pr->P1.pat.p, pr->P1.off.p, m1, pr->nrm1.p));
+    if (m1 > 0)
+        hipLaunchKernelGGL(k_with_norm, dim3(div_up(m1, kBlock)), dim3(kBlock), 0, ctx->stream, m1, pr->P1.off.p,
+                           pr->nrm1.p, pr->ct1n.p);
+    PWCHK(pw_grid_build(ctx, pr->cloud1.p, pr->n1, 2.0f * pr->prm.Res1, &pr->g_c1));
+    PWCHK(pw_grid_build(ctx, pr->P1.ct.p, m1, pr->prm.SVRes1, &pr->g_ct1));
+    // pristine source copies
+    HIPCHK(ctx, pr->cloud2_0.reserve((size_t)std::max(pr->n2, 1)));
+    HIPCHK(ctx, pr->pat2_0.reserve((size_t)std::max(pr->P2.tot, 1)));
+    HIPCHK(ctx, pr->ct2_0.reserve((size_t)std::max(m2, 1)));
+    HIPCHK(ctx, pr->bp2_0.reserve((size_t)std::max(m2, 1) * 6));
+    HIPCHK(ctx, hipMemcpyAsync(pr->cloud2_0.p, pr->cloud2.p, (size_t)pr->n2 * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(pr->pat2_0.p, pr->P2.pat.p, (size_t)pr->P2.tot * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(pr->ct2_0.p, pr->P2.ct.p, (size_t)m2 * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(pr->bp2_0.p, pr->P2.bp.p, (size_t)m2 * 6 * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    // work buffers
+    const size_t M2 = (size_t)std::max(m2, 1);
+    HIPCHK(ctx, pr->nrm2.reserve(M2));
+    HIPCHK(ctx, pr->mCT.reserve(M2));
+    HIPCHK(ctx, pr->dCT.reserve(M2));
+    HIPCHK(ctx, pr->mBP.reserve(M2 * 6));
+    HIPCHK(ctx, pr->dBP.reserve(M2 * 6));
+    HIPCHK(ctx, pr->stable.reserve(M2));
+    HIPCHK(ctx, pr->list.reserve(M2 + 1));
+    HIPCHK(ctx, pr->soff.reserve(M2 + 1));
+    HIPCHK(ctx, pr->stCT.reserve(M2));
+    HIPCHK(ctx, pr->stN.reserve(M2));
+    HIPCHK(ctx, pr->d2dense.reserve((size_t)std::max(std::max(pr->P2.tot, pr->n2), 1)));
+    HIPCHK(ctx, pr->scal.reserve(16));
+    HIPCHK(ctx, pr->sel_scratch.reserve(8 + 3 * 2048));
+    HIPCHK(ctx, pr->sel_out.reserve(1));
+    HIPCHK(ctx, pr->examined.reserve(1));
+    PWCHK(pr->icp.reserve(ctx, m2));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipGetLastError());
+    return PWICP_OK;
+}
+
+int upload4(pwicp_context* ctx, const float* h, int n, DevBuf<float4>* d) {
+    HIPCHK(ctx, d->reserve((size_t)std::max(n, 1)));
+    if (n > 0) HIPCHK(ctx, hipMemcpyAsync(d->p, h, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    return PWICP_OK;
+}
+
+int upload_patches(pwicp_context* ctx, const float* pat, const int32_t* off, int m, PatchSet* P) {
+    P->m = m;
+    P->tot = m > 0 ? off[m] : 0;
+    PWCHK(upload4(ctx, pat, P->tot, &P->pat));
+    HIPCHK(ctx, P->off.reserve((size_t)m + 1));
+    HIPCHK(ctx, hipMemcpyAsync(P->off.p, off, ((size_t)m + 1) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, P->ct.reserve((size_t)std::max(m, 1)));
+    HIPCHK(ctx, P->bp.reserve((size_t)std::max(m, 1) * 6));
+    HIPCHK(ctx, P->bpstd.reserve((size_t)std::max(m, 1)));
+    HIPCHK(ctx, P->ctstd.reserve((size_t)std::max(m, 1)));
+    PWCHK(pw_patch_stats_launch(ctx, P->pat.p, P->off.p, m, P->ct.p, P->bp.p, P->bpstd.p, P->ctstd.p));
+    return PWICP_OK;
+}
+
+bool params_ok(const pwicp_params* p) {
+    return p && p->Res1 > 0 && p->Res2 > 0 && p->SVRes1 > 0 && p->SVRes2 > 0 && p->DTmin > 0 &&
+           (!p->isManualDTinit || p->DTinit > 0);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pwicp_pair_create(pwicp_context* ctx, const float* cloud1, int n1, const int32_t* labels1, int nsv1,
+                      const float* cloud2, int n2, const int32_t* labels2, int nsv2, const pwicp_params* params,
+                      pwicp_pair** out) {
+    if (!ctx) return PWICP_E_INVALID;
+    if (!out || !cloud1 || !cloud2 || !labels1 || !labels2 || n1 <= 0 || n2 <= 0 || nsv1 < 0 || nsv2 < 0 ||
+        !params_ok(params)) {
+        ctx->set_err("pwicp_pair_create: invalid argument");
+        return PWICP_E_INVALID;
+    }
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    pwicp_pair* pr = new (std::nothrow) pwicp_pair();
+    if (!pr) return PWICP_E_NOMEM;
+    pr->ctx = ctx; pr->prm = *params; pr->n1 = n1; pr->n2 = n2;
+    int rc = PWICP_OK;
+    DevBuf<int> l1, l2;
+    do {
+        if ((rc = upload4(ctx, cloud1, n1, &pr->cloud1)) != PWICP_OK) break;
+        if ((rc = upload4(ctx, cloud2, n2, &pr->cloud2)) != PWICP_OK) break;
+        if (l1.reserve((size_t)n1) != hipSuccess || l2.reserve((size_t)n2) != hipSuccess) { rc = PWICP_E_NOMEM; break; }
+        if (hipMemcpyAsync(l1.p, labels1, (size_t)n1 * sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(l2.p, labels2, (size_t)n2 * sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            rc = PWICP_E_NO_DEVICE; break;
+        }
+        if ((rc = pw_select_patches_dev(ctx, pr->cloud1.p, n1, l1.p, nsv1, &pr->P1)) != PWICP_OK) break;
+        if ((rc = pw_select_patches_dev(ctx, pr->cloud2.p, n2, l2.p, nsv2, &pr->P2)) != PWICP_OK) break;
+        rc = finish_create(pr);
+    } while (0);
+    if (rc != PWICP_OK) { delete pr; return rc; }
+    *out = pr;
+    return PWICP_OK;
+}
+
+int pwicp_pair_create_from_patches(pwicp_context* ctx, const float* cloud1, int n1, const float* patch1,
+                                   const int32_t* off1, int m1, const float* cloud2, int n2, const float* patch2,
+                                   const int32_t* off2, int m2, const pwicp_params* params, pwicp_pair** out) {
+    if (!ctx) return PWICP_E_INVALID;
+    if (!out || !cloud1 || !cloud2 || !patch1 || !patch2 || !off1 || !off2 || n1 <= 0 || n2 <= 0 || m1 < 0 || m2 < 0 ||
+        !params_ok(params)) {
+        ctx->set_err("pwicp_pair_create_from_patches: invalid argument");
+        return PWICP_E_INVALID;
+    }
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    pwicp_pair* pr = new (std::nothrow) pwicp_pair();
+    if (!pr) return PWICP_E_NOMEM;
+    pr->ctx = ctx; pr->prm = *params; pr->n1 = n1; pr->n2 = n2;
+    int rc = PWICP_OK;
+    do {
+        if ((rc = upload4(ctx, cloud1, n1, &pr->cloud1)) != PWICP_OK) break;
+        if ((rc = upload4(ctx, cloud2, n2, &pr->cloud2)) != PWICP_OK) break;
+        if ((rc = upload_patches(ctx, patch1, off1, m1, &pr->P1)) != PWICP_OK) break;
+        if ((rc = upload_patches(ctx, patch2, off2, m2, &pr->P2)) != PWICP_OK) break;
+        rc = finish_create(pr);
+    } while (0);
+    if (rc != PWICP_OK) { delete pr; return rc; }
+    *out = pr;
+    return PWICP_OK;
+}
+
+void pwicp_pair_destroy(pwicp_pair* pr) {
+    if (!pr) return;
+    (void)hipSetDevice(pr->ctx->device);
+    (void)hipStreamSynchronize(pr->ctx->stream);
+    delete pr;
+}
+
+int pwicp_pair_num_patches(const pwicp_pair* pr, int* m1, int* m2) {
+    if (!pr) return PWICP_E_INVALID;
+    if (m1) *m1 = pr->P1.m;
+    if (m2) *m2 = pr->P2.m;
+    return PWICP_OK;
+}
+
+int pwicp_pair_reset(pwicp_pair* pr) {
+    if (!pr) return PWICP_E_INVALID;
+    pwicp_context* ctx = pr->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(pr->cloud2.p, pr->cloud2_0.p, (size_t)pr->n2 * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(pr->P2.pat.p, pr->pat2_0.p, (size_t)pr->P2.tot * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(pr->P2.ct.p, pr->ct2_0.p, (size_t)pr->P2.m * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(pr->P2.bp.p, pr->bp2_0.p, (size_t)pr->P2.m * 6 * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    return PWICP_OK;
+}
+
+int pwicp_pair_download_source(pwicp_pair* pr, float* cloud2_xyz4) {
+    if (!pr || !cloud2_xyz4) return PWICP_E_INVALID;
+    pwicp_context* ctx = pr->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(cloud2_xyz4, pr->cloud2.p, (size_t)pr->n2 * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PWICP_OK;
+}
+
+static int read_scal(pwicp_pair* pr, unsigned* h) {
+    pwicp_context* ctx = pr->ctx;
+    HIPCHK(ctx, hipMemcpyAsync(h, pr->scal.p, 16 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PWICP_OK;
+}
+
+static int select_p75(pwicp_pair* pr, int n, double* out) {
+    pwicp_context* ctx = pr->ctx;
+    int k = (int)((float)n * 0.75f);            // C.cpp:177
+    if (k >= n) k = n - 1;
+    PWCHK(pw_select_kth_launch(ctx, pr->d2dense.p, n, k, pr->sel_scratch.p, pr->sel_out.p));
+    float v = 0.f;
+    HIPCHK(ctx, hipMemcpyAsync(&v, pr->sel_out.p, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *out = (double)sqrtf(v);                    // C.cpp:277
+    return PWICP_OK;
+}
+
+int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
+    if (!pr || !res) return PWICP_E_INVALID;
+    pwicp_context* ctx = pr->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    memset(res, 0, sizeof(*res));
+    for (int i = 0; i < 16; ++i) res->T16[i] = (i % 5 == 0) ? 1.f : 0.f;
+    const pwicp_params& prm = pr->prm;
+    const int m1 = pr->P1.m, m2 = pr->P2.m, nbp2 = 6 * m2;
+    size_t n_ev = 0;
+    std::vector<std::pair<size_t, int>> ev_kind;   // (start event index, kind 0 dense / 1 inner)
+
+    // R.cpp:626-631
+    float DTinit = prm.DTinit;
+    if (!prm.isManualDTinit) {
+        PWCHK(pw_nn_launch(ctx, pr->g_c1.d, pr->cloud2.p, pr->n2, nullptr, pr->d2dense.p, nullptr));
+        double d75 = 0;
+        PWCHK(select_p75(pr, pr->n2, &d75));
+        DTinit = (float)(d75 * 3.0);
+    }
+    float currDT = DTinit;
+    const float DTmin = prm.DTmin;
+    bool stage2 = false, stage3 = false;     // g_toStage2 / g_toStage3 (R.cpp:623-624), per call here
+    float BB1 = 0.f, BB2 = 0.f;              // R.cpp:672-673
+    res->DTseries[0] = currDT;
+
+    // tight bbox of the current source cloud (kept up to date by the transform kernel)
+    unsigned hs[16];
+    {
+        static const unsigned init[16] = {0xffffffffu, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0, 0, 0, 0, 0, 0};
+        HIPCHK(ctx, hipMemcpyAsync(pr->scal.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+        Mat4 I{};
+        hipLaunchKernelGGL(k_transform_bbox, dim3(std::min(div_up(pr->n2, kBlock), ctx->n_cu * 8)), dim3(kBlock), 0,
+                           ctx->stream, pr->cloud2.p, pr->n2, I, 0, pr->scal.p);
+        PWCHK(read_scal(pr, hs));
+    }
+    float bmin[3], bmax[3];
+    for (int d = 0; d < 3; ++d) { bmin[d] = ord2f_host(hs[4 + d]); bmax[d] = ord2f_host(hs[7 + d]); }
+    HIPCHK(ctx, hipMemsetAsync(pr->examined.p, 0, sizeof(unsigned long long), ctx->stream));
+
+    int status = PWICP_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (!stage3) {                                                   // R.cpp:680
+        const int k = res->n_outer;
+        if (k >= PWICP_MAX_OUTER) break;
+        if (currDT <= DTmin) currDT = DTmin;                            // R.cpp:724-725
+        if (4 > m2) { status = PWICP_E_TOO_FEW_PATCHES; break; }        // R.cpp:728-731
+
+        // (1) R.cpp:737-747 — the target-centroid grid is static and built once
+        PWCHK(pw_nn_launch(ctx, pr->g_ct1.d, pr->P2.ct.p, m2, pr->mCT.p, pr->dCT.p, nullptr));
+        PWCHK(pw_nn_launch(ctx, pr->g_ct1.d, pr->P2.bp.p, nbp2, pr->mBP.p, pr->dBP.p, nullptr));
+        res->n_corr += (long long)m2 + nbp2;
+        // source patch normals for CTcloud2_withNorm (R.cpp:824): recomputed from the transformed patch points
+        PWCHK(pw_patch_normals_launch(ctx, pr->P2.pat.p, pr->P2.off.p, m2, pr->nrm2.p));
+        // (2)-(4)
+        {
+            static const unsigned init4[4] = {0xffffffffu, 0u, 0u, 0u};
+            HIPCHK(ctx, hipMemcpyAsync(pr->scal.p, init4, sizeof(init4), hipMemcpyHostToDevice, ctx->stream));
+        }
+        const float DTctct = currDT + 1 * (prm.SVRes1 + prm.SVRes2);   // R.cpp:817
+        hipLaunchKernelGGL(k_classify, dim3(div_up(m2, kBlock)), dim3(kBlock), 0, ctx->stream, m2, pr->mCT.p, pr->dCT.p,
+                           pr->mBP.p, pr->dBP.p, pr->P1.ctstd.p, pr->P2.bpstd.p, pr->nrm1.p, pr->P1.ct.p, pr->P2.ct.p,
+                           pr->P2.bp.p, currDT, DTmin, DTctct, pr->stable.p, pr->scal.p);
+        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, ctx->stream, m2, pr->stable.p, pr->P2.off.p, pr->P2.ct.p,
+                           pr->nrm2.p, pr->list.p, pr->soff.p, pr->stCT.p, pr->stN.p, pr->icp.src.p, pr->icp.srcn.p,
+                           pr->scal.p);
+        PWCHK(read_scal(pr, hs));
+        float LoDet_min;
+        memcpy(&LoDet_min, &hs[0], 4);
+        const int ns = (int)hs[2], nsp = (int)hs[3];
+        res->n_stable[k] = ns; res->n_stable_pts[k] = nsp; res->LoDmin[k] = LoDet_min;
+        if (4 > ns) { status = PWICP_E_TOO_FEW_STABLE; break; }        // R.cpp:864-867
+
+        // (5) R.cpp:875-877
+        float Tk[16];
+        int n_in = 0;
+        {
+            hipEvent_t e0 = pr->event(n_ev), e1 = pr->event(n_ev + 1);
+            ev_kind.push_back({n_ev, 1});
+            n_ev += 2;
+            HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+            PWCHK(pw_icp_run(ctx, pr->g_ct1.d, pr->P1.ct.p, pr->ct1n.p, &pr->icp, ns, 1e-6, Tk, &n_in));
+            HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+        }
+        res->n_inner[k] = n_in; res->n_inner_total += n_in;
+        res->n_corr += (long long)ns * std::max(n_in, 1);
+        memcpy(res->Tk[k], Tk, sizeof(Tk));
+
+        // (6) R.cpp:881-888
+        double bb[6];
+        octree_bbox(bmin, bmax, (double)(prm.Res2 * 2), bb);
+        const float maxBB = bb_corner_change(bb, Tk);
+        res->maxBB[k] = maxBB;
+
+        // (7) R.cpp:891-935, verbatim control flow
+        const float minLoD = DTmin;
+        res->d75[k] = -1.0;
+        if (!stage2 && maxBB < minLoD) stage2 = true;
+        else if (currDT == LoDet_min) stage3 = true;
+        if (!stage2) {
+            // dense NN of the stable patches' points against the full target cloud (C.cpp:266-281)
+            hipEvent_t e0 = pr->event(n_ev), e1 = pr->event(n_ev + 1);
+            ev_kind.push_back({n_ev, 0});
+            n_ev += 2;
+            HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+            PWCHK(pw_nn_patches_launch(ctx, pr->g_c1.d, pr->P2.pat.p, pr->P2.off.p, pr->list.p, pr->soff.p, ns, nsp,
+                                       pr->d2dense.p, pr->examined.p));
+            HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+            double Dist75 = 0;
+            PWCHK(select_p75(pr, nsp, &Dist75));
+            res->n_corr += nsp; res->n_corr_dense += nsp; res->n_dense_nn_launches++;
+            res->d75[k] = Dist75;
+            if ((double)currDT > Dist75) currDT = (float)Dist75; else stage2 = true;
+            if (currDT <= LoDet_min) currDT = LoDet_min;
+            BB2 = BB1; BB1 = maxBB;
+        }
+        if (stage2 && !stage3) {
+            const float upperBound = 0.8f, lowerBound = 0.5f;
+            const float alpha = fabsf(BB1 / BB2);
+            if (std::isnan(alpha) || std::isinf(alpha)) currDT = currDT * upperBound;
+            else if (alpha < lowerBound) currDT = currDT * lowerBound;
+            else if (alpha > upperBound) currDT = currDT * upperBound;
+            else currDT = currDT * alpha;
+            if (currDT <= LoDet_min) currDT = LoDet_min;
+            BB2 = BB1; BB1 = maxBB;
+        }
+
+        // (8) R.cpp:943-954: cloud2 (+ its new bbox), centroids, boundary points, patch points
+        Mat4 T;
+        memcpy(T.m, Tk, sizeof(Tk));
+        {
+            static const unsigned initb[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+            HIPCHK(ctx, hipMemcpyAsync(pr->scal.p + 4, initb, sizeof(initb), hipMemcpyHostToDevice, ctx->stream));
+        }
+        hipLaunchKernelGGL(k_transform_bbox, dim3(std::min(div_up(pr->n2, kBlock), ctx->n_cu * 8)), dim3(kBlock), 0,
+                           ctx->stream, pr->cloud2.p, pr->n2, T, 1, pr->scal.p);
+        if (m2 > 0) {
+            hipLaunchKernelGGL(k_transform, dim3(div_up(m2, kBlock)), dim3(kBlock), 0, ctx->stream, pr->P2.ct.p, m2, T);
+            hipLaunchKernelGGL(k_transform, dim3(div_up(nbp2, kBlock)), dim3(kBlock), 0, ctx->stream, pr->P2.bp.p, nbp2, T);
+            hipLaunchKernelGGL(k_transform, dim3(div_up(pr->P2.tot, kBlock)), dim3(kBlock), 0, ctx->stream, pr->P2.pat.p,
+                               pr->P2.tot, T);
+        }
+        // (9) R.cpp:958-961: stable centroids as copied BEFORE the update (R.cpp:868)
+        if (stage3) {
+            PWCHK(pw_vcm_run(ctx, pr->g_ct1.d, pr->P1.ct.p, pr->ct1n.p, &pr->icp, pr->stCT.p, ns, res->VCM));
+            res->n_corr += ns;
+        }
+        PWCHK(read_scal(pr, hs));
+        for (int d = 0; d < 3; ++d) { bmin[d] = ord2f_host(hs[4 + d]); bmax[d] = ord2f_host(hs[7 + d]); }
+
+        // R.cpp:687-689
+        mat4_mul(Tk, res->T16, res->T16);
+        res->n_outer = k + 1;
+        res->DTseries[k + 1] = currDT;
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    res->t_loop_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (auto& e : ev_kind) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pr->ev[e.first], pr->ev[e.first + 1]) == hipSuccess) {
+            if (e.second == 0) res->t_dense_nn_ms += ms; else res->t_inner_ms += ms;
+        }
+    }
+    unsigned long long ex = 0;
+    HIPCHK(ctx, hipMemcpy(&ex, pr->examined.p, sizeof(ex), hipMemcpyDeviceToHost));
+    res->dense_kbar = res->n_corr_dense > 0 ? (double)ex / (double)res->n_corr_dense : 0.0;
+    res->status = status;
+    HIPCHK(ctx, hipGetLastError());
+    (void)m1;
+    return status;
+}
+
+int pwicp_pair_bench_dense_nn(pwicp_pair* pr, int n_launches, double* ms_per_launch, long long* n_queries,
+                              double* kbar, double* cell_edge) {
+    if (!pr || n_launches <= 0) return PWICP_E_INVALID;
+    pwicp_context* ctx = pr->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int m2 = pr->P2.m, tot = pr->P2.tot;
+    if (m2 <= 0 || tot <= 0) { ctx->set_err("bench_dense_nn: no source patches"); return PWICP_E_INVALID; }
+    hipLaunchKernelGGL(k_iota_list, dim3(div_up(m2 + 1, kBlock)), dim3(kBlock), 0, ctx->stream, pr->list.p, pr->soff.p,
+                       pr->P2.off.p, m2);
+    HIPCHK(ctx, hipMemsetAsync(pr->examined.p, 0, sizeof(unsigned long long), ctx->stream));
+    // warm-up launch (also measures Kbar)
+    PWCHK(pw_nn_patches_launch(ctx, pr->g_c1.d, pr->P2.pat.p, pr->P2.off.p, pr->list.p, pr->soff.p, m2, tot,
+                               pr->d2dense.p, pr->examined.p));
+    unsigned long long ex = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&ex, pr->examined.p, sizeof(ex), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    hipEvent_t e0 = pr->event(0), e1 = pr->event(1);
+    HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+    for (int i = 0; i < n_launches; ++i)
+        PWCHK(pw_nn_patches_launch(ctx, pr->g_c1.d, pr->P2.pat.p, pr->P2.off.p, pr->list.p, pr->soff.p, m2, tot,
+                                   pr->d2dense.p, nullptr));
+    HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
+    if (ms_per_launch) *ms_per_launch = (double)ms / n_launches;
+    if (n_queries) *n_queries = tot;
+    if (kbar) *kbar = (double)ex / (double)tot;
+    if (cell_edge) *cell_edge = pr->g_c1.d.h;
+    return PWICP_OK;
+}
+
+}  // extern "C"

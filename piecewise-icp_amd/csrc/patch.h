@@ -1,0 +1,22 @@
+// Device-resident set of selected patches of one cloud (CSR) + per-patch statistics.
+#pragma once
+#include "common.h"
+
+struct PatchSet {
+    int m = 0;      // number of patches
+    int tot = 0;    // number of patch points
+    DevBuf<float4> pat;   // [tot] refined patch points, concatenated
+    DevBuf<int> off;      // [m+1]
+    DevBuf<int> src;      // [tot] original point index
+    DevBuf<float4> ct;    // [m]  centroids
+    DevBuf<float4> bp;    // [6m] boundary points (Xmax,Xmin,Ymax,Ymin,Zmax,Zmin)
+    DevBuf<float> bpstd;  // [m]
+    DevBuf<float> ctstd;  // [m]
+};
+
+int pw_patch_normals_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, int m, float4* d_nrm);
+int pw_patch_stats_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, int m, float4* ct, float4* bp,
+                          float* bpstd, float* ctstd);
+int pw_select_patches_dev(pwicp_context* ctx, const float4* d_cloud, int n, const int* d_labels, int nsv,
+                          PatchSet* out);
+int pw_point_patch_ids_launch(pwicp_context* ctx, const int* d_off, int m, int* d_pid);

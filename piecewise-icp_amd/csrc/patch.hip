@@ -1,0 +1,395 @@
+// Per-patch statistics kernels: plane normals (float single-pass covariance + closed-form smallest
+// eigenvector), PCA plane, 2-sigma refinement, eigen-feature gate, centroid, 6 boundary points, sigmas.
+//
+// Reference: calPatchNormal src/CommonFunc.cpp:284-333, generateCentroidCloudWithPatchNormals
+// CommonFunc.cpp:357-382, calPatchSTD CommonFunc.cpp:336-354, PatchRefinement src/Segmentation.cpp:195-228,
+// calPatchFeature Segmentation.cpp:231-257, calPatchCTandBP Segmentation.cpp:260-303, calBPandCTSTD
+// Segmentation.cpp:306-321, patch extraction/selection Segmentation.cpp:97-150.
+//
+// Summation order inside a patch is the storage order (the reference's float sums are order dependent
+// and feed threshold decisions), so one lane owns one patch and walks it sequentially.
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+#include "devmath.h"
+#include "patch.h"
+
+using namespace pwdev;
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// pcl::computeMeanAndCovarianceMatrix (float, single pass) + solvePlaneParameters; false if n < 3
+__device__ inline bool point_normal(const float4* __restrict__ p, int n, float* nrm) {
+    if (n < 3) return false;
+    float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
+    for (int i = 0; i < n; ++i) {
+        float4 v = p[i];
+        a0 += v.x * v.x; a1 += v.x * v.y; a2 += v.x * v.z;
+        a3 += v.y * v.y; a4 += v.y * v.z; a5 += v.z * v.z;
+        a6 += v.x; a7 += v.y; a8 += v.z;
+    }
+    float fn = (float)n;
+    a0 /= fn; a1 /= fn; a2 /= fn; a3 /= fn; a4 /= fn; a5 /= fn; a6 /= fn; a7 /= fn; a8 /= fn;
+    float cov[9];
+    cov[0] = a0 - a6 * a6; cov[1] = a1 - a6 * a7; cov[2] = a2 - a6 * a8;
+    cov[4] = a3 - a7 * a7; cov[5] = a4 - a7 * a8; cov[8] = a5 - a8 * a8;
+    cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
+    eigen33_smallest(cov, nrm);
+    return true;
+}
+
+// scatter (double accumulation of float demeaned coords) of the kept points; returns the float mean
+template <bool FILTER>
+__device__ inline void mean_and_scatter(const float4* __restrict__ p, const unsigned char* __restrict__ keep,
+                                        int n, int cnt, float* mean, double* S) {
+    float c0 = 0, c1 = 0, c2 = 0;
+    for (int i = 0; i < n; ++i) {
+        if (FILTER && !keep[i]) continue;
+        float4 v = p[i];
+        c0 += v.x; c1 += v.y; c2 += v.z;
+    }
+    c0 /= (float)cnt; c1 /= (float)cnt; c2 /= (float)cnt;
+    double s0 = 0, s1 = 0, s2 = 0, s4 = 0, s5 = 0, s8 = 0;
+    for (int i = 0; i < n; ++i) {
+        if (FILTER && !keep[i]) continue;
+        float4 v = p[i];
+        float dx = v.x - c0, dy = v.y - c1, dz = v.z - c2;
+        s0 += (double)dx * dx; s1 += (double)dx * dy; s2 += (double)dx * dz;
+        s4 += (double)dy * dy; s5 += (double)dy * dz; s8 += (double)dz * dz;
+    }
+    mean[0] = c0; mean[1] = c1; mean[2] = c2;
+    S[0] = s0; S[1] = s1; S[2] = s2; S[3] = s1; S[4] = s4; S[5] = s5; S[6] = s2; S[7] = s5; S[8] = s8;
+}
+
+// pcl::PCA plane (a,b,c,d): normal = eigenvector of the smallest eigenvalue of the float scatter matrix
+template <bool FILTER>
+__device__ inline void pca_plane(const float4* __restrict__ p, const unsigned char* __restrict__ keep, int n,
+                                 int cnt, float* abcd) {
+    float c[3];
+    double S[9], A[9], w[3], V[9];
+    mean_and_scatter<FILTER>(p, keep, n, cnt, c, S);
+    for (int i = 0; i < 9; ++i) A[i] = (double)(float)S[i];
+    jacobi3(A, w, V);
+    float a = (float)V[0], b = (float)V[3], cc = (float)V[6];
+    abcd[0] = a; abcd[1] = b; abcd[2] = cc;
+    abcd[3] = -((a * c[0] + b * c[1]) + cc * c[2]);
+}
+
+__device__ __forceinline__ double pt2plane(float4 v, const float* abcd) {
+    float s = abcd[0] * v.x + abcd[1] * v.y + abcd[2] * v.z + abcd[3];
+    return (double)fabsf(s);
+}
+
+// calPatchSTD over the kept points
+template <bool FILTER>
+__device__ inline float patch_std(const float4* __restrict__ p, const unsigned char* __restrict__ keep, int n,
+                                  int cnt) {
+    float abcd[4];
+    pca_plane<FILTER>(p, keep, n, cnt, abcd);
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) {
+        if (FILTER && !keep[i]) continue;
+        double d = pt2plane(p[i], abcd);
+        s += d * d;
+    }
+    return (float)sqrt(s / (double)(cnt - 1));
+}
+
+// calPatchNormal incl. its fallback branch; returns its bool
+__device__ inline bool cal_patch_normal(const float4* __restrict__ p, int n, float* out) {
+    float nrm[3];
+    if (n > 4 && point_normal(p, n, nrm)) {
+        float nLen = sqrtf(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+        if (fabs((double)nLen - 1.0) < 1e-5) {
+            out[0] = nrm[0]; out[1] = nrm[1]; out[2] = nrm[2];
+            return true;
+        }
+        float mean[3];
+        double S[9], C[9], w[3], V[9];
+        mean_and_scatter<false>(p, nullptr, n, n, mean, S);
+        for (int i = 0; i < 9; ++i) C[i] = (double)((float)S[i] / (float)n);
+        jacobi3(C, w, V);
+        out[0] = (float)V[0]; out[1] = (float)V[3]; out[2] = (float)V[6];
+        float nLen2 = sqrtf(out[0] * out[0] + out[1] * out[1] + out[2] * out[2]);
+        return fabs((double)nLen2 - 1.0) < 1e-5;
+    }
+    out[0] = 0; out[1] = 0; out[2] = 1;
+    return false;
+}
+
+template <bool FILTER>
+__device__ inline void ct_bp(const float4* __restrict__ p, const unsigned char* __restrict__ keep, int n, int cnt,
+                             float4* ct, float4* bp) {
+    float c0 = 0, c1 = 0, c2 = 0;
+    const float inf = INFINITY;
+    float4 b0 = make_float4(-inf, 0, 0, 1), b1 = make_float4(inf, 0, 0, 1), b2 = make_float4(0, -inf, 0, 1),
+           b3 = make_float4(0, inf, 0, 1), b4 = make_float4(0, 0, -inf, 1), b5 = make_float4(0, 0, inf, 1);
+    for (int i = 0; i < n; ++i) {
+        if (FILTER && !keep[i]) continue;
+        float4 v = p[i];
+        v.w = 1.0f;
+        c0 += v.x; c1 += v.y; c2 += v.z;
+        if (v.x > b0.x) b0 = v;
+        if (v.x < b1.x) b1 = v;
+        if (v.y > b2.y) b2 = v;
+        if (v.y < b3.y) b3 = v;
+        if (v.z > b4.z) b4 = v;
+        if (v.z < b5.z) b5 = v;
+    }
+    *ct = make_float4(c0 / (float)cnt, c1 / (float)cnt, c2 / (float)cnt, 1.0f);
+    bp[0] = b0; bp[1] = b1; bp[2] = b2; bp[3] = b3; bp[4] = b4; bp[5] = b5;
+}
+
+// ------------------------------------------------------------------------------------------------------
+__global__ void k_patch_normals(const float4* __restrict__ pat, const int* __restrict__ off, int m,
+                                float4* __restrict__ nrm_out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    float nv[3];
+    bool ok = cal_patch_normal(pat + off[i], off[i + 1] - off[i], nv);
+    // w carries calPatchNormal's return value (1 / 0)
+    nrm_out[i] = ok ? make_float4(nv[0], nv[1], nv[2], 1.0f) : make_float4(nv[0], nv[1], nv[2], 0.0f);
+}
+
+// CT / BP / sigma of already selected patches
+__global__ void k_patch_stats(const float4* __restrict__ pat, const int* __restrict__ off, int m,
+                              float4* __restrict__ ct, float4* __restrict__ bp, float* __restrict__ bpstd,
+                              float* __restrict__ ctstd) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const float4* p = pat + off[i];
+    int n = off[i + 1] - off[i];
+    float4 c, b[6];
+    ct_bp<false>(p, nullptr, n, n, &c, b);
+    ct[i] = c;
+    for (int k = 0; k < 6; ++k) bp[6 * i + k] = b[k];
+    float sd = (n >= 2) ? patch_std<false>(p, nullptr, n, n) : 0.0f;
+    bpstd[i] = sd;
+    ctstd[i] = sd / (float)n;        // S.cpp:317-319
+}
+
+__global__ void k_gather_sorted(const float4* __restrict__ cloud, const int* __restrict__ order, int n,
+                                float4* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = cloud[order[i]];
+}
+
+__global__ void k_iota(int* p, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+
+__global__ void k_label_hist(const int* __restrict__ labels, int n, int nsv, int* __restrict__ cnt,
+                             int* __restrict__ bad) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int l = labels[i];
+    if (l < 0 || l >= nsv) { atomicAdd(bad, 1); return; }
+    atomicAdd(&cnt[l], 1);
+}
+
+// One lane per supervoxel: S.cpp:107-150 (size gate, refinement, size gate, feature gate, CT/BP) + sigma.
+__global__ void k_select(const float4* __restrict__ sp, const int* __restrict__ svoff, int nsv,
+                         unsigned char* __restrict__ keep, int* __restrict__ kept_cnt,
+                         float4* __restrict__ ct, float4* __restrict__ bp, float* __restrict__ bpstd,
+                         float* __restrict__ ctstd) {
+    const int minPtNum = 20;     // C.h:42
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsv) return;
+    const float4* p = sp + svoff[s];
+    unsigned char* kp = keep + svoff[s];
+    int n = svoff[s + 1] - svoff[s];
+    kept_cnt[s] = 0;
+    if (n < minPtNum) return;                                   // S.cpp:109
+    // PatchRefinement, S.cpp:195-228
+    float abcd[4];
+    pca_plane<false>(p, nullptr, n, n, abcd);
+    double ss = 0.0;
+    for (int i = 0; i < n; ++i) { double d = pt2plane(p[i], abcd); ss += d * d; }
+    ss = sqrt(ss / (double)n);
+    double thr = fabs(2.0 * ss);
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) {
+        unsigned char k = fabs(pt2plane(p[i], abcd)) < thr ? 1 : 0;
+        kp[i] = k;
+        cnt += k;
+    }
+    if (cnt < minPtNum) return;                                 // S.cpp:119
+    // calPatchFeature, S.cpp:231-257
+    float mean[3];
+    double S[9], C[9], w[3], V[9];
+    mean_and_scatter<true>(p, kp, n, cnt, mean, S);
+    for (int i = 0; i < 9; ++i) C[i] = (double)((float)S[i] / (float)cnt);
+    jacobi3(C, w, V);
+    float e0 = (float)fabs(w[0]), e1 = (float)fabs(w[1]), e2 = (float)fabs(w[2]);
+    // sort descending (2-pass bubble)
+    float t;
+    if (e0 < e1) { t = e0; e0 = e1; e1 = t; }
+    if (e1 < e2) { t = e1; e1 = e2; e2 = t; }
+    if (e0 < e1) { t = e0; e0 = e1; e1 = t; }
+    float variation = e2 / (e0 + e1 + e2);
+    float planarity = (e1 - e2) / e0;
+    if (variation > 0.02f || planarity < 0.25f) return;         // S.cpp:127
+    float4 c, b[6];
+    ct_bp<true>(p, kp, n, cnt, &c, b);
+    ct[s] = c;
+    for (int k = 0; k < 6; ++k) bp[6 * s + k] = b[k];
+    float sd = patch_std<true>(p, kp, n, cnt);
+    bpstd[s] = sd;
+    ctstd[s] = sd / (float)cnt;
+    kept_cnt[s] = cnt;
+}
+
+// flags -> (valid ? 1 : 0) for the patch index scan
+__global__ void k_valid_flags(const int* __restrict__ kept_cnt, int nsv, int* __restrict__ flag) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < nsv) flag[s] = kept_cnt[s] > 0 ? 1 : 0;
+    if (s == nsv) flag[s] = 0;
+}
+
+// one lane per supervoxel: copy its kept points to the final CSR position
+__global__ void k_emit(const float4* __restrict__ sp, const int* __restrict__ order, const int* __restrict__ svoff,
+                       int nsv, const unsigned char* __restrict__ keep, const int* __restrict__ kept_cnt,
+                       const int* __restrict__ pidx, const int* __restrict__ poff,
+                       const float4* __restrict__ ct, const float4* __restrict__ bp,
+                       const float* __restrict__ bpstd, const float* __restrict__ ctstd,
+                       float4* __restrict__ o_pat, int* __restrict__ o_off, int* __restrict__ o_src,
+                       float4* __restrict__ o_ct, float4* __restrict__ o_bp, float* __restrict__ o_bpstd,
+                       float* __restrict__ o_ctstd) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsv || kept_cnt[s] <= 0) return;
+    int j = pidx[s], w = poff[s];
+    o_off[j] = w;
+    const int base = svoff[s], n = svoff[s + 1] - base;
+    for (int i = 0; i < n; ++i)
+        if (keep[base + i]) {
+            float4 v = sp[base + i];
+            v.w = 1.0f;
+            o_pat[w] = v;
+            o_src[w] = order[base + i];
+            ++w;
+        }
+    o_ct[j] = ct[s];
+    for (int k = 0; k < 6; ++k) o_bp[6 * j + k] = bp[6 * s + k];
+    o_bpstd[j] = bpstd[s];
+    o_ctstd[j] = ctstd[s];
+}
+
+__global__ void k_point_patch_ids(const int* __restrict__ off, int m, int* __restrict__ pid) {
+    int j = blockIdx.x;
+    for (int i = off[j] + threadIdx.x; i < off[j + 1]; i += blockDim.x) pid[i] = j;
+}
+
+}  // namespace
+
+// ======================================================================================================
+int pw_patch_normals_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, int m, float4* d_nrm) {
+    if (m <= 0) return PWICP_OK;
+    hipLaunchKernelGGL(k_patch_normals, dim3(div_up(m, 64)), dim3(64), 0, ctx->stream, d_pat, d_off, m, d_nrm);
+    HIPCHK(ctx, hipGetLastError());
+    return PWICP_OK;
+}
+
+int pw_patch_stats_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, int m, float4* ct, float4* bp,
+                          float* bpstd, float* ctstd) {
+    if (m <= 0) return PWICP_OK;
+    hipLaunchKernelGGL(k_patch_stats, dim3(div_up(m, 64)), dim3(64), 0, ctx->stream, d_pat, d_off, m, ct, bp,
+                       bpstd, ctstd);
+    HIPCHK(ctx, hipGetLastError());
+    return PWICP_OK;
+}
+
+int pw_select_patches_dev(pwicp_context* ctx, const float4* d_cloud, int n, const int* d_labels, int nsv,
+                          PatchSet* out) {
+    out->m = 0;
+    out->tot = 0;
+    if (n <= 0 || nsv <= 0) {
+        HIPCHK(ctx, out->off.reserve(1));
+        HIPCHK(ctx, hipMemsetAsync(out->off.p, 0, sizeof(int), ctx->stream));
+        return PWICP_OK;
+    }
+    // supervoxel sizes and offsets
+    DevBuf<int> svoff, bad, tmp;
+    HIPCHK(ctx, svoff.reserve((size_t)nsv + 1));
+    HIPCHK(ctx, bad.reserve(1));
+    HIPCHK(ctx, hipMemsetAsync(svoff.p, 0, ((size_t)nsv + 1) * sizeof(int), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(bad.p, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_label_hist, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_labels, n, nsv,
+                       svoff.p, bad.p);
+    PWCHK(pw_exclusive_scan(ctx, svoff.p, (long long)nsv + 1, &tmp));
+    int hbad = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&hbad, bad.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (hbad) { ctx->set_err("pwicp_select_patches: label out of range [0, n_supervoxels)"); return PWICP_E_INVALID; }
+
+    // stable grouping by label (point order inside a supervoxel, S.cpp:99-103): LSD radix sort of (label, index)
+    DevBuf<int> keys_out, order_in, order;
+    HIPCHK(ctx, keys_out.reserve((size_t)n));
+    HIPCHK(ctx, order_in.reserve((size_t)n));
+    HIPCHK(ctx, order.reserve((size_t)n));
+    hipLaunchKernelGGL(k_iota, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, order_in.p, n);
+    int end_bit = 1;
+    while (end_bit < 31 && (1ll << end_bit) < (long long)nsv) ++end_bit;
+    size_t tbytes = 0;
+    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tbytes, d_labels, keys_out.p, order_in.p, order.p, n, 0,
+                                                   end_bit, ctx->stream));
+    DevBuf<unsigned char> tsort;
+    HIPCHK(ctx, tsort.reserve(tbytes));
+    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(tsort.p, tbytes, d_labels, keys_out.p, order_in.p, order.p, n, 0,
+                                                   end_bit, ctx->stream));
+    DevBuf<float4> sp;
+    HIPCHK(ctx, sp.reserve((size_t)n));
+    hipLaunchKernelGGL(k_gather_sorted, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_cloud, order.p, n,
+                       sp.p);
+
+    DevBuf<unsigned char> keep;
+    DevBuf<int> kept, pidx;
+    DevBuf<float4> ct, bp;
+    DevBuf<float> bpstd, ctstd;
+    HIPCHK(ctx, keep.reserve((size_t)n));
+    HIPCHK(ctx, kept.reserve((size_t)nsv + 1));
+    HIPCHK(ctx, pidx.reserve((size_t)nsv + 1));
+    HIPCHK(ctx, ct.reserve((size_t)nsv));
+    HIPCHK(ctx, bp.reserve((size_t)nsv * 6));
+    HIPCHK(ctx, bpstd.reserve((size_t)nsv));
+    HIPCHK(ctx, ctstd.reserve((size_t)nsv));
+    HIPCHK(ctx, hipMemsetAsync(kept.p, 0, ((size_t)nsv + 1) * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_select, dim3(div_up(nsv, 64)), dim3(64), 0, ctx->stream, sp.p, svoff.p, nsv, keep.p, kept.p,
+                       ct.p, bp.p, bpstd.p, ctstd.p);
+    hipLaunchKernelGGL(k_valid_flags, dim3(div_up(nsv + 1, kBlock)), dim3(kBlock), 0, ctx->stream, kept.p, nsv, pidx.p);
+    // kept_cnt of rejected supervoxels is 0, so its exclusive scan is the output point offset
+    DevBuf<int> poff;
+    HIPCHK(ctx, poff.reserve((size_t)nsv + 1));
+    HIPCHK(ctx, hipMemcpyAsync(poff.p, kept.p, ((size_t)nsv + 1) * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    PWCHK(pw_exclusive_scan(ctx, poff.p, (long long)nsv + 1, &tmp));
+    PWCHK(pw_exclusive_scan(ctx, pidx.p, (long long)nsv + 1, &tmp));
+    int hm = 0, htot = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&hm, pidx.p + nsv, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&htot, poff.p + nsv, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    out->m = hm;
+    out->tot = htot;
+    HIPCHK(ctx, out->pat.reserve((size_t)std::max(htot, 1)));
+    HIPCHK(ctx, out->src.reserve((size_t)std::max(htot, 1)));
+    HIPCHK(ctx, out->off.reserve((size_t)hm + 1));
+    HIPCHK(ctx, out->ct.reserve((size_t)std::max(hm, 1)));
+    HIPCHK(ctx, out->bp.reserve((size_t)std::max(hm, 1) * 6));
+    HIPCHK(ctx, out->bpstd.reserve((size_t)std::max(hm, 1)));
+    HIPCHK(ctx, out->ctstd.reserve((size_t)std::max(hm, 1)));
+    hipLaunchKernelGGL(k_emit, dim3(div_up(nsv, 64)), dim3(64), 0, ctx->stream, sp.p, order.p, svoff.p, nsv, keep.p,
+                       kept.p, pidx.p, poff.p, ct.p, bp.p, bpstd.p, ctstd.p, out->pat.p, out->off.p, out->src.p,
+                       out->ct.p, out->bp.p, out->bpstd.p, out->ctstd.p);
+    HIPCHK(ctx, hipMemcpyAsync(out->off.p + hm, &htot, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipGetLastError());
+    return PWICP_OK;
+}
+
+int pw_point_patch_ids_launch(pwicp_context* ctx, const int* d_off, int m, int* d_pid) {
+    if (m <= 0) return PWICP_OK;
+    hipLaunchKernelGGL(k_point_patch_ids, dim3(m), dim3(64), 0, ctx->stream, d_off, m, d_pid);
+    HIPCHK(ctx, hipGetLastError());
+    return PWICP_OK;
+}

@@ -1,0 +1,6 @@
+"""pwicp_amd — thin ctypes mirror of libpwicp.so (the MI355X-native Piecewise-ICP hot path).
+
+The library is HIP-only: importing works anywhere, but every compute call raises PwicpError when
+no HIP device is present (there is no CPU fallback)."""
+from .binding import (PwicpError, Context, Pair, Params, Result, lib_path, load_library,  # noqa: F401
+                      device_count, f4)

@@ -1,0 +1,261 @@
+"""ctypes binding of include/pwicp.h.  Names mirror the reference's own functions where one
+exists (calPercentileDistBetween2PC, P2PICPwithPatchNormal, calTransParaVCM, Piecewise_ICP ...)."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PWICP_MAX_OUTER = 256
+
+STATUS = {0: "OK", -1: "NO_DEVICE", -2: "INVALID", -3: "TOO_FEW_PATCHES", -4: "TOO_FEW_STABLE",
+          -5: "NOMEM", -6: "INTERNAL"}
+
+
+class PwicpError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__("pwicp: %s (%d) %s" % (STATUS.get(code, "?"), code, msg))
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("Res1", C.c_float), ("Res2", C.c_float), ("SVRes1", C.c_float), ("SVRes2", C.c_float),
+                ("isManualDTinit", C.c_int), ("DTinit", C.c_float), ("DTmin", C.c_float)]
+
+
+class Result(C.Structure):
+    _fields_ = [("status", C.c_int), ("n_outer", C.c_int), ("T16", C.c_float * 16), ("VCM", C.c_double * 36),
+                ("DTseries", C.c_float * (PWICP_MAX_OUTER + 1)),
+                ("n_inner", C.c_int * PWICP_MAX_OUTER), ("n_stable", C.c_int * PWICP_MAX_OUTER),
+                ("n_stable_pts", C.c_int * PWICP_MAX_OUTER), ("LoDmin", C.c_float * PWICP_MAX_OUTER),
+                ("maxBB", C.c_float * PWICP_MAX_OUTER), ("d75", C.c_double * PWICP_MAX_OUTER),
+                ("Tk", (C.c_float * 16) * PWICP_MAX_OUTER),
+                ("n_corr", C.c_longlong), ("n_corr_dense", C.c_longlong), ("n_inner_total", C.c_longlong),
+                ("t_loop_ms", C.c_double), ("t_dense_nn_ms", C.c_double), ("n_dense_nn_launches", C.c_int),
+                ("t_inner_ms", C.c_double), ("dense_kbar", C.c_double)]
+
+
+def lib_path():
+    return os.path.join(os.path.dirname(_HERE), "libpwicp.so")
+
+
+_lib = None
+fp = C.POINTER(C.c_float)
+ip = C.POINTER(C.c_int32)
+dp = C.POINTER(C.c_double)
+u8p = C.POINTER(C.c_uint8)
+
+
+def load_library():
+    """Loads libpwicp.so (built by __graft_entry__.build()).  Raises if it is missing — the
+    product has no fallback implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise PwicpError(-6, "libpwicp.so not built: run `python __graft_entry__.py` (build())")
+    L = C.CDLL(p)
+    vp = C.c_void_p
+    L.pwicp_version.restype = C.c_char_p
+    L.pwicp_last_error.restype = C.c_char_p
+    L.pwicp_last_error.argtypes = [vp]
+    L.pwicp_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.pwicp_destroy.argtypes = [vp]
+    L.pwicp_nn_search.argtypes = [vp, fp, C.c_int, fp, C.c_int, ip, fp]
+    L.pwicp_percentile_dist.argtypes = [vp, fp, C.c_int, fp, C.c_int, C.c_float, dp]
+    L.pwicp_overlap_ratio.argtypes = [vp, fp, C.c_int, fp, C.c_int, C.c_float, fp]
+    for name, args in [
+        ("pwicp_patch_normals", [vp, fp, ip, C.c_int, fp, u8p]),
+        ("pwicp_select_patches", [vp, fp, C.c_int, ip, C.c_int, ip, ip, fp, ip, ip, fp, fp, fp, fp]),
+        ("pwicp_p2p_icp", [vp, fp, fp, C.c_int, fp, fp, C.c_int, C.c_double, fp, ip]),
+        ("pwicp_trans_para_vcm", [vp, fp, fp, C.c_int, fp, C.c_int, dp]),
+        ("pwicp_pair_create", [vp, fp, C.c_int, ip, C.c_int, fp, C.c_int, ip, C.c_int, C.POINTER(Params),
+                               C.POINTER(vp)]),
+        ("pwicp_pair_create_from_patches", [vp, fp, C.c_int, fp, ip, C.c_int, fp, C.c_int, fp, ip, C.c_int,
+                                            C.POINTER(Params), C.POINTER(vp)]),
+        ("pwicp_pair_destroy", [vp]),
+        ("pwicp_pair_num_patches", [vp, ip, ip]),
+        ("pwicp_pair_reset", [vp]),
+        ("pwicp_pair_run", [vp, C.POINTER(Result)]),
+        ("pwicp_pair_download_source", [vp, fp]),
+        ("pwicp_pair_bench_dense_nn", [vp, C.c_int, dp, C.POINTER(C.c_longlong), dp, dp]),
+    ]:
+        if hasattr(L, name):
+            getattr(L, name).argtypes = args
+    _lib = L
+    return L
+
+
+def device_count():
+    return int(load_library().pwicp_device_count())
+
+
+def f4(a):
+    """(n,3|4) -> contiguous float32 (n,4) pcl::PointXYZ layout (pad = 1)."""
+    a = np.asarray(a, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] not in (3, 4):
+        raise ValueError("expected (n,3) or (n,4)")
+    if a.shape[1] == 3:
+        out = np.ones((a.shape[0], 4), dtype=np.float32)
+        out[:, :3] = a
+        return out
+    return np.ascontiguousarray(a)
+
+
+def _p(a, t=fp):
+    return a.ctypes.data_as(t)
+
+
+class Context:
+    """One per GPU (per process rank).  Replaces the reference's module-level state."""
+
+    def __init__(self, device_id=0):
+        self._L = load_library()
+        h = C.c_void_p()
+        rc = self._L.pwicp_create(C.byref(h), int(device_id))
+        if rc != 0:
+            raise PwicpError(rc, "pwicp_create(device %d): no usable HIP device" % device_id)
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pwicp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise PwicpError(rc, self._L.pwicp_last_error(self._h).decode("utf-8", "replace"))
+
+    # -- building blocks ---------------------------------------------------------------------
+    def determineCorrespondences(self, target, source):
+        """CorrespondenceEstimation::determineCorrespondences(.., DBL_MAX): (index_match, sq_distance)."""
+        t, q = f4(target), f4(source)
+        idx = np.empty(len(q), np.int32)
+        d2 = np.empty(len(q), np.float32)
+        self._chk(self._L.pwicp_nn_search(self._h, _p(t), len(t), _p(q), len(q), _p(idx, ip), _p(d2)))
+        return idx, d2
+
+    def calPercentileDistBetween2PC(self, cloud1, cloud2, percentile=0.75):
+        c1, c2 = f4(cloud1), f4(cloud2)
+        out = C.c_double()
+        self._chk(self._L.pwicp_percentile_dist(self._h, _p(c1), len(c1), _p(c2), len(c2), percentile, C.byref(out)))
+        return out.value
+
+    def calOverlapRatioByC2Cdist(self, cloud1, cloud2, DTinit):
+        c1, c2 = f4(cloud1), f4(cloud2)
+        out = C.c_float()
+        self._chk(self._L.pwicp_overlap_ratio(self._h, _p(c1), len(c1), _p(c2), len(c2), DTinit, C.byref(out)))
+        return out.value
+
+    def patchNormals(self, patch_xyz4, offsets):
+        pat = f4(patch_xyz4)
+        off = np.ascontiguousarray(offsets, np.int32)
+        m = len(off) - 1
+        nrm = np.zeros((m, 4), np.float32)
+        ok = np.zeros(m, np.uint8)
+        self._chk(self._L.pwicp_patch_normals(self._h, _p(pat), _p(off, ip), m, _p(nrm), _p(ok, u8p)))
+        return nrm, ok
+
+    def selectPatches(self, cloud, labels, nsv):
+        """PatchGenerationAndRefinement after segmentation + calBPandCTSTD.
+        Returns dict(pat, off, src, ct, bp, bpstd, ctstd)."""
+        c = f4(cloud)
+        lab = np.ascontiguousarray(labels, np.int32)
+        m = C.c_int32()
+        tot = C.c_int32()
+        self._chk(self._L.pwicp_select_patches(self._h, _p(c), len(c), _p(lab, ip), int(nsv), C.byref(m), C.byref(tot),
+                                               None, None, None, None, None, None, None))
+        m, tot = m.value, tot.value
+        pat = np.zeros((max(tot, 1), 4), np.float32)
+        off = np.zeros(m + 1, np.int32)
+        src = np.zeros(max(tot, 1), np.int32)
+        ct = np.zeros((max(m, 1), 4), np.float32)
+        bp = np.zeros((max(m, 1) * 6, 4), np.float32)
+        sbp = np.zeros(max(m, 1), np.float32)
+        sct = np.zeros(max(m, 1), np.float32)
+        mm, tt = C.c_int32(), C.c_int32()
+        self._chk(self._L.pwicp_select_patches(self._h, _p(c), len(c), _p(lab, ip), int(nsv), C.byref(mm), C.byref(tt),
+                                               _p(pat), _p(off, ip), _p(src, ip), _p(ct), _p(bp), _p(sbp), _p(sct)))
+        return dict(pat=pat[:tot], off=off, src=src[:tot], ct=ct[:m], bp=bp[:6 * m], bpstd=sbp[:m], ctstd=sct[:m])
+
+    def P2PICPwithPatchNormal(self, tgt, tgt_n, src, src_n, euclid_eps=1e-6):
+        t, tn, s, sn = f4(tgt), f4(tgt_n), f4(src), f4(src_n)
+        T = np.zeros(16, np.float32)
+        it = C.c_int32()
+        self._chk(self._L.pwicp_p2p_icp(self._h, _p(t), _p(tn), len(t), _p(s), _p(sn), len(s), euclid_eps, _p(T),
+                                        C.byref(it)))
+        return T.reshape(4, 4), it.value
+
+    def calTransParaVCM(self, tgt, tgt_n, src_stable):
+        t, tn, s = f4(tgt), f4(tgt_n), f4(src_stable)
+        V = np.zeros(36, np.float64)
+        self._chk(self._L.pwicp_trans_para_vcm(self._h, _p(t), _p(tn), len(t), _p(s), len(s), _p(V, dp)))
+        return V.reshape(6, 6)
+
+
+class Pair:
+    """A target/source pair resident in HBM; run() is the Piecewise_ICP while-loop."""
+
+    def __init__(self, ctx, cloud1, labels1, nsv1, cloud2, labels2, nsv2, params, patches=None):
+        self._ctx = ctx
+        self._L = ctx._L
+        self.n2 = len(cloud2)
+        c1, c2 = f4(cloud1), f4(cloud2)
+        h = C.c_void_p()
+        if patches is None:
+            l1 = np.ascontiguousarray(labels1, np.int32)
+            l2 = np.ascontiguousarray(labels2, np.int32)
+            ctx._chk(self._L.pwicp_pair_create(ctx._h, _p(c1), len(c1), _p(l1, ip), int(nsv1), _p(c2), len(c2),
+                                               _p(l2, ip), int(nsv2), C.byref(params), C.byref(h)))
+        else:
+            (pat1, off1), (pat2, off2) = patches
+            pat1, pat2 = f4(pat1), f4(pat2)
+            off1 = np.ascontiguousarray(off1, np.int32)
+            off2 = np.ascontiguousarray(off2, np.int32)
+            ctx._chk(self._L.pwicp_pair_create_from_patches(ctx._h, _p(c1), len(c1), _p(pat1), _p(off1, ip),
+                                                            len(off1) - 1, _p(c2), len(c2), _p(pat2), _p(off2, ip),
+                                                            len(off2) - 1, C.byref(params), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pwicp_pair_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def num_patches(self):
+        a, b = C.c_int32(), C.c_int32()
+        self._ctx._chk(self._L.pwicp_pair_num_patches(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def reset(self):
+        self._ctx._chk(self._L.pwicp_pair_reset(self._h))
+
+    def run(self, check=True):
+        r = Result()
+        rc = self._L.pwicp_pair_run(self._h, C.byref(r))
+        if check:
+            self._ctx._chk(rc)
+        return r
+
+    def download_source(self):
+        out = np.zeros((self.n2, 4), np.float32)
+        self._ctx._chk(self._L.pwicp_pair_download_source(self._h, _p(out)))
+        return out
+
+    def bench_dense_nn(self, n_launches=10):
+        ms, nq, kb, edge = C.c_double(), C.c_longlong(), C.c_double(), C.c_double()
+        self._ctx._chk(self._L.pwicp_pair_bench_dense_nn(self._h, n_launches, C.byref(ms), C.byref(nq), C.byref(kb),
+                                                         C.byref(edge)))
+        return ms.value, nq.value, kb.value, edge.value
