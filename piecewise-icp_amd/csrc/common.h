@@ -76,7 +76,7 @@ static inline int div_up(long long a, int b) { return (int)((a + b - 1) / b); }
 // Points are bucketed by cell with a counting sort; a cell row along x is contiguous in memory,
 // so the 3 x-neighbour cells of a stencil row are ONE contiguous range of points.
 // ---------------------------------------------------------------------------------------------
-struct GridDesc {
+struct GridLevel {
     float ox, oy, oz;        // origin = min corner of the bounding box
     float h, inv_h;          // cell edge
     float slack;             // bound on |computed cell boundary - true boundary| (rounding)
@@ -86,11 +86,17 @@ struct GridDesc {
     const float4* pts;       // sorted by cell; w = __int_as_float(original index)
 };
 
+// Two levels over the same points: `fine` serves the common 27-cell stencil, `coarse` (4x the edge) resolves
+// far queries without walking many empty fine cells.
+struct GridDesc {
+    GridLevel fine, coarse;
+};
+
 struct Grid {
     GridDesc d{};
-    DevBuf<int> cell_start;
-    DevBuf<float4> pts;
-    double kbar27 = 0.0;     // mean #points in the 27-cell stencil around an occupied cell, point weighted
+    DevBuf<int> cell_start, ccell_start;
+    DevBuf<float4> pts, cpts;
+    double kbar27 = 0.0;     // mean #points in the fine 27-cell stencil around an occupied cell, point weighted
 };
 
 // grid.hip
@@ -103,7 +109,12 @@ int pw_nn_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_q, int n
 int pw_nn_patches_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pat, const int* d_off,
                          const int* d_list, const int* d_soff, int n_list, int n_pts, float* d_d2,
                          unsigned long long* d_examined);
-// k-th smallest (0-based) of n non-negative floats; result written to d_out[0]; scratch >= 3*2048+8 uints
+// LDS-staged dense NN: query i = patch point qorder[i] (skipped, sentinel written, unless stable[pt_patch[.]])
+int pw_nn_dense_lds_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pat, const int* d_qorder,
+                           const int* d_pt_patch, const int* d_stable, int nq, float* d_d2,
+                           unsigned long long* d_examined);
+int pw_morton_order(pwicp_context* ctx, const GridDesc& g, const float4* d_pts, int n, DevBuf<int>* order);
+// k-th smallest (0-based) of the non-sentinel entries of n non-negative floats; result written to d_out[0]; scratch >= 3*2048+8 uints
 int pw_select_kth_launch(pwicp_context* ctx, const float* d_vals, int n, int k, unsigned* d_scratch, float* d_out);
 // count of values with sqrtf(v) < thr  -> d_count[0]
 int pw_count_below_launch(pwicp_context* ctx, const float* d_d2, int n, float thr, unsigned* d_count);

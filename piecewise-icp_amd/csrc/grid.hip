@@ -12,6 +12,9 @@
 // rounding slack of the cell assignment); otherwise it grows the block shell by shell.
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
+
+#include <hipcub/hipcub.hpp>
 
 #include "common.h"
 #include "nn_device.h"
@@ -37,7 +40,8 @@ __host__ __device__ __forceinline__ float ord2f(unsigned u) {
 
 // ---- bounding box ------------------------------------------------------------------------------
 // out[0..2] = min (ordered-uint encoded), out[3..5] = max, out[6] = max |coord|
-__global__ void k_bbox(const float4* __restrict__ p, int n, unsigned* __restrict__ out) {
+__global__ void __launch_bounds__(kBlock) k_bbox(const float4* __restrict__ p, int n, unsigned* __restrict__ out) {
+    __shared__ float sh[kBlock / 64][6];
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float4 v = p[i];
@@ -53,17 +57,21 @@ __global__ void k_bbox(const float4* __restrict__ p, int n, unsigned* __restrict
             mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], o));
         }
     }
-    if ((threadIdx.x & 63) == 0) {
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            atomicMin(&out[d], f2ord(mn[d]));
-            atomicMax(&out[3 + d], f2ord(mx[d]));
-        }
+        for (int d = 0; d < 3; ++d) { sh[wave][d] = mn[d]; sh[wave][3 + d] = mx[d]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float a = sh[0][threadIdx.x], b = sh[0][3 + threadIdx.x];
+        for (int w = 1; w < kBlock / 64; ++w) { a = fminf(a, sh[w][threadIdx.x]); b = fmaxf(b, sh[w][3 + threadIdx.x]); }
+        atomicMin(&out[threadIdx.x], f2ord(a));
+        atomicMax(&out[3 + threadIdx.x], f2ord(b));
     }
 }
 
 // ---- counting sort by cell -----------------------------------------------------------------------
-__global__ void k_cell_count(const float4* __restrict__ p, int n, GridDesc g, int* __restrict__ cnt,
+__global__ void k_cell_count(const float4* __restrict__ p, int n, GridLevel g, int* __restrict__ cnt,
                              int* __restrict__ cell_id, int* __restrict__ rank) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -166,8 +174,8 @@ __global__ void __launch_bounds__(kBlock) k_nn_points(GridDesc g, const float4* 
     if (i < nq) {
         float4 v = q[i];
         NNBest b = nn_query(g, v.x, v.y, v.z, cnt);
-        if (idx) idx[i] = b.idx;
-        d2[i] = b.d2;
+        if (idx) idx[i] = b.found() ? b.idx() : -1;
+        d2[i] = b.d2();
     }
     add_examined(examined, cnt);
 }
@@ -188,9 +196,241 @@ __global__ void __launch_bounds__(kBlock) k_nn_patches(GridDesc g, const float4*
         }
         float4 v = pat[off[list[lo]] + (i - soff[lo])];
         NNBest b = nn_query(g, v.x, v.y, v.z, cnt);
-        d2[i] = b.d2;
+        d2[i] = b.d2();
     }
     add_examined(examined, cnt);
+}
+
+// ---- dense 1-NN, LDS-staged ---------------------------------------------------------------------------------
+// Queries arrive in Morton order of their (initial) fine cell, so the 256 queries of a block occupy a compact
+// box of cells.  The block stages that box (+-2 cells halo) once — the begin/end table of its cell rows and the
+// target points, each row one coalesced copy — and every lane scans its 27-cell stencil, then if necessary the
+// 5x5x5 shell, out of LDS.  Only queries that are still unresolved (farther than ~2 cell edges from any target
+// point), queries outside the grid, or blocks whose box does not fit the LDS budget take the global-memory
+// two-level path of nn_device.h.  Same arithmetic, same tie rule: results are bit-identical to k_nn_points.
+constexpr int kPtCap = 2048;      // staged points   (32 KiB)
+constexpr int kCsCap = 3072;      // staged begin/end words (12 KiB)
+constexpr int kRowCap = 256;      // staged cell rows
+constexpr int kHalo = 2;
+constexpr unsigned kSentinel = 0xffffffffu;   // d2 slot of a query that is not part of this launch
+
+__device__ __forceinline__ void scan_points_lds(const float4* s_pts, int lo, int hi, float qx, float qy, float qz,
+                                                NNBest& b) {
+    int j = lo;
+    for (; j + 1 < hi; j += 2) {
+        const float4 p0 = s_pts[j], p1 = s_pts[j + 1];
+        nn_consider(p0, qx, qy, qz, b);
+        nn_consider(p1, qx, qy, qz, b);
+    }
+    if (j < hi) nn_consider(s_pts[j], qx, qy, qz, b);
+}
+
+__global__ void __launch_bounds__(kBlock) k_nn_dense_lds(GridDesc gd, const float4* __restrict__ pat,
+                                                         const int* __restrict__ qorder,
+                                                         const int* __restrict__ pt_patch,
+                                                         const int* __restrict__ stable, int nq,
+                                                         float* __restrict__ d2out,
+                                                         unsigned long long* __restrict__ examined) {
+    __shared__ float4 s_pts[kPtCap];
+    __shared__ int s_cs[kCsCap];
+    __shared__ int s_rowoff[kRowCap + 1];
+    __shared__ int s_red[kBlock / 64][6];
+    __shared__ int s_box[8];
+    const GridLevel& g = gd.fine;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x * kBlock + tid;
+    bool active = false;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < nq) {
+        const int p = qorder[i];
+        if (stable[pt_patch[p]]) { active = true; q = pat[p]; }
+    }
+    int cx = 0, cy = 0, cz = 0;
+    bool ingrid = false;
+    if (active) {
+        cx = cell_of(q.x, g.ox, g.inv_h); cy = cell_of(q.y, g.oy, g.inv_h); cz = cell_of(q.z, g.oz, g.inv_h);
+        ingrid = cx >= 0 && cx < g.nx && cy >= 0 && cy < g.ny && cz >= 0 && cz < g.nz;
+    }
+    // box of the block's in-grid query cells
+    {
+        int mn0 = ingrid ? cx : 0x7fffffff, mn1 = ingrid ? cy : 0x7fffffff, mn2 = ingrid ? cz : 0x7fffffff;
+        int mx0 = ingrid ? cx : -1, mx1 = ingrid ? cy : -1, mx2 = ingrid ? cz : -1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn0 = min(mn0, __shfl_xor(mn0, o)); mn1 = min(mn1, __shfl_xor(mn1, o)); mn2 = min(mn2, __shfl_xor(mn2, o));
+            mx0 = max(mx0, __shfl_xor(mx0, o)); mx1 = max(mx1, __shfl_xor(mx1, o)); mx2 = max(mx2, __shfl_xor(mx2, o));
+        }
+        if (lane == 0) {
+            s_red[wave][0] = mn0; s_red[wave][1] = mn1; s_red[wave][2] = mn2;
+            s_red[wave][3] = mx0; s_red[wave][4] = mx1; s_red[wave][5] = mx2;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-1, -1, -1};
+        for (int w = 0; w < kBlock / 64; ++w)
+            for (int d = 0; d < 3; ++d) { mn[d] = min(mn[d], s_red[w][d]); mx[d] = max(mx[d], s_red[w][3 + d]); }
+        int ok = mx[0] >= 0;
+        const int x0 = max(mn[0] - kHalo, 0), x1 = min(mx[0] + kHalo, g.nx - 1);
+        const int y0 = max(mn[1] - kHalo, 0), y1 = min(mx[1] + kHalo, g.ny - 1);
+        const int z0 = max(mn[2] - kHalo, 0), z1 = min(mx[2] + kHalo, g.nz - 1);
+        if (ok) {
+            const long long nrows = (long long)(y1 - y0 + 1) * (z1 - z0 + 1);
+            if (nrows > kRowCap || nrows * (x1 - x0 + 2) > kCsCap) ok = 0;
+        }
+        s_box[0] = x0; s_box[1] = x1; s_box[2] = y0; s_box[3] = y1; s_box[4] = z0; s_box[5] = z1; s_box[6] = ok;
+    }
+    __syncthreads();
+    const int x0 = s_box[0], x1 = s_box[1], y0 = s_box[2], y1 = s_box[3], z0 = s_box[4];
+    int staged = s_box[6];
+    const int bw1 = x1 - x0 + 2;                 // begin/end words per row
+    const int by = y1 - y0 + 1;
+    const int nrows = staged ? by * (s_box[5] - z0 + 1) : 0;
+    if (staged) {
+        for (int idx = tid; idx < nrows * bw1; idx += kBlock) {
+            const int t = idx / bw1, c = idx - t * bw1;
+            const int y = y0 + t % by, z = z0 + t / by;
+            s_cs[idx] = g.cell_start[(z * g.ny + y) * g.nx + x0 + c];
+        }
+    }
+    __syncthreads();
+    if (staged) {
+        // exclusive scan of the row point counts (nrows <= 256 = one element per thread)
+        const int cnt = (tid < nrows) ? (s_cs[tid * bw1 + bw1 - 1] - s_cs[tid * bw1]) : 0;
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) s_red[wave][0] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += s_red[w][0];
+        if (tid < nrows) s_rowoff[tid] = base + incl - cnt;
+        if (tid == kBlock - 1) s_rowoff[kRowCap] = base + incl;      // total
+    }
+    __syncthreads();
+    if (staged && s_rowoff[kRowCap] > kPtCap) staged = 0;           // uniform
+    if (staged) {
+        for (int t = wave; t < nrows; t += kBlock / 64) {
+            const int glo = s_cs[t * bw1], n = s_cs[t * bw1 + bw1 - 1] - glo, dst = s_rowoff[t];
+            for (int k = lane; k < n; k += 64) s_pts[dst + k] = g.pts[glo + k];
+        }
+    }
+    __syncthreads();
+    unsigned cnt = 0;
+    if (active) {
+        NNBest b;
+        b.key = kKeyInit;
+        bool done = false;
+        if (staged && ingrid) {
+            // LDS index range of cells [xa, xb] (clipped to the grid) of row (y, z); empty outside the grid
+            auto lds_range = [&](int y, int z, int xa, int xb, int& lo, int& hi) {
+                lo = 0; hi = 0;
+                if (y < 0 || y >= g.ny || z < 0 || z >= g.nz) return;
+                xa = max(xa, 0); xb = min(xb, g.nx - 1);
+                if (xa > xb) return;
+                const int t = (z - z0) * by + (y - y0);
+                const int rb = t * bw1;
+                const int first = s_cs[rb];
+                lo = s_rowoff[t] + (s_cs[rb + xa - x0] - first);
+                hi = s_rowoff[t] + (s_cs[rb + xb + 1 - x0] - first);
+            };
+            int lo[9], hi[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) lds_range(cy + (k % 3) - 1, cz + (k / 3) - 1, cx - 1, cx + 1, lo[k], hi[k]);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                scan_points_lds(s_pts, lo[k], hi[k], q.x, q.y, q.z, b);
+                cnt += (unsigned)(hi[k] - lo[k]);
+            }
+            done = nn_resolved(g, 1, b);
+            if (!done) {
+                for (int t = 0; t < 25; ++t) {
+                    const int dz = t / 5 - 2, dy = t % 5 - 2;
+                    int l0, h0, l1 = 0, h1 = 0;
+                    if (dz == -2 || dz == 2 || dy == -2 || dy == 2) {
+                        lds_range(cy + dy, cz + dz, cx - 2, cx + 2, l0, h0);
+                    } else {
+                        lds_range(cy + dy, cz + dz, cx - 2, cx - 2, l0, h0);
+                        lds_range(cy + dy, cz + dz, cx + 2, cx + 2, l1, h1);
+                    }
+                    scan_points_lds(s_pts, l0, h0, q.x, q.y, q.z, b);
+                    scan_points_lds(s_pts, l1, h1, q.x, q.y, q.z, b);
+                    cnt += (unsigned)(h0 - l0) + (unsigned)(h1 - l1);
+                }
+                done = nn_resolved(g, 2, b);
+            }
+        }
+        if (!done) {
+            unsigned ex = 0;
+            if (b.found()) {
+                // seeded continuation on the coarse level (stages 2/3 of nn_query)
+                const GridLevel& c = gd.coarse;
+                const float rho = sqrtf(b.d2()) * 1.00001f + 2.0f * c.slack;
+                const int a0 = max(cell_of(q.x - rho, c.ox, c.inv_h), 0), a1 = min(cell_of(q.x + rho, c.ox, c.inv_h), c.nx - 1);
+                const int b0 = max(cell_of(q.y - rho, c.oy, c.inv_h), 0), b1 = min(cell_of(q.y + rho, c.oy, c.inv_h), c.ny - 1);
+                const int c0 = max(cell_of(q.z - rho, c.oz, c.inv_h), 0), c1 = min(cell_of(q.z + rho, c.oz, c.inv_h), c.nz - 1);
+                if ((b1 - b0 + 1) * (c1 - c0 + 1) <= 64) {
+                    if (a0 <= a1 && b0 <= b1 && c0 <= c1) ex = scan_box(c, a0, a1, b0, b1, c0, c1, q.x, q.y, q.z, b);
+                } else {
+                    ex = nn_expand(c, q.x, q.y, q.z, b);
+                }
+            } else {
+                b = nn_query(gd, q.x, q.y, q.z, ex);
+            }
+            cnt += ex;
+        }
+        d2out[i] = b.d2();
+    } else if (i < nq) {
+        d2out[i] = __uint_as_float(kSentinel);
+    }
+    add_examined(examined, cnt);
+}
+
+
+// same interface as k_nn_dense_lds, straight from global memory (L1/L2) with the two-level search
+__global__ void __launch_bounds__(kBlock) k_nn_dense_direct(GridDesc gd, const float4* __restrict__ pat,
+                                                            const int* __restrict__ qorder,
+                                                            const int* __restrict__ pt_patch,
+                                                            const int* __restrict__ stable, int nq,
+                                                            float* __restrict__ d2out,
+                                                            unsigned long long* __restrict__ examined) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    unsigned cnt = 0;
+    if (i < nq) {
+        const int p = qorder ? qorder[i] : i;
+        if (stable[pt_patch[p]]) {
+            const float4 q = pat[p];
+            NNBest b = nn_query(gd, q.x, q.y, q.z, cnt);
+            d2out[i] = b.d2();
+        } else {
+            d2out[i] = __uint_as_float(kSentinel);
+        }
+    }
+    add_examined(examined, cnt);
+}
+
+// Morton code (10 bits per axis) of the fine cell of each point, for the one-off query ordering
+__device__ __forceinline__ unsigned part1by2(unsigned x) {
+    x &= 0x3ffu;
+    x = (x | (x << 16)) & 0x030000ffu;
+    x = (x | (x << 8)) & 0x0300f00fu;
+    x = (x | (x << 4)) & 0x030c30c3u;
+    x = (x | (x << 2)) & 0x09249249u;
+    return x;
+}
+__global__ void k_morton_keys(GridLevel g, const float4* __restrict__ p, int n, int shift, unsigned* __restrict__ keys,
+                              int* __restrict__ vals) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 v = p[i];
+    const unsigned cx = (unsigned)min(max(cell_of(v.x, g.ox, g.inv_h), 0), g.nx - 1) >> shift;
+    const unsigned cy = (unsigned)min(max(cell_of(v.y, g.oy, g.inv_h), 0), g.ny - 1) >> shift;
+    const unsigned cz = (unsigned)min(max(cell_of(v.z, g.oz, g.inv_h), 0), g.nz - 1) >> shift;
+    keys[i] = part1by2(cx) | (part1by2(cy) << 1) | (part1by2(cz) << 2);
+    vals[i] = i;
 }
 
 // ---- k-th smallest of non-negative floats: 3-pass radix select on the bit pattern ---------------------
@@ -210,6 +450,7 @@ __global__ void k_select_hist(const float* __restrict__ v, int n, unsigned* __re
     const unsigned prefix = scratch[0];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         unsigned u = __float_as_uint(v[i]);
+        if (u == 0xffffffffu) continue;          // slot of a query that was not part of the launch
         if (PASS == 0) {
             atomicAdd(&h[u >> 21], 1u);
         } else if (PASS == 1) {
@@ -270,7 +511,7 @@ __global__ void k_count_below(const float* __restrict__ d2, int n, float thr, un
 }
 
 // mean number of points in the 27-cell stencil, weighted by the points of the centre cell
-__global__ void k_kbar27(GridDesc g, unsigned long long* __restrict__ acc) {
+__global__ void k_kbar27(GridLevel g, unsigned long long* __restrict__ acc) {
     long long ncell = (long long)g.nx * g.ny * g.nz;
     unsigned long long s = 0;
     for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < ncell;
@@ -308,23 +549,69 @@ int pw_exclusive_scan(pwicp_context* ctx, int* d_data, long long n, DevBuf<int>*
     return PWICP_OK;
 }
 
+namespace {
+
+// one level: counting sort of the points by cell of edge h over the bounding box [mn, mx]
+int build_level(pwicp_context* ctx, const float4* d_pts, int n, float h, const float* mn, const float* mx,
+                GridLevel* d, DevBuf<int>* cell_start, DevBuf<float4>* pts) {
+    // cap the dense cell array at 2^28 cells (1 GiB of int32): coarser cells stay exact, only slower
+    for (;;) {
+        double cells = 1.0;
+        for (int k = 0; k < 3; ++k) cells *= std::floor((double)(mx[k] - mn[k]) / h) + 2.0;
+        if (cells <= 268435456.0) break;
+        h *= 1.26f;
+    }
+    d->n = n;
+    d->h = h;
+    d->inv_h = 1.0f / h;
+    d->ox = mn[0]; d->oy = mn[1]; d->oz = mn[2];
+    d->nx = (int)std::floor((mx[0] - mn[0]) * d->inv_h) + 1;
+    d->ny = (int)std::floor((mx[1] - mn[1]) * d->inv_h) + 1;
+    d->nz = (int)std::floor((mx[2] - mn[2]) * d->inv_h) + 1;
+    float maxabs = 0.f;
+    for (int k = 0; k < 3; ++k) maxabs = std::max(maxabs, std::max(std::fabs(mn[k]), std::fabs(mx[k])));
+    const int maxdim = std::max(d->nx, std::max(d->ny, d->nz));
+    d->slack = h * 1.0e-6f * (float)(maxdim + 1) + 4.0f * FLT_EPSILON * maxabs;
+
+    const long long ncell = (long long)d->nx * d->ny * d->nz;
+    HIPCHK(ctx, cell_start->reserve((size_t)ncell + 1));
+    HIPCHK(ctx, pts->reserve((size_t)n));
+    HIPCHK(ctx, hipMemsetAsync(cell_start->p, 0, (size_t)(ncell + 1) * sizeof(int), ctx->stream));
+    DevBuf<int> cell_id, rank, tmp;
+    HIPCHK(ctx, cell_id.reserve((size_t)n));
+    HIPCHK(ctx, rank.reserve((size_t)n));
+    d->cell_start = cell_start->p;
+    d->pts = pts->p;
+    hipLaunchKernelGGL(k_cell_count, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_pts, n, *d,
+                       cell_start->p, cell_id.p, rank.p);
+    PWCHK(pw_exclusive_scan(ctx, cell_start->p, ncell + 1, &tmp));
+    hipLaunchKernelGGL(k_cell_scatter, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_pts, n,
+                       cell_start->p, cell_id.p, rank.p, pts->p);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // temporaries die here
+    HIPCHK(ctx, hipGetLastError());
+    return PWICP_OK;
+}
+
+}  // namespace
+
 int pw_grid_build(pwicp_context* ctx, const float4* d_pts, int n, float cell_edge, Grid* g) {
     GridDesc& d = g->d;
     memset(&d, 0, sizeof(d));
-    d.n = n;
     if (n <= 0) {
-        d.nx = d.ny = d.nz = 1; d.h = 1.f; d.inv_h = 1.f;
         HIPCHK(ctx, g->cell_start.reserve(2));
         HIPCHK(ctx, hipMemsetAsync(g->cell_start.p, 0, 2 * sizeof(int), ctx->stream));
         HIPCHK(ctx, g->pts.reserve(1));
-        d.cell_start = g->cell_start.p; d.pts = g->pts.p;
+        GridLevel e{};
+        e.nx = e.ny = e.nz = 1; e.h = 1.f; e.inv_h = 1.f; e.n = 0;
+        e.cell_start = g->cell_start.p; e.pts = g->pts.p;
+        d.fine = e; d.coarse = e;
         return PWICP_OK;
     }
     DevBuf<unsigned> bb;
     HIPCHK(ctx, bb.reserve(8));
-    unsigned init[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
+    static const unsigned init[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
     HIPCHK(ctx, hipMemcpyAsync(bb.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-    int nb = std::min(div_up(n, kBlock), ctx->n_cu * 8);
+    int nb = std::min(div_up(n, kBlock), ctx->n_cu * 4);
     hipLaunchKernelGGL(k_bbox, dim3(nb), dim3(kBlock), 0, ctx->stream, d_pts, n, bb.p);
     unsigned hb[8];
     HIPCHK(ctx, hipMemcpyAsync(hb, bb.p, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
@@ -336,45 +623,16 @@ int pw_grid_build(pwicp_context* ctx, const float4* d_pts, int n, float cell_edg
             ctx->set_err("pw_grid_build: non-finite coordinates in target cloud");
             return PWICP_E_INVALID;
         }
-    float h = cell_edge > 0.f ? cell_edge : 1.f;
-    // cap the dense cell array at 2^28 cells (1 GiB of int32): coarser cells stay exact, only slower
-    for (;;) {
-        double cells = 1.0;
-        for (int k = 0; k < 3; ++k) cells *= std::floor((double)(mx[k] - mn[k]) / h) + 2.0;
-        if (cells <= 268435456.0) break;
-        h *= 1.26f;
-    }
-    d.h = h;
-    d.inv_h = 1.0f / h;
-    d.ox = mn[0]; d.oy = mn[1]; d.oz = mn[2];
-    d.nx = (int)std::floor((mx[0] - mn[0]) * d.inv_h) + 1;
-    d.ny = (int)std::floor((mx[1] - mn[1]) * d.inv_h) + 1;
-    d.nz = (int)std::floor((mx[2] - mn[2]) * d.inv_h) + 1;
-    float maxabs = 0.f;
-    for (int k = 0; k < 3; ++k) maxabs = std::max(maxabs, std::max(std::fabs(mn[k]), std::fabs(mx[k])));
-    int maxdim = std::max(d.nx, std::max(d.ny, d.nz));
-    d.slack = h * 1.0e-6f * (float)(maxdim + 1) + 4.0f * FLT_EPSILON * maxabs;
-
-    long long ncell = (long long)d.nx * d.ny * d.nz;
-    HIPCHK(ctx, g->cell_start.reserve((size_t)ncell + 1));
-    HIPCHK(ctx, g->pts.reserve((size_t)n));
-    HIPCHK(ctx, hipMemsetAsync(g->cell_start.p, 0, (size_t)(ncell + 1) * sizeof(int), ctx->stream));
-    DevBuf<int> cell_id, rank, tmp;
-    HIPCHK(ctx, cell_id.reserve((size_t)n));
-    HIPCHK(ctx, rank.reserve((size_t)n));
-    d.cell_start = g->cell_start.p;
-    d.pts = g->pts.p;
-    hipLaunchKernelGGL(k_cell_count, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_pts, n, d,
-                       g->cell_start.p, cell_id.p, rank.p);
-    PWCHK(pw_exclusive_scan(ctx, g->cell_start.p, ncell + 1, &tmp));
-    hipLaunchKernelGGL(k_cell_scatter, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_pts, n,
-                       g->cell_start.p, cell_id.p, rank.p, g->pts.p);
-    // Kbar of the 27-cell stencil (reported with every run)
+    const float h = cell_edge > 0.f ? cell_edge : 1.f;
+    PWCHK(build_level(ctx, d_pts, n, h, mn, mx, &d.fine, &g->cell_start, &g->pts));
+    PWCHK(build_level(ctx, d_pts, n, 4.0f * d.fine.h, mn, mx, &d.coarse, &g->ccell_start, &g->cpts));
+    // Kbar of the fine 27-cell stencil (reported with every run)
     DevBuf<unsigned long long> acc;
     HIPCHK(ctx, acc.reserve(1));
     HIPCHK(ctx, hipMemsetAsync(acc.p, 0, sizeof(unsigned long long), ctx->stream));
+    const long long ncell = (long long)d.fine.nx * d.fine.ny * d.fine.nz;
     int nbk = (int)std::min<long long>((ncell + kBlock - 1) / kBlock, (long long)ctx->n_cu * 16);
-    hipLaunchKernelGGL(k_kbar27, dim3(nbk), dim3(kBlock), 0, ctx->stream, d, acc.p);
+    hipLaunchKernelGGL(k_kbar27, dim3(nbk), dim3(kBlock), 0, ctx->stream, d.fine, acc.p);
     unsigned long long hacc = 0;
     HIPCHK(ctx, hipMemcpyAsync(&hacc, acc.p, sizeof(hacc), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -423,6 +681,47 @@ int pw_count_below_launch(pwicp_context* ctx, const float* d_d2, int n, float th
         int nb = std::min(div_up(n, kBlock), ctx->n_cu * 4);
         hipLaunchKernelGGL(k_count_below, dim3(nb), dim3(kBlock), 0, ctx->stream, d_d2, n, thr, d_count);
     }
+    HIPCHK(ctx, hipGetLastError());
+    return PWICP_OK;
+}
+
+int pw_nn_dense_lds_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pat, const int* d_qorder,
+                           const int* d_pt_patch, const int* d_stable, int nq, float* d_d2,
+                           unsigned long long* d_examined) {
+    if (nq <= 0) return PWICP_OK;
+    static int variant = -1;      // 0 LDS-staged, 1 direct + Morton order, 2 direct + patch order (experiments)
+    if (variant < 0) { const char* e = getenv("PWICP_DENSE_KERNEL"); variant = e ? atoi(e) : 1; }
+    if (variant == 0)
+        hipLaunchKernelGGL(k_nn_dense_lds, dim3(div_up(nq, kBlock)), dim3(kBlock), 0, ctx->stream, g, d_pat, d_qorder,
+                           d_pt_patch, d_stable, nq, d_d2, d_examined);
+    else
+        hipLaunchKernelGGL(k_nn_dense_direct, dim3(div_up(nq, kBlock)), dim3(kBlock), 0, ctx->stream, g, d_pat,
+                           variant == 1 ? d_qorder : (const int*)nullptr, d_pt_patch, d_stable, nq, d_d2, d_examined);
+    HIPCHK(ctx, hipGetLastError());
+    return PWICP_OK;
+}
+
+// permutation of 0..n-1 that lists the points in Morton order of their fine cell in grid g
+int pw_morton_order(pwicp_context* ctx, const GridDesc& g, const float4* d_pts, int n, DevBuf<int>* order) {
+    HIPCHK(ctx, order->reserve((size_t)std::max(n, 1)));
+    if (n <= 0) return PWICP_OK;
+    int shift = 0;
+    while (((std::max(g.fine.nx, std::max(g.fine.ny, g.fine.nz)) - 1) >> shift) > 1023) ++shift;
+    DevBuf<unsigned> keys, keys_out;
+    DevBuf<int> vals;
+    HIPCHK(ctx, keys.reserve((size_t)n));
+    HIPCHK(ctx, keys_out.reserve((size_t)n));
+    HIPCHK(ctx, vals.reserve((size_t)n));
+    hipLaunchKernelGGL(k_morton_keys, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, g.fine, d_pts, n, shift,
+                       keys.p, vals.p);
+    size_t tbytes = 0;
+    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tbytes, keys.p, keys_out.p, vals.p, order->p, n, 0, 30,
+                                                   ctx->stream));
+    DevBuf<unsigned char> tmp;
+    HIPCHK(ctx, tmp.reserve(tbytes));
+    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tbytes, keys.p, keys_out.p, vals.p, order->p, n, 0, 30,
+                                                   ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }

@@ -60,7 +60,8 @@ __global__ void __launch_bounds__(kBlock) k_icp_accum(GridDesc g, const float4* 
         }
         unsigned ex;
         NNBest b = nn_query(g, p.x, p.y, p.z, ex);
-        const float4 t = tgt[b.idx], n = tgt_n[b.idx];
+        const int bi = b.idx();
+        const float4 t = tgt[bi], n = tgt_n[bi];
         const float sx = p.x, sy = p.y, sz = p.z, dx = t.x, dy = t.y, dz = t.z, nx = n.x, ny = n.y, nz = n.z;
         const double a = (double)(nz * sy - ny * sz);
         const double bb = (double)(nx * sz - nz * sx);
@@ -73,7 +74,7 @@ __global__ void __launch_bounds__(kBlock) k_icp_accum(GridDesc g, const float4* 
         v[20] = (double)(nz * nz);
         const double d = (double)(nx * dx + ny * dy + nz * dz - nx * sx - ny * sy - nz * sz);
         v[21] = a * d; v[22] = bb * d; v[23] = c * d; v[24] = nx * d; v[25] = ny * d; v[26] = nz * d;
-        v[27] = (double)b.d2;
+        v[27] = (double)b.d2();
     }
     block_reduce_store(v, kNSums, partials + (size_t)blockIdx.x * kNSums);
 }
@@ -171,9 +172,10 @@ __global__ void __launch_bounds__(kBlock) k_vcm_accum(GridDesc g, const float4* 
         float4 q = src[i];
         unsigned ex;
         NNBest b = nn_query(g, q.x, q.y, q.z, ex);
-        match[i] = b.idx;
+        const int bi = b.idx();
+        match[i] = bi;
         double a[6], L;
-        vcm_row(q, tgt[b.idx], tgt_n[b.idx], a, &L);
+        vcm_row(q, tgt[bi], tgt_n[bi], a, &L);
         int k = 0;
         for (int r = 0; r < 6; ++r)
             for (int c = r; c < 6; ++c) v[k++] = a[r] * a[c];
@@ -254,7 +256,7 @@ int pw_icp_run(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const
                double euclid_eps, float* T16, int* iters_out) {
     for (int k = 0; k < 16; ++k) T16[k] = (k % 5 == 0) ? 1.f : 0.f;
     if (iters_out) *iters_out = 0;
-    if (ns < 3 || g.n <= 0) return PWICP_OK;      // min_number_correspondences_ = 3: no update
+    if (ns < 3 || g.fine.n <= 0) return PWICP_OK;      // min_number_correspondences_ = 3: no update
     const int nb = div_up(ns, kBlock);
     hipLaunchKernelGGL(k_icp_init, dim3(1), dim3(64), 0, ctx->stream, w->state.p);
     IcpState h;

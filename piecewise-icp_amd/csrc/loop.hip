@@ -7,6 +7,7 @@
 // runs the reference's distance-threshold schedule (Registration.cpp:891-935) verbatim.
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <new>
 
 #include "common.h"
@@ -94,56 +95,50 @@ __global__ void __launch_bounds__(kBlock) k_classify(
 
 // Order-preserving compaction of the stable patches (single block): list, point prefix, stable centroids with
 // normals (generateCentroidCloudWithPatchNormals semantics: (0,0,1) unless > 6 points and a valid normal).
+// Two exclusive scans (count, points) per 1024-patch chunk: wave shuffles + one LDS hop.
 __global__ void __launch_bounds__(1024) k_compact(int m2, const int* __restrict__ stable, const int* __restrict__ off2,
                                                   const float4* __restrict__ ct2, const float4* __restrict__ nrm2,
                                                   int* __restrict__ list, int* __restrict__ soff,
                                                   float4* __restrict__ stCT, float4* __restrict__ stN,
                                                   float4* __restrict__ wsrc, float4* __restrict__ wsrcn,
                                                   unsigned* __restrict__ scal) {
-    __shared__ int sh[1024];
+    __shared__ int wsum_n[16], wsum_p[16];
     __shared__ int carry_n, carry_p;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) { carry_n = 0; carry_p = 0; }
     __syncthreads();
     for (int base = 0; base < m2; base += 1024) {
         const int i = base + threadIdx.x;
         const int f = (i < m2) ? stable[i] : 0;
-        const int sz = f ? (off2[i + 1] - off2[i]) : 0;
-        // scan of flags
-        sh[threadIdx.x] = f;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            int t = (threadIdx.x >= o) ? sh[threadIdx.x - o] : 0;
-            __syncthreads();
-            sh[threadIdx.x] += t;
-            __syncthreads();
+        const int np = (i < m2) ? (off2[i + 1] - off2[i]) : 0;
+        const int sz = f ? np : 0;
+        int in = f, ip = sz;                       // inclusive scans inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int tn = __shfl_up(in, o), tp = __shfl_up(ip, o);
+            if (lane >= o) { in += tn; ip += tp; }
         }
-        const int pos = carry_n + sh[threadIdx.x] - f;
-        const int tot_n = sh[1023];
+        if (lane == 63) { wsum_n[wave] = in; wsum_p[wave] = ip; }
         __syncthreads();
-        // scan of sizes
-        sh[threadIdx.x] = sz;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            int t = (threadIdx.x >= o) ? sh[threadIdx.x - o] : 0;
-            __syncthreads();
-            sh[threadIdx.x] += t;
-            __syncthreads();
+        int on = 0, op = 0, totn = 0, totp = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) { on += wsum_n[w]; op += wsum_p[w]; }
+            totn += wsum_n[w]; totp += wsum_p[w];
         }
-        const int ppos = carry_p + sh[threadIdx.x] - sz;
-        const int tot_p = sh[1023];
+        const int pos = carry_n + on + in - f;
+        const int ppos = carry_p + op + ip - sz;
         if (f) {
             list[pos] = i;
             soff[pos] = ppos;
             const float4 c = ct2[i];
             float4 n = nrm2[i];
-            const int np = off2[i + 1] - off2[i];
             if (!(np > 6 && n.w != 0.0f)) n = make_float4(0.f, 0.f, 1.f, 0.f);
             n.w = 0.f;
             stCT[pos] = c; stN[pos] = n;
             wsrc[pos] = c; wsrcn[pos] = n;
         }
         __syncthreads();
-        if (threadIdx.x == 0) { carry_n += tot_n; carry_p += tot_p; }
+        if (threadIdx.x == 0) { carry_n += totn; carry_p += totp; }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -169,9 +164,11 @@ __global__ void __launch_bounds__(kBlock) k_transform(float4* __restrict__ p, in
     if (i < n) p[i] = xform_point(T.m, p[i]);
 }
 
-// transform + bounding box of the result (for the next iteration's octree box, R.cpp:881-886)
+// transform + bounding box of the result (for the next iteration's octree box, R.cpp:881-886).
+// min/max are exact whatever the reduction order: wave shuffles -> LDS -> one atomic set per block.
 __global__ void __launch_bounds__(kBlock) k_transform_bbox(float4* __restrict__ p, int n, Mat4 T, int apply,
                                                            unsigned* __restrict__ scal) {
+    __shared__ float sh[kBlock / 64][6];
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float4 v = p[i];
@@ -187,12 +184,17 @@ __global__ void __launch_bounds__(kBlock) k_transform_bbox(float4* __restrict__ 
             mn[d] = fminf(mn[d], __shfl_xor(mn[d], o));
             mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], o));
         }
+    const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0)
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            atomicMin(&scal[4 + d], f2ord_dev(mn[d]));
-            atomicMax(&scal[7 + d], f2ord_dev(mx[d]));
-        }
+        for (int d = 0; d < 3; ++d) { sh[wave][d] = mn[d]; sh[wave][3 + d] = mx[d]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float a = sh[0][threadIdx.x], b = sh[0][3 + threadIdx.x];
+        for (int w = 1; w < kBlock / 64; ++w) { a = fminf(a, sh[w][threadIdx.x]); b = fmaxf(b, sh[w][3 + threadIdx.x]); }
+        atomicMin(&scal[4 + threadIdx.x], f2ord_dev(a));
+        atomicMax(&scal[7 + threadIdx.x], f2ord_dev(b));
+    }
 }
 
 __global__ void k_iota_list(int* list, int* soff, const int* __restrict__ off, int m) {
@@ -257,6 +259,9 @@ struct pwicp_pair {
     PatchSet P2;
     DevBuf<float4> pat2_0, ct2_0, bp2_0;
     DevBuf<float4> nrm2;
+    DevBuf<int> pt_patch2;   // patch id of every source patch point
+    DevBuf<int> qorder;      // source patch points in Morton order of their initial target-grid cell
+    DevBuf<int> all_stable;  // all-ones flags (bench replay over every patch)
     // per-iteration work
     DevBuf<int> mCT, mBP, stable, list, soff;
     DevBuf<float> dCT, dBP, d2dense;
@@ -265,6 +270,9 @@ struct pwicp_pair {
     DevBuf<unsigned> scal, sel_scratch;
     DevBuf<float> sel_out;
     DevBuf<unsigned long long> examined;
+    // configuration of the first Stage-1 dense NN launch of the last run (replayed by bench_dense_nn)
+    DevBuf<int> list0, soff0;
+    int ns0 = 0, nsp0 = 0;
     std::vector<hipEvent_t> ev;
     ~pwicp_pair() {
         for (auto e : ev) (void)hipEventDestroy(e);
@@ -291,8 +299,18 @@ int finish_create(pwicp_pair* pr) {
     if (m1 > 0)
         hipLaunchKernelGGL(k_with_norm, dim3(div_up(m1, kBlock)), dim3(kBlock), 0, ctx->stream, m1, pr->P1.off.p,
                            pr->nrm1.p, pr->ct1n.p);
-    PWCHK(pw_grid_build(ctx, pr->cloud1.p, pr->n1, 2.0f * pr->prm.Res1, &pr->g_c1));
-    PWCHK(pw_grid_build(ctx, pr->P1.ct.p, m1, pr->prm.SVRes1, &pr->g_ct1));
+    // cell edges: dense cloud grid = 2 x point spacing (27-cell stencil ~ 40-50 points); centroid grid = 4 x patch
+    // size, so that the far queries of displaced (unstable) patches still resolve within one or two rings.
+    // Tuning knobs for experiments only (results do not depend on them; the search is exact for any edge).
+    float f_dense = 2.0f, f_ct = 4.0f;
+    if (const char* e = getenv("PWICP_DENSE_CELL_FACTOR")) { float v = (float)atof(e); if (v > 0.f) f_dense = v; }
+    if (const char* e = getenv("PWICP_CT_CELL_FACTOR")) { float v = (float)atof(e); if (v > 0.f) f_ct = v; }
+    PWCHK(pw_grid_build(ctx, pr->cloud1.p, pr->n1, f_dense * pr->prm.Res1, &pr->g_c1));
+    PWCHK(pw_grid_build(ctx, pr->P1.ct.p, m1, f_ct * pr->prm.SVRes1, &pr->g_ct1));
+    // dense-query order (one-off): Morton order of the source patch points in the target grid
+    HIPCHK(ctx, pr->pt_patch2.reserve((size_t)std::max(pr->P2.tot, 1)));
+    PWCHK(pw_point_patch_ids_launch(ctx, pr->P2.off.p, m2, pr->pt_patch2.p));
+    PWCHK(pw_morton_order(ctx, pr->g_c1.d, pr->P2.pat.p, pr->P2.tot, &pr->qorder));
     // pristine source copies
     HIPCHK(ctx, pr->cloud2_0.reserve((size_t)std::max(pr->n2, 1)));
     HIPCHK(ctx, pr->pat2_0.reserve((size_t)std::max(pr->P2.tot, 1)));
@@ -312,6 +330,8 @@ int finish_create(pwicp_pair* pr) {
     HIPCHK(ctx, pr->stable.reserve(M2));
     HIPCHK(ctx, pr->list.reserve(M2 + 1));
     HIPCHK(ctx, pr->soff.reserve(M2 + 1));
+    HIPCHK(ctx, pr->list0.reserve(M2 + 1));
+    HIPCHK(ctx, pr->soff0.reserve(M2 + 1));
     HIPCHK(ctx, pr->stCT.reserve(M2));
     HIPCHK(ctx, pr->stN.reserve(M2));
     HIPCHK(ctx, pr->d2dense.reserve((size_t)std::max(std::max(pr->P2.tot, pr->n2), 1)));
@@ -455,11 +475,12 @@ static int read_scal(pwicp_pair* pr, unsigned* h) {
     return PWICP_OK;
 }
 
-static int select_p75(pwicp_pair* pr, int n, double* out) {
+// n_slots entries in d2dense of which n_valid are real distances (the rest carry the sentinel)
+static int select_p75(pwicp_pair* pr, int n_slots, int n_valid, double* out) {
     pwicp_context* ctx = pr->ctx;
-    int k = (int)((float)n * 0.75f);            // C.cpp:177
-    if (k >= n) k = n - 1;
-    PWCHK(pw_select_kth_launch(ctx, pr->d2dense.p, n, k, pr->sel_scratch.p, pr->sel_out.p));
+    int k = (int)((float)n_valid * 0.75f);      // C.cpp:177
+    if (k >= n_valid) k = n_valid - 1;
+    PWCHK(pw_select_kth_launch(ctx, pr->d2dense.p, n_slots, k, pr->sel_scratch.p, pr->sel_out.p));
     float v = 0.f;
     HIPCHK(ctx, hipMemcpyAsync(&v, pr->sel_out.p, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -483,7 +504,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     if (!prm.isManualDTinit) {
         PWCHK(pw_nn_launch(ctx, pr->g_c1.d, pr->cloud2.p, pr->n2, nullptr, pr->d2dense.p, nullptr));
         double d75 = 0;
-        PWCHK(select_p75(pr, pr->n2, &d75));
+        PWCHK(select_p75(pr, pr->n2, pr->n2, &d75));
         DTinit = (float)(d75 * 3.0);
     }
     float currDT = DTinit;
@@ -498,7 +519,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         static const unsigned init[16] = {0xffffffffu, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0, 0, 0, 0, 0, 0};
         HIPCHK(ctx, hipMemcpyAsync(pr->scal.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
         Mat4 I{};
-        hipLaunchKernelGGL(k_transform_bbox, dim3(std::min(div_up(pr->n2, kBlock), ctx->n_cu * 8)), dim3(kBlock), 0,
+        hipLaunchKernelGGL(k_transform_bbox, dim3(std::min(div_up(pr->n2, kBlock), ctx->n_cu * 4)), dim3(kBlock), 0,
                            ctx->stream, pr->cloud2.p, pr->n2, I, 0, pr->scal.p);
         PWCHK(read_scal(pr, hs));
     }
@@ -571,11 +592,15 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
             ev_kind.push_back({n_ev, 0});
             n_ev += 2;
             HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
-            PWCHK(pw_nn_patches_launch(ctx, pr->g_c1.d, pr->P2.pat.p, pr->P2.off.p, pr->list.p, pr->soff.p, ns, nsp,
-                                       pr->d2dense.p, pr->examined.p));
+            PWCHK(pw_nn_dense_lds_launch(ctx, pr->g_c1.d, pr->P2.pat.p, pr->qorder.p, pr->pt_patch2.p, pr->stable.p,
+                                         pr->P2.tot, pr->d2dense.p, pr->examined.p));
             HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+            if (res->n_dense_nn_launches == 0) {      // remember the first launch for stand-alone replays
+                HIPCHK(ctx, hipMemcpyAsync(pr->list0.p, pr->stable.p, (size_t)m2 * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+                pr->ns0 = ns; pr->nsp0 = nsp;
+            }
             double Dist75 = 0;
-            PWCHK(select_p75(pr, nsp, &Dist75));
+            PWCHK(select_p75(pr, pr->P2.tot, nsp, &Dist75));
             res->n_corr += nsp; res->n_corr_dense += nsp; res->n_dense_nn_launches++;
             res->d75[k] = Dist75;
             if ((double)currDT > Dist75) currDT = (float)Dist75; else stage2 = true;
@@ -600,7 +625,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
             static const unsigned initb[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
             HIPCHK(ctx, hipMemcpyAsync(pr->scal.p + 4, initb, sizeof(initb), hipMemcpyHostToDevice, ctx->stream));
         }
-        hipLaunchKernelGGL(k_transform_bbox, dim3(std::min(div_up(pr->n2, kBlock), ctx->n_cu * 8)), dim3(kBlock), 0,
+        hipLaunchKernelGGL(k_transform_bbox, dim3(std::min(div_up(pr->n2, kBlock), ctx->n_cu * 4)), dim3(kBlock), 0,
                            ctx->stream, pr->cloud2.p, pr->n2, T, 1, pr->scal.p);
         if (m2 > 0) {
             hipLaunchKernelGGL(k_transform, dim3(div_up(m2, kBlock)), dim3(kBlock), 0, ctx->stream, pr->P2.ct.p, m2, T);
@@ -643,30 +668,39 @@ int pwicp_pair_bench_dense_nn(pwicp_pair* pr, int n_launches, double* ms_per_lau
     if (!pr || n_launches <= 0) return PWICP_E_INVALID;
     pwicp_context* ctx = pr->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    // Replays the first Stage-1 dense launch of the last pwicp_pair_run (same stable flags) on the pristine
+    // source patch points; over ALL source patches if no run happened yet.
     const int m2 = pr->P2.m, tot = pr->P2.tot;
     if (m2 <= 0 || tot <= 0) { ctx->set_err("bench_dense_nn: no source patches"); return PWICP_E_INVALID; }
-    hipLaunchKernelGGL(k_iota_list, dim3(div_up(m2 + 1, kBlock)), dim3(kBlock), 0, ctx->stream, pr->list.p, pr->soff.p,
-                       pr->P2.off.p, m2);
+    const int* flags = pr->list0.p;
+    int npts = pr->nsp0;
+    if (pr->ns0 <= 0) {
+        HIPCHK(ctx, pr->all_stable.reserve((size_t)m2));
+        std::vector<int> ones((size_t)m2, 1);
+        HIPCHK(ctx, hipMemcpy(pr->all_stable.p, ones.data(), (size_t)m2 * sizeof(int), hipMemcpyHostToDevice));
+        flags = pr->all_stable.p;
+        npts = tot;
+    }
     HIPCHK(ctx, hipMemsetAsync(pr->examined.p, 0, sizeof(unsigned long long), ctx->stream));
     // warm-up launch (also measures Kbar)
-    PWCHK(pw_nn_patches_launch(ctx, pr->g_c1.d, pr->P2.pat.p, pr->P2.off.p, pr->list.p, pr->soff.p, m2, tot,
-                               pr->d2dense.p, pr->examined.p));
+    PWCHK(pw_nn_dense_lds_launch(ctx, pr->g_c1.d, pr->pat2_0.p, pr->qorder.p, pr->pt_patch2.p, flags, tot,
+                                 pr->d2dense.p, pr->examined.p));
     unsigned long long ex = 0;
     HIPCHK(ctx, hipMemcpyAsync(&ex, pr->examined.p, sizeof(ex), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     hipEvent_t e0 = pr->event(0), e1 = pr->event(1);
     HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
     for (int i = 0; i < n_launches; ++i)
-        PWCHK(pw_nn_patches_launch(ctx, pr->g_c1.d, pr->P2.pat.p, pr->P2.off.p, pr->list.p, pr->soff.p, m2, tot,
-                                   pr->d2dense.p, nullptr));
+        PWCHK(pw_nn_dense_lds_launch(ctx, pr->g_c1.d, pr->pat2_0.p, pr->qorder.p, pr->pt_patch2.p, flags, tot,
+                                     pr->d2dense.p, nullptr));
     HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
     HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
     if (ms_per_launch) *ms_per_launch = (double)ms / n_launches;
-    if (n_queries) *n_queries = tot;
-    if (kbar) *kbar = (double)ex / (double)tot;
-    if (cell_edge) *cell_edge = pr->g_c1.d.h;
+    if (n_queries) *n_queries = npts;
+    if (kbar) *kbar = (double)ex / (double)npts;
+    if (cell_edge) *cell_edge = pr->g_c1.d.fine.h;
     return PWICP_OK;
 }
 

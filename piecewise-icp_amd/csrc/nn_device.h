@@ -1,5 +1,17 @@
-// Device-side exact 1-NN search over a GridDesc (shared by the search, ICP and VCM kernels).
-// See grid.hip for the exactness argument.
+// Device-side exact 1-NN search over a two-level uniform grid (shared by the search, ICP and VCM kernels).
+//
+// Result = argmin over ALL target points of the float expression ((dx*dx) + dy*dy) + dz*dz
+// (flann::L2_Simple<float>), ties to the lowest index.  Three stages, each exact on its own terms:
+//   1. the 27-cell stencil of the FINE level (9 contiguous row ranges).  Done if the best float d2 is provably
+//      below that of every point outside the stencil (conservative bound incl. cell-assignment rounding slack).
+//   2. otherwise, with a candidate at distance rho: every closer point lies in the cube [q-rho, q+rho]; scan
+//      exactly the COARSE cells that cube touches (a handful of row ranges) — no ring-by-ring growth.
+//   3. with no candidate (empty stencil) or an oversized cube: block/shell expansion on the coarse level until
+//      the same kind of bound holds or the whole grid has been scanned.
+//
+// Memory-level parallelism: the per-query work is a chain of dependent loads (cell_start -> points), so rows
+// are processed in batches — all begin/end loads of a batch are issued before the first point load, and the
+// point loop is unrolled by two with both loads up front.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -13,70 +25,164 @@ __device__ __forceinline__ int cell_of(float p, float o, float inv_h) {
     return (t == t) ? (int)t : 0;
 }
 
-// ---- exact 1-NN ------------------------------------------------------------------------------------
+// Best candidate as ONE 64-bit key: (float bits of d2) << 32 | index.  d2 >= +0, so the unsigned order of the
+// key is the lexicographic order (d2, index): a single unsigned min implements "smaller distance, ties to the
+// lowest index" without branches.  NaN distances (bits > +inf) can never win, as with `d2 < best`.
 struct NNBest {
-    float d2;
-    int idx;
+    unsigned long long key;
+    __device__ __forceinline__ float d2() const { return __uint_as_float((unsigned)(key >> 32)); }
+    __device__ __forceinline__ int idx() const { return (int)(unsigned)(key & 0xffffffffull); }
+    __device__ __forceinline__ bool found() const { return (unsigned)(key & 0xffffffffull) != 0x7fffffffu; }
 };
+
+constexpr int kNoIdx = 0x7fffffff;
+constexpr unsigned long long kKeyInit = (0x7f800000ull << 32) | 0x7fffffffull;    // (+inf, no index)
+
+__device__ __forceinline__ void nn_consider(const float4 p, float qx, float qy, float qz, NNBest& b) {
+    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+    float d2 = dx * dx;     // flann::L2_Simple<float>: result += diff*diff, x then y then z
+    d2 = d2 + dy * dy;
+    d2 = d2 + dz * dz;
+    const unsigned long long k = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)__float_as_uint(p.w);
+    b.key = (k < b.key) ? k : b.key;
+}
 
 __device__ __forceinline__ void scan_points(const float4* __restrict__ pts, int lo, int hi, float qx, float qy,
                                             float qz, NNBest& b) {
-    for (int j = lo; j < hi; ++j) {
-        float4 p = pts[j];
-        float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-        float d2 = dx * dx;     // flann::L2_Simple<float>: result += diff*diff, x then y then z
-        d2 = d2 + dy * dy;
-        d2 = d2 + dz * dz;
-        int id = __float_as_int(p.w);
-        if (d2 < b.d2 || (d2 == b.d2 && id < b.idx)) { b.d2 = d2; b.idx = id; }
+    int j = lo;
+    for (; j + 1 < hi; j += 2) {
+        const float4 p0 = pts[j], p1 = pts[j + 1];
+        nn_consider(p0, qx, qy, qz, b);
+        nn_consider(p1, qx, qy, qz, b);
     }
+    if (j < hi) nn_consider(pts[j], qx, qy, qz, b);
 }
 
-// points of the x-range [x0,x1] (clipped) of row (y,z); returns #points scanned
-__device__ __forceinline__ int scan_row(const GridDesc& g, int y, int z, int x0, int x1, float qx, float qy,
-                                        float qz, NNBest& b) {
-    if (y < 0 || y >= g.ny || z < 0 || z >= g.nz) return 0;
+// [begin,end) of the points of cells x0..x1 (clipped) of row (y,z); empty if the row is outside the grid
+__device__ __forceinline__ void row_range(const GridLevel& g, int y, int z, int x0, int x1, int& lo, int& hi) {
+    lo = 0; hi = 0;
+    if (y < 0 || y >= g.ny || z < 0 || z >= g.nz) return;
     x0 = max(x0, 0);
     x1 = min(x1, g.nx - 1);
-    if (x0 > x1) return 0;
-    int row = (z * g.ny + y) * g.nx;
-    int lo = g.cell_start[row + x0], hi = g.cell_start[row + x1 + 1];
-    scan_points(g.pts, lo, hi, qx, qy, qz, b);
-    return hi - lo;
+    if (x0 > x1) return;
+    const int row = (z * g.ny + y) * g.nx;
+    lo = g.cell_start[row + x0];
+    hi = g.cell_start[row + x1 + 1];
 }
 
-__device__ __forceinline__ NNBest nn_query(const GridDesc& g, float qx, float qy, float qz, unsigned& examined) {
-    NNBest b;
-    b.d2 = INFINITY;
-    b.idx = 0x7fffffff;
-    if (g.n <= 0) { b.idx = -1; return b; }
-    int cx = cell_of(qx, g.ox, g.inv_h), cy = cell_of(qy, g.oy, g.inv_h), cz = cell_of(qz, g.oz, g.inv_h);
-    // Chebyshev distance (in cells) from the query cell to the grid box, and the ring that covers it all
-    int ex = max(0, max(-cx, cx - (g.nx - 1)));
-    int ey = max(0, max(-cy, cy - (g.ny - 1)));
-    int ez = max(0, max(-cz, cz - (g.nz - 1)));
-    int r = max(max(ex, ey), max(ez, 1));
-    int rcover = max(max(max(cx, g.nx - 1 - cx), max(cy, g.ny - 1 - cy)), max(cz, g.nz - 1 - cz));
+// all rows (y in [y0,y1], z in [z0,z1]) with the x-range [x0,x1]
+__device__ __forceinline__ unsigned scan_box(const GridLevel& g, int x0, int x1, int y0, int y1, int z0, int z1,
+                                             float qx, float qy, float qz, NNBest& b) {
     unsigned cnt = 0;
-    // full block of radius r
-    for (int dz = -r; dz <= r; ++dz)
-        for (int dy = -r; dy <= r; ++dy) cnt += scan_row(g, cy + dy, cz + dz, cx - r, cx + r, qx, qy, qz, b);
-    for (;;) {
-        float bound = (float)r * g.h - 2.0f * g.slack;
-        if (b.idx != 0x7fffffff && bound > 0.0f && b.d2 < bound * bound * 0.99999f) break;
-        if (r >= rcover) break;
-        ++r;
-        for (int dz = -r; dz <= r; ++dz)
-            for (int dy = -r; dy <= r; ++dy) {
+    const int wy = y1 - y0 + 1;
+    const int nrows = wy * (z1 - z0 + 1);
+    for (int t0 = 0; t0 < nrows; t0 += 4) {
+        int lo[4], hi[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = t0 + k;
+            lo[k] = hi[k] = 0;
+            if (t < nrows) row_range(g, y0 + t % wy, z0 + t / wy, x0, x1, lo[k], hi[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            scan_points(g.pts, lo[k], hi[k], qx, qy, qz, b);
+            cnt += (unsigned)(hi[k] - lo[k]);
+        }
+    }
+    return cnt;
+}
+
+// the shell of Chebyshev radius r around (cx,cy,cz)
+__device__ __forceinline__ unsigned scan_shell(const GridLevel& g, int cx, int cy, int cz, int r, float qx, float qy,
+                                               float qz, NNBest& b) {
+    unsigned cnt = 0;
+    const int w = 2 * r + 1;
+    const int nrows = w * w;
+    for (int t0 = 0; t0 < nrows; t0 += 4) {
+        int lo[8], hi[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = t0 + k;
+            lo[2 * k] = hi[2 * k] = lo[2 * k + 1] = hi[2 * k + 1] = 0;
+            if (t < nrows) {
+                const int dz = t / w - r, dy = t % w - r;
                 if (dz == -r || dz == r || dy == -r || dy == r) {
-                    cnt += scan_row(g, cy + dy, cz + dz, cx - r, cx + r, qx, qy, qz, b);
+                    row_range(g, cy + dy, cz + dz, cx - r, cx + r, lo[2 * k], hi[2 * k]);
                 } else {
-                    cnt += scan_row(g, cy + dy, cz + dz, cx - r, cx - r, qx, qy, qz, b);
-                    cnt += scan_row(g, cy + dy, cz + dz, cx + r, cx + r, qx, qy, qz, b);
+                    row_range(g, cy + dy, cz + dz, cx - r, cx - r, lo[2 * k], hi[2 * k]);
+                    row_range(g, cy + dy, cz + dz, cx + r, cx + r, lo[2 * k + 1], hi[2 * k + 1]);
                 }
             }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            scan_points(g.pts, lo[k], hi[k], qx, qy, qz, b);
+            cnt += (unsigned)(hi[k] - lo[k]);
+        }
     }
-    if (b.idx == 0x7fffffff) b.idx = -1;
+    return cnt;
+}
+
+// true when every point outside the scanned block of Chebyshev radius r has a larger float d2 than b
+__device__ __forceinline__ bool nn_resolved(const GridLevel& g, int r, const NNBest& b) {
+    const float bound = (float)r * g.h - 2.0f * g.slack;
+    return b.found() && bound > 0.0f && b.d2() < bound * bound * 0.99999f;
+}
+
+// stage 3: block of radius r0 (where the grid starts) then shell by shell, on one level
+__device__ __forceinline__ unsigned nn_expand(const GridLevel& g, float qx, float qy, float qz, NNBest& b) {
+    const int cx = cell_of(qx, g.ox, g.inv_h), cy = cell_of(qy, g.oy, g.inv_h), cz = cell_of(qz, g.oz, g.inv_h);
+    const int ex = max(0, max(-cx, cx - (g.nx - 1)));
+    const int ey = max(0, max(-cy, cy - (g.ny - 1)));
+    const int ez = max(0, max(-cz, cz - (g.nz - 1)));
+    int r = max(max(ex, ey), max(ez, 1));
+    const int rcover = max(max(max(cx, g.nx - 1 - cx), max(cy, g.ny - 1 - cy)), max(cz, g.nz - 1 - cz));
+    unsigned cnt = scan_box(g, cx - r, cx + r, cy - r, cy + r, cz - r, cz + r, qx, qy, qz, b);
+    for (;;) {
+        if (nn_resolved(g, r, b)) break;
+        if (r >= rcover) break;
+        ++r;
+        cnt += scan_shell(g, cx, cy, cz, r, qx, qy, qz, b);
+    }
+    return cnt;
+}
+
+__device__ __forceinline__ NNBest nn_query(const GridDesc& gd, float qx, float qy, float qz, unsigned& examined) {
+    const GridLevel& g = gd.fine;
+    NNBest b;
+    b.key = kKeyInit;
+    examined = 0;
+    if (g.n <= 0) return b;
+    unsigned cnt = 0;
+    // ---- stage 1: fine 27-cell stencil -------------------------------------------------------------------
+    {
+        const int cx = cell_of(qx, g.ox, g.inv_h), cy = cell_of(qy, g.oy, g.inv_h), cz = cell_of(qz, g.oz, g.inv_h);
+        int lo[9], hi[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) row_range(g, cy + (k % 3) - 1, cz + (k / 3) - 1, cx - 1, cx + 1, lo[k], hi[k]);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            scan_points(g.pts, lo[k], hi[k], qx, qy, qz, b);
+            cnt += (unsigned)(hi[k] - lo[k]);
+        }
+        if (nn_resolved(g, 1, b)) { examined = cnt; return b; }
+    }
+    const GridLevel& c = gd.coarse;
+    // ---- stage 2: candidate known -> scan the coarse cells touching the cube [q - rho, q + rho] ------------
+    if (b.found()) {
+        const float rho = sqrtf(b.d2()) * 1.00001f + 2.0f * c.slack;
+        const int x0 = max(cell_of(qx - rho, c.ox, c.inv_h), 0), x1 = min(cell_of(qx + rho, c.ox, c.inv_h), c.nx - 1);
+        const int y0 = max(cell_of(qy - rho, c.oy, c.inv_h), 0), y1 = min(cell_of(qy + rho, c.oy, c.inv_h), c.ny - 1);
+        const int z0 = max(cell_of(qz - rho, c.oz, c.inv_h), 0), z1 = min(cell_of(qz + rho, c.oz, c.inv_h), c.nz - 1);
+        if ((y1 - y0 + 1) * (z1 - z0 + 1) <= 64) {
+            if (x0 <= x1 && y0 <= y1 && z0 <= z1) cnt += scan_box(c, x0, x1, y0, y1, z0, z1, qx, qy, qz, b);
+            examined = cnt;
+            return b;
+        }
+    }
+    // ---- stage 3: expansion on the coarse level ---------------------------------------------------------------
+    cnt += nn_expand(c, qx, qy, qz, b);
     examined = cnt;
     return b;
 }
@@ -88,4 +194,3 @@ __device__ __forceinline__ void add_examined(unsigned long long* ctr, unsigned c
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
     if ((threadIdx.x & 63) == 0) atomicAdd(ctr, c);
 }
-

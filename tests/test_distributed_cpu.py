@@ -1,0 +1,89 @@
+"""4D series: pair schedule, sharding, gather (world_size 2, gloo, CPU) and composition to the reference."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+import _golden as G
+from pwicp_amd import fourd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_pair_schedule_modes():
+    assert fourd.pair_schedule(0, 5, 0) == [(0, 1), (0, 2), (0, 3), (0, 4)]
+    assert fourd.pair_schedule(0, 6, 2) == [(0, 1), (0, 2), (1, 3), (2, 4), (3, 5)]
+    assert fourd.pair_schedule(0, 4, -1, {1: 0, 2: 0, 3: 1}) == [(0, 1), (0, 2), (1, 3)]
+    assert fourd.shard(list(range(5)), 1, 2) == [(1, 1), (3, 3)]
+
+
+def _read_matrices(path, n):
+    vals = open(path).read().split()
+    T, V, pos = [], [], 0
+    for _ in range(n):
+        pos += 1
+        T.append(np.array(vals[pos:pos + 16], float).reshape(4, 4).astype(np.float32)); pos += 16
+        V.append(np.array(vals[pos:pos + 36], float).reshape(6, 6)); pos += 36
+    return T, V
+
+
+def test_compose_adaptive_matches_reference_files():
+    """calTransToReferenceEpoch on the reference's own TransMatrices.txt reproduces its TransMatrices_toRef.txt
+    with the adaptive pair map recovered in SURVEY §4."""
+    gold = os.path.join(G.GOLD, "reference_results")
+    T, V = _read_matrices(os.path.join(gold, "TransMatrices.txt"), 19)
+    Tr, Vr = _read_matrices(os.path.join(gold, "TransMatrices_toRef.txt"), 19)
+    amap = {2: 1, 3: 1, 4: 1, 5: 1, 6: 1, 7: 3, 8: 4, 9: 4, 10: 5, 11: 6, 12: 6, 13: 7, 14: 9, 15: 12, 16: 13, 17: 14,
+            18: 14, 19: 14, 20: 14}
+    rel = {s - 1: t - 1 for s, t in amap.items()}          # relative to startEpoch (R.cpp:570)
+    T2, V2 = fourd.compose_to_reference(T, V, -1, rel)
+    for i in range(19):
+        assert np.abs(T2[i] - Tr[i]).max() < 5e-6
+        assert np.allclose(V2[i], Vr[i], rtol=2e-3, atol=3e-12)
+
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(%r, "piecewise-icp_amd"))
+    from pwicp_amd import fourd
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    pairs = fourd.pair_schedule(0, 6, 0)                      # 5 pairs over 2 ranks
+    mine = fourd.shard(pairs, rank, world)
+    recs = []
+    for pid, (t, s) in mine:                                  # stand-in registrar: deterministic function of the pair
+        T = np.eye(4, dtype=np.float32); T[0, 3] = 0.5 * s + t
+        V = np.full((6, 6), float(pid))
+        recs.append(fourd.pack_record(pid, 0, 3 + pid, 7, T, V, 1000 * pid))
+    table = fourd.gather_records(recs, len(pairs), world, dist=dist)
+    assert sorted(table) == list(range(5)), sorted(table)
+    for pid, (t, s) in enumerate(pairs):
+        r = table[pid]
+        assert r["n_outer"] == 3 + pid and r["n_corr"] == 1000 * pid and abs(r["T"][3] - (0.5 * s + t)) < 1e-6
+        assert r["VCM"][35] == float(pid)
+    dist.barrier()
+    if rank == 0:
+        print("GATHER_OK")
+    dist.destroy_process_group()
+''')
+
+
+def test_shard_and_gather_world2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "GATHER_OK" in out.stdout
+
+
+def test_record_is_384_bytes():
+    r = fourd.pack_record(3, 0, 4, 9, np.eye(4), np.zeros((6, 6)), 12345)
+    assert r.nbytes == 384 == fourd.RECORD_BYTES

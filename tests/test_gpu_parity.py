@@ -1,0 +1,270 @@
+"""Parity of the HIP hot path (through the C ABI) against the CPU oracle on identical inputs.
+Integer / index results and every float the control flow depends on must be BIT-EXACT; the final transform is
+additionally checked against north_star's tolerance (1e-5 rad / 1e-4 m)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import _data
+import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+ANG_TOL, TR_TOL = 1e-5, 1e-4     # BASELINE.json north_star
+
+
+def test_native_library_is_the_one_running(ctx):
+    import pwicp_amd
+    assert os.path.exists(pwicp_amd.lib_path())
+    maps = open("/proc/self/maps").read()
+    assert "libpwicp.so" in maps
+
+
+@pytest.mark.parametrize("n", [1, 7, 1000, 50000])
+def test_nn_bit_exact(ctx, oracle, n):
+    rng = np.random.default_rng(n)
+    tgt, src, _ = _data.pair(max(n, 400))
+    tgt = tgt[:n] if n < 400 else tgt
+    q = src[: max(n, 64)].copy()
+    q[:10] += np.float32(2.0)                      # far and outside the bounding box
+    q[10:20, 0] -= np.float32(9.0)
+    idx, d2 = ctx.determineCorrespondences(tgt, q)
+    oi, od = oracle.nn1(tgt, q)
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(d2, od)
+
+
+def test_nn_ties_duplicates_and_empty_query(ctx, oracle):
+    t = np.array([[0, 0, 0], [1, 0, 0], [1, 0, 0], [-1, 0, 0], [1, 0, 0]], np.float32)
+    q = np.array([[1, 0, 0], [0.5, 0, 0], [0, 0, 0], [100, 100, 100]], np.float32)
+    idx, d2 = ctx.determineCorrespondences(t, q)
+    oi, od = oracle.nn1(t, q)
+    assert list(idx) == list(oi) == [1, 0, 0, 1]
+    assert np.array_equal(d2, od)
+    idx, d2 = ctx.determineCorrespondences(t, np.zeros((0, 3), np.float32))
+    assert len(idx) == 0
+
+
+def test_nn_large_offset_coordinates(ctx, oracle):
+    """Unreduced coordinates (+1e4 m, the rockfall-like case of SURVEY §8d cfg 3): float cell assignment slack."""
+    tgt, src, _ = _data.pair(30000, offset=(1.0e4, -2.0e4, 3.0e3), reduce=False)
+    idx, d2 = ctx.determineCorrespondences(tgt, src)
+    oi, od = oracle.nn1(tgt, src)
+    assert np.array_equal(d2, od)
+    assert np.array_equal(idx, oi)
+
+
+def test_percentile_and_overlap(ctx, oracle):
+    tgt, src, _ = _data.pair(60000)
+    p = ctx.calPercentileDistBetween2PC(tgt, src, 0.75)
+    po = oracle.lib().orc_percentile_dist(oracle._p(oracle.f4(tgt)), len(tgt), oracle._p(oracle.f4(src)), len(src), 0.75)
+    assert p == po
+    r = ctx.calOverlapRatioByC2Cdist(tgt, src, 0.01)
+    ro = oracle.lib().orc_overlap_ratio(oracle._p(oracle.f4(tgt)), len(tgt), oracle._p(oracle.f4(src)), len(src), 0.01)
+    assert r == ro
+
+
+def _labels(cloud, which):
+    from pwicp_amd import synth
+    import _oracle as O
+    if which == "ref" and O.ref_frontend_available():
+        return O.ref_frontend(cloud, 10 * _data.R)
+    return synth.grid_labels(cloud, 10 * _data.R)
+
+
+@pytest.mark.parametrize("n,which", [(20000, "ref"), (100000, "grid")])
+def test_select_patches_and_normals_bit_exact(ctx, oracle, n, which):
+    tgt, src, _ = _data.pair(n)
+    lab, nsv = _labels(src, which)
+    Po = oracle.select_patches(src, lab, nsv)
+    Pg = ctx.selectPatches(src, lab, nsv)
+    assert np.array_equal(Po.off, Pg["off"])
+    for k in ("pat", "src", "ct", "bp", "bpstd", "ctstd"):
+        assert np.array_equal(getattr(Po, k), Pg[k]), k
+    nrm, ok = ctx.patchNormals(Po.pat, Po.off)
+    for i in range(0, Po.m, max(1, Po.m // 200)):
+        seg = np.ascontiguousarray(Po.pat[Po.off[i]:Po.off[i + 1]])
+        a, b, c = C.c_float(), C.c_float(), C.c_float()
+        o = oracle.lib().orc_cal_patch_normal(oracle._p(seg), len(seg), C.byref(a), C.byref(b), C.byref(c))
+        assert o == ok[i]
+        assert (a.value, b.value, c.value) == tuple(nrm[i, :3])
+
+
+def test_select_patches_edge_cases(ctx, oracle):
+    tgt, _, _ = _data.pair(5000)
+    # everything in one label; tiny labels; labels with no points
+    for lab, nsv in [(np.zeros(len(tgt), np.int32), 1), (np.arange(len(tgt), dtype=np.int32) % 997, 997),
+                     ((np.arange(len(tgt), dtype=np.int32) % 3) * 5, 20)]:
+        Po = oracle.select_patches(tgt, lab, nsv)
+        Pg = ctx.selectPatches(tgt, lab, nsv)
+        assert np.array_equal(Po.off, Pg["off"]) and np.array_equal(Po.pat, Pg["pat"])
+    import pwicp_amd
+    with pytest.raises(pwicp_amd.PwicpError):
+        ctx.selectPatches(tgt, np.full(len(tgt), 7, np.int32), 3)      # label out of range -> error, not UB
+
+
+def test_inner_icp_and_vcm(ctx, oracle):
+    tgt, src, _ = _data.pair(40000)
+    lab1, n1 = _labels(tgt, "grid")
+    lab2, n2 = _labels(src, "grid")
+    P1 = oracle.select_patches(tgt, lab1, n1)
+    P2 = oracle.select_patches(src, lab2, n2)
+    n1v, _ = ctx.patchNormals(P1.pat, P1.off)
+    n2v, _ = ctx.patchNormals(P2.pat, P2.off)
+    Tg, it = ctx.P2PICPwithPatchNormal(P1.ct, n1v, P2.ct, n2v, 1e-6)
+    To = np.zeros(16, np.float32)
+    ito = oracle.lib().orc_p2p_icp(oracle._p(oracle.f4(P1.ct)), oracle._p(oracle.f4(n1v)), P1.m, oracle._p(oracle.f4(P2.ct)),
+                                   oracle._p(oracle.f4(n2v)), P2.m, 1e-6, oracle._p(To), None)
+    assert it == ito
+    assert np.abs(_data.euler(Tg) - _data.euler(To)).max() < ANG_TOL
+    assert np.abs(Tg[:3, 3] - To.reshape(4, 4)[:3, 3]).max() < TR_TOL
+    assert np.abs(Tg.reshape(16) - To).max() <= 2 ** -23           # at most one float ulp of ~1
+    Vg = ctx.calTransParaVCM(P1.ct, n1v, P2.ct)
+    Vo = np.zeros(36)
+    oracle.lib().orc_cal_trans_para_vcm(oracle._p(oracle.f4(P1.ct)), oracle._p(oracle.f4(n1v)), P1.m,
+                                        oracle._p(oracle.f4(P2.ct)), P2.m, oracle._p(Vo, oracle.dp))
+    assert np.allclose(Vg.reshape(36), Vo, rtol=1e-9, atol=1e-18)
+
+
+def _loop_both(ctx, oracle, tgt, src, l1, n1, l2, n2, manual=True):
+    import pwicp_amd as P
+    R = _data.R
+    prm = _data.params(manual)
+    pair = P.Pair(ctx, tgt, l1, n1, src, l2, n2, prm)
+    res = pair.run(check=False)
+    P1 = oracle.select_patches(tgt, l1, n1)
+    P2 = oracle.select_patches(src, l2, n2)
+    io = oracle.run_loop(tgt, src, P1, P2, R, R, 10 * R, 10 * R, 10 * R, 0.8 * R, manual_dt=manual)
+    return pair, res, io
+
+
+def _assert_loop_parity(res, io):
+    assert res.status == 0 and io.status == 0
+    assert res.n_outer == io.n_outer
+    k = io.n_outer
+    assert list(res.n_inner[:k]) == list(io.n_inner[:k])
+    assert list(res.n_stable[:k]) == list(io.n_stable[:k])
+    assert list(res.n_stable_pts[:k]) == list(io.n_stable_pts[:k])
+    assert [float(x) for x in res.DTseries[:k + 1]] == [float(x) for x in io.DTseries[:k + 1]]      # bit-exact floats
+    assert [res.d75[i] for i in range(k)] == [io.d75[i] for i in range(k)]
+    assert [float(res.LoDmin[i]) for i in range(k)] == [float(io.LoDmin[i]) for i in range(k)]
+    assert [float(res.maxBB[i]) for i in range(k)] == [float(io.maxBB[i]) for i in range(k)]
+    assert res.n_corr == io.n_corr
+    Tg = np.array(res.T16, np.float64).reshape(4, 4)
+    To = np.array(io.T16, np.float64).reshape(4, 4)
+    assert np.abs(_data.euler(Tg) - _data.euler(To)).max() < ANG_TOL
+    assert np.abs(Tg[:3, 3] - To[:3, 3]).max() < TR_TOL
+    assert np.allclose(np.array(res.VCM), np.array(io.VCM), rtol=1e-6, atol=1e-20)
+
+
+@pytest.mark.parametrize("n,which,epoch", [(20000, "ref", 1), (60000, "ref", 2), (200000, "grid", 3)])
+def test_loop_parity_with_oracle(ctx, oracle, n, which, epoch):
+    tgt, src, Tgt = _data.pair(n, epoch=epoch)
+    l1, n1 = _labels(tgt, which)
+    l2, n2 = _labels(src, which)
+    pair, res, io = _loop_both(ctx, oracle, tgt, src, l1, n1, l2, n2)
+    _assert_loop_parity(res, io)
+    # reset + rerun is deterministic (no atomics on floats anywhere in the path)
+    pair.reset()
+    res2 = pair.run()
+    assert np.array_equal(np.array(res2.T16), np.array(res.T16)) and np.array_equal(np.array(res2.VCM), np.array(res.VCM))
+    # the source cloud on the device was transformed exactly like the oracle's (R.cpp:943-945)
+    moved = pair.download_source()
+    c2 = oracle.f4(src).copy()
+    for i in range(io.n_outer):
+        Tk = np.array(io.Tk[i], np.float32)
+        oracle.lib().orc_transform_points(oracle._p(c2), len(c2), oracle._p(Tk))
+    assert np.array_equal(moved[:, :3], c2[:, :3])
+    pair.close()
+
+
+def test_loop_auto_dtinit(ctx, oracle):
+    tgt, src, _ = _data.pair(30000)
+    l1, n1 = _labels(tgt, "grid")
+    l2, n2 = _labels(src, "grid")
+    pair, res, io = _loop_both(ctx, oracle, tgt, src, l1, n1, l2, n2, manual=False)
+    _assert_loop_parity(res, io)
+    pair.close()
+
+
+def test_too_few_patches_is_an_error_code_not_exit(ctx):
+    import pwicp_amd as P
+    tgt, src, _ = _data.pair(3000)
+    lab = np.zeros(len(src), np.int32)
+    pair = P.Pair(ctx, tgt, np.zeros(len(tgt), np.int32), 1, src, lab, 1, _data.params())
+    res = pair.run(check=False)
+    assert res.status == -3          # PWICP_E_TOO_FEW_PATCHES (reference: std::exit, R.cpp:728-731)
+    pair.close()
+
+
+def test_full_size_properties_1m(ctx):
+    """BASELINE configs[1] size (1 M points per cloud): size-independent properties instead of the oracle."""
+    import pwicp_amd as P
+    from pwicp_amd import synth
+    tgt, src, Tgt = _data.pair(1000000)
+    l1, n1 = synth.grid_labels(tgt, 10 * _data.R)
+    l2, n2 = synth.grid_labels(src, 10 * _data.R)
+    pair = P.Pair(ctx, tgt, l1, n1, src, l2, n2, _data.params())
+    res = pair.run()
+    k = res.n_outer
+    dts = np.array(res.DTseries[:k + 1])
+    assert res.status == 0 and 2 <= k <= 20
+    assert np.all(np.diff(dts) <= 0) and dts[-1] >= 0.8 * _data.R * (1 - 1e-6)         # monotone schedule, floor DTmin
+    # ground truth of the generator (source -> target, both reduced by the target centroid)
+    c = synth.make_tile(1000000, _data.R)[0].mean(0).astype(np.float64)
+    S = np.eye(4); S[:3, 3] = -c
+    Tfull = np.linalg.inv(S) @ np.array(res.T16, np.float64).reshape(4, 4) @ S
+    assert np.abs(_data.euler(Tfull) - _data.euler(Tgt)).max() < 1e-4
+    assert np.abs(Tfull[:3, 3] - Tgt[:3, 3]).max() < 1e-3
+    # product of the per-iteration matrices equals the accumulated matrix (float Eigen order)
+    acc = np.eye(4, dtype=np.float32)
+    for i in range(k):
+        Tk = np.array(res.Tk[i], np.float32).reshape(4, 4)
+        new = np.zeros((4, 4), np.float32)
+        for a in range(4):
+            for b in range(4):
+                s = np.float32(Tk[a, 0] * acc[0, b])
+                for kk in range(1, 4):
+                    s = np.float32(s + np.float32(Tk[a, kk] * acc[kk, b]))
+                new[a, b] = s
+        acc = new
+    assert np.array_equal(acc.reshape(16), np.array(res.T16, np.float32))
+    # idempotence: registering the registered source again moves it by < the detection level
+    moved = pair.download_source()
+    pair2 = P.Pair(ctx, tgt, l1, n1, moved[:, :3], l2, n2, _data.params())
+    res2 = pair2.run()
+    T2 = np.array(res2.T16, np.float64).reshape(4, 4)
+    assert np.abs(_data.euler(T2)).max() < 5e-5 and np.abs(T2[:3, 3]).max() < 5e-4
+    # NN: sampled brute-force check at full size
+    idx, d2 = ctx.determineCorrespondences(tgt, src[:2000])
+    for i in range(0, 2000, 40):
+        d = ((tgt - src[i]) ** 2).sum(1)
+        assert abs(d.min() - d2[i]) <= 1e-6 * max(d.min(), 1e-12) + 1e-12
+    pair.close(); pair2.close()
+
+
+def test_golden_epoch2_through_gpu(ctx, oracle):
+    """The reference's own result for Epoch_002 -> Epoch_001, hot path on the GPU."""
+    if not oracle.ref_frontend_available():
+        pytest.skip("oracle/_ref not built")
+    import pwicp_amd as P
+    from pwicp_amd.pcd import read_pcd
+    p1 = G.preprocess_4d(oracle, read_pcd(G.epoch_path(1)))
+    p2 = G.preprocess_4d(oracle, read_pcd(G.epoch_path(2)))
+    r1, r2, shift = G.reduce_pair(p1, p2)
+    l1, n1 = oracle.ref_frontend(r1, 0.05)
+    l2, n2 = oracle.ref_frontend(r2, 0.05)
+    prm = P.Params(0.005, 0.005, 0.05, 0.05, 1, 0.05, 0.004)
+    pair = P.Pair(ctx, r1, l1, n1, r2, l2, n2, prm)
+    res = pair.run()
+    assert pair.num_patches() == (1822, 1846)
+    Tf = G.final_matrix(res.T16, shift)
+    Tg, Vg, stds = G.parse_transmatrix_file(os.path.join(G.GOLD, "reference_results", "2_Direct2Ref_TransMatrix.txt"))
+    assert np.abs(G.euler(Tf) - G.euler(Tg)).max() < 5e-6
+    assert np.abs(Tf[:3, 3].astype(float) - Tg[:3, 3]).max() < 5e-6
+    V = np.array(res.VCM).reshape(6, 6)
+    mine = np.concatenate([1000 * 63.6619772368 * np.sqrt(np.diag(V)[:3]), 1000 * np.sqrt(np.diag(V)[3:])])
+    assert np.allclose(mine, stds, rtol=5e-3)
+    pair.close()
