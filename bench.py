@@ -158,7 +158,7 @@ def main():
                 traffic = json.load(open(tfile)).get("k_nn_patches_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_nn_patches", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        roofline = {"bound": "hbm", "kernel": "k_nn_dense_direct", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "bytes_per_correspondence": round(b_nn, 1), "kbar": round(kbar, 2),
                     "queries_per_launch": int(nq), "avg_launch_us": round(dur_s * 1e6, 2),

@@ -43,9 +43,12 @@ __device__ __forceinline__ void block_reduce_store(double* v, int nv, double* __
 
 __global__ void __launch_bounds__(kBlock) k_icp_accum(GridDesc g, const float4* __restrict__ tgt,
                                                       const float4* __restrict__ tgt_n, float4* __restrict__ src,
-                                                      float4* __restrict__ srcn, int ns, const IcpState* st,
+                                                      float4* __restrict__ srcn, int ns_host,
+                                                      const unsigned* __restrict__ ns_dev, const IcpState* st,
                                                       double* __restrict__ partials) {
     if (st->done) return;
+    const int ns = ns_dev ? (int)*ns_dev : ns_host;          // the count may live on the device (no host sync)
+    if ((int)(blockIdx.x * blockDim.x) >= ns) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     double v[kNSums];
 #pragma unroll
@@ -94,9 +97,11 @@ __device__ inline void construct_T(const double* x, float* T) {
     T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
 }
 
-__global__ void __launch_bounds__(64) k_icp_solve(IcpState* st, const double* __restrict__ partials, int nblocks,
-                                                  int ns, double mse_rel) {
+__global__ void __launch_bounds__(64) k_icp_solve(IcpState* st, const double* __restrict__ partials, int ns_host,
+                                                  const unsigned* __restrict__ ns_dev, double mse_rel) {
     if (st->done) return;
+    const int ns = ns_dev ? (int)*ns_dev : ns_host;
+    const int nblocks = (ns + kBlock - 1) / kBlock;
     __shared__ double sums[kNSums];
     if (threadIdx.x < kNSums) {
         double s = 0.0;
@@ -251,23 +256,32 @@ int IcpWork::reserve(pwicp_context* ctx, int ns_max) {
     return PWICP_OK;
 }
 
+// Enqueues n_iter inner iterations (accumulate + solve each) on the stream; no host synchronisation.  The number
+// of source points is ns_host, or *ns_dev when ns_dev != nullptr (then ns_max bounds the launch grid).
+int pw_icp_enqueue(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
+                   int ns_max, const unsigned* ns_dev, double euclid_eps, int n_iter) {
+    if (ns_max <= 0) return PWICP_OK;
+    const int nb = div_up(ns_max, kBlock);
+    for (int k = 0; k < n_iter; ++k) {
+        hipLaunchKernelGGL(k_icp_accum, dim3(nb), dim3(kBlock), 0, ctx->stream, g, d_tgt, d_tgt_n, w->src.p, w->srcn.p,
+                           ns_max, ns_dev, w->state.p, w->partials.p);
+        hipLaunchKernelGGL(k_icp_solve, dim3(1), dim3(64), 0, ctx->stream, w->state.p, w->partials.p, ns_max, ns_dev,
+                           euclid_eps);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return PWICP_OK;
+}
+
 // d_src / d_srcn: working copies (modified in place). Returns final T and the iteration count.
 int pw_icp_run(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w, int ns,
                double euclid_eps, float* T16, int* iters_out) {
     for (int k = 0; k < 16; ++k) T16[k] = (k % 5 == 0) ? 1.f : 0.f;
     if (iters_out) *iters_out = 0;
     if (ns < 3 || g.fine.n <= 0) return PWICP_OK;      // min_number_correspondences_ = 3: no update
-    const int nb = div_up(ns, kBlock);
     hipLaunchKernelGGL(k_icp_init, dim3(1), dim3(64), 0, ctx->stream, w->state.p);
     IcpState h;
-    const int batch = 4;
     for (int done_iters = 0; done_iters < 100;) {
-        for (int k = 0; k < batch; ++k) {
-            hipLaunchKernelGGL(k_icp_accum, dim3(nb), dim3(kBlock), 0, ctx->stream, g, d_tgt, d_tgt_n, w->src.p,
-                               w->srcn.p, ns, w->state.p, w->partials.p);
-            hipLaunchKernelGGL(k_icp_solve, dim3(1), dim3(64), 0, ctx->stream, w->state.p, w->partials.p, nb, ns,
-                               euclid_eps);
-        }
+        PWCHK(pw_icp_enqueue(ctx, g, d_tgt, d_tgt_n, w, ns, nullptr, euclid_eps, 4));
         HIPCHK(ctx, hipMemcpyAsync(&h, w->state.p, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         done_iters = h.iters;

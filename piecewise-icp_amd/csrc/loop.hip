@@ -95,19 +95,18 @@ __global__ void __launch_bounds__(kBlock) k_classify(
 
 // Order-preserving compaction of the stable patches (single block): list, point prefix, stable centroids with
 // normals (generateCentroidCloudWithPatchNormals semantics: (0,0,1) unless > 6 points and a valid normal).
-// Two exclusive scans (count, points) per 1024-patch chunk: wave shuffles + one LDS hop.
+// 1024 patches per pass, coalesced; exclusive scans of (count, points) by wave shuffles + one LDS hop.
+// Thread 0 also writes the counts into the iteration's scalar slot and resets the inner-ICP state.
 __global__ void __launch_bounds__(1024) k_compact(int m2, const int* __restrict__ stable, const int* __restrict__ off2,
                                                   const float4* __restrict__ ct2, const float4* __restrict__ nrm2,
                                                   int* __restrict__ list, int* __restrict__ soff,
                                                   float4* __restrict__ stCT, float4* __restrict__ stN,
                                                   float4* __restrict__ wsrc, float4* __restrict__ wsrcn,
-                                                  unsigned* __restrict__ scal) {
-    __shared__ int wsum_n[16], wsum_p[16];
-    __shared__ int carry_n, carry_p;
+                                                  unsigned* __restrict__ scal, IcpState* __restrict__ st) {
+    __shared__ int wsum_n[2][16], wsum_p[2][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) { carry_n = 0; carry_p = 0; }
-    __syncthreads();
-    for (int base = 0; base < m2; base += 1024) {
+    int carry_n = 0, carry_p = 0, buf = 0;
+    for (int base = 0; base < m2; base += 1024, buf ^= 1) {
         const int i = base + threadIdx.x;
         const int f = (i < m2) ? stable[i] : 0;
         const int np = (i < m2) ? (off2[i + 1] - off2[i]) : 0;
@@ -118,16 +117,17 @@ __global__ void __launch_bounds__(1024) k_compact(int m2, const int* __restrict_
             const int tn = __shfl_up(in, o), tp = __shfl_up(ip, o);
             if (lane >= o) { in += tn; ip += tp; }
         }
-        if (lane == 63) { wsum_n[wave] = in; wsum_p[wave] = ip; }
-        __syncthreads();
+        if (lane == 63) { wsum_n[buf][wave] = in; wsum_p[buf][wave] = ip; }
+        __syncthreads();                           // double-buffered wave sums: one barrier per pass
         int on = 0, op = 0, totn = 0, totp = 0;
+#pragma unroll
         for (int w = 0; w < 16; ++w) {
-            if (w < wave) { on += wsum_n[w]; op += wsum_p[w]; }
-            totn += wsum_n[w]; totp += wsum_p[w];
+            const int a = wsum_n[buf][w], b = wsum_p[buf][w];
+            if (w < wave) { on += a; op += b; }
+            totn += a; totp += b;
         }
-        const int pos = carry_n + on + in - f;
-        const int ppos = carry_p + op + ip - sz;
         if (f) {
+            const int pos = carry_n + on + in - f, ppos = carry_p + op + ip - sz;
             list[pos] = i;
             soff[pos] = ppos;
             const float4 c = ct2[i];
@@ -137,14 +137,18 @@ __global__ void __launch_bounds__(1024) k_compact(int m2, const int* __restrict_
             stCT[pos] = c; stN[pos] = n;
             wsrc[pos] = c; wsrcn[pos] = n;
         }
-        __syncthreads();
-        if (threadIdx.x == 0) { carry_n += totn; carry_p += totp; }
-        __syncthreads();
+        carry_n += totn; carry_p += totp;
     }
     if (threadIdx.x == 0) {
         soff[carry_n] = carry_p;
         scal[2] = (unsigned)carry_n;
         scal[3] = (unsigned)carry_p;
+        for (int k = 0; k < 16; ++k) {
+            st->T[k] = (k % 5 == 0) ? 1.f : 0.f;
+            st->Tfinal[k] = (k % 5 == 0) ? 1.f : 0.f;
+        }
+        st->iters = 0; st->done = (carry_n < 3) ? 1 : 0; st->reason = 0; st->pad = 0;
+        st->prev_mse = 1.7976931348623157e308;
     }
 }
 
@@ -159,9 +163,101 @@ __global__ void k_with_norm(int m, const int* __restrict__ off, const float4* __
     out[i] = n;
 }
 
-__global__ void __launch_bounds__(kBlock) k_transform(float4* __restrict__ p, int n, Mat4 T) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = xform_point(T.m, p[i]);
+constexpr int kBoxParts = 64;
+// (8) R.cpp:943-954 in ONE launch: blocks [0, nb_cloud) transform cloud2 and reduce its new bounding box (for the
+// next iteration's octree box, R.cpp:881-886); the remaining blocks transform centroids+boundary points and
+// the patch points.  min/max are exact whatever the reduction order.
+__global__ void __launch_bounds__(kBlock) k_transform_all(float4* __restrict__ cloud, int n, int nb_cloud,
+                                                          float4* __restrict__ ctbp, int n_ctbp,
+                                                          float4* __restrict__ pat, int n_pat, Mat4 T,
+                                                          unsigned* __restrict__ bbox_part) {
+    __shared__ float sh[kBlock / 64][6];
+    if ((int)blockIdx.x >= nb_cloud) {
+        const int nb = gridDim.x - nb_cloud, stride = nb * kBlock, ntot = n_ctbp + n_pat;
+        for (int i = (blockIdx.x - nb_cloud) * kBlock + threadIdx.x; i < ntot; i += 4 * stride) {
+            float4* q[4];
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = i + u * stride;
+                q[u] = (j < n_ctbp) ? (ctbp + j) : (pat + (j - n_ctbp));
+                if (j < ntot) v[u] = *q[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i + u * stride < ntot) *q[u] = xform_point(T.m, v[u]);
+        }
+        return;
+    }
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    {
+        const int stride = nb_cloud * kBlock;
+        for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += 4 * stride) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i + u * stride < n) v[u] = cloud[i + u * stride];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i + u * stride < n) {
+                    const float4 w = xform_point(T.m, v[u]);
+                    cloud[i + u * stride] = w;
+                    mn[0] = fminf(mn[0], w.x); mx[0] = fmaxf(mx[0], w.x);
+                    mn[1] = fminf(mn[1], w.y); mx[1] = fmaxf(mx[1], w.y);
+                    mn[2] = fminf(mn[2], w.z); mx[2] = fmaxf(mx[2], w.z);
+                }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            mn[d] = fminf(mn[d], __shfl_xor(mn[d], o));
+            mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], o));
+        }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { sh[wave][d] = mn[d]; sh[wave][3 + d] = mx[d]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float a = sh[0][threadIdx.x], b = sh[0][3 + threadIdx.x];
+        for (int w = 1; w < kBlock / 64; ++w) { a = fminf(a, sh[w][threadIdx.x]); b = fmaxf(b, sh[w][3 + threadIdx.x]); }
+        // 64 partial boxes, one 128-byte line each: same-line atomics from all XCDs serialise (~5 ns apiece)
+        unsigned* part = bbox_part + (blockIdx.x & (kBoxParts - 1)) * 32;
+        atomicMin(&part[threadIdx.x], f2ord_dev(a));
+        atomicMax(&part[3 + threadIdx.x], f2ord_dev(b));
+    }
+}
+
+// folds the 64 partial boxes of the last transform into its slot and re-arms them (one wave)
+__global__ void __launch_bounds__(64) k_bbox_fold(unsigned* __restrict__ bbox_part, unsigned* __restrict__ slot) {
+    const int t = threadIdx.x;
+    unsigned mn[3], mx[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { mn[d] = bbox_part[t * 32 + d]; mx[d] = bbox_part[t * 32 + 3 + d]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            mn[d] = min(mn[d], (unsigned)__shfl_xor((int)mn[d], o));
+            mx[d] = max(mx[d], (unsigned)__shfl_xor((int)mx[d], o));
+        }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { bbox_part[t * 32 + d] = 0xffffffffu; bbox_part[t * 32 + 3 + d] = 0u; }
+    if (t == 0 && slot)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { slot[4 + d] = mn[d]; slot[7 + d] = mx[d]; }
+}
+
+// one 16-word scalar slot per outer iteration: [0] LoDmin [1] LoDmax [2] n stable [3] n stable points
+// [4..6] bbox min, [7..9] bbox max of cloud2 AFTER this iteration's transform (ordered-uint encoded)
+constexpr int kSlot = 16;
+__global__ void k_scal_init(unsigned* __restrict__ scal, int n_slots) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slots * kSlot) return;
+    const int w = i % kSlot;
+    scal[i] = (w == 0 || (w >= 4 && w <= 6)) ? 0xffffffffu : 0u;
 }
 
 // transform + bounding box of the result (for the next iteration's octree box, R.cpp:881-886).
@@ -257,17 +353,19 @@ struct pwicp_pair {
     int n2 = 0;
     DevBuf<float4> cloud2, cloud2_0;
     PatchSet P2;
-    DevBuf<float4> pat2_0, ct2_0, bp2_0;
+    DevBuf<float4> pat2_0;
+    DevBuf<float4> ctbp2, ctbp2_0;   // live / pristine source centroids [0,m2) followed by boundary points [m2,7m2)
+    float bmin0[3] = {0, 0, 0}, bmax0[3] = {0, 0, 0};   // tight bbox of the uploaded source cloud
     DevBuf<float4> nrm2;
     DevBuf<int> pt_patch2;   // patch id of every source patch point
     DevBuf<int> qorder;      // source patch points in Morton order of their initial target-grid cell
     DevBuf<int> all_stable;  // all-ones flags (bench replay over every patch)
     // per-iteration work
-    DevBuf<int> mCT, mBP, stable, list, soff;
-    DevBuf<float> dCT, dBP, d2dense;
+    DevBuf<int> mCTBP, stable, list, soff;   // matches of the 7*m2 centroid+boundary queries
+    DevBuf<float> dCTBP, d2dense;
     DevBuf<float4> stCT, stN;
     IcpWork icp;
-    DevBuf<unsigned> scal, sel_scratch;
+    DevBuf<unsigned> scal, sel_scratch, bbox_part;
     DevBuf<float> sel_out;
     DevBuf<unsigned long long> examined;
     // configuration of the first Stage-1 dense NN launch of the last run (replayed by bench_dense_nn)
@@ -299,10 +397,10 @@ int finish_create(pwicp_pair* pr) {
     if (m1 > 0)
         hipLaunchKernelGGL(k_with_norm, dim3(div_up(m1, kBlock)), dim3(kBlock), 0, ctx->stream, m1, pr->P1.off.p,
                            pr->nrm1.p, pr->ct1n.p);
-    // cell edges: dense cloud grid = 2 x point spacing (27-cell stencil ~ 40-50 points); centroid grid = 4 x patch
-    // size, so that the far queries of displaced (unstable) patches still resolve within one or two rings.
+    // cell edges: dense cloud grid = 2 x point spacing (27-cell stencil ~ 40-50 points); centroid grid = 1 x patch
+    // size (its 4x coarse level resolves the far queries of displaced, unstable patches).
     // Tuning knobs for experiments only (results do not depend on them; the search is exact for any edge).
-    float f_dense = 2.0f, f_ct = 4.0f;
+    float f_dense = 2.0f, f_ct = 1.0f;
     if (const char* e = getenv("PWICP_DENSE_CELL_FACTOR")) { float v = (float)atof(e); if (v > 0.f) f_dense = v; }
     if (const char* e = getenv("PWICP_CT_CELL_FACTOR")) { float v = (float)atof(e); if (v > 0.f) f_ct = v; }
     PWCHK(pw_grid_build(ctx, pr->cloud1.p, pr->n1, f_dense * pr->prm.Res1, &pr->g_c1));
@@ -311,22 +409,22 @@ int finish_create(pwicp_pair* pr) {
     HIPCHK(ctx, pr->pt_patch2.reserve((size_t)std::max(pr->P2.tot, 1)));
     PWCHK(pw_point_patch_ids_launch(ctx, pr->P2.off.p, m2, pr->pt_patch2.p));
     PWCHK(pw_morton_order(ctx, pr->g_c1.d, pr->P2.pat.p, pr->P2.tot, &pr->qorder));
-    // pristine source copies
+    // pristine source copies; centroids and boundary points live in ONE buffer so that a single NN launch and a
+    // single transform launch serve both (R.cpp:737-747, 946-949)
     HIPCHK(ctx, pr->cloud2_0.reserve((size_t)std::max(pr->n2, 1)));
     HIPCHK(ctx, pr->pat2_0.reserve((size_t)std::max(pr->P2.tot, 1)));
-    HIPCHK(ctx, pr->ct2_0.reserve((size_t)std::max(m2, 1)));
-    HIPCHK(ctx, pr->bp2_0.reserve((size_t)std::max(m2, 1) * 6));
+    HIPCHK(ctx, pr->ctbp2.reserve((size_t)std::max(m2, 1) * 7));
+    HIPCHK(ctx, pr->ctbp2_0.reserve((size_t)std::max(m2, 1) * 7));
     HIPCHK(ctx, hipMemcpyAsync(pr->cloud2_0.p, pr->cloud2.p, (size_t)pr->n2 * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(pr->pat2_0.p, pr->P2.pat.p, (size_t)pr->P2.tot * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(pr->ct2_0.p, pr->P2.ct.p, (size_t)m2 * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(pr->bp2_0.p, pr->P2.bp.p, (size_t)m2 * 6 * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(pr->ctbp2_0.p, pr->P2.ct.p, (size_t)m2 * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(pr->ctbp2_0.p + m2, pr->P2.bp.p, (size_t)m2 * 6 * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(pr->ctbp2.p, pr->ctbp2_0.p, (size_t)m2 * 7 * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
     // work buffers
     const size_t M2 = (size_t)std::max(m2, 1);
     HIPCHK(ctx, pr->nrm2.reserve(M2));
-    HIPCHK(ctx, pr->mCT.reserve(M2));
-    HIPCHK(ctx, pr->dCT.reserve(M2));
-    HIPCHK(ctx, pr->mBP.reserve(M2 * 6));
-    HIPCHK(ctx, pr->dBP.reserve(M2 * 6));
+    HIPCHK(ctx, pr->mCTBP.reserve(M2 * 7));
+    HIPCHK(ctx, pr->dCTBP.reserve(M2 * 7));
     HIPCHK(ctx, pr->stable.reserve(M2));
     HIPCHK(ctx, pr->list.reserve(M2 + 1));
     HIPCHK(ctx, pr->soff.reserve(M2 + 1));
@@ -335,10 +433,22 @@ int finish_create(pwicp_pair* pr) {
     HIPCHK(ctx, pr->stCT.reserve(M2));
     HIPCHK(ctx, pr->stN.reserve(M2));
     HIPCHK(ctx, pr->d2dense.reserve((size_t)std::max(std::max(pr->P2.tot, pr->n2), 1)));
-    HIPCHK(ctx, pr->scal.reserve(16));
+    HIPCHK(ctx, pr->scal.reserve((size_t)kSlot * (PWICP_MAX_OUTER + 1)));
+    HIPCHK(ctx, pr->bbox_part.reserve((size_t)kBoxParts * 32));
+    hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(64), 0, ctx->stream, pr->bbox_part.p, (unsigned*)nullptr);   // arm
+    {   // tight bbox of the uploaded source cloud (R.cpp:881-886 needs it in the first iteration)
+        hipLaunchKernelGGL(k_scal_init, dim3(1), dim3(64), 0, ctx->stream, pr->scal.p, 1);
+        Mat4 I{};
+        hipLaunchKernelGGL(k_transform_bbox, dim3(std::min(div_up(pr->n2, kBlock), ctx->n_cu * 4)), dim3(kBlock), 0,
+                           ctx->stream, pr->cloud2.p, pr->n2, I, 0, pr->scal.p);
+        unsigned hb[kSlot];
+        HIPCHK(ctx, hipMemcpyAsync(hb, pr->scal.p, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int d = 0; d < 3; ++d) { pr->bmin0[d] = ord2f_host(hb[4 + d]); pr->bmax0[d] = ord2f_host(hb[7 + d]); }
+    }
     HIPCHK(ctx, pr->sel_scratch.reserve(8 + 3 * 2048));
     HIPCHK(ctx, pr->sel_out.reserve(1));
-    HIPCHK(ctx, pr->examined.reserve(1));
+    HIPCHK(ctx, pr->examined.reserve(256 * 16));
     PWCHK(pr->icp.reserve(ctx, m2));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipGetLastError());
@@ -454,8 +564,7 @@ int pwicp_pair_reset(pwicp_pair* pr) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemcpyAsync(pr->cloud2.p, pr->cloud2_0.p, (size_t)pr->n2 * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(pr->P2.pat.p, pr->pat2_0.p, (size_t)pr->P2.tot * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(pr->P2.ct.p, pr->ct2_0.p, (size_t)pr->P2.m * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(pr->P2.bp.p, pr->bp2_0.p, (size_t)pr->P2.m * 6 * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(pr->ctbp2.p, pr->ctbp2_0.p, (size_t)pr->P2.m * 7 * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
     return PWICP_OK;
 }
 
@@ -464,13 +573,6 @@ int pwicp_pair_download_source(pwicp_pair* pr, float* cloud2_xyz4) {
     pwicp_context* ctx = pr->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemcpyAsync(cloud2_xyz4, pr->cloud2.p, (size_t)pr->n2 * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return PWICP_OK;
-}
-
-static int read_scal(pwicp_pair* pr, unsigned* h) {
-    pwicp_context* ctx = pr->ctx;
-    HIPCHK(ctx, hipMemcpyAsync(h, pr->scal.p, 16 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return PWICP_OK;
 }
@@ -495,7 +597,9 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     memset(res, 0, sizeof(*res));
     for (int i = 0; i < 16; ++i) res->T16[i] = (i % 5 == 0) ? 1.f : 0.f;
     const pwicp_params& prm = pr->prm;
-    const int m1 = pr->P1.m, m2 = pr->P2.m, nbp2 = 6 * m2;
+    const int m2 = pr->P2.m, nbp2 = 6 * m2;
+    float4* const ct2 = pr->ctbp2.p;
+    float4* const bp2 = pr->ctbp2.p + m2;
     size_t n_ev = 0;
     std::vector<std::pair<size_t, int>> ev_kind;   // (start event index, kind 0 dense / 1 inner)
 
@@ -513,64 +617,69 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     float BB1 = 0.f, BB2 = 0.f;              // R.cpp:672-673
     res->DTseries[0] = currDT;
 
-    // tight bbox of the current source cloud (kept up to date by the transform kernel)
-    unsigned hs[16];
-    {
-        static const unsigned init[16] = {0xffffffffu, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0, 0, 0, 0, 0, 0};
-        HIPCHK(ctx, hipMemcpyAsync(pr->scal.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-        Mat4 I{};
-        hipLaunchKernelGGL(k_transform_bbox, dim3(std::min(div_up(pr->n2, kBlock), ctx->n_cu * 4)), dim3(kBlock), 0,
-                           ctx->stream, pr->cloud2.p, pr->n2, I, 0, pr->scal.p);
-        PWCHK(read_scal(pr, hs));
-    }
+    // tight bbox of the current source cloud: uploaded state now, then refreshed by every transform launch
     float bmin[3], bmax[3];
-    for (int d = 0; d < 3; ++d) { bmin[d] = ord2f_host(hs[4 + d]); bmax[d] = ord2f_host(hs[7 + d]); }
-    HIPCHK(ctx, hipMemsetAsync(pr->examined.p, 0, sizeof(unsigned long long), ctx->stream));
+    for (int d = 0; d < 3; ++d) { bmin[d] = pr->bmin0[d]; bmax[d] = pr->bmax0[d]; }
+    hipLaunchKernelGGL(k_scal_init, dim3(div_up(kSlot * (PWICP_MAX_OUTER + 1), kBlock)), dim3(kBlock), 0, ctx->stream,
+                       pr->scal.p, PWICP_MAX_OUTER + 1);
+    HIPCHK(ctx, hipMemsetAsync(pr->examined.p, 0, 256 * 16 * sizeof(unsigned long long), ctx->stream));
 
     int status = PWICP_OK;
+    int prev_inner = 2;
     const auto t0 = std::chrono::steady_clock::now();
     while (!stage3) {                                                   // R.cpp:680
         const int k = res->n_outer;
         if (k >= PWICP_MAX_OUTER) break;
         if (currDT <= DTmin) currDT = DTmin;                            // R.cpp:724-725
         if (4 > m2) { status = PWICP_E_TOO_FEW_PATCHES; break; }        // R.cpp:728-731
+        unsigned* const slot = pr->scal.p + (size_t)kSlot * k;
 
-        // (1) R.cpp:737-747 — the target-centroid grid is static and built once
-        PWCHK(pw_nn_launch(ctx, pr->g_ct1.d, pr->P2.ct.p, m2, pr->mCT.p, pr->dCT.p, nullptr));
-        PWCHK(pw_nn_launch(ctx, pr->g_ct1.d, pr->P2.bp.p, nbp2, pr->mBP.p, pr->dBP.p, nullptr));
+        // (1) R.cpp:737-747 — CT2 and BP2 queries in one launch; the target-centroid grid is static
+        PWCHK(pw_nn_launch(ctx, pr->g_ct1.d, pr->ctbp2.p, 7 * m2, pr->mCTBP.p, pr->dCTBP.p, nullptr));
         res->n_corr += (long long)m2 + nbp2;
         // source patch normals for CTcloud2_withNorm (R.cpp:824): recomputed from the transformed patch points
         PWCHK(pw_patch_normals_launch(ctx, pr->P2.pat.p, pr->P2.off.p, m2, pr->nrm2.p));
         // (2)-(4)
-        {
-            static const unsigned init4[4] = {0xffffffffu, 0u, 0u, 0u};
-            HIPCHK(ctx, hipMemcpyAsync(pr->scal.p, init4, sizeof(init4), hipMemcpyHostToDevice, ctx->stream));
-        }
         const float DTctct = currDT + 1 * (prm.SVRes1 + prm.SVRes2);   // R.cpp:817
-        hipLaunchKernelGGL(k_classify, dim3(div_up(m2, kBlock)), dim3(kBlock), 0, ctx->stream, m2, pr->mCT.p, pr->dCT.p,
-                           pr->mBP.p, pr->dBP.p, pr->P1.ctstd.p, pr->P2.bpstd.p, pr->nrm1.p, pr->P1.ct.p, pr->P2.ct.p,
-                           pr->P2.bp.p, currDT, DTmin, DTctct, pr->stable.p, pr->scal.p);
-        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, ctx->stream, m2, pr->stable.p, pr->P2.off.p, pr->P2.ct.p,
+        hipLaunchKernelGGL(k_classify, dim3(div_up(m2, kBlock)), dim3(kBlock), 0, ctx->stream, m2, pr->mCTBP.p,
+                           pr->dCTBP.p, pr->mCTBP.p + m2, pr->dCTBP.p + m2, pr->P1.ctstd.p, pr->P2.bpstd.p, pr->nrm1.p,
+                           pr->P1.ct.p, ct2, bp2, currDT, DTmin, DTctct, pr->stable.p, slot);
+        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, ctx->stream, m2, pr->stable.p, pr->P2.off.p, ct2,
                            pr->nrm2.p, pr->list.p, pr->soff.p, pr->stCT.p, pr->stN.p, pr->icp.src.p, pr->icp.srcn.p,
-                           pr->scal.p);
-        PWCHK(read_scal(pr, hs));
-        float LoDet_min;
-        memcpy(&LoDet_min, &hs[0], 4);
-        const int ns = (int)hs[2], nsp = (int)hs[3];
-        res->n_stable[k] = ns; res->n_stable_pts[k] = nsp; res->LoDmin[k] = LoDet_min;
-        if (4 > ns) { status = PWICP_E_TOO_FEW_STABLE; break; }        // R.cpp:864-867
-
-        // (5) R.cpp:875-877
-        float Tk[16];
-        int n_in = 0;
+                           slot, pr->icp.state.p);
+        // (5) R.cpp:875-877: inner ICP enqueued right behind, its point count read from the slot on the device;
+        // ONE host round trip returns the counts, LoD_min and the ICP state together
+        unsigned hs[kSlot], hb[6];
+        IcpState hst;
         {
             hipEvent_t e0 = pr->event(n_ev), e1 = pr->event(n_ev + 1);
             ev_kind.push_back({n_ev, 1});
             n_ev += 2;
             HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
-            PWCHK(pw_icp_run(ctx, pr->g_ct1.d, pr->P1.ct.p, pr->ct1n.p, &pr->icp, ns, 1e-6, Tk, &n_in));
+            int batch = std::max(1, prev_inner);
+            for (;;) {
+                PWCHK(pw_icp_enqueue(ctx, pr->g_ct1.d, pr->P1.ct.p, pr->ct1n.p, &pr->icp, m2, slot + 2, 1e-6, batch));
+                HIPCHK(ctx, hipMemcpyAsync(hs, slot, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipMemcpyAsync(&hst, pr->icp.state.p, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
+                // bbox of cloud2 after the PREVIOUS iteration's transform (written into the previous slot)
+                if (k > 0) HIPCHK(ctx, hipMemcpyAsync(hb, slot - kSlot + 4, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                if (hst.done || hst.iters >= 100) break;
+                batch = 2;
+            }
             HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
         }
+        if (k > 0)
+            for (int d = 0; d < 3; ++d) { bmin[d] = ord2f_host(hb[d]); bmax[d] = ord2f_host(hb[3 + d]); }
+        float LoDet_min;
+        memcpy(&LoDet_min, &hs[0], 4);
+        const int ns = (int)hs[2], nsp = (int)hs[3];
+        res->n_stable[k] = ns; res->n_stable_pts[k] = nsp; res->LoDmin[k] = LoDet_min;
+        if (4 > ns) { status = PWICP_E_TOO_FEW_STABLE; break; }        // R.cpp:864-867
+        float Tk[16];
+        memcpy(Tk, hst.Tfinal, sizeof(Tk));
+        const int n_in = hst.iters;
+        prev_inner = n_in;
         res->n_inner[k] = n_in; res->n_inner_total += n_in;
         res->n_corr += (long long)ns * std::max(n_in, 1);
         memcpy(res->Tk[k], Tk, sizeof(Tk));
@@ -618,29 +727,21 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
             BB2 = BB1; BB1 = maxBB;
         }
 
-        // (8) R.cpp:943-954: cloud2 (+ its new bbox), centroids, boundary points, patch points
+        // (8) R.cpp:943-954: cloud2 (+ its new bbox into this slot), centroids + boundary points, patch points
         Mat4 T;
         memcpy(T.m, Tk, sizeof(Tk));
         {
-            static const unsigned initb[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-            HIPCHK(ctx, hipMemcpyAsync(pr->scal.p + 4, initb, sizeof(initb), hipMemcpyHostToDevice, ctx->stream));
-        }
-        hipLaunchKernelGGL(k_transform_bbox, dim3(std::min(div_up(pr->n2, kBlock), ctx->n_cu * 4)), dim3(kBlock), 0,
-                           ctx->stream, pr->cloud2.p, pr->n2, T, 1, pr->scal.p);
-        if (m2 > 0) {
-            hipLaunchKernelGGL(k_transform, dim3(div_up(m2, kBlock)), dim3(kBlock), 0, ctx->stream, pr->P2.ct.p, m2, T);
-            hipLaunchKernelGGL(k_transform, dim3(div_up(nbp2, kBlock)), dim3(kBlock), 0, ctx->stream, pr->P2.bp.p, nbp2, T);
-            hipLaunchKernelGGL(k_transform, dim3(div_up(pr->P2.tot, kBlock)), dim3(kBlock), 0, ctx->stream, pr->P2.pat.p,
-                               pr->P2.tot, T);
+            const int nb_cloud = std::min(div_up(pr->n2, kBlock), ctx->n_cu * 8);
+            const int nb_rest = std::min(div_up(7 * m2 + pr->P2.tot, kBlock), ctx->n_cu * 8);
+            hipLaunchKernelGGL(k_transform_all, dim3(nb_cloud + nb_rest), dim3(kBlock), 0, ctx->stream, pr->cloud2.p, pr->n2,
+                               nb_cloud, pr->ctbp2.p, 7 * m2, pr->P2.pat.p, pr->P2.tot, T, pr->bbox_part.p);
+            hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(64), 0, ctx->stream, pr->bbox_part.p, slot);
         }
         // (9) R.cpp:958-961: stable centroids as copied BEFORE the update (R.cpp:868)
         if (stage3) {
             PWCHK(pw_vcm_run(ctx, pr->g_ct1.d, pr->P1.ct.p, pr->ct1n.p, &pr->icp, pr->stCT.p, ns, res->VCM));
             res->n_corr += ns;
         }
-        PWCHK(read_scal(pr, hs));
-        for (int d = 0; d < 3; ++d) { bmin[d] = ord2f_host(hs[4 + d]); bmax[d] = ord2f_host(hs[7 + d]); }
-
         // R.cpp:687-689
         mat4_mul(Tk, res->T16, res->T16);
         res->n_outer = k + 1;
@@ -655,11 +756,14 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         }
     }
     unsigned long long ex = 0;
-    HIPCHK(ctx, hipMemcpy(&ex, pr->examined.p, sizeof(ex), hipMemcpyDeviceToHost));
+    {   // diagnostic counter (points examined), kept in 256 separate cache lines on the device
+        std::vector<unsigned long long> hx(256 * 16);
+        HIPCHK(ctx, hipMemcpy(hx.data(), pr->examined.p, hx.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 256; ++i) ex += hx[(size_t)i * 16];
+    }
     res->dense_kbar = res->n_corr_dense > 0 ? (double)ex / (double)res->n_corr_dense : 0.0;
     res->status = status;
     HIPCHK(ctx, hipGetLastError());
-    (void)m1;
     return status;
 }
 
@@ -681,13 +785,17 @@ int pwicp_pair_bench_dense_nn(pwicp_pair* pr, int n_launches, double* ms_per_lau
         flags = pr->all_stable.p;
         npts = tot;
     }
-    HIPCHK(ctx, hipMemsetAsync(pr->examined.p, 0, sizeof(unsigned long long), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(pr->examined.p, 0, 256 * 16 * sizeof(unsigned long long), ctx->stream));
     // warm-up launch (also measures Kbar)
     PWCHK(pw_nn_dense_lds_launch(ctx, pr->g_c1.d, pr->pat2_0.p, pr->qorder.p, pr->pt_patch2.p, flags, tot,
                                  pr->d2dense.p, pr->examined.p));
     unsigned long long ex = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&ex, pr->examined.p, sizeof(ex), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        std::vector<unsigned long long> hx(256 * 16);
+        HIPCHK(ctx, hipMemcpyAsync(hx.data(), pr->examined.p, hx.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < 256; ++i) ex += hx[(size_t)i * 16];
+    }
     hipEvent_t e0 = pr->event(0), e1 = pr->event(1);
     HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
     for (int i = 0; i < n_launches; ++i)

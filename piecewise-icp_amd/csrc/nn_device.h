@@ -187,10 +187,12 @@ __device__ __forceinline__ NNBest nn_query(const GridDesc& gd, float qx, float q
     return b;
 }
 
+// diagnostic: points examined.  `ctr` is an array of 256 counters, 128 bytes apart (one per cache line), indexed
+// by block: same-line atomics from every wave would serialise (~5 ns each) and dominate a fast kernel.
 __device__ __forceinline__ void add_examined(unsigned long long* ctr, unsigned cnt) {
     if (!ctr) return;
     unsigned long long c = cnt;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if ((threadIdx.x & 63) == 0) atomicAdd(ctr, c);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&ctr[(blockIdx.x & 255) * 16], c);
 }

@@ -143,14 +143,68 @@ __device__ inline void ct_bp(const float4* __restrict__ p, const unsigned char* 
 }
 
 // ------------------------------------------------------------------------------------------------------
-__global__ void k_patch_normals(const float4* __restrict__ pat, const int* __restrict__ off, int m,
-                                float4* __restrict__ nrm_out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    float nv[3];
-    bool ok = cal_patch_normal(pat + off[i], off[i + 1] - off[i], nv);
+// One lane per patch, 64 patches per block.  The block's patches are one contiguous run of the CSR point array:
+// it is streamed through LDS in chunks with coalesced float4 loads, and every lane consumes the part of ITS
+// patch that lies in the chunk — in storage order, so the nine float running sums are those of
+// pcl::computeMeanAndCovarianceMatrix exactly.  The rare fallback branch of calPatchNormal re-reads the patch.
+constexpr int kNrmChunk = 2048;      // points per LDS chunk (32 KiB)
+__global__ void __launch_bounds__(256) k_patch_normals(const float4* __restrict__ pat, const int* __restrict__ off, int m,
+                                                       float4* __restrict__ nrm_out) {
+    __shared__ float4 s_p[kNrmChunk];
+    const int p0 = blockIdx.x * 64, p1 = min(p0 + 64, m);
+    const int i = p0 + threadIdx.x;
+    const bool owner = threadIdx.x < 64 && i < m;      // lanes of wave 0 own one patch each; all 4 waves load
+    const int lo = owner ? off[i] : 0, hi = owner ? off[i + 1] : 0;
+    const int blo = off[p0], bhi = off[p1];
+    float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
+    for (int c0 = blo; c0 < bhi; c0 += kNrmChunk) {
+        const int c1 = min(c0 + kNrmChunk, bhi);
+        __syncthreads();
+        {   // 2048 points / 256 threads = 8 coalesced float4 loads per thread, all issued before the LDS stores
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = c0 + threadIdx.x + u * 256;
+                if (j < c1) v[u] = pat[j];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = c0 + threadIdx.x + u * 256;
+                if (j < c1) s_p[j - c0] = v[u];
+            }
+        }
+        __syncthreads();
+        const int s = max(lo, c0), e = min(hi, c1);
+        for (int j = s; j < e; ++j) {
+            const float4 v = s_p[j - c0];
+            a0 += v.x * v.x; a1 += v.x * v.y; a2 += v.x * v.z;
+            a3 += v.y * v.y; a4 += v.y * v.z; a5 += v.z * v.z;
+            a6 += v.x; a7 += v.y; a8 += v.z;
+        }
+    }
+    if (!owner) return;
+    const int n = hi - lo;
+    float nv[3] = {0.f, 0.f, 1.f};
+    bool ok = false;
+    if (n > 4 && n >= 3) {
+        const float fn = (float)n;
+        a0 /= fn; a1 /= fn; a2 /= fn; a3 /= fn; a4 /= fn; a5 /= fn; a6 /= fn; a7 /= fn; a8 /= fn;
+        float cov[9];
+        cov[0] = a0 - a6 * a6; cov[1] = a1 - a6 * a7; cov[2] = a2 - a6 * a8;
+        cov[4] = a3 - a7 * a7; cov[5] = a4 - a7 * a8; cov[8] = a5 - a8 * a8;
+        cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
+        float e[3];
+        eigen33_smallest(cov, e);
+        const float nLen = sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+        if (fabs((double)nLen - 1.0) < 1e-5) {
+            nv[0] = e[0]; nv[1] = e[1]; nv[2] = e[2];
+            ok = true;
+        } else {
+            ok = cal_patch_normal(pat + lo, n, nv);      // takes the SVD-fallback branch (C.cpp:303-326)
+        }
+    }
     // w carries calPatchNormal's return value (1 / 0)
-    nrm_out[i] = ok ? make_float4(nv[0], nv[1], nv[2], 1.0f) : make_float4(nv[0], nv[1], nv[2], 0.0f);
+    nrm_out[i] = make_float4(nv[0], nv[1], nv[2], ok ? 1.0f : 0.0f);
 }
 
 // CT / BP / sigma of already selected patches
@@ -287,7 +341,7 @@ __global__ void k_point_patch_ids(const int* __restrict__ off, int m, int* __res
 // ======================================================================================================
 int pw_patch_normals_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, int m, float4* d_nrm) {
     if (m <= 0) return PWICP_OK;
-    hipLaunchKernelGGL(k_patch_normals, dim3(div_up(m, 64)), dim3(64), 0, ctx->stream, d_pat, d_off, m, d_nrm);
+    hipLaunchKernelGGL(k_patch_normals, dim3(div_up(m, 64)), dim3(256), 0, ctx->stream, d_pat, d_off, m, d_nrm);
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }
