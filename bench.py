@@ -155,7 +155,7 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("k_nn_patches_bytes_per_launch")
+                traffic = json.load(open(tfile)).get("k_nn_dense_bytes_per_launch")
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": "k_nn_dense_direct", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

@@ -390,24 +390,60 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_lds(GridDesc gd, const floa
 }
 
 
-// same interface as k_nn_dense_lds, straight from global memory (L1/L2) with the two-level search
+// Dense 1-NN straight from global memory (L1/L2) with the two-level search.  Stage 1 (27-cell stencil) runs for
+// every query; the queries it leaves unresolved are then COMPACTED inside the block (ballot + LDS) so that the
+// expensive far path runs on densely packed waves instead of a few lanes per wave (intra-wave divergence
+// between resolved and unresolved lanes was ~3x the useful VALU work).  No global atomics.
 __global__ void __launch_bounds__(kBlock) k_nn_dense_direct(GridDesc gd, const float4* __restrict__ pat,
                                                             const int* __restrict__ qorder,
                                                             const int* __restrict__ pt_patch,
                                                             const int* __restrict__ stable, int nq,
                                                             float* __restrict__ d2out,
                                                             unsigned long long* __restrict__ examined) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+    __shared__ float4 s_q[kBlock];
+    __shared__ unsigned long long s_key[kBlock];
+    __shared__ int s_slot[kBlock];
+    __shared__ int s_wcnt[kBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x * kBlock + tid;
     unsigned cnt = 0;
+    bool unresolved = false;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    NNBest b;
+    b.key = kKeyInit;
     if (i < nq) {
         const int p = qorder ? qorder[i] : i;
         if (stable[pt_patch[p]]) {
-            const float4 q = pat[p];
-            NNBest b = nn_query(gd, q.x, q.y, q.z, cnt);
-            d2out[i] = b.d2();
+            q = pat[p];
+            if (gd.fine.n > 0 && !nn_stage1(gd, q.x, q.y, q.z, b, cnt)) unresolved = true;
+            else d2out[i] = b.d2();
         } else {
             d2out[i] = __uint_as_float(kSentinel);
         }
+    }
+    // block-level compaction of the unresolved queries
+    const unsigned long long mask = __ballot(unresolved);
+    const int before = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wcnt[wave] = __popcll(mask);
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) {
+        if (w < wave) base += s_wcnt[w];
+        total += s_wcnt[w];
+    }
+    if (unresolved) {
+        s_q[base + before] = q;
+        s_key[base + before] = b.key;
+        s_slot[base + before] = i;
+    }
+    __syncthreads();
+    if (tid < total) {
+        const float4 u = s_q[tid];
+        NNBest c;
+        c.key = s_key[tid];
+        nn_stage23(gd, u.x, u.y, u.z, c, cnt);
+        d2out[s_slot[tid]] = c.d2();
     }
     add_examined(examined, cnt);
 }

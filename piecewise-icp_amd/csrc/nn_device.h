@@ -148,41 +148,45 @@ __device__ __forceinline__ unsigned nn_expand(const GridLevel& g, float qx, floa
     return cnt;
 }
 
-__device__ __forceinline__ NNBest nn_query(const GridDesc& gd, float qx, float qy, float qz, unsigned& examined) {
+// stage 1: fine 27-cell stencil; returns true when the result is final
+__device__ __forceinline__ bool nn_stage1(const GridDesc& gd, float qx, float qy, float qz, NNBest& b, unsigned& cnt) {
     const GridLevel& g = gd.fine;
-    NNBest b;
-    b.key = kKeyInit;
-    examined = 0;
-    if (g.n <= 0) return b;
-    unsigned cnt = 0;
-    // ---- stage 1: fine 27-cell stencil -------------------------------------------------------------------
-    {
-        const int cx = cell_of(qx, g.ox, g.inv_h), cy = cell_of(qy, g.oy, g.inv_h), cz = cell_of(qz, g.oz, g.inv_h);
-        int lo[9], hi[9];
+    const int cx = cell_of(qx, g.ox, g.inv_h), cy = cell_of(qy, g.oy, g.inv_h), cz = cell_of(qz, g.oz, g.inv_h);
+    int lo[9], hi[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) row_range(g, cy + (k % 3) - 1, cz + (k / 3) - 1, cx - 1, cx + 1, lo[k], hi[k]);
+    for (int k = 0; k < 9; ++k) row_range(g, cy + (k % 3) - 1, cz + (k / 3) - 1, cx - 1, cx + 1, lo[k], hi[k]);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            scan_points(g.pts, lo[k], hi[k], qx, qy, qz, b);
-            cnt += (unsigned)(hi[k] - lo[k]);
-        }
-        if (nn_resolved(g, 1, b)) { examined = cnt; return b; }
+    for (int k = 0; k < 9; ++k) {
+        scan_points(g.pts, lo[k], hi[k], qx, qy, qz, b);
+        cnt += (unsigned)(hi[k] - lo[k]);
     }
+    return nn_resolved(g, 1, b);
+}
+
+// stages 2 and 3 on the coarse level, seeded with the best candidate so far (if any)
+__device__ __forceinline__ void nn_stage23(const GridDesc& gd, float qx, float qy, float qz, NNBest& b, unsigned& cnt) {
     const GridLevel& c = gd.coarse;
-    // ---- stage 2: candidate known -> scan the coarse cells touching the cube [q - rho, q + rho] ------------
     if (b.found()) {
+        // candidate known -> scan the coarse cells touching the cube [q - rho, q + rho]
         const float rho = sqrtf(b.d2()) * 1.00001f + 2.0f * c.slack;
         const int x0 = max(cell_of(qx - rho, c.ox, c.inv_h), 0), x1 = min(cell_of(qx + rho, c.ox, c.inv_h), c.nx - 1);
         const int y0 = max(cell_of(qy - rho, c.oy, c.inv_h), 0), y1 = min(cell_of(qy + rho, c.oy, c.inv_h), c.ny - 1);
         const int z0 = max(cell_of(qz - rho, c.oz, c.inv_h), 0), z1 = min(cell_of(qz + rho, c.oz, c.inv_h), c.nz - 1);
         if ((y1 - y0 + 1) * (z1 - z0 + 1) <= 64) {
             if (x0 <= x1 && y0 <= y1 && z0 <= z1) cnt += scan_box(c, x0, x1, y0, y1, z0, z1, qx, qy, qz, b);
-            examined = cnt;
-            return b;
+            return;
         }
     }
-    // ---- stage 3: expansion on the coarse level ---------------------------------------------------------------
-    cnt += nn_expand(c, qx, qy, qz, b);
+    cnt += nn_expand(c, qx, qy, qz, b);       // block / shell expansion on the coarse level
+}
+
+__device__ __forceinline__ NNBest nn_query(const GridDesc& gd, float qx, float qy, float qz, unsigned& examined) {
+    NNBest b;
+    b.key = kKeyInit;
+    examined = 0;
+    if (gd.fine.n <= 0) return b;
+    unsigned cnt = 0;
+    if (!nn_stage1(gd, qx, qy, qz, b, cnt)) nn_stage23(gd, qx, qy, qz, b, cnt);
     examined = cnt;
     return b;
 }
