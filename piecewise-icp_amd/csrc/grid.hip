@@ -166,17 +166,98 @@ __global__ void k_scan_apply(int* __restrict__ d, long long n, const int* __rest
     }
 }
 
+// Stage 1 for every query, then the unresolved ones are compacted inside the block (ballot + LDS) so that the
+// far path (stages 2/3) runs on densely packed waves.  Shared by k_nn_points and k_nn_dense_direct.
+// `slot` = output index of this lane's query (< 0: lane inactive).
+__device__ __forceinline__ void nn_block_search(const GridDesc& gd, bool active, float4 q, int slot,
+                                                int* __restrict__ idx_out, float* __restrict__ d2_out,
+                                                unsigned& cnt) {
+    __shared__ float4 s_q[kBlock];
+    __shared__ unsigned long long s_key[kBlock];
+    __shared__ int s_slot[kBlock];
+    __shared__ int s_wcnt[kBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    bool unresolved = false;
+    NNBest b;
+    b.key = kKeyInit;
+    if (active) {
+        if (gd.fine.n > 0 && !nn_stage1(gd, q.x, q.y, q.z, b, cnt)) unresolved = true;
+        else {
+            if (idx_out) idx_out[slot] = b.found() ? b.idx() : -1;
+            d2_out[slot] = b.d2();
+        }
+    }
+    const unsigned long long mask = __ballot(unresolved);
+    const int before = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wcnt[wave] = __popcll(mask);
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) {
+        if (w < wave) base += s_wcnt[w];
+        total += s_wcnt[w];
+    }
+    if (unresolved) {
+        s_q[base + before] = q;
+        s_key[base + before] = b.key;
+        s_slot[base + before] = slot;
+    }
+    __syncthreads();
+    if (total <= kBlock / 8) {
+        // few far queries in this block (the tail case): 8 lanes share one query so that its long scan is not a
+        // single lane's serial chain.  Only the data-independent ball-box path is shared; the rest stays per lane.
+        const int qi = tid >> 3, sub = tid & 7;
+        if (qi < total) {
+            const float4 u = s_q[qi];
+            NNBest c;
+            c.key = s_key[qi];
+            const GridLevel& cl = gd.coarse;
+            bool coop = false;
+            int x0 = 0, x1 = -1, y0 = 0, y1 = -1, z0 = 0, z1 = -1;
+            if (c.found()) {
+                const float rho = sqrtf(c.d2()) * 1.00001f + 2.0f * cl.slack;
+                x0 = max(cell_of(u.x - rho, cl.ox, cl.inv_h), 0); x1 = min(cell_of(u.x + rho, cl.ox, cl.inv_h), cl.nx - 1);
+                y0 = max(cell_of(u.y - rho, cl.oy, cl.inv_h), 0); y1 = min(cell_of(u.y + rho, cl.oy, cl.inv_h), cl.ny - 1);
+                z0 = max(cell_of(u.z - rho, cl.oz, cl.inv_h), 0); z1 = min(cell_of(u.z + rho, cl.oz, cl.inv_h), cl.nz - 1);
+                coop = (y1 - y0 + 1) * (z1 - z0 + 1) <= 64;
+            }
+            if (coop) {
+                if (x0 <= x1 && y0 <= y1 && z0 <= z1)
+                    cnt += scan_box_coop(cl, x0, x1, y0, y1, z0, z1, sub, 8, u.x, u.y, u.z, c);
+                // min over the 8 lanes of the group (lanes 8k..8k+7 of one wave)
+#pragma unroll
+                for (int o = 1; o < 8; o <<= 1) {
+                    const unsigned long long other = __shfl_xor(c.key, o);
+                    c.key = other < c.key ? other : c.key;
+                }
+            } else if (sub == 0) {
+                nn_stage23(gd, u.x, u.y, u.z, c, cnt);
+            }
+            if (sub == 0) {
+                const int o = s_slot[qi];
+                if (idx_out) idx_out[o] = c.found() ? c.idx() : -1;
+                d2_out[o] = c.d2();
+            }
+        }
+    } else if (tid < total) {
+        const float4 u = s_q[tid];
+        NNBest c;
+        c.key = s_key[tid];
+        nn_stage23(gd, u.x, u.y, u.z, c, cnt);
+        const int o = s_slot[tid];
+        if (idx_out) idx_out[o] = c.found() ? c.idx() : -1;
+        d2_out[o] = c.d2();
+    }
+}
+
 __global__ void __launch_bounds__(kBlock) k_nn_points(GridDesc g, const float4* __restrict__ q, int nq,
                                                       int* __restrict__ idx, float* __restrict__ d2,
                                                       unsigned long long* __restrict__ examined) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned cnt = 0;
-    if (i < nq) {
-        float4 v = q[i];
-        NNBest b = nn_query(g, v.x, v.y, v.z, cnt);
-        if (idx) idx[i] = b.found() ? b.idx() : -1;
-        d2[i] = b.d2();
-    }
+    const bool active = i < nq;
+    const float4 v = active ? q[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    nn_block_search(g, active, v, i, idx, d2, cnt);
     add_examined(examined, cnt);
 }
 
@@ -400,51 +481,16 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_direct(GridDesc gd, const f
                                                             const int* __restrict__ stable, int nq,
                                                             float* __restrict__ d2out,
                                                             unsigned long long* __restrict__ examined) {
-    __shared__ float4 s_q[kBlock];
-    __shared__ unsigned long long s_key[kBlock];
-    __shared__ int s_slot[kBlock];
-    __shared__ int s_wcnt[kBlock / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = blockIdx.x * kBlock + tid;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
     unsigned cnt = 0;
-    bool unresolved = false;
+    bool active = false;
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-    NNBest b;
-    b.key = kKeyInit;
     if (i < nq) {
         const int p = qorder ? qorder[i] : i;
-        if (stable[pt_patch[p]]) {
-            q = pat[p];
-            if (gd.fine.n > 0 && !nn_stage1(gd, q.x, q.y, q.z, b, cnt)) unresolved = true;
-            else d2out[i] = b.d2();
-        } else {
-            d2out[i] = __uint_as_float(kSentinel);
-        }
+        if (stable[pt_patch[p]]) { active = true; q = pat[p]; }
+        else d2out[i] = __uint_as_float(kSentinel);
     }
-    // block-level compaction of the unresolved queries
-    const unsigned long long mask = __ballot(unresolved);
-    const int before = __popcll(mask & ((1ull << lane) - 1ull));
-    if (lane == 0) s_wcnt[wave] = __popcll(mask);
-    __syncthreads();
-    int base = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w) {
-        if (w < wave) base += s_wcnt[w];
-        total += s_wcnt[w];
-    }
-    if (unresolved) {
-        s_q[base + before] = q;
-        s_key[base + before] = b.key;
-        s_slot[base + before] = i;
-    }
-    __syncthreads();
-    if (tid < total) {
-        const float4 u = s_q[tid];
-        NNBest c;
-        c.key = s_key[tid];
-        nn_stage23(gd, u.x, u.y, u.z, c, cnt);
-        d2out[s_slot[tid]] = c.d2();
-    }
+    nn_block_search(gd, active, q, i, nullptr, d2out, cnt);
     add_examined(examined, cnt);
 }
 

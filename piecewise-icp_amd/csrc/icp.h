@@ -25,5 +25,7 @@ int pw_icp_enqueue(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, c
                    int ns_max, const unsigned* ns_dev, double euclid_eps, int n_iter);
 int pw_icp_run(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w, int ns,
                double euclid_eps, float* T16, int* iters_out);
+int pw_vcm_enqueue(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
+                   const float4* d_src, int ns);
 int pw_vcm_run(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
                const float4* d_src, int ns, double* VCM36);

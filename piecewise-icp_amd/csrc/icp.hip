@@ -293,6 +293,21 @@ int pw_icp_run(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const
     return PWICP_OK;
 }
 
+// enqueue only: the 6x6 result is left in w->vcm (device)
+int pw_vcm_enqueue(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
+                   const float4* d_src, int ns) {
+    if (ns <= 0) return PWICP_OK;
+    const int nb = div_up(ns, kBlock);
+    hipLaunchKernelGGL(k_vcm_accum, dim3(nb), dim3(kBlock), 0, ctx->stream, g, d_tgt, d_tgt_n, d_src, ns, w->match.p,
+                       w->partials.p);
+    hipLaunchKernelGGL(k_vcm_solve, dim3(1), dim3(64), 0, ctx->stream, w->partials.p, nb, w->qx.p);
+    hipLaunchKernelGGL(k_vcm_resid, dim3(nb), dim3(kBlock), 0, ctx->stream, d_tgt, d_tgt_n, d_src, ns, w->match.p,
+                       w->qx.p, w->partials.p);
+    hipLaunchKernelGGL(k_vcm_final, dim3(1), dim3(64), 0, ctx->stream, w->partials.p, nb, ns, w->qx.p, w->vcm.p);
+    HIPCHK(ctx, hipGetLastError());
+    return PWICP_OK;
+}
+
 int pw_vcm_run(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
                const float4* d_src, int ns, double* VCM36) {
     if (ns <= 0) { for (int i = 0; i < 36; ++i) VCM36[i] = NAN; return PWICP_OK; }

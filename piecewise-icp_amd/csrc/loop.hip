@@ -250,6 +250,30 @@ __global__ void __launch_bounds__(64) k_bbox_fold(unsigned* __restrict__ bbox_pa
         for (int d = 0; d < 3; ++d) { slot[4 + d] = mn[d]; slot[7 + d] = mx[d]; }
 }
 
+// Device -> host mailbox: copies up to three word ranges into pinned, coherent host memory and then publishes a
+// sequence number with a system-scope release.  The host spins on the sequence word instead of paying a
+// hipMemcpy + hipStreamSynchronize round trip per outer iteration (stream order guarantees the producers ran).
+__global__ void __launch_bounds__(64) k_mail(const unsigned* __restrict__ a, int na, const unsigned* __restrict__ b, int nb,
+                                             const unsigned* __restrict__ c, int nc, unsigned* __restrict__ dst,
+                                             unsigned* seq_ptr, unsigned seq) {
+    const int t = threadIdx.x;
+    for (int i = t; i < na; i += 64) dst[i] = a[i];
+    for (int i = t; i < nb; i += 64) dst[na + i] = b[i];
+    for (int i = t; i < nc; i += 64) dst[na + nb + i] = c[i];
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(seq_ptr, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// sums the 256 spread diagnostic counters into ctr[256*16] (one wave)
+__global__ void __launch_bounds__(64) k_fold_examined(unsigned long long* __restrict__ ctr) {
+    unsigned long long c = 0;
+    for (int i = threadIdx.x; i < 256; i += 64) c += ctr[i * 16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (threadIdx.x == 0) ctr[256 * 16] = c;
+}
+
 // one 16-word scalar slot per outer iteration: [0] LoDmin [1] LoDmax [2] n stable [3] n stable points
 // [4..6] bbox min, [7..9] bbox max of cloud2 AFTER this iteration's transform (ordered-uint encoded)
 constexpr int kSlot = 16;
@@ -372,8 +396,13 @@ struct pwicp_pair {
     DevBuf<int> list0, soff0;
     int ns0 = 0, nsp0 = 0;
     std::vector<hipEvent_t> ev;
+    // mailbox in pinned coherent host memory: [0] sequence word, [16..] payload
+    unsigned* mail_h = nullptr;
+    unsigned* mail_d = nullptr;
+    unsigned mail_seq = 0;
     ~pwicp_pair() {
         for (auto e : ev) (void)hipEventDestroy(e);
+        if (mail_h) (void)hipHostFree(mail_h);
     }
     hipEvent_t event(size_t i) {
         while (ev.size() <= i) {
@@ -448,8 +477,11 @@ int finish_create(pwicp_pair* pr) {
     }
     HIPCHK(ctx, pr->sel_scratch.reserve(8 + 3 * 2048));
     HIPCHK(ctx, pr->sel_out.reserve(1));
-    HIPCHK(ctx, pr->examined.reserve(256 * 16));
+    HIPCHK(ctx, pr->examined.reserve(256 * 16 + 2));
     PWCHK(pr->icp.reserve(ctx, m2));
+    HIPCHK(ctx, hipHostMalloc((void**)&pr->mail_h, 256 * sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(pr->mail_h, 0, 256 * sizeof(unsigned));
+    HIPCHK(ctx, hipHostGetDevicePointer((void**)&pr->mail_d, pr->mail_h, 0));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
@@ -577,15 +609,40 @@ int pwicp_pair_download_source(pwicp_pair* pr, float* cloud2_xyz4) {
     return PWICP_OK;
 }
 
+// waits until the mailbox sequence word reaches `seq` (spin, then fall back to a stream synchronisation)
+static int mail_wait(pwicp_pair* pr, unsigned seq) {
+    pwicp_context* ctx = pr->ctx;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(&pr->mail_h[0], __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 0x3ff) == 0 &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) {
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            if (__atomic_load_n(&pr->mail_h[0], __ATOMIC_ACQUIRE) != seq) {
+                ctx->set_err("pwicp: device mailbox never signalled");
+                return PWICP_E_INTERNAL;
+            }
+            break;
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    return PWICP_OK;
+}
+
 // n_slots entries in d2dense of which n_valid are real distances (the rest carry the sentinel)
 static int select_p75(pwicp_pair* pr, int n_slots, int n_valid, double* out) {
     pwicp_context* ctx = pr->ctx;
     int k = (int)((float)n_valid * 0.75f);      // C.cpp:177
     if (k >= n_valid) k = n_valid - 1;
     PWCHK(pw_select_kth_launch(ctx, pr->d2dense.p, n_slots, k, pr->sel_scratch.p, pr->sel_out.p));
-    float v = 0.f;
-    HIPCHK(ctx, hipMemcpyAsync(&v, pr->sel_out.p, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned seq = ++pr->mail_seq;
+    hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, ctx->stream, (const unsigned*)pr->sel_out.p, 1, (const unsigned*)nullptr, 0,
+                       (const unsigned*)nullptr, 0, pr->mail_d + 16, pr->mail_d, seq);
+    PWCHK(mail_wait(pr, seq));
+    float v;
+    memcpy(&v, pr->mail_h + 16, 4);
     *out = (double)sqrtf(v);                    // C.cpp:277
     return PWICP_OK;
 }
@@ -622,10 +679,11 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     for (int d = 0; d < 3; ++d) { bmin[d] = pr->bmin0[d]; bmax[d] = pr->bmax0[d]; }
     hipLaunchKernelGGL(k_scal_init, dim3(div_up(kSlot * (PWICP_MAX_OUTER + 1), kBlock)), dim3(kBlock), 0, ctx->stream,
                        pr->scal.p, PWICP_MAX_OUTER + 1);
-    HIPCHK(ctx, hipMemsetAsync(pr->examined.p, 0, 256 * 16 * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(pr->examined.p, 0, (256 * 16 + 2) * sizeof(unsigned long long), ctx->stream));
 
     int status = PWICP_OK;
     int prev_inner = 2;
+    bool vcm_pending = false;
     const auto t0 = std::chrono::steady_clock::now();
     while (!stage3) {                                                   // R.cpp:680
         const int k = res->n_outer;
@@ -659,11 +717,17 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
             int batch = std::max(1, prev_inner);
             for (;;) {
                 PWCHK(pw_icp_enqueue(ctx, pr->g_ct1.d, pr->P1.ct.p, pr->ct1n.p, &pr->icp, m2, slot + 2, 1e-6, batch));
-                HIPCHK(ctx, hipMemcpyAsync(hs, slot, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
-                HIPCHK(ctx, hipMemcpyAsync(&hst, pr->icp.state.p, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
-                // bbox of cloud2 after the PREVIOUS iteration's transform (written into the previous slot)
-                if (k > 0) HIPCHK(ctx, hipMemcpyAsync(hb, slot - kSlot + 4, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
-                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                // one mailbox message: this slot | bbox words of the PREVIOUS slot (cloud2 after the previous
+                // iteration's transform) | the ICP state
+                const unsigned seq = ++pr->mail_seq;
+                hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, ctx->stream, (const unsigned*)slot, kSlot,
+                                   (const unsigned*)(k > 0 ? slot - kSlot + 4 : slot + 4), 6,
+                                   (const unsigned*)pr->icp.state.p, (int)(sizeof(IcpState) / 4), pr->mail_d + 16, pr->mail_d,
+                                   seq);
+                PWCHK(mail_wait(pr, seq));
+                memcpy(hs, pr->mail_h + 16, sizeof(hs));
+                memcpy(hb, pr->mail_h + 16 + kSlot, sizeof(hb));
+                memcpy(&hst, pr->mail_h + 16 + kSlot + 6, sizeof(IcpState));
                 if (hst.done || hst.iters >= 100) break;
                 batch = 2;
             }
@@ -739,7 +803,8 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         }
         // (9) R.cpp:958-961: stable centroids as copied BEFORE the update (R.cpp:868)
         if (stage3) {
-            PWCHK(pw_vcm_run(ctx, pr->g_ct1.d, pr->P1.ct.p, pr->ct1n.p, &pr->icp, pr->stCT.p, ns, res->VCM));
+            PWCHK(pw_vcm_enqueue(ctx, pr->g_ct1.d, pr->P1.ct.p, pr->ct1n.p, &pr->icp, pr->stCT.p, ns));
+            vcm_pending = true;
             res->n_corr += ns;
         }
         // R.cpp:687-689
@@ -747,19 +812,25 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         res->n_outer = k + 1;
         res->DTseries[k + 1] = currDT;
     }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // final message: the VCM (R.cpp:958-961) and the diagnostic counter; its arrival also means the stream is idle
+    unsigned long long ex = 0;
+    {
+        hipLaunchKernelGGL(k_fold_examined, dim3(1), dim3(64), 0, ctx->stream, pr->examined.p);
+        const unsigned seq = ++pr->mail_seq;
+        hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, ctx->stream, (const unsigned*)pr->icp.vcm.p, 72,
+                           (const unsigned*)(pr->examined.p + 256 * 16), 2, (const unsigned*)nullptr, 0, pr->mail_d + 16,
+                           pr->mail_d, seq);
+        PWCHK(mail_wait(pr, seq));
+        if (vcm_pending) memcpy(res->VCM, pr->mail_h + 16, 36 * sizeof(double));
+        memcpy(&ex, pr->mail_h + 16 + 72, sizeof(ex));
+    }
     res->t_loop_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // events below must have completed
     for (auto& e : ev_kind) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, pr->ev[e.first], pr->ev[e.first + 1]) == hipSuccess) {
             if (e.second == 0) res->t_dense_nn_ms += ms; else res->t_inner_ms += ms;
         }
-    }
-    unsigned long long ex = 0;
-    {   // diagnostic counter (points examined), kept in 256 separate cache lines on the device
-        std::vector<unsigned long long> hx(256 * 16);
-        HIPCHK(ctx, hipMemcpy(hx.data(), pr->examined.p, hx.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        for (int i = 0; i < 256; ++i) ex += hx[(size_t)i * 16];
     }
     res->dense_kbar = res->n_corr_dense > 0 ? (double)ex / (double)res->n_corr_dense : 0.0;
     res->status = status;

@@ -58,6 +58,12 @@ __device__ __forceinline__ void scan_points(const float4* __restrict__ pts, int 
     if (j < hi) nn_consider(pts[j], qx, qy, qz, b);
 }
 
+// lane `sub` of a group of `stride` lanes takes every stride-th point (cooperative far path)
+__device__ __forceinline__ void scan_points_strided(const float4* __restrict__ pts, int lo, int hi, int sub, int stride,
+                                                    float qx, float qy, float qz, NNBest& b) {
+    for (int j = lo + sub; j < hi; j += stride) nn_consider(pts[j], qx, qy, qz, b);
+}
+
 // [begin,end) of the points of cells x0..x1 (clipped) of row (y,z); empty if the row is outside the grid
 __device__ __forceinline__ void row_range(const GridLevel& g, int y, int z, int x0, int x1, int& lo, int& hi) {
     lo = 0; hi = 0;
@@ -88,6 +94,29 @@ __device__ __forceinline__ unsigned scan_box(const GridLevel& g, int x0, int x1,
         for (int k = 0; k < 4; ++k) {
             scan_points(g.pts, lo[k], hi[k], qx, qy, qz, b);
             cnt += (unsigned)(hi[k] - lo[k]);
+        }
+    }
+    return cnt;
+}
+
+// scan_box shared by a group of `stride` lanes: same rows for every lane, points interleaved
+__device__ __forceinline__ unsigned scan_box_coop(const GridLevel& g, int x0, int x1, int y0, int y1, int z0, int z1,
+                                                  int sub, int stride, float qx, float qy, float qz, NNBest& b) {
+    unsigned cnt = 0;
+    const int wy = y1 - y0 + 1;
+    const int nrows = wy * (z1 - z0 + 1);
+    for (int t0 = 0; t0 < nrows; t0 += 4) {
+        int lo[4], hi[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = t0 + k;
+            lo[k] = hi[k] = 0;
+            if (t < nrows) row_range(g, y0 + t % wy, z0 + t / wy, x0, x1, lo[k], hi[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            scan_points_strided(g.pts, lo[k], hi[k], sub, stride, qx, qy, qz, b);
+            if (sub == 0) cnt += (unsigned)(hi[k] - lo[k]);
         }
     }
     return cnt;

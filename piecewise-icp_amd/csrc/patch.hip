@@ -143,46 +143,34 @@ __device__ inline void ct_bp(const float4* __restrict__ p, const unsigned char* 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// One lane per patch, 64 patches per block.  The block's patches are one contiguous run of the CSR point array:
-// it is streamed through LDS in chunks with coalesced float4 loads, and every lane consumes the part of ITS
-// patch that lies in the chunk — in storage order, so the nine float running sums are those of
-// pcl::computeMeanAndCovarianceMatrix exactly.  The rare fallback branch of calPatchNormal re-reads the patch.
-constexpr int kNrmChunk = 2048;      // points per LDS chunk (32 KiB)
-__global__ void __launch_bounds__(256) k_patch_normals(const float4* __restrict__ pat, const int* __restrict__ off, int m,
-                                                       float4* __restrict__ nrm_out) {
-    __shared__ float4 s_p[kNrmChunk];
-    const int p0 = blockIdx.x * 64, p1 = min(p0 + 64, m);
-    const int i = p0 + threadIdx.x;
-    const bool owner = threadIdx.x < 64 && i < m;      // lanes of wave 0 own one patch each; all 4 waves load
-    const int lo = owner ? off[i] : 0, hi = owner ? off[i + 1] : 0;
-    const int blo = off[p0], bhi = off[p1];
+// One lane per patch.  A lane walks ITS patch in storage order — the nine float running sums are those of
+// pcl::computeMeanAndCovarianceMatrix exactly — but the loads are issued eight points ahead of the adds, so the
+// (inherently serial) accumulation no longer waits a full memory latency per point.  Each lane streams through
+// its own cache lines (8 points per 128-byte line).
+__global__ void __launch_bounds__(64) k_patch_normals(const float4* __restrict__ pat, const int* __restrict__ off, int m,
+                                                      float4* __restrict__ nrm_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const int lo = off[i], hi = off[i + 1];
     float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
-    for (int c0 = blo; c0 < bhi; c0 += kNrmChunk) {
-        const int c1 = min(c0 + kNrmChunk, bhi);
-        __syncthreads();
-        {   // 2048 points / 256 threads = 8 coalesced float4 loads per thread, all issued before the LDS stores
-            float4 v[8];
+    int j = lo;
+    for (; j + 8 <= hi; j += 8) {
+        float4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = c0 + threadIdx.x + u * 256;
-                if (j < c1) v[u] = pat[j];
-            }
+        for (int u = 0; u < 8; ++u) v[u] = pat[j + u];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = c0 + threadIdx.x + u * 256;
-                if (j < c1) s_p[j - c0] = v[u];
-            }
-        }
-        __syncthreads();
-        const int s = max(lo, c0), e = min(hi, c1);
-        for (int j = s; j < e; ++j) {
-            const float4 v = s_p[j - c0];
-            a0 += v.x * v.x; a1 += v.x * v.y; a2 += v.x * v.z;
-            a3 += v.y * v.y; a4 += v.y * v.z; a5 += v.z * v.z;
-            a6 += v.x; a7 += v.y; a8 += v.z;
+        for (int u = 0; u < 8; ++u) {
+            a0 += v[u].x * v[u].x; a1 += v[u].x * v[u].y; a2 += v[u].x * v[u].z;
+            a3 += v[u].y * v[u].y; a4 += v[u].y * v[u].z; a5 += v[u].z * v[u].z;
+            a6 += v[u].x; a7 += v[u].y; a8 += v[u].z;
         }
     }
-    if (!owner) return;
+    for (; j < hi; ++j) {
+        const float4 v = pat[j];
+        a0 += v.x * v.x; a1 += v.x * v.y; a2 += v.x * v.z;
+        a3 += v.y * v.y; a4 += v.y * v.z; a5 += v.z * v.z;
+        a6 += v.x; a7 += v.y; a8 += v.z;
+    }
     const int n = hi - lo;
     float nv[3] = {0.f, 0.f, 1.f};
     bool ok = false;
@@ -341,7 +329,7 @@ __global__ void k_point_patch_ids(const int* __restrict__ off, int m, int* __res
 // ======================================================================================================
 int pw_patch_normals_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, int m, float4* d_nrm) {
     if (m <= 0) return PWICP_OK;
-    hipLaunchKernelGGL(k_patch_normals, dim3(div_up(m, 64)), dim3(256), 0, ctx->stream, d_pat, d_off, m, d_nrm);
+    hipLaunchKernelGGL(k_patch_normals, dim3(div_up(m, 64)), dim3(64), 0, ctx->stream, d_pat, d_off, m, d_nrm);
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }
