@@ -42,14 +42,17 @@ def make_pair(n_points, epoch):
     return tgt, l1, n1, src, l2, n2, Tgt
 
 
+LABELS = "supervoxel"
+
+
 def segment(cloud, sv):
-    """Supervoxel labels.  The segmentation front end is outside the timed hot path."""
+    """Supervoxel labels from the product's own front end (host stage, setup: outside the timed hot path,
+    SURVEY §8 row f1); `--labels grid` substitutes square grid cells for quick runs."""
     from pwicp_amd import synth
-    try:
-        from pwicp_amd import frontend          # product front end, when built
-        return frontend.segment(cloud, sv)
-    except Exception:
+    if LABELS == "grid":
         return synth.grid_labels(cloud, sv)
+    from pwicp_amd import frontend
+    return frontend.segment(cloud, sv)
 
 
 def cpu_baseline(tgt, l1, n1, src, l2, n2, passes=2):
@@ -75,7 +78,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=1000000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--labels", choices=["supervoxel", "grid"], default="supervoxel")
     args = ap.parse_args()
+    global LABELS
+    LABELS = args.labels
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -179,7 +185,8 @@ def main():
                        "points_per_cloud": args.points, "spacing_m": r, "patches_target_source": list(pair.num_patches()),
                        "outer_iterations": n_outer, "inner_iterations": n_inner,
                        "correspondences_per_step": int(res.n_corr), "parallelism": "pair-per-gpu x%d" % world,
-                       "segmentation": "grid cells (front end is setup, untimed)"},
+                       "segmentation": ("boundary-preserving supervoxels, product front end (host, setup, untimed)"
+                                        if args.labels == "supervoxel" else "grid cells (setup, untimed)")},
             "ms_per_outer_iteration": round(res.t_loop_ms / max(n_outer, 1), 4),
             "ms_per_inner_iteration": round(res.t_inner_ms / max(n_inner, 1), 4),
             "setup_s": round(t_setup, 3),

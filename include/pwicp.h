@@ -24,6 +24,7 @@
 #ifndef PWICP_H
 #define PWICP_H
 
+#include <stdbool.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -173,6 +174,26 @@ PWICP_API int pwicp_pair_reset(pwicp_pair* pair);
 PWICP_API int pwicp_pair_run(pwicp_pair* pair, pwicp_result* result);
 /* Copies the current (transformed) source cloud back: cloud2 after the loop (R.cpp:943-945). */
 PWICP_API int pwicp_pair_download_source(pwicp_pair* pair, float* cloud2_xyz4);
+
+/* ---- host-side setup stages and the reference's file-in / file-out entry points -------------------------------- */
+/* These run on the HOST today ("next" for the GPU); they are what the reference does
+ * before and after the loop, exported so that the two entry points below are a complete drop-in. */
+
+/* Supervoxel label of every point.  Replaces the first half of PatchGenerationAndRefinement (S.cpp:18-68):
+ * k-NN (knn = 45 in the reference, C.h:41, query point included), PCA normals, boundary-preserving supervoxel
+ * segmentation at `sv_resolution`. */
+PWICP_API int pwicp_frontend_segment(const float* cloud_xyz4, int n, float sv_resolution, int knn,
+                                     int32_t* labels, int* n_supervoxels);
+/* PCpreprocessing(cloud, out, true, voxel_size, sor_k, sor_mult) (C.cpp:423-452). out_xyz4 holds n points. */
+PWICP_API int pwicp_preprocess(const float* cloud_xyz4, int n, float voxel_size, int sor_k, double sor_mult,
+                               float* out_xyz4, int* n_out);
+/* calPCresolution (C.cpp:239-263) */
+PWICP_API float pwicp_pc_resolution(const float* cloud_xyz4, int n);
+
+/* The reference's exported functions, same signatures (include/Registration.h:36, 49; python/main.py:15-18).
+ * Device: $PWICP_DEVICE or $LOCAL_RANK (default 0).  Never exit(): false on any failure. */
+PWICP_API bool PiecewiseICP_pair_call(const char* confile, const char* outfile);
+PWICP_API bool PiecewiseICP_4D_call(const char* confile, int startEpoch, int epochNum, int pairMode, float overlapThd);
 
 /* ---- one dense NN launch on resident data, for roofline measurement (bench.py) --------------- */
 /* Runs the dense 1-NN kernel for all source patch points of `pair` against cloud1 `n_launches`

@@ -1,0 +1,345 @@
+// The reference's two exported entry points, on top of the core C ABI (pwicp.h):
+//   bool PiecewiseICP_pair_call(const char* confile, const char* outfile)            include/Registration.h:49
+//   bool PiecewiseICP_4D_call(const char* confile, int startEpoch, int epochNum, int pairMode, float overlapThd)
+//                                                                                     include/Registration.h:36
+// Same names, argument meaning, side effects (result files) and `bool` return; never exit()s.
+//
+// Reference: PiecewiseICP_pair_call src/Registration.cpp:219-398, PiecewiseICP_4D_call Registration.cpp:17-215,
+// Piecewise_ICP_4D Registration.cpp:402-548, calAdaptivePairSequence Registration.cpp:552-589,
+// calTransToReferenceEpoch Registration.cpp:977-1153, calAbsErrorOfTransPara Registration.cpp:1157-1251.
+// Pipeline per pair: load PCD -> VoxelGrid + SOR -> subtract the target centroid -> supervoxel labels (host front
+// end) -> pwicp_pair_create / pwicp_pair_run (the fine-registration loop on the GPU) -> T_final = S^-1 T S -> files.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "io.h"
+#include "pwicp.h"
+
+extern "C" int pwicp_frontend_segment(const float*, int, float, int, int32_t*, int*);
+
+using namespace pwhost;
+
+namespace {
+
+constexpr int kNN = 45;      // include/CommonFunc.h:41
+
+struct PairOutput {
+    float T[16];
+    float para[6];           // Rx,Ry,Rz [gon], tx,ty,tz [m]
+    double VCM[36];
+    pwicp_result res;
+};
+
+// Piecewise_ICP_4D without its file output (R.cpp:402-480); sor_mult 5.0 (4D) or 2.7 (pair)
+bool register_pair(pwicp_context* ctx, const std::vector<float>& cloud1, const std::vector<float>& cloud2,
+                   const ConfigPara& cfg, float Res1, float Res2, double sor_mult, PairOutput* out) {
+    const int n1 = (int)(cloud1.size() / 4), n2 = (int)(cloud2.size() / 4);
+    std::cout << "Original PC-1 point number: " << n1 << "\t Original PC-2 point number: " << n2 << std::endl;
+    std::cout << "PC-1 avg. point spacing: " << Res1 << "\t PC-2 avg. point spacing: " << Res2 << std::endl << std::endl;
+    // pre-process (R.cpp:412-416)
+    std::vector<float> p1((size_t)n1 * 4), p2((size_t)n2 * 4), tmp((size_t)std::max(n1, n2) * 4);
+    int m1 = voxel_grid(cloud1.data(), n1, Res1, tmp.data());
+    m1 = sor_filter(tmp.data(), m1, 14, sor_mult, p1.data());
+    int m2 = voxel_grid(cloud2.data(), n2, Res2, tmp.data());
+    m2 = sor_filter(tmp.data(), m2, 14, sor_mult, p2.data());
+    if (m1 < kNN + 1 || m2 < kNN + 1) { std::cerr << "Error: too few points after preprocessing.\n"; return false; }
+    // reduction by the centroid of PC1 (R.cpp:419-436): pcl::compute3DCentroid float sums, float shift
+    float acc[3] = {0, 0, 0};
+    for (int i = 0; i < m1; ++i) { acc[0] += p1[4 * (size_t)i]; acc[1] += p1[4 * (size_t)i + 1]; acc[2] += p1[4 * (size_t)i + 2]; }
+    float shift[3];
+    for (int d = 0; d < 3; ++d) shift[d] = -1 * (acc[d] / (float)m1);
+    const float S[16] = {1, 0, 0, shift[0], 0, 1, 0, shift[1], 0, 0, 1, shift[2], 0, 0, 0, 1};
+    const float Sinv[16] = {1, 0, 0, -1 * shift[0], 0, 1, 0, -1 * shift[1], 0, 0, 1, -1 * shift[2], 0, 0, 0, 1};
+    auto apply_shift = [&](std::vector<float>& p, int m) {       // pcl::transformPointCloud with a pure translation
+        for (int i = 0; i < m; ++i) {
+            float* q = p.data() + 4 * (size_t)i;
+            const float x = q[0], y = q[1], z = q[2];
+            q[0] = S[0] * x + S[1] * y + S[2] * z + S[3];
+            q[1] = S[4] * x + S[5] * y + S[6] * z + S[7];
+            q[2] = S[8] * x + S[9] * y + S[10] * z + S[11];
+        }
+    };
+    apply_shift(p1, m1);
+    apply_shift(p2, m2);
+    std::cout << "Preprocessed PC-1 point number: " << m1 << "\tPreprocessed PC-2 point number: " << m2 << std::endl << std::endl;
+
+    // supervoxel size (R.cpp:635-640) and labels (S.cpp:18-68)
+    const float SVRes1 = cfg.isSetResSVsize ? cfg.SVsize1 : Res1 * 10, SVRes2 = cfg.isSetResSVsize ? cfg.SVsize2 : Res2 * 10;
+    std::vector<int32_t> lab1((size_t)m1), lab2((size_t)m2);
+    int nsv1 = 0, nsv2 = 0;
+    if (pwicp_frontend_segment(p1.data(), m1, SVRes1, kNN, lab1.data(), &nsv1) != PWICP_OK ||
+        pwicp_frontend_segment(p2.data(), m2, SVRes2, kNN, lab2.data(), &nsv2) != PWICP_OK) {
+        std::cerr << "Error: supervoxel segmentation failed.\n";
+        return false;
+    }
+    std::cout << "--->>> " << nsv1 << " / " << nsv2 << " supervoxels are generated." << std::endl;
+
+    pwicp_params prm{Res1, Res2, SVRes1, SVRes2, cfg.isSetDTinit ? 1 : 0, cfg.DTinit, cfg.DTmin};
+    pwicp_pair* pair = nullptr;
+    if (pwicp_pair_create(ctx, p1.data(), m1, lab1.data(), nsv1, p2.data(), m2, lab2.data(), nsv2, &prm, &pair) != PWICP_OK) {
+        std::cerr << "Error: " << pwicp_last_error(ctx) << "\n";
+        return false;
+    }
+    int M1 = 0, M2 = 0;
+    pwicp_pair_num_patches(pair, &M1, &M2);
+    std::cout << "PC-1 selected patch number: " << M1 << "\tPC-2 selected patch number: " << M2 << std::endl;
+    const int rc = pwicp_pair_run(pair, &out->res);
+    pwicp_pair_destroy(pair);
+    if (rc != PWICP_OK) {
+        std::cerr << "Error: registration failed (status " << rc << "): " << pwicp_last_error(ctx) << "\n";
+        return false;
+    }
+    for (int k = 0; k < out->res.n_outer; ++k)
+        std::cout << "--->>> Iteration No." << k + 1 << " | Current DT = " << out->res.DTseries[k + 1] * 100 << " cm. \n";
+    // T_final = S^-1 * T * S (R.cpp:461), parameters (R.cpp:464-480)
+    float tmpM[16];
+    mat4_mul(Sinv, out->res.T16, tmpM);
+    mat4_mul(tmpM, S, out->T);
+    float ang[3];
+    matrix2angle(out->T, ang);
+    out->para[0] = (float)(ang[0] * ARC_TO_GON); out->para[1] = (float)(ang[1] * ARC_TO_GON); out->para[2] = (float)(ang[2] * ARC_TO_GON);
+    out->para[3] = out->T[3]; out->para[4] = out->T[7]; out->para[5] = out->T[11];
+    std::memcpy(out->VCM, out->res.VCM, sizeof(out->VCM));
+    return true;
+}
+
+// calTransToReferenceEpoch, R.cpp:977-1153 (re-reads the pairwise file, exactly as the reference does)
+bool trans_to_reference(const std::string& tm_file, int pairMode, const std::map<int, int>& reg_pair, int n,
+                        const std::string& out_tm, const std::string& out_tp) {
+    std::vector<int> stamps;
+    std::vector<std::array<float, 16>> Ts;
+    std::vector<std::array<double, 36>> Vs;
+    if (!read_transmatrices(tm_file, n, &stamps, &Ts, &Vs)) { std::cerr << "Error: Cannot open transMatFile!\n"; return false; }
+    std::ofstream oTM(out_tm.c_str()), oTP(out_tp.c_str());
+    if (!oTM || !oTP) { std::cerr << "Error: Cannot open transMat2RefFile!\n"; return false; }
+    oTP << trans_parameters_header() << std::endl;
+    for (int i = 0; i < n; ++i) {
+        std::array<float, 16> accT;
+        std::array<double, 36> accV;
+        if (pairMode < 0) {
+            accT = Ts[(size_t)i];
+            accV = Vs[(size_t)i];
+            int idx = i + 1;
+            for (int j = 0; j < i + 1; ++j) {
+                auto it = reg_pair.find(idx);
+                idx = it == reg_pair.end() ? 0 : it->second;
+                if (idx == 0) break;
+                const std::array<float, 16>& M = Ts[(size_t)idx - 1];
+                float nt[16];
+                mat4_mul(M.data(), accT.data(), nt);
+                std::memcpy(accT.data(), nt, sizeof(nt));
+                // adjoint [[R,0],[t x R, R]] in double (R.cpp:1074-1083)
+                double R[9], t[3];
+                for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) R[3 * r + c] = (double)M[(size_t)(4 * r + c)]; t[r] = (double)M[(size_t)(4 * r + 3)]; }
+                const double SS[9] = {0, -t[2], t[1], t[2], 0, -t[0], -t[1], t[0], 0};
+                double txR[9];
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += SS[3 * r + k] * R[3 * k + c]; txR[3 * r + c] = s; }
+                double Adj[36] = {0};
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c) { Adj[6 * r + c] = R[3 * r + c]; Adj[6 * (r + 3) + c + 3] = R[3 * r + c]; Adj[6 * (r + 3) + c] = txR[3 * r + c]; }
+                double AV[36], AVA[36];
+                for (int r = 0; r < 6; ++r)
+                    for (int c = 0; c < 6; ++c) { double s = 0; for (int k = 0; k < 6; ++k) s += Adj[6 * r + k] * accV[(size_t)(6 * k + c)]; AV[6 * r + c] = s; }
+                for (int r = 0; r < 6; ++r)
+                    for (int c = 0; c < 6; ++c) { double s = 0; for (int k = 0; k < 6; ++k) s += AV[6 * r + k] * Adj[6 * c + k]; AVA[6 * r + c] = s; }
+                for (int k = 0; k < 36; ++k) accV[(size_t)k] = Vs[(size_t)idx - 1][(size_t)k] + AVA[k];
+            }
+        } else if (pairMode == 0 || i < pairMode) {
+            accT = Ts[(size_t)i];
+            accV = Vs[(size_t)i];
+        } else {
+            accT = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+            accV.fill(0.0);
+            for (int j = 0; j < n; ++j) {
+                const int src = i - pairMode * j;
+                float nt[16];
+                mat4_mul(Ts[(size_t)src].data(), accT.data(), nt);
+                std::memcpy(accT.data(), nt, sizeof(nt));
+                for (int k = 0; k < 36; ++k) accV[(size_t)k] = Vs[(size_t)src][(size_t)k] + accV[(size_t)k];
+                if (src < pairMode) break;
+            }
+        }
+        // R.cpp:1112-1149 (this file uses std::endl per row)
+        oTM << std::fixed << std::setprecision(12);
+        oTM << stamps[(size_t)i] << "\n";
+        for (int r = 0; r < 4; ++r) { for (int c = 0; c < 4; ++c) oTM << accT[(size_t)(4 * r + c)] << " "; oTM << std::endl; }
+        for (int r = 0; r < 6; ++r) { for (int c = 0; c < 6; ++c) oTM << accV[(size_t)(6 * r + c)] << " "; oTM << std::endl; }
+        float ang[3];
+        matrix2angle(accT.data(), ang);
+        const float para[6] = {(float)(ang[0] * ARC_TO_GON), (float)(ang[1] * ARC_TO_GON), (float)(ang[2] * ARC_TO_GON),
+                               accT[3], accT[7], accT[11]};
+        append_transparameters(oTP, stamps[(size_t)i], para, accV.data());
+    }
+    return true;
+}
+
+// calAbsErrorOfTransPara, R.cpp:1157-1251; optional here (the reference hard-codes the GT path and exits if missing)
+void abs_error_report(const std::string& toref_file, const std::string& gt_file, int all_epochs, int start, const std::string& out_file) {
+    const int n = all_epochs - start - 1;
+    std::vector<int> stamps;
+    std::vector<std::array<float, 16>> Ts;
+    std::vector<std::array<double, 36>> Vs;
+    if (!read_transmatrices(toref_file, n, &stamps, &Ts, &Vs)) return;
+    std::ifstream gt(gt_file);
+    if (!gt) return;
+    std::vector<std::array<float, 16>> G;
+    for (int i = 0; i < all_epochs; ++i) {
+        int stamp;
+        std::array<float, 16> T;
+        if (!(gt >> stamp)) return;
+        for (int k = 0; k < 16; ++k) if (!(gt >> T[(size_t)k])) return;
+        G.push_back(T);
+    }
+    std::ofstream o(out_file);
+    if (!o) return;
+    o << "Err_Rx[mgon]  Err_Ry[mgon]  Err_Rz[mgon]  Err_tx[mm]  Err_ty[mm]  Err_tz[mm]" << std::endl;
+    for (int i = 0; i < n; ++i) {
+        float a[3], b[3];
+        matrix2angle(Ts[(size_t)i].data(), a);
+        matrix2angle(G[(size_t)(start + 1 + i)].data(), b);
+        const float e[6] = {1000 * std::fabs((float)(b[0] * ARC_TO_GON) - (float)(a[0] * ARC_TO_GON)),
+                            1000 * std::fabs((float)(b[1] * ARC_TO_GON) - (float)(a[1] * ARC_TO_GON)),
+                            1000 * std::fabs((float)(b[2] * ARC_TO_GON) - (float)(a[2] * ARC_TO_GON)),
+                            1000 * std::fabs(G[(size_t)(start + 1 + i)][3] - Ts[(size_t)i][3]),
+                            1000 * std::fabs(G[(size_t)(start + 1 + i)][7] - Ts[(size_t)i][7]),
+                            1000 * std::fabs(G[(size_t)(start + 1 + i)][11] - Ts[(size_t)i][11])};
+        o << e[0] << " " << e[1] << " " << e[2] << " " << e[3] << " " << e[4] << " " << e[5] << " " << std::endl;
+    }
+}
+
+int env_device() {
+    const char* e = getenv("PWICP_DEVICE");
+    if (!e) e = getenv("LOCAL_RANK");
+    return e ? atoi(e) : 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+PWICP_API bool PiecewiseICP_pair_call(const char* confile, const char* outfile) {
+    if (!confile || !outfile) return false;
+    ConfigPara cfg;
+    std::cout << "Loading parameter configuration file: " << confile << "\n\n";
+    if (!read_config(confile, &cfg)) { std::cerr << "Error: Cannot open configuration file! Aborting.\n\n"; return false; }
+    std::vector<float> c1, c2;
+    if (!load_pcd(cfg.FolderFilePath1, &c1) || !load_pcd(cfg.FolderFilePath2, &c2) || c1.empty() || c2.empty()) return false;   // R.cpp:252-256
+    float Res1 = cfg.PCres1, Res2 = cfg.PCres2;
+    if (!cfg.isSetResSVsize) { Res1 = pc_resolution(c1.data(), (int)(c1.size() / 4)); Res2 = pc_resolution(c2.data(), (int)(c2.size() / 4)); }
+    pwicp_context* ctx = nullptr;
+    if (pwicp_create(&ctx, env_device()) != PWICP_OK) { std::cerr << "Error: no usable HIP device (pwicp has no CPU fallback).\n"; return false; }
+    PairOutput out;
+    const bool ok = register_pair(ctx, c1, c2, cfg, Res1, Res2, 2.7, &out);          // SOR multiplier 2.7 (R.cpp:272-273)
+    pwicp_destroy(ctx);
+    if (!ok) return false;
+    if (!write_transmatrix_file(std::string(outfile) + "TransMatrix.txt", out.T, out.VCM)) return false;
+    std::cout << "--->>> Transformation results saved.\n";
+    // registered source cloud (R.cpp:331-333, 391-394): the ORIGINAL source transformed by T_final
+    const int n2 = (int)(c2.size() / 4);
+    std::vector<float> moved(c2);
+    for (int i = 0; i < n2; ++i) {
+        float* q = moved.data() + 4 * (size_t)i;
+        const float x = q[0], y = q[1], z = q[2];
+        q[0] = out.T[0] * x + out.T[1] * y + out.T[2] * z + out.T[3];
+        q[1] = out.T[4] * x + out.T[5] * y + out.T[6] * z + out.T[7];
+        q[2] = out.T[8] * x + out.T[9] * y + out.T[10] * z + out.T[11];
+    }
+    if (!save_pcd_binary(std::string(outfile) + "RegisteredSourceCloud.pcd", moved.data(), n2)) return false;
+    std::cout << "--->>> Registered source cloud saved.\n\n";
+    return true;
+}
+
+PWICP_API bool PiecewiseICP_4D_call(const char* confile, int startEpoch, int epochNum, int pairMode, float overlapThd) {
+    if (!confile) return false;
+    ConfigPara cfg;
+    std::cout << "Loading parameter configuration file: " << confile << "\n\n";
+    if (!read_config(confile, &cfg)) { std::cerr << "Error: Cannot open configuration file! Aborting.\n\n"; return false; }
+    const std::string inputFolder = cfg.FolderFilePath1, outputFolder = cfg.FolderFilePath2;
+    std::vector<std::string> files;
+    std::vector<long> times;
+    const int fileCount = extract_all_files(inputFolder, &files, &times);
+    std::cout << "--->>> " << fileCount << " scan files are successfully extracted. \n\n";
+    if (startEpoch < 0 || epochNum > fileCount || startEpoch >= epochNum) { std::cerr << "Error: epoch range outside the folder content.\n"; return false; }
+    pwicp_context* ctx = nullptr;
+    if (pwicp_create(&ctx, env_device()) != PWICP_OK) { std::cerr << "Error: no usable HIP device (pwicp has no CPU fallback).\n"; return false; }
+
+    // adaptive pair sequence (R.cpp:552-589), overlap ratio on the GPU (R.cpp:593-614)
+    std::map<int, int> regPairs;
+    const std::string adaptivePairFile = "RegPairFile.txt";
+    if (pairMode < 0) {
+        std::cout << "--->>> Adaptive pair sequence determination... \n";
+        int idxTarget = startEpoch;
+        std::vector<std::vector<float>> cache((size_t)fileCount);
+        auto cloud = [&](int i) -> std::vector<float>& { if (cache[(size_t)i].empty()) load_pcd(files[(size_t)i], &cache[(size_t)i]); return cache[(size_t)i]; };
+        for (int j = startEpoch + 1; j < fileCount; ++j) {
+            float ratio = 0;
+            for (int i = idxTarget; i < j; ++i) {
+                std::vector<float>&a = cloud(i), &b = cloud(j);
+                if (pwicp_overlap_ratio(ctx, a.data(), (int)(a.size() / 4), b.data(), (int)(b.size() / 4), cfg.DTinit, &ratio) != PWICP_OK) { pwicp_destroy(ctx); return false; }
+                idxTarget = i;
+                if (ratio > overlapThd) break;
+            }
+            regPairs[j - startEpoch] = idxTarget - startEpoch;
+            std::cout << "Pair: " << idxTarget - startEpoch << " - " << j - startEpoch << ";  Overlap ratio = " << 100 * ratio << "% \n";
+        }
+        std::ofstream pf(adaptivePairFile);
+        if (!pf) { std::cerr << "Error: Cannot open adaptivePairFile!\n"; pwicp_destroy(ctx); return false; }
+        for (auto& kv : regPairs) pf << kv.first << " " << kv.second << std::endl;
+    }
+
+    const std::string fTM = outputFolder + "TransMatrices.txt", fTP = outputFolder + "TransParameters.txt";
+    std::ofstream oTM(fTM.c_str()), oTP(fTP.c_str());
+    if (!oTM || !oTP) { std::cerr << "Error: Unable to open output file(s).\n"; pwicp_destroy(ctx); return false; }
+    oTP << trans_parameters_header() << std::endl;
+
+    std::vector<float> refCloud, c1, c2;
+    load_pcd(files[(size_t)startEpoch], &refCloud);
+    int done = 0;
+    for (int i = startEpoch; i < epochNum - 1; ++i) {               // R.cpp:89-187
+        const int step = i - startEpoch + 1;
+        int refIdx = startEpoch;
+        if (pairMode > 0) refIdx = (pairMode >= step) ? startEpoch : (i + 1 - pairMode);
+        else if (pairMode < 0) refIdx = regPairs[i + 1];
+        std::cout << "\n//////////////////////  Process Pair_" << step << ":  Epoch-" << times[(size_t)refIdx] << " and Epoch-"
+                  << times[(size_t)i + 1] << "   //////////////////////////////////////////// \n\n";
+        std::string prefix = outputFolder + std::to_string(times[(size_t)i + 1]);
+        if (pairMode == 0) { prefix += "_Direct2Ref_"; c1 = refCloud; }
+        else { prefix += pairMode > 0 ? "_Fixed_" : "_Adaptive_"; load_pcd(files[(size_t)refIdx], &c1); }
+        load_pcd(files[(size_t)i + 1], &c2);
+        if (c1.empty() || c2.empty()) { std::cerr << "Step " << step << " failed. Skipping to next.\n\n"; continue; }
+        float Res1 = cfg.PCres1, Res2 = cfg.PCres2;
+        if (!cfg.isSetResSVsize) { Res1 = pc_resolution(c1.data(), (int)(c1.size() / 4)); Res2 = pc_resolution(c2.data(), (int)(c2.size() / 4)); }
+        PairOutput out;
+        if (!register_pair(ctx, c1, c2, cfg, Res1, Res2, 5.0, &out) ||               // SOR multiplier 5.0 (R.cpp:415-416)
+            !write_transmatrix_file(prefix + "TransMatrix.txt", out.T, out.VCM)) {
+            std::cerr << "Step " << step << " failed. Skipping to next.\n\n";          // R.cpp:145-147
+            continue;
+        }
+        append_transmatrices(oTM, times[(size_t)i + 1], out.T, out.VCM);
+        append_transparameters(oTP, times[(size_t)i + 1], out.para, out.VCM);
+        ++done;
+    }
+    oTM.close();
+    oTP.close();
+    pwicp_destroy(ctx);
+    const int n = epochNum - startEpoch - 1;
+    if (done != n) { std::cerr << "Warning: " << n - done << " pair(s) failed; composition to the reference epoch skipped.\n"; return done > 0; }
+    if (!trans_to_reference(fTM, pairMode, regPairs, n, outputFolder + "TransMatrices_toRef.txt", outputFolder + "TransParameters_toRef.txt"))
+        return false;
+    // accuracy report only if the ground-truth file of the synthetic data set is present (the reference hard-codes
+    // this path and exits when it is missing, R.cpp:207-211, 1189-1192)
+    abs_error_report(outputFolder + "TransMatrices_toRef.txt", "data/data_synthetic/defined_transformations.txt", epochNum, startEpoch,
+                     outputFolder + "TransPara_AbsError.txt");
+    return true;
+}
+
+}  // extern "C"

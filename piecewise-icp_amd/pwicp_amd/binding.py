@@ -82,6 +82,14 @@ def load_library():
     ]:
         if hasattr(L, name):
             getattr(L, name).argtypes = args
+    L.pwicp_frontend_segment.argtypes = [fp, C.c_int, C.c_float, C.c_int, ip, ip]
+    L.pwicp_preprocess.argtypes = [fp, C.c_int, C.c_float, C.c_int, C.c_double, fp, ip]
+    L.pwicp_pc_resolution.argtypes = [fp, C.c_int]
+    L.pwicp_pc_resolution.restype = C.c_float
+    L.PiecewiseICP_pair_call.argtypes = [C.c_char_p, C.c_char_p]
+    L.PiecewiseICP_pair_call.restype = C.c_bool
+    L.PiecewiseICP_4D_call.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_float]
+    L.PiecewiseICP_4D_call.restype = C.c_bool
     _lib = L
     return L
 
@@ -104,6 +112,40 @@ def f4(a):
 
 def _p(a, t=fp):
     return a.ctypes.data_as(t)
+
+
+# ---- host-side setup stages (no GPU needed) ------------------------------------------------------------------
+def frontend_segment(cloud, sv_resolution, knn=45):
+    """Supervoxel labels (PatchGenerationAndRefinement, S.cpp:18-68). Returns (labels int32, n_supervoxels)."""
+    L = load_library()
+    c = f4(cloud)
+    lab = np.empty(len(c), np.int32)
+    nsv = C.c_int32()
+    rc = L.pwicp_frontend_segment(_p(c), len(c), float(sv_resolution), int(knn), _p(lab, ip), C.byref(nsv))
+    if rc != 0:
+        raise PwicpError(rc, "pwicp_frontend_segment")
+    return lab, nsv.value
+
+
+def preprocess(cloud, voxel_size, sor_k=14, sor_mult=5.0):
+    """PCpreprocessing (VoxelGrid + SOR, C.cpp:423-452). Returns float32 (m,4)."""
+    L = load_library()
+    c = f4(cloud)
+    out = np.empty_like(c)
+    m = C.c_int32()
+    rc = L.pwicp_preprocess(_p(c), len(c), float(voxel_size), int(sor_k), float(sor_mult), _p(out), C.byref(m))
+    if rc != 0:
+        raise PwicpError(rc, "pwicp_preprocess")
+    return out[:m.value].copy()
+
+
+def PiecewiseICP_pair_call(confile, outfile):
+    return bool(load_library().PiecewiseICP_pair_call(str(confile).encode(), str(outfile).encode()))
+
+
+def PiecewiseICP_4D_call(confile, startEpoch, epochNum, pairMode, overlapThd=0.75):
+    return bool(load_library().PiecewiseICP_4D_call(str(confile).encode(), int(startEpoch), int(epochNum), int(pairMode),
+                                                    float(overlapThd)))
 
 
 class Context:
