@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--points", type=int, default=1000000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--labels", choices=["supervoxel", "grid"], default="supervoxel")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for debugging)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="debug: every rank uses GPU 0 (functional check of the N>1 path on a 1-GPU box; needs --backend gloo)")
     args = ap.parse_args()
     global LABELS
     LABELS = args.labels
@@ -94,12 +97,17 @@ def main():
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.single_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist_mod.init_process_group(backend=args.backend)
         dist = dist_mod
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank) if args.backend == "nccl" or world == 1 else torch.device("cpu")
 
     # ---- setup (untimed): data, labels, upload, patch selection/statistics, grids ------------------------
     tgt, l1, n1, src, l2, n2, Tgt = make_pair(args.points, epoch=rank + 1)
@@ -113,7 +121,10 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            if args.backend == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     def step():

@@ -76,3 +76,23 @@ def test_all_direct2ref_pairs(oracle, target):
     assert len(tight) >= 16
     with open(os.path.join(G.GOLD, "oracle_vs_reference.json"), "w") as f:
         json.dump(rows, f, indent=1)
+
+
+@pytest.mark.skipif(not os.path.isdir(G.REF_ROOT), reason="reference tree not mounted")
+def test_adaptive_pair_sequence_matches_reference_outputs(oracle):
+    """calAdaptivePairSequence (R.cpp:552-589) with the oracle's overlap ratio on the reference's 20 raw epochs
+    reproduces the pair map recovered from the reference's own Adaptive result files."""
+    from pwicp_amd.pcd import read_pcd
+    clouds = [oracle.f4(read_pcd(G.epoch_path(e))) for e in range(1, 21)]
+    expect = {2: 1, 3: 1, 4: 1, 5: 1, 6: 1, 7: 3, 8: 4, 9: 4, 10: 5, 11: 6, 12: 6, 13: 7, 14: 9, 15: 12, 16: 13, 17: 14,
+              18: 14, 19: 14, 20: 14}
+    got = {}
+    idx_target = 0
+    for j in range(1, 20):
+        for i in range(idx_target, j):
+            r = oracle.lib().orc_overlap_ratio(oracle._p(clouds[i]), len(clouds[i]), oracle._p(clouds[j]), len(clouds[j]), 0.05)
+            idx_target = i
+            if r > 0.75:
+                break
+        got[j + 1] = idx_target + 1
+    assert got == expect
