@@ -27,7 +27,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MI
 R_SPACING = 0.005
 
 
-def make_pair(n_points, epoch):
+def make_pair(n_points, epoch, ctx):
     """Synthetic reference tile + source epoch, reduced to the target centroid
     (Registration.cpp:277-294) and labelled."""
     from pwicp_amd import synth
@@ -37,22 +37,21 @@ def make_pair(n_points, epoch):
     c = tgt.mean(axis=0)
     tgt = (tgt - c).astype(np.float32)
     src = (src - c).astype(np.float32)
-    l1, n1 = segment(tgt, 10 * r)
-    l2, n2 = segment(src, 10 * r)
+    l1, n1 = segment(tgt, 10 * r, ctx)
+    l2, n2 = segment(src, 10 * r, ctx)
     return tgt, l1, n1, src, l2, n2, Tgt
 
 
 LABELS = "supervoxel"
 
 
-def segment(cloud, sv):
-    """Supervoxel labels from the product's own front end (host stage, setup: outside the timed hot path,
-    SURVEY §8 row f1); `--labels grid` substitutes square grid cells for quick runs."""
+def segment(cloud, sv, ctx):
+    """Supervoxel labels from the product's own front end (k-NN graph on the GPU, normals + fusion on the host;
+    setup, outside the timed hot path); `--labels grid` substitutes square grid cells."""
     from pwicp_amd import synth
     if LABELS == "grid":
         return synth.grid_labels(cloud, sv)
-    from pwicp_amd import frontend
-    return frontend.segment(cloud, sv)
+    return ctx.frontend_segment(cloud, sv, 45, R_SPACING)
 
 
 def cpu_baseline(tgt, l1, n1, src, l2, n2, passes=2):
@@ -110,9 +109,9 @@ def main():
     dev = torch.device("cuda", local_rank) if args.backend == "nccl" or world == 1 else torch.device("cpu")
 
     # ---- setup (untimed): data, labels, upload, patch selection/statistics, grids ------------------------
-    tgt, l1, n1, src, l2, n2, Tgt = make_pair(args.points, epoch=rank + 1)
-    r = R_SPACING
     ctx = P.Context(local_rank)
+    tgt, l1, n1, src, l2, n2, Tgt = make_pair(args.points, epoch=rank + 1, ctx=ctx)
+    r = R_SPACING
     prm = P.Params(r, r, 10 * r, 10 * r, 1, 10 * r, 0.8 * r)
     t0 = time.time()
     pair = P.Pair(ctx, tgt, l1, n1, src, l2, n2, prm)
@@ -196,7 +195,7 @@ def main():
                        "points_per_cloud": args.points, "spacing_m": r, "patches_target_source": list(pair.num_patches()),
                        "outer_iterations": n_outer, "inner_iterations": n_inner,
                        "correspondences_per_step": int(res.n_corr), "parallelism": "pair-per-gpu x%d" % world,
-                       "segmentation": ("boundary-preserving supervoxels, product front end (host, setup, untimed)"
+                       "segmentation": ("boundary-preserving supervoxels, product front end (GPU k-NN graph + host fusion; setup, untimed)"
                                         if args.labels == "supervoxel" else "grid cells (setup, untimed)")},
             "ms_per_outer_iteration": round(res.t_loop_ms / max(n_outer, 1), 4),
             "ms_per_inner_iteration": round(res.t_inner_ms / max(n_inner, 1), 4),

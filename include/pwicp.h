@@ -184,6 +184,13 @@ PWICP_API int pwicp_pair_download_source(pwicp_pair* pair, float* cloud2_xyz4);
  * segmentation at `sv_resolution`. */
 PWICP_API int pwicp_frontend_segment(const float* cloud_xyz4, int n, float sv_resolution, int knn,
                                      int32_t* labels, int* n_supervoxels);
+/* Exact k nearest neighbours of every point within its own cloud, on the GPU: neighbors[i*k .. i*k+k) in ascending
+ * order of the double squared distance, ties by index, the point itself first.  Replaces the
+ * cl::KDTree::FindKNearestNeighbors loop of S.cpp:30-41.  cell_edge <= 0: estimated from the cloud. */
+PWICP_API int pwicp_knn(pwicp_context* ctx, const float* cloud_xyz4, int n, int k, float cell_edge, int32_t* neighbors);
+/* pwicp_frontend_segment with the k-NN graph built on the GPU (identical labels). point_spacing <= 0: estimated. */
+PWICP_API int pwicp_frontend_segment_dev(pwicp_context* ctx, const float* cloud_xyz4, int n, float sv_resolution,
+                                         int knn, float point_spacing, int32_t* labels, int* n_supervoxels);
 /* PCpreprocessing(cloud, out, true, voxel_size, sor_k, sor_mult) (C.cpp:423-452). out_xyz4 holds n points. */
 PWICP_API int pwicp_preprocess(const float* cloud_xyz4, int n, float voxel_size, int sor_k, double sor_mult,
                                float* out_xyz4, int* n_out);

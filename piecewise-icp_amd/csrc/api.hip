@@ -150,6 +150,25 @@ int pwicp_overlap_ratio(pwicp_context* ctx, const float* cloud1_xyz4, int n1, co
 
 }  // extern "C"
 
+extern "C" {
+
+int pwicp_knn(pwicp_context* ctx, const float* cloud_xyz4, int n, int k, float cell_edge, int32_t* neighbors) {
+    if (!ctx) return PWICP_E_INVALID;
+    if (!cloud_xyz4 || !neighbors || n <= 0 || k <= 0 || k > n) { ctx->set_err("pwicp_knn: invalid argument"); return PWICP_E_INVALID; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevBuf<float4> pts;
+    PWCHK(upload(ctx, cloud_xyz4, n, &pts));
+    Grid g;
+    PWCHK(pw_grid_build(ctx, pts.p, n, cell_edge > 0.f ? cell_edge : estimate_cell_edge(cloud_xyz4, n), &g));
+    DevBuf<int> nb;
+    HIPCHK(ctx, nb.reserve((size_t)n * k));
+    PWCHK(pw_knn_launch(ctx, g.d, k, nb.p));
+    HIPCHK(ctx, hipMemcpy(neighbors, nb.p, (size_t)n * k * sizeof(int), hipMemcpyDeviceToHost));
+    return PWICP_OK;
+}
+
+}  // extern "C"
+
 // ---- patch-level and ICP building blocks -------------------------------------------------------------------
 extern "C" {
 

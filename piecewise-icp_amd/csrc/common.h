@@ -104,16 +104,12 @@ int pw_grid_build(pwicp_context* ctx, const float4* d_pts, int n, float cell_edg
 // exact 1-NN of d_q[0..nq) ; d_idx may be null; d_examined (optional) accumulates #points examined
 int pw_nn_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_q, int nq, int* d_idx, float* d_d2,
                  unsigned long long* d_examined);
-// dense NN over the points of the listed patches: query i in [0, n_pts) belongs to stable patch j with
-// d_soff[j] <= i < d_soff[j+1]; its point is pat[off[list[j]] + i - soff[j]]
-int pw_nn_patches_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pat, const int* d_off,
-                         const int* d_list, const int* d_soff, int n_list, int n_pts, float* d_d2,
-                         unsigned long long* d_examined);
-// LDS-staged dense NN: query i = patch point qorder[i] (skipped, sentinel written, unless stable[pt_patch[.]])
-int pw_nn_dense_lds_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pat, const int* d_qorder,
+// dense NN of patch points: query i = patch point qorder[i] (skipped, sentinel written, unless stable[pt_patch[.]])
+int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pat, const int* d_qorder,
                            const int* d_pt_patch, const int* d_stable, int nq, float* d_d2,
                            unsigned long long* d_examined);
 int pw_morton_order(pwicp_context* ctx, const GridDesc& g, const float4* d_pts, int n, DevBuf<int>* order);
+int pw_knn_launch(pwicp_context* ctx, const GridDesc& g, int k, int* d_nb);
 // k-th smallest (0-based) of the non-sentinel entries of n non-negative floats; result written to d_out[0]; scratch >= 3*2048+8 uints
 int pw_select_kth_launch(pwicp_context* ctx, const float* d_vals, int n, int k, unsigned* d_scratch, float* d_out);
 // count of values with sqrtf(v) < thr  -> d_count[0]

@@ -261,28 +261,7 @@ __global__ void __launch_bounds__(kBlock) k_nn_points(GridDesc g, const float4* 
     add_examined(examined, cnt);
 }
 
-__global__ void __launch_bounds__(kBlock) k_nn_patches(GridDesc g, const float4* __restrict__ pat,
-                                                       const int* __restrict__ off, const int* __restrict__ list,
-                                                       const int* __restrict__ soff, int n_list, int n_pts,
-                                                       float* __restrict__ d2,
-                                                       unsigned long long* __restrict__ examined) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned cnt = 0;
-    if (i < n_pts) {
-        // largest j with soff[j] <= i
-        int lo = 0, hi = n_list;
-        while (hi - lo > 1) {
-            int mid = (lo + hi) >> 1;
-            if (soff[mid] <= i) lo = mid; else hi = mid;
-        }
-        float4 v = pat[off[list[lo]] + (i - soff[lo])];
-        NNBest b = nn_query(g, v.x, v.y, v.z, cnt);
-        d2[i] = b.d2();
-    }
-    add_examined(examined, cnt);
-}
-
-// ---- dense 1-NN, LDS-staged ---------------------------------------------------------------------------------
+// ---- dense 1-NN, LDS-staged (EXPERIMENTAL variant, not the default: measured slower than k_nn_dense_direct) ----
 // Queries arrive in Morton order of their (initial) fine cell, so the 256 queries of a block occupy a compact
 // box of cells.  The block stages that box (+-2 cells halo) once — the begin/end table of its cell rows and the
 // target points, each row one coalesced copy — and every lane scans its 27-cell stencil, then if necessary the
@@ -515,6 +494,67 @@ __global__ void k_morton_keys(GridLevel g, const float4* __restrict__ p, int n, 
     vals[i] = i;
 }
 
+// ---- exact k-NN of every point of a cloud within the cloud itself (segmentation front end) ------------------------
+// Replaces the per-point cl::KDTree::FindKNearestNeighbors loop of PatchGenerationAndRefinement
+// (src/Segmentation.cpp:30-41; codelibrary/util/tree/kd_tree.h:266-280): the k nearest points (the query itself
+// included, distance 0) in ascending order of the DOUBLE squared distance ((dx*dx)+dy*dy)+dz*dz of the
+// float->double converted coordinates (util/metric/squared_euclidean.h), ties by index.
+// One lane per point, in cell order (neighbouring lanes scan the same cells).  The lane's sorted candidate list
+// lives in global memory in column layout (entry e of lane t at [e*n + t]: coalesced across the wave).
+// The (2r+1)^3 block is grown until the k-th distance is provably smaller than anything outside the block.
+__global__ void __launch_bounds__(kBlock) k_knn(GridLevel g, int k, double* __restrict__ nd, int* __restrict__ ni,
+                                                int* __restrict__ out_nb) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = g.n;
+    if (t >= n) return;
+    const float4 q = g.pts[t];
+    const int self = __float_as_int(q.w);
+    const double qx = (double)q.x, qy = (double)q.y, qz = (double)q.z;
+    const int cx = cell_of(q.x, g.ox, g.inv_h), cy = cell_of(q.y, g.oy, g.inv_h), cz = cell_of(q.z, g.oz, g.inv_h);
+    const int rcover = max(max(max(cx, g.nx - 1 - cx), max(cy, g.ny - 1 - cy)), max(cz, g.nz - 1 - cz));
+    int cnt = 0;
+    for (int r = 2;; ++r) {
+        cnt = 0;
+        for (int dz = -r; dz <= r; ++dz)
+            for (int dy = -r; dy <= r; ++dy) {
+                int lo, hi;
+                row_range(g, cy + dy, cz + dz, cx - r, cx + r, lo, hi);
+                for (int j = lo; j < hi; ++j) {
+                    const float4 p = g.pts[j];
+                    const double dx = qx - (double)p.x, dy2 = qy - (double)p.y, dz2 = qz - (double)p.z;
+                    double d2 = dx * dx;
+                    d2 = d2 + dy2 * dy2;
+                    d2 = d2 + dz2 * dz2;
+                    const int id = __float_as_int(p.w);
+                    // sorted insertion by (d2, id)
+                    if (cnt == k) {
+                        const double wd = nd[(size_t)(k - 1) * n + t];
+                        const int wi = ni[(size_t)(k - 1) * n + t];
+                        if (!(d2 < wd || (d2 == wd && id < wi))) continue;
+                    }
+                    int pos = cnt < k ? cnt : k - 1;
+                    while (pos > 0) {
+                        const double pd = nd[(size_t)(pos - 1) * n + t];
+                        const int pi = ni[(size_t)(pos - 1) * n + t];
+                        if (!(d2 < pd || (d2 == pd && id < pi))) break;
+                        nd[(size_t)pos * n + t] = pd;
+                        ni[(size_t)pos * n + t] = pi;
+                        --pos;
+                    }
+                    nd[(size_t)pos * n + t] = d2;
+                    ni[(size_t)pos * n + t] = id;
+                    if (cnt < k) ++cnt;
+                }
+            }
+        if (r >= rcover) break;
+        if (cnt == k) {
+            const double bound = (double)r * (double)g.h - 2.0 * (double)g.slack;
+            if (bound > 0.0 && nd[(size_t)(k - 1) * n + t] < bound * bound * 0.99999) break;
+        }
+    }
+    for (int e = 0; e < k; ++e) out_nb[(size_t)self * k + e] = (e < cnt) ? ni[(size_t)e * n + t] : -1;
+}
+
 // ---- k-th smallest of non-negative floats: 3-pass radix select on the bit pattern ---------------------
 // scratch layout: [0] prefix, [1] k remaining, [8 + pass*2048 ...] histograms
 constexpr int kSelBins = 2048;
@@ -732,16 +772,6 @@ int pw_nn_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_q, int n
     return PWICP_OK;
 }
 
-int pw_nn_patches_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pat, const int* d_off,
-                         const int* d_list, const int* d_soff, int n_list, int n_pts, float* d_d2,
-                         unsigned long long* d_examined) {
-    if (n_pts <= 0) return PWICP_OK;
-    hipLaunchKernelGGL(k_nn_patches, dim3(div_up(n_pts, kBlock)), dim3(kBlock), 0, ctx->stream, g, d_pat, d_off,
-                       d_list, d_soff, n_list, n_pts, d_d2, d_examined);
-    HIPCHK(ctx, hipGetLastError());
-    return PWICP_OK;
-}
-
 int pw_select_kth_launch(pwicp_context* ctx, const float* d_vals, int n, int k, unsigned* d_scratch, float* d_out) {
     if (n <= 0) return PWICP_E_INVALID;
     int nb = std::min(div_up(n, kBlock), ctx->n_cu * 4);
@@ -767,11 +797,13 @@ int pw_count_below_launch(pwicp_context* ctx, const float* d_d2, int n, float th
     return PWICP_OK;
 }
 
-int pw_nn_dense_lds_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pat, const int* d_qorder,
+int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pat, const int* d_qorder,
                            const int* d_pt_patch, const int* d_stable, int nq, float* d_d2,
                            unsigned long long* d_examined) {
     if (nq <= 0) return PWICP_OK;
-    static int variant = -1;      // 0 LDS-staged, 1 direct + Morton order, 2 direct + patch order (experiments)
+    // default: direct kernel, queries in Morton order.  PWICP_DENSE_KERNEL=0 selects the LDS-staged variant,
+    // =2 the direct kernel in patch order — both kept for A/B measurements only.
+    static int variant = -1;
     if (variant < 0) { const char* e = getenv("PWICP_DENSE_KERNEL"); variant = e ? atoi(e) : 1; }
     if (variant == 0)
         hipLaunchKernelGGL(k_nn_dense_lds, dim3(div_up(nq, kBlock)), dim3(kBlock), 0, ctx->stream, g, d_pat, d_qorder,
@@ -803,6 +835,20 @@ int pw_morton_order(pwicp_context* ctx, const GridDesc& g, const float4* d_pts, 
     HIPCHK(ctx, tmp.reserve(tbytes));
     HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tbytes, keys.p, keys_out.p, vals.p, order->p, n, 0, 30,
                                                    ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipGetLastError());
+    return PWICP_OK;
+}
+
+// k nearest neighbours of every point of the cloud within the cloud (row i of d_nb = neighbours of point i)
+int pw_knn_launch(pwicp_context* ctx, const GridDesc& g, int k, int* d_nb) {
+    const int n = g.fine.n;
+    if (n <= 0) return PWICP_OK;
+    DevBuf<double> nd;
+    DevBuf<int> ni;
+    HIPCHK(ctx, nd.reserve((size_t)n * k));
+    HIPCHK(ctx, ni.reserve((size_t)n * k));
+    hipLaunchKernelGGL(k_knn, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, g.fine, k, nd.p, ni.p, d_nb);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;

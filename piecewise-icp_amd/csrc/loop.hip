@@ -317,12 +317,6 @@ __global__ void __launch_bounds__(kBlock) k_transform_bbox(float4* __restrict__ 
     }
 }
 
-__global__ void k_iota_list(int* list, int* soff, const int* __restrict__ off, int m) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m) { list[i] = i; soff[i] = off[i]; }
-    if (i == m) soff[m] = off[m];
-}
-
 // ---- host-side scalar pieces of the reference's control logic --------------------------------------------
 // pcl::octree::OctreePointCloud::defineBoundingBox + getKeyBitSize, from the tight
 // float min/max of the cloud.  resolution = double(Res2 * 2)  (R.cpp:882)
@@ -392,8 +386,8 @@ struct pwicp_pair {
     DevBuf<unsigned> scal, sel_scratch, bbox_part;
     DevBuf<float> sel_out;
     DevBuf<unsigned long long> examined;
-    // configuration of the first Stage-1 dense NN launch of the last run (replayed by bench_dense_nn)
-    DevBuf<int> list0, soff0;
+    // stable flags of the first Stage-1 dense NN launch of the last run (replayed by bench_dense_nn)
+    DevBuf<int> stable0;
     int ns0 = 0, nsp0 = 0;
     std::vector<hipEvent_t> ev;
     // mailbox in pinned coherent host memory: [0] sequence word, [16..] payload
@@ -457,8 +451,7 @@ int finish_create(pwicp_pair* pr) {
     HIPCHK(ctx, pr->stable.reserve(M2));
     HIPCHK(ctx, pr->list.reserve(M2 + 1));
     HIPCHK(ctx, pr->soff.reserve(M2 + 1));
-    HIPCHK(ctx, pr->list0.reserve(M2 + 1));
-    HIPCHK(ctx, pr->soff0.reserve(M2 + 1));
+    HIPCHK(ctx, pr->stable0.reserve(M2 + 1));
     HIPCHK(ctx, pr->stCT.reserve(M2));
     HIPCHK(ctx, pr->stN.reserve(M2));
     HIPCHK(ctx, pr->d2dense.reserve((size_t)std::max(std::max(pr->P2.tot, pr->n2), 1)));
@@ -765,11 +758,11 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
             ev_kind.push_back({n_ev, 0});
             n_ev += 2;
             HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
-            PWCHK(pw_nn_dense_lds_launch(ctx, pr->g_c1.d, pr->P2.pat.p, pr->qorder.p, pr->pt_patch2.p, pr->stable.p,
+            PWCHK(pw_nn_dense_launch(ctx, pr->g_c1.d, pr->P2.pat.p, pr->qorder.p, pr->pt_patch2.p, pr->stable.p,
                                          pr->P2.tot, pr->d2dense.p, pr->examined.p));
             HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
             if (res->n_dense_nn_launches == 0) {      // remember the first launch for stand-alone replays
-                HIPCHK(ctx, hipMemcpyAsync(pr->list0.p, pr->stable.p, (size_t)m2 * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+                HIPCHK(ctx, hipMemcpyAsync(pr->stable0.p, pr->stable.p, (size_t)m2 * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
                 pr->ns0 = ns; pr->nsp0 = nsp;
             }
             double Dist75 = 0;
@@ -847,7 +840,7 @@ int pwicp_pair_bench_dense_nn(pwicp_pair* pr, int n_launches, double* ms_per_lau
     // source patch points; over ALL source patches if no run happened yet.
     const int m2 = pr->P2.m, tot = pr->P2.tot;
     if (m2 <= 0 || tot <= 0) { ctx->set_err("bench_dense_nn: no source patches"); return PWICP_E_INVALID; }
-    const int* flags = pr->list0.p;
+    const int* flags = pr->stable0.p;
     int npts = pr->nsp0;
     if (pr->ns0 <= 0) {
         HIPCHK(ctx, pr->all_stable.reserve((size_t)m2));
@@ -858,7 +851,7 @@ int pwicp_pair_bench_dense_nn(pwicp_pair* pr, int n_launches, double* ms_per_lau
     }
     HIPCHK(ctx, hipMemsetAsync(pr->examined.p, 0, 256 * 16 * sizeof(unsigned long long), ctx->stream));
     // warm-up launch (also measures Kbar)
-    PWCHK(pw_nn_dense_lds_launch(ctx, pr->g_c1.d, pr->pat2_0.p, pr->qorder.p, pr->pt_patch2.p, flags, tot,
+    PWCHK(pw_nn_dense_launch(ctx, pr->g_c1.d, pr->pat2_0.p, pr->qorder.p, pr->pt_patch2.p, flags, tot,
                                  pr->d2dense.p, pr->examined.p));
     unsigned long long ex = 0;
     {
@@ -870,7 +863,7 @@ int pwicp_pair_bench_dense_nn(pwicp_pair* pr, int n_launches, double* ms_per_lau
     hipEvent_t e0 = pr->event(0), e1 = pr->event(1);
     HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
     for (int i = 0; i < n_launches; ++i)
-        PWCHK(pw_nn_dense_lds_launch(ctx, pr->g_c1.d, pr->pat2_0.p, pr->qorder.p, pr->pt_patch2.p, flags, tot,
+        PWCHK(pw_nn_dense_launch(ctx, pr->g_c1.d, pr->pat2_0.p, pr->qorder.p, pr->pt_patch2.p, flags, tot,
                                      pr->d2dense.p, nullptr));
     HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -225,13 +225,28 @@ int supervoxel_segmentation(const Metric& metric, const std::vector<std::vector<
     return (int)supervoxels.size();
 }
 
+// normals (S.cpp:39-44) + segmentation (S.cpp:51-67) from given neighbour lists
+int segment_from_neighbors(const std::vector<double>& pts, int n, const std::vector<std::vector<int>>& neighbors,
+                           float sv_resolution, int32_t* labels, int* n_supervoxels) {
+    std::vector<V3> normals((size_t)n);
+    for (int i = 0; i < n; ++i) normals[(size_t)i] = pca_normal(pts.data(), neighbors[(size_t)i].data(), (int)neighbors[(size_t)i].size());
+    const double res = (double)sv_resolution;
+    Metric metric{pts.data(), normals.data(), res};
+    const int n_sv = count_occupied_cells(pts.data(), n, res);
+    std::vector<int> lab;
+    const int got = supervoxel_segmentation(metric, neighbors, n, n_sv, &lab);
+    for (int i = 0; i < n; ++i) labels[i] = lab[(size_t)i];
+    *n_supervoxels = got;
+    return PWICP_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
-// kNN = 45 in the reference (include/CommonFunc.h:41)
+// kNN = 45 in the reference (include/CommonFunc.h:41).  Host-only variant: k-NN with the host KD-tree.
 PWICP_API int pwicp_frontend_segment(const float* cloud_xyz4, int n, float sv_resolution, int knn, int32_t* labels,
-                           int* n_supervoxels) {
+                                     int* n_supervoxels) {
     if (!cloud_xyz4 || !labels || !n_supervoxels || n <= 0 || knn <= 0 || knn >= n || !(sv_resolution > 0.f))
         return PWICP_E_INVALID;
     std::vector<double> pts((size_t)n * 3);                                  // S.cpp:18-22: float -> double
@@ -240,23 +255,30 @@ PWICP_API int pwicp_frontend_segment(const float* cloud_xyz4, int n, float sv_re
     pwhost::KdTree<double> tree;
     tree.build(pts.data(), n, 3);
     std::vector<std::vector<int>> neighbors((size_t)n);
-    std::vector<V3> normals((size_t)n);
     std::vector<pwhost::KdTree<double>::Hit> hits((size_t)knn);
-    for (int i = 0; i < n; ++i) {                                             // S.cpp:37-45
+    for (int i = 0; i < n; ++i) {                                             // S.cpp:37-41
         const int c = tree.knn(pts.data() + 3 * (size_t)i, knn, hits.data());
         std::vector<int>& nb = neighbors[(size_t)i];
         nb.resize((size_t)c);
         for (int k = 0; k < c; ++k) nb[(size_t)k] = hits[(size_t)k].idx;
-        normals[(size_t)i] = pca_normal(pts.data(), nb.data(), c);
     }
-    const double res = (double)sv_resolution;                                 // S.cpp:51, 63-67
-    Metric metric{pts.data(), normals.data(), res};
-    const int n_sv = count_occupied_cells(pts.data(), n, res);
-    std::vector<int> lab;
-    const int got = supervoxel_segmentation(metric, neighbors, n, n_sv, &lab);
-    for (int i = 0; i < n; ++i) labels[i] = lab[(size_t)i];
-    *n_supervoxels = got;
-    return PWICP_OK;
+    return segment_from_neighbors(pts, n, neighbors, sv_resolution, labels, n_supervoxels);
+}
+
+// Same result, with the k-NN graph built on the GPU (pwicp_knn): the variant the entry points use.
+PWICP_API int pwicp_frontend_segment_dev(pwicp_context* ctx, const float* cloud_xyz4, int n, float sv_resolution, int knn,
+                                         float point_spacing, int32_t* labels, int* n_supervoxels) {
+    if (!ctx || !cloud_xyz4 || !labels || !n_supervoxels || n <= 0 || knn <= 0 || knn >= n || !(sv_resolution > 0.f))
+        return PWICP_E_INVALID;
+    std::vector<int32_t> nb((size_t)n * knn);
+    const int rc = pwicp_knn(ctx, cloud_xyz4, n, knn, point_spacing > 0.f ? 2.0f * point_spacing : 0.f, nb.data());
+    if (rc != PWICP_OK) return rc;
+    std::vector<double> pts((size_t)n * 3);
+    for (int i = 0; i < n; ++i)
+        for (int d = 0; d < 3; ++d) pts[3 * (size_t)i + d] = (double)cloud_xyz4[4 * (size_t)i + d];
+    std::vector<std::vector<int>> neighbors((size_t)n);
+    for (int i = 0; i < n; ++i) neighbors[(size_t)i].assign(nb.begin() + (size_t)i * knn, nb.begin() + (size_t)(i + 1) * knn);
+    return segment_from_neighbors(pts, n, neighbors, sv_resolution, labels, n_supervoxels);
 }
 
 }  // extern "C"

@@ -23,7 +23,6 @@
 #include "io.h"
 #include "pwicp.h"
 
-extern "C" int pwicp_frontend_segment(const float*, int, float, int, int32_t*, int*);
 
 using namespace pwhost;
 
@@ -75,8 +74,8 @@ bool register_pair(pwicp_context* ctx, const std::vector<float>& cloud1, const s
     const float SVRes1 = cfg.isSetResSVsize ? cfg.SVsize1 : Res1 * 10, SVRes2 = cfg.isSetResSVsize ? cfg.SVsize2 : Res2 * 10;
     std::vector<int32_t> lab1((size_t)m1), lab2((size_t)m2);
     int nsv1 = 0, nsv2 = 0;
-    if (pwicp_frontend_segment(p1.data(), m1, SVRes1, kNN, lab1.data(), &nsv1) != PWICP_OK ||
-        pwicp_frontend_segment(p2.data(), m2, SVRes2, kNN, lab2.data(), &nsv2) != PWICP_OK) {
+    if (pwicp_frontend_segment_dev(ctx, p1.data(), m1, SVRes1, kNN, Res1, lab1.data(), &nsv1) != PWICP_OK ||
+        pwicp_frontend_segment_dev(ctx, p2.data(), m2, SVRes2, kNN, Res2, lab2.data(), &nsv2) != PWICP_OK) {
         std::cerr << "Error: supervoxel segmentation failed.\n";
         return false;
     }

@@ -83,6 +83,8 @@ def load_library():
         if hasattr(L, name):
             getattr(L, name).argtypes = args
     L.pwicp_frontend_segment.argtypes = [fp, C.c_int, C.c_float, C.c_int, ip, ip]
+    L.pwicp_knn.argtypes = [vp, fp, C.c_int, C.c_int, C.c_float, ip]
+    L.pwicp_frontend_segment_dev.argtypes = [vp, fp, C.c_int, C.c_float, C.c_int, C.c_float, ip, ip]
     L.pwicp_preprocess.argtypes = [fp, C.c_int, C.c_float, C.c_int, C.c_double, fp, ip]
     L.pwicp_pc_resolution.argtypes = [fp, C.c_int]
     L.pwicp_pc_resolution.restype = C.c_float
@@ -194,6 +196,22 @@ class Context:
         out = C.c_float()
         self._chk(self._L.pwicp_overlap_ratio(self._h, _p(c1), len(c1), _p(c2), len(c2), DTinit, C.byref(out)))
         return out.value
+
+    def knn(self, cloud, k, cell_edge=0.0):
+        """k nearest neighbours of every point within the cloud (GPU): int32 (n, k), self first."""
+        c = f4(cloud)
+        nb = np.empty((len(c), k), np.int32)
+        self._chk(self._L.pwicp_knn(self._h, _p(c), len(c), int(k), float(cell_edge), _p(nb, ip)))
+        return nb
+
+    def frontend_segment(self, cloud, sv_resolution, knn=45, point_spacing=0.0):
+        """Supervoxel labels with the k-NN graph built on the GPU (same labels as frontend_segment)."""
+        c = f4(cloud)
+        lab = np.empty(len(c), np.int32)
+        nsv = C.c_int32()
+        self._chk(self._L.pwicp_frontend_segment_dev(self._h, _p(c), len(c), float(sv_resolution), int(knn),
+                                                      float(point_spacing), _p(lab, ip), C.byref(nsv)))
+        return lab, nsv.value
 
     def patchNormals(self, patch_xyz4, offsets):
         pat = f4(patch_xyz4)

@@ -149,3 +149,31 @@ def test_pair_entry_point(tmp_path, ctx, oracle):
     assert moved.shape == src.shape
     expect = (src.astype(np.float64) @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
     assert np.abs(moved - expect).max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_gpu_knn_and_frontend_match_host(ctx, oracle):
+    """k-NN graph on the GPU == host KD-tree lists (order included); labels == host front end == reference front end."""
+    import pwicp_amd as P
+    from scipy.spatial import cKDTree
+    tgt, src, _ = _data.pair(30000)
+    nb = ctx.knn(src, 45, 2 * _data.R)
+    assert nb.shape == (len(src), 45) and np.array_equal(nb[:, 0], np.arange(len(src)))
+    d, ii = cKDTree(src.astype(np.float64)).query(src.astype(np.float64), k=45)
+    # same neighbour sets and same order up to exact distance ties
+    dn = np.linalg.norm(src[nb].astype(np.float64) - src[:, None, :].astype(np.float64), axis=2)
+    assert np.allclose(dn, d, rtol=0, atol=1e-12) and np.all(np.diff(dn, axis=1) >= 0)
+    assert (nb != ii).mean() < 1e-3
+    lab_g, n_g = ctx.frontend_segment(src, 10 * _data.R, 45, _data.R)
+    lab_h, n_h = P.frontend_segment(src, 10 * _data.R)
+    assert n_g == n_h and np.array_equal(lab_g, lab_h)
+    if oracle.ref_frontend_available():
+        lab_r, n_r = oracle.ref_frontend(src, 10 * _data.R)
+        assert n_g == n_r and np.array_equal(lab_g, lab_r)
+    # sparse / clustered input: k larger than a cell block holds -> the search radius must grow
+    rng = np.random.default_rng(3)
+    pts = np.vstack([rng.normal(0, 0.01, (300, 3)), rng.normal(1.0, 0.3, (200, 3))]).astype(np.float32)
+    nb2 = ctx.knn(pts, 45)
+    d2, i2 = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=45)
+    dn2 = np.linalg.norm(pts[nb2].astype(np.float64) - pts[:, None, :].astype(np.float64), axis=2)
+    assert np.allclose(dn2, d2, rtol=0, atol=1e-12)
