@@ -261,6 +261,21 @@ __global__ void __launch_bounds__(kBlock) k_nn_points(GridDesc g, const float4* 
     add_examined(examined, cnt);
 }
 
+// few queries (centroid level): 8 lanes per query, see nn_query_group
+__global__ void __launch_bounds__(kBlock) k_nn_points_group(GridDesc g, const float4* __restrict__ q, int nq,
+                                                            int* __restrict__ idx, float* __restrict__ d2) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = t / kGroup, sub = t % kGroup;
+    // a whole group is in or out of range together (kBlock is a multiple of kGroup)
+    if (i >= nq) return;
+    const float4 v = q[i];
+    const NNBest b = nn_query_group(g, v.x, v.y, v.z, sub);
+    if (sub == 0) {
+        if (idx) idx[i] = b.found() ? b.idx() : -1;
+        d2[i] = b.d2();
+    }
+}
+
 // ---- dense 1-NN, LDS-staged (EXPERIMENTAL variant, not the default: measured slower than k_nn_dense_direct) ----
 // Queries arrive in Morton order of their (initial) fine cell, so the 256 queries of a block occupy a compact
 // box of cells.  The block stages that box (+-2 cells halo) once — the begin/end table of its cell rows and the
@@ -766,6 +781,13 @@ int pw_grid_build(pwicp_context* ctx, const float4* d_pts, int n, float cell_edg
 int pw_nn_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_q, int nq, int* d_idx, float* d_d2,
                  unsigned long long* d_examined) {
     if (nq <= 0) return PWICP_OK;
+    // small launches are latency bound: spread each query over 8 lanes; large ones are throughput bound: one lane each
+    if (!d_examined && nq <= 262144) {
+        hipLaunchKernelGGL(k_nn_points_group, dim3(div_up((long long)nq * kGroup, kBlock)), dim3(kBlock), 0, ctx->stream, g,
+                           d_q, nq, d_idx, d_d2);
+        HIPCHK(ctx, hipGetLastError());
+        return PWICP_OK;
+    }
     hipLaunchKernelGGL(k_nn_points, dim3(div_up(nq, kBlock)), dim3(kBlock), 0, ctx->stream, g, d_q, nq, d_idx,
                        d_d2, d_examined);
     HIPCHK(ctx, hipGetLastError());

@@ -220,6 +220,100 @@ __device__ __forceinline__ NNBest nn_query(const GridDesc& gd, float qx, float q
     return b;
 }
 
+// ---- group-cooperative search: kGroup consecutive lanes share ONE query ------------------------------------------------
+// For launches with few queries (centroids, boundary points) the cost of a query is its chain of dependent memory
+// round trips (begin/end words -> points, row after row), not throughput.  Spreading the rows of a query over the
+// lanes of a group shortens that chain ~5x.  All decisions are taken on group-uniform values (after a min over the
+// group), so the lanes of a group never diverge; the result is the same exact (d2, index) minimum.
+constexpr int kGroup = 8;
+
+__device__ __forceinline__ void group_min(NNBest& b) {
+#pragma unroll
+    for (int o = 1; o < kGroup; o <<= 1) {
+        const unsigned long long other = __shfl_xor(b.key, o);
+        b.key = other < b.key ? other : b.key;
+    }
+}
+
+// rows (y in [y0,y1], z in [z0,z1]) x [x0,x1] dealt round-robin to the lanes of the group
+__device__ __forceinline__ void scan_box_group(const GridLevel& g, int x0, int x1, int y0, int y1, int z0, int z1, int sub,
+                                               float qx, float qy, float qz, NNBest& b) {
+    const int wy = y1 - y0 + 1;
+    const int nrows = wy * (z1 - z0 + 1);
+    for (int t0 = sub; t0 < nrows; t0 += 2 * kGroup) {
+        int lo[2], hi[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int t = t0 + k * kGroup;
+            lo[k] = hi[k] = 0;
+            if (t < nrows) row_range(g, y0 + t % wy, z0 + t / wy, x0, x1, lo[k], hi[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) scan_points(g.pts, lo[k], hi[k], qx, qy, qz, b);
+    }
+}
+
+__device__ __forceinline__ NNBest nn_query_group(const GridDesc& gd, float qx, float qy, float qz, int sub) {
+    NNBest b;
+    b.key = kKeyInit;
+    const GridLevel& g = gd.fine;
+    if (g.n <= 0) return b;
+    // stage 1: the 9 stencil rows over the 8 lanes (lane 0 also takes the ninth)
+    {
+        const int cx = cell_of(qx, g.ox, g.inv_h), cy = cell_of(qy, g.oy, g.inv_h), cz = cell_of(qz, g.oz, g.inv_h);
+        int lo0, hi0, lo1 = 0, hi1 = 0;
+        row_range(g, cy + (sub % 3) - 1, cz + (sub / 3) - 1, cx - 1, cx + 1, lo0, hi0);
+        if (sub == 0) row_range(g, cy + 1, cz + 1, cx - 1, cx + 1, lo1, hi1);
+        scan_points(g.pts, lo0, hi0, qx, qy, qz, b);
+        scan_points(g.pts, lo1, hi1, qx, qy, qz, b);
+        group_min(b);
+        if (nn_resolved(g, 1, b)) return b;
+    }
+    const GridLevel& c = gd.coarse;
+    // stage 2: candidate known -> coarse cells touching the cube [q - rho, q + rho]
+    if (b.found()) {
+        const float rho = sqrtf(b.d2()) * 1.00001f + 2.0f * c.slack;
+        const int x0 = max(cell_of(qx - rho, c.ox, c.inv_h), 0), x1 = min(cell_of(qx + rho, c.ox, c.inv_h), c.nx - 1);
+        const int y0 = max(cell_of(qy - rho, c.oy, c.inv_h), 0), y1 = min(cell_of(qy + rho, c.oy, c.inv_h), c.ny - 1);
+        const int z0 = max(cell_of(qz - rho, c.oz, c.inv_h), 0), z1 = min(cell_of(qz + rho, c.oz, c.inv_h), c.nz - 1);
+        if ((y1 - y0 + 1) * (z1 - z0 + 1) <= 64) {
+            if (x0 <= x1 && y0 <= y1 && z0 <= z1) scan_box_group(c, x0, x1, y0, y1, z0, z1, sub, qx, qy, qz, b);
+            group_min(b);
+            return b;
+        }
+    }
+    // stage 3: block, then shells, on the coarse level; a group-min after every block/shell keeps the stop test uniform
+    {
+        const int cx = cell_of(qx, c.ox, c.inv_h), cy = cell_of(qy, c.oy, c.inv_h), cz = cell_of(qz, c.oz, c.inv_h);
+        const int ex = max(0, max(-cx, cx - (c.nx - 1)));
+        const int ey = max(0, max(-cy, cy - (c.ny - 1)));
+        const int ez = max(0, max(-cz, cz - (c.nz - 1)));
+        int r = max(max(ex, ey), max(ez, 1));
+        const int rcover = max(max(max(cx, c.nx - 1 - cx), max(cy, c.ny - 1 - cy)), max(cz, c.nz - 1 - cz));
+        scan_box_group(c, cx - r, cx + r, cy - r, cy + r, cz - r, cz + r, sub, qx, qy, qz, b);
+        group_min(b);
+        while (!nn_resolved(c, r, b) && r < rcover) {
+            ++r;
+            // shell of radius r: rows dealt round-robin; inner rows contribute their two end cells
+            const int w = 2 * r + 1;
+            for (int t = sub; t < w * w; t += kGroup) {
+                const int dz = t / w - r, dy = t % w - r;
+                int lo0, hi0, lo1 = 0, hi1 = 0;
+                if (dz == -r || dz == r || dy == -r || dy == r) {
+                    row_range(c, cy + dy, cz + dz, cx - r, cx + r, lo0, hi0);
+                } else {
+                    row_range(c, cy + dy, cz + dz, cx - r, cx - r, lo0, hi0);
+                    row_range(c, cy + dy, cz + dz, cx + r, cx + r, lo1, hi1);
+                }
+                scan_points(c.pts, lo0, hi0, qx, qy, qz, b);
+                scan_points(c.pts, lo1, hi1, qx, qy, qz, b);
+            }
+            group_min(b);
+        }
+    }
+    return b;
+}
+
 // diagnostic: points examined.  `ctr` is an array of 256 counters, 128 bytes apart (one per cache line), indexed
 // by block: same-line atomics from every wave would serialise (~5 ns each) and dominate a fast kernel.
 __device__ __forceinline__ void add_examined(unsigned long long* ctr, unsigned cnt) {
