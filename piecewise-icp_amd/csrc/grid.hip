@@ -581,25 +581,32 @@ __global__ void k_select_init(unsigned* scratch, int k) {
 
 template <int PASS>
 __global__ void k_select_hist(const float* __restrict__ v, int n, unsigned* __restrict__ scratch) {
-    __shared__ unsigned h[kSelBins];
-    for (int t = threadIdx.x; t < kSelBins; t += blockDim.x) h[t] = 0;
+    // 8 replicas of the histogram, chosen by lane: squared distances cluster in a few exponent bins, and same-bin
+    // LDS atomics from the 64 lanes of a wave would serialise
+    __shared__ unsigned h[8 * kSelBins];
+    for (int t = threadIdx.x; t < 8 * kSelBins; t += blockDim.x) h[t] = 0;
     __syncthreads();
+    unsigned* hr = h + (threadIdx.x & 7) * kSelBins;
     const unsigned prefix = scratch[0];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         unsigned u = __float_as_uint(v[i]);
         if (u == 0xffffffffu) continue;          // slot of a query that was not part of the launch
         if (PASS == 0) {
-            atomicAdd(&h[u >> 21], 1u);
+            atomicAdd(&hr[u >> 21], 1u);
         } else if (PASS == 1) {
-            if ((u >> 21) == (prefix >> 21)) atomicAdd(&h[(u >> 10) & 2047u], 1u);
+            if ((u >> 21) == (prefix >> 21)) atomicAdd(&hr[(u >> 10) & 2047u], 1u);
         } else {
-            if ((u >> 10) == (prefix >> 10)) atomicAdd(&h[u & 1023u], 1u);
+            if ((u >> 10) == (prefix >> 10)) atomicAdd(&hr[u & 1023u], 1u);
         }
     }
     __syncthreads();
     unsigned* gh = scratch + 8 + PASS * kSelBins;
-    for (int t = threadIdx.x; t < kSelBins; t += blockDim.x)
-        if (h[t]) atomicAdd(&gh[t], h[t]);
+    for (int t = threadIdx.x; t < kSelBins; t += blockDim.x) {
+        unsigned s = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s += h[r * kSelBins + t];
+        if (s) atomicAdd(&gh[t], s);
+    }
 }
 
 template <int PASS>
@@ -796,7 +803,8 @@ int pw_nn_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_q, int n
 
 int pw_select_kth_launch(pwicp_context* ctx, const float* d_vals, int n, int k, unsigned* d_scratch, float* d_out) {
     if (n <= 0) return PWICP_E_INVALID;
-    int nb = std::min(div_up(n, kBlock), ctx->n_cu * 4);
+    // few blocks: every block ends with one global atomic per non-empty bin, and same-address atomics serialise
+    int nb = std::min(div_up(n, kBlock), std::max(ctx->n_cu / 2, 1));
     hipLaunchKernelGGL(k_select_init, dim3(div_up(8 + 3 * kSelBins, kBlock)), dim3(kBlock), 0, ctx->stream,
                        d_scratch, k);
     hipLaunchKernelGGL(k_select_hist<0>, dim3(nb), dim3(kBlock), 0, ctx->stream, d_vals, n, d_scratch);

@@ -82,19 +82,52 @@ __global__ void __launch_bounds__(kBlock) k_icp_accum(GridDesc g, const float4* 
     block_reduce_store(v, kNSums, partials + (size_t)blockIdx.x * kNSums);
 }
 
-__device__ inline void construct_T(const double* x, float* T) {
-    const double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cg = cos(x[2]), sg = sin(x[2]);
-    T[0] = (float)(cg * cb);
-    T[1] = (float)(-sg * ca + cg * sb * sa);
-    T[2] = (float)(sg * sa + cg * sb * ca);
-    T[4] = (float)(sg * cb);
-    T[5] = (float)(cg * ca + sg * sb * sa);
-    T[6] = (float)(-cg * sa + sg * sb * ca);
-    T[8] = (float)(-sb);
-    T[9] = (float)(cb * sa);
-    T[10] = (float)(cb * ca);
-    T[3] = (float)x[3]; T[7] = (float)x[4]; T[11] = (float)x[5];
-    T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
+// 6x6 inverse by LU with partial pivoting on ONE wave, operands in LDS.  Element (i,j) is owned by lane 6*i+j; every
+// element goes through exactly the operations of the serial algorithm (devmath.h inv6) in the same order, so the
+// result is bit-identical — only independent elements are updated side by side.  A is destroyed; inv receives A^-1.
+__device__ __forceinline__ void inv6_wave(double (*A)[6], double (*inv)[6], int* piv, bool* singular) {
+    const int t = threadIdx.x;
+    if (t < 6) piv[t] = t;
+    if (t == 0) *singular = false;
+    __syncthreads();
+    for (int k = 0; k < 6; ++k) {
+        if (t == 0) {
+            int p = k;
+            double best = fabs(A[k][k]);
+            for (int i = k + 1; i < 6; ++i)
+                if (fabs(A[i][k]) > best) { best = fabs(A[i][k]); p = i; }
+            if (best == 0.0) *singular = true;
+            piv[6] = p;                                   // scratch: pivot row of this step
+        }
+        __syncthreads();
+        const int p = piv[6];
+        if (p != k && t < 6) { const double tmp = A[k][t]; A[k][t] = A[p][t]; A[p][t] = tmp; }
+        if (p != k && t == 6) { const int tp = piv[k]; piv[k] = piv[p]; piv[p] = tp; }
+        __syncthreads();
+        if (t > k && t < 6) A[t][k] = A[t][k] / A[k][k];
+        __syncthreads();
+        if (t < 36) {
+            const int i = t / 6, j = t % 6;
+            if (i > k && j > k) A[i][j] = A[i][j] - A[i][k] * A[k][j];
+        }
+        __syncthreads();
+    }
+    if (t < 6) {          // column t of the inverse: forward then back substitution (independent columns)
+        double y[6];
+        for (int i = 0; i < 6; ++i) {
+            double s = (piv[i] == t) ? 1.0 : 0.0;
+            for (int j = 0; j < i; ++j) s = s - A[i][j] * y[j];
+            y[i] = s;
+        }
+        for (int i = 5; i >= 0; --i) {
+            double s = y[i];
+            for (int j = i + 1; j < 6; ++j) s = s - A[i][j] * inv[j][t];
+            inv[i][t] = s / A[i][i];
+        }
+    }
+    __syncthreads();
+    if (*singular && t < 36) inv[t / 6][t % 6] = NAN;
+    __syncthreads();
 }
 
 __global__ void __launch_bounds__(64) k_icp_solve(IcpState* st, const double* __restrict__ partials, int ns_host,
@@ -103,32 +136,57 @@ __global__ void __launch_bounds__(64) k_icp_solve(IcpState* st, const double* __
     const int ns = ns_dev ? (int)*ns_dev : ns_host;
     const int nblocks = (ns + kBlock - 1) / kBlock;
     __shared__ double sums[kNSums];
-    if (threadIdx.x < kNSums) {
+    __shared__ double A[6][6], inv[6][6], x[6], sc[6];
+    __shared__ int piv[8];
+    __shared__ bool singular;
+    __shared__ float T[16], F[16];
+    const int t = threadIdx.x;
+    if (t < kNSums) {
         double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * kNSums + threadIdx.x];
-        sums[threadIdx.x] = s;
+        for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * kNSums + t];
+        sums[t] = s;
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    double A[36];
-    const int map[21][2] = {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {1, 1}, {1, 2}, {1, 3}, {1, 4}, {1, 5},
-                            {2, 2}, {2, 3}, {2, 4}, {2, 5}, {3, 3}, {3, 4}, {3, 5}, {4, 4}, {4, 5}, {5, 5}};
-    for (int k = 0; k < 21; ++k) {
-        A[6 * map[k][0] + map[k][1]] = sums[k];
-        A[6 * map[k][1] + map[k][0]] = sums[k];
+    if (t < 36) {           // symmetric fill from the 21 upper-triangle sums
+        const int i = t / 6, j = t % 6, r = min(i, j), c = max(i, j);
+        A[i][j] = sums[r * 6 - r * (r - 1) / 2 + (c - r)];
     }
-    double inv[36], x[6];
-    if (!inv6(A, inv))
-        for (int k = 0; k < 36; ++k) inv[k] = NAN;
-    for (int r = 0; r < 6; ++r) {
+    __syncthreads();
+    inv6_wave(A, inv, piv, &singular);
+    if (t < 6) {
         double s = 0.0;
-        for (int c = 0; c < 6; ++c) s += inv[6 * r + c] * sums[21 + c];
-        x[r] = s;
+        for (int c = 0; c < 6; ++c) s += inv[t][c] * sums[21 + c];
+        x[t] = s;
     }
-    float T[16];
-    construct_T(x, T);
-    for (int k = 0; k < 16; ++k) st->T[k] = T[k];
-    mat4_mul(T, st->Tfinal, st->Tfinal);
+    __syncthreads();
+    if (t < 3) { sc[t] = cos(x[t]); sc[3 + t] = sin(x[t]); }     // alpha, beta, gamma
+    __syncthreads();
+    if (t == 0) {
+        const double ca = sc[0], cb = sc[1], cg = sc[2], sa = sc[3], sb = sc[4], sg = sc[5];
+        T[0] = (float)(cg * cb);
+        T[1] = (float)(-sg * ca + cg * sb * sa);
+        T[2] = (float)(sg * sa + cg * sb * ca);
+        T[4] = (float)(sg * cb);
+        T[5] = (float)(cg * ca + sg * sb * sa);
+        T[6] = (float)(-cg * sa + sg * sb * ca);
+        T[8] = (float)(-sb);
+        T[9] = (float)(cb * sa);
+        T[10] = (float)(cb * ca);
+        T[3] = (float)x[3]; T[7] = (float)x[4]; T[11] = (float)x[5];
+        T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
+    }
+    if (t < 16) F[t] = st->Tfinal[t];
+    __syncthreads();
+    if (t < 16) {           // final = T * final (Eigen order), one element per lane
+        const int i = t / 4, j = t % 4;
+        float s = T[4 * i + 0] * F[0 + j];
+        s = s + T[4 * i + 1] * F[4 + j];
+        s = s + T[4 * i + 2] * F[8 + j];
+        s = s + T[4 * i + 3] * F[12 + j];
+        st->Tfinal[t] = s;
+        st->T[t] = T[t];
+    }
+    if (t != 0) return;
     const int iters = st->iters + 1;
     st->iters = iters;
     // pcl::registration::DefaultConvergenceCriteria<float>::hasConverged()
@@ -192,25 +250,27 @@ __global__ void __launch_bounds__(kBlock) k_vcm_accum(GridDesc g, const float4* 
 // out: Q[36], X[6]
 __global__ void __launch_bounds__(64) k_vcm_solve(const double* __restrict__ partials, int nblocks, double* __restrict__ QX) {
     __shared__ double sums[kVSums];
-    if (threadIdx.x < kVSums) {
+    __shared__ double A[6][6], Q[6][6];
+    __shared__ int piv[8];
+    __shared__ bool singular;
+    const int t = threadIdx.x;
+    if (t < kVSums) {
         double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * kNSums + threadIdx.x];
-        sums[threadIdx.x] = s;
+        for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * kNSums + t];
+        sums[t] = s;
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    double A[36];
-    int k = 0;
-    for (int r = 0; r < 6; ++r)
-        for (int c = r; c < 6; ++c) { A[6 * r + c] = sums[k]; A[6 * c + r] = sums[k]; ++k; }
-    double Q[36];
-    if (!inv6(A, Q))
-        for (int i = 0; i < 36; ++i) Q[i] = NAN;
-    for (int i = 0; i < 36; ++i) QX[i] = Q[i];
-    for (int r = 0; r < 6; ++r) {
+    if (t < 36) {
+        const int i = t / 6, j = t % 6, r = min(i, j), c = max(i, j);
+        A[i][j] = sums[r * 6 - r * (r - 1) / 2 + (c - r)];
+    }
+    __syncthreads();
+    inv6_wave(A, Q, piv, &singular);
+    if (t < 36) QX[t] = Q[t / 6][t % 6];
+    if (t < 6) {
         double s = 0;
-        for (int c = 0; c < 6; ++c) s += Q[6 * r + c] * sums[21 + c];
-        QX[36 + r] = s;
+        for (int c = 0; c < 6; ++c) s += Q[t][c] * sums[21 + c];
+        QX[36 + t] = s;
     }
 }
 

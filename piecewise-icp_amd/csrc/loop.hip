@@ -45,10 +45,12 @@ __global__ void __launch_bounds__(kBlock) k_classify(
     int m2, const int* __restrict__ mCT, const float* __restrict__ dCT, const int* __restrict__ mBP,
     const float* __restrict__ dBP, const float* __restrict__ ctstd1, const float* __restrict__ bpstd2,
     const float4* __restrict__ nrm1, const float4* __restrict__ ct1, const float4* __restrict__ ct2,
-    const float4* __restrict__ bp2, float currDT, float DTmin, float DTctct, int* __restrict__ stable,
-    unsigned* __restrict__ scal) {
+    const float4* __restrict__ bp2, const int* __restrict__ off2, float currDT, float DTmin, float DTctct,
+    int* __restrict__ stable, int* __restrict__ blk_cnt, unsigned* __restrict__ scal) {
+    __shared__ int s_cnt[kBlock / 64][2];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float lod_min = INFINITY, lod_max = 0.0f;
+    int st_flag = 0, st_pts = 0;
     if (i < m2) {
         // (2) level of detection, R.cpp:756-766
         const float maxLoD = DTmin * 2.0f, minLoD = DTmin;
@@ -80,12 +82,25 @@ __global__ void __launch_bounds__(kBlock) k_classify(
             } else res = sqrtf(dBP[6 * i + k]);
             if (thr < res) pass = false;
         }
-        stable[i] = (pass && (p2pt < DTctct)) ? 1 : 0;
+        st_flag = (pass && (p2pt < DTctct)) ? 1 : 0;
+        stable[i] = st_flag;
+        st_pts = st_flag ? (off2[i + 1] - off2[i]) : 0;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         lod_min = fminf(lod_min, __shfl_xor(lod_min, o));
         lod_max = fmaxf(lod_max, __shfl_xor(lod_max, o));
+        st_flag += __shfl_xor(st_flag, o);
+        st_pts += __shfl_xor(st_pts, o);
+    }
+    // stable patches / points of this block, for the parallel compaction that follows
+    if ((threadIdx.x & 63) == 0) { s_cnt[threadIdx.x >> 6][0] = st_flag; s_cnt[threadIdx.x >> 6][1] = st_pts; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0, b = 0;
+        for (int w = 0; w < kBlock / 64; ++w) { a += s_cnt[w][0]; b += s_cnt[w][1]; }
+        blk_cnt[2 * blockIdx.x] = a;
+        blk_cnt[2 * blockIdx.x + 1] = b;
     }
     if ((threadIdx.x & 63) == 0 && lod_max > 0.0f) {
         atomicMin(&scal[0], __float_as_uint(lod_min));   // positive floats order like their bit patterns
@@ -93,61 +108,72 @@ __global__ void __launch_bounds__(kBlock) k_classify(
     }
 }
 
-// Order-preserving compaction of the stable patches (single block): list, point prefix, stable centroids with
-// normals (generateCentroidCloudWithPatchNormals semantics: (0,0,1) unless > 6 points and a valid normal).
-// 1024 patches per pass, coalesced; exclusive scans of (count, points) by wave shuffles + one LDS hop.
-// Thread 0 also writes the counts into the iteration's scalar slot and resets the inner-ICP state.
-__global__ void __launch_bounds__(1024) k_compact(int m2, const int* __restrict__ stable, const int* __restrict__ off2,
-                                                  const float4* __restrict__ ct2, const float4* __restrict__ nrm2,
-                                                  int* __restrict__ list, int* __restrict__ soff,
-                                                  float4* __restrict__ stCT, float4* __restrict__ stN,
-                                                  float4* __restrict__ wsrc, float4* __restrict__ wsrcn,
-                                                  unsigned* __restrict__ scal, IcpState* __restrict__ st) {
-    __shared__ int wsum_n[2][16], wsum_p[2][16];
+// Order-preserving compaction of the stable patches, one block per 256 patches (same grid as k_classify, which
+// left the per-block counts in blk_cnt): base = sum of the preceding blocks' counts, then a block-local scan.
+// Outputs: list, point prefix, stable centroids with normals (generateCentroidCloudWithPatchNormals semantics:
+// (0,0,1) unless > 6 points and a valid normal), the ICP working copies.  Block 0 also writes the totals into the
+// iteration's scalar slot and resets the inner-ICP state.
+__global__ void __launch_bounds__(kBlock) k_compact(int m2, const int* __restrict__ stable, const int* __restrict__ off2,
+                                                    const float4* __restrict__ ct2, const float4* __restrict__ nrm2,
+                                                    const int* __restrict__ blk_cnt, int* __restrict__ list,
+                                                    int* __restrict__ soff, float4* __restrict__ stCT,
+                                                    float4* __restrict__ stN, float4* __restrict__ wsrc,
+                                                    float4* __restrict__ wsrcn, unsigned* __restrict__ scal,
+                                                    IcpState* __restrict__ st) {
+    __shared__ int s_red[kBlock / 64][4];
+    __shared__ int s_w[kBlock / 64][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int carry_n = 0, carry_p = 0, buf = 0;
-    for (int base = 0; base < m2; base += 1024, buf ^= 1) {
-        const int i = base + threadIdx.x;
-        const int f = (i < m2) ? stable[i] : 0;
-        const int np = (i < m2) ? (off2[i + 1] - off2[i]) : 0;
-        const int sz = f ? np : 0;
-        int in = f, ip = sz;                       // inclusive scans inside the wave
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int tn = __shfl_up(in, o), tp = __shfl_up(ip, o);
-            if (lane >= o) { in += tn; ip += tp; }
-        }
-        if (lane == 63) { wsum_n[buf][wave] = in; wsum_p[buf][wave] = ip; }
-        __syncthreads();                           // double-buffered wave sums: one barrier per pass
-        int on = 0, op = 0, totn = 0, totp = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const int a = wsum_n[buf][w], b = wsum_p[buf][w];
-            if (w < wave) { on += a; op += b; }
-            totn += a; totp += b;
-        }
-        if (f) {
-            const int pos = carry_n + on + in - f, ppos = carry_p + op + ip - sz;
-            list[pos] = i;
-            soff[pos] = ppos;
-            const float4 c = ct2[i];
-            float4 n = nrm2[i];
-            if (!(np > 6 && n.w != 0.0f)) n = make_float4(0.f, 0.f, 1.f, 0.f);
-            n.w = 0.f;
-            stCT[pos] = c; stN[pos] = n;
-            wsrc[pos] = c; wsrcn[pos] = n;
-        }
-        carry_n += totn; carry_p += totp;
+    const int nb = gridDim.x, me = blockIdx.x;
+    // own data first (independent of the counts: both loads are in flight together)
+    const int i = me * kBlock + threadIdx.x;
+    const int f = (i < m2) ? stable[i] : 0;
+    const int np = (i < m2) ? (off2[i + 1] - off2[i]) : 0;
+    const int sz = f ? np : 0;
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f), n = make_float4(0.f, 0.f, 1.f, 0.f);
+    if (f) { c = ct2[i]; n = nrm2[i]; }
+    int bn = 0, bp = 0, tn = 0, tp = 0;
+    for (int b = threadIdx.x; b < nb; b += kBlock) {
+        const int a0 = blk_cnt[2 * b], a1 = blk_cnt[2 * b + 1];
+        tn += a0; tp += a1;
+        if (b < me) { bn += a0; bp += a1; }
     }
-    if (threadIdx.x == 0) {
-        soff[carry_n] = carry_p;
-        scal[2] = (unsigned)carry_n;
-        scal[3] = (unsigned)carry_p;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        bn += __shfl_xor(bn, o); bp += __shfl_xor(bp, o); tn += __shfl_xor(tn, o); tp += __shfl_xor(tp, o);
+    }
+    int in = f, ip = sz;                             // inclusive scans inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int a0 = __shfl_up(in, o), a1 = __shfl_up(ip, o);
+        if (lane >= o) { in += a0; ip += a1; }
+    }
+    if (lane == 0) { s_red[wave][0] = bn; s_red[wave][1] = bp; s_red[wave][2] = tn; s_red[wave][3] = tp; }
+    if (lane == 63) { s_w[wave][0] = in; s_w[wave][1] = ip; }
+    __syncthreads();
+    int base_n = 0, base_p = 0, tot_n = 0, tot_p = 0, on = 0, op = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) {
+        base_n += s_red[w][0]; base_p += s_red[w][1]; tot_n += s_red[w][2]; tot_p += s_red[w][3];
+        if (w < wave) { on += s_w[w][0]; op += s_w[w][1]; }
+    }
+    if (f) {
+        const int pos = base_n + on + in - f, ppos = base_p + op + ip - sz;
+        if (!(np > 6 && n.w != 0.0f)) n = make_float4(0.f, 0.f, 1.f, 0.f);
+        n.w = 0.f;
+        list[pos] = i;
+        soff[pos] = ppos;
+        stCT[pos] = c; stN[pos] = n;
+        wsrc[pos] = c; wsrcn[pos] = n;
+    }
+    if (me == 0 && threadIdx.x == 0) {
+        soff[tot_n] = tot_p;
+        scal[2] = (unsigned)tot_n;
+        scal[3] = (unsigned)tot_p;
         for (int k = 0; k < 16; ++k) {
             st->T[k] = (k % 5 == 0) ? 1.f : 0.f;
             st->Tfinal[k] = (k % 5 == 0) ? 1.f : 0.f;
         }
-        st->iters = 0; st->done = (carry_n < 3) ? 1 : 0; st->reason = 0; st->pad = 0;
+        st->iters = 0; st->done = (tot_n < 3) ? 1 : 0; st->reason = 0; st->pad = 0;
         st->prev_mse = 1.7976931348623157e308;
     }
 }
@@ -379,7 +405,7 @@ struct pwicp_pair {
     DevBuf<int> qorder;      // source patch points in Morton order of their initial target-grid cell
     DevBuf<int> all_stable;  // all-ones flags (bench replay over every patch)
     // per-iteration work
-    DevBuf<int> mCTBP, stable, list, soff;   // matches of the 7*m2 centroid+boundary queries
+    DevBuf<int> mCTBP, stable, list, soff, blk_cnt;   // matches of the 7*m2 centroid+boundary queries
     DevBuf<float> dCTBP, d2dense;
     DevBuf<float4> stCT, stN;
     IcpWork icp;
@@ -420,10 +446,11 @@ int finish_create(pwicp_pair* pr) {
     if (m1 > 0)
         hipLaunchKernelGGL(k_with_norm, dim3(div_up(m1, kBlock)), dim3(kBlock), 0, ctx->stream, m1, pr->P1.off.p,
                            pr->nrm1.p, pr->ct1n.p);
-    // cell edges: dense cloud grid = 2 x point spacing (27-cell stencil ~ 40-50 points); centroid grid = 1 x patch
+    // cell edges: dense cloud grid = 3 x point spacing (27-cell stencil ~ 80 points; measured optimum: most first-
+    // iteration queries, 1-2 spacings from the target, still resolve in the stencil); centroid grid = 1 x patch
     // size (its 4x coarse level resolves the far queries of displaced, unstable patches).
     // Tuning knobs for experiments only (results do not depend on them; the search is exact for any edge).
-    float f_dense = 2.0f, f_ct = 1.0f;
+    float f_dense = 3.0f, f_ct = 1.0f;
     if (const char* e = getenv("PWICP_DENSE_CELL_FACTOR")) { float v = (float)atof(e); if (v > 0.f) f_dense = v; }
     if (const char* e = getenv("PWICP_CT_CELL_FACTOR")) { float v = (float)atof(e); if (v > 0.f) f_ct = v; }
     PWCHK(pw_grid_build(ctx, pr->cloud1.p, pr->n1, f_dense * pr->prm.Res1, &pr->g_c1));
@@ -449,6 +476,7 @@ int finish_create(pwicp_pair* pr) {
     HIPCHK(ctx, pr->mCTBP.reserve(M2 * 7));
     HIPCHK(ctx, pr->dCTBP.reserve(M2 * 7));
     HIPCHK(ctx, pr->stable.reserve(M2));
+    HIPCHK(ctx, pr->blk_cnt.reserve(2 * (size_t)div_up((long long)M2, kBlock) + 2));
     HIPCHK(ctx, pr->list.reserve(M2 + 1));
     HIPCHK(ctx, pr->soff.reserve(M2 + 1));
     HIPCHK(ctx, pr->stable0.reserve(M2 + 1));
@@ -694,10 +722,10 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         const float DTctct = currDT + 1 * (prm.SVRes1 + prm.SVRes2);   // R.cpp:817
         hipLaunchKernelGGL(k_classify, dim3(div_up(m2, kBlock)), dim3(kBlock), 0, ctx->stream, m2, pr->mCTBP.p,
                            pr->dCTBP.p, pr->mCTBP.p + m2, pr->dCTBP.p + m2, pr->P1.ctstd.p, pr->P2.bpstd.p, pr->nrm1.p,
-                           pr->P1.ct.p, ct2, bp2, currDT, DTmin, DTctct, pr->stable.p, slot);
-        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, ctx->stream, m2, pr->stable.p, pr->P2.off.p, ct2,
-                           pr->nrm2.p, pr->list.p, pr->soff.p, pr->stCT.p, pr->stN.p, pr->icp.src.p, pr->icp.srcn.p,
-                           slot, pr->icp.state.p);
+                           pr->P1.ct.p, ct2, bp2, pr->P2.off.p, currDT, DTmin, DTctct, pr->stable.p, pr->blk_cnt.p, slot);
+        hipLaunchKernelGGL(k_compact, dim3(div_up(m2, kBlock)), dim3(kBlock), 0, ctx->stream, m2, pr->stable.p, pr->P2.off.p,
+                           ct2, pr->nrm2.p, pr->blk_cnt.p, pr->list.p, pr->soff.p, pr->stCT.p, pr->stN.p, pr->icp.src.p,
+                           pr->icp.srcn.p, slot, pr->icp.state.p);
         // (5) R.cpp:875-877: inner ICP enqueued right behind, its point count read from the slot on the device;
         // ONE host round trip returns the counts, LoD_min and the ICP state together
         unsigned hs[kSlot], hb[6];
