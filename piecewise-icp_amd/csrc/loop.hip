@@ -110,63 +110,56 @@ __global__ void __launch_bounds__(kBlock) k_classify(
 
 // Order-preserving compaction of the stable patches, one block per 256 patches (same grid as k_classify, which
 // left the per-block counts in blk_cnt): base = sum of the preceding blocks' counts, then a block-local scan.
-// Outputs: list, point prefix, stable centroids with normals (generateCentroidCloudWithPatchNormals semantics:
+// Outputs: stable centroids with normals (generateCentroidCloudWithPatchNormals semantics:
 // (0,0,1) unless > 6 points and a valid normal), the ICP working copies.  Block 0 also writes the totals into the
 // iteration's scalar slot and resets the inner-ICP state.
 __global__ void __launch_bounds__(kBlock) k_compact(int m2, const int* __restrict__ stable, const int* __restrict__ off2,
                                                     const float4* __restrict__ ct2, const float4* __restrict__ nrm2,
-                                                    const int* __restrict__ blk_cnt, int* __restrict__ list,
-                                                    int* __restrict__ soff, float4* __restrict__ stCT,
+                                                    const int* __restrict__ blk_cnt, float4* __restrict__ stCT,
                                                     float4* __restrict__ stN, float4* __restrict__ wsrc,
                                                     float4* __restrict__ wsrcn, unsigned* __restrict__ scal,
                                                     IcpState* __restrict__ st) {
-    __shared__ int s_red[kBlock / 64][4];
-    __shared__ int s_w[kBlock / 64][2];
+    __shared__ int s_red[kBlock / 64][3];
+    __shared__ int s_w[kBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nb = gridDim.x, me = blockIdx.x;
     // own data first (independent of the counts: both loads are in flight together)
     const int i = me * kBlock + threadIdx.x;
     const int f = (i < m2) ? stable[i] : 0;
     const int np = (i < m2) ? (off2[i + 1] - off2[i]) : 0;
-    const int sz = f ? np : 0;
     float4 c = make_float4(0.f, 0.f, 0.f, 0.f), n = make_float4(0.f, 0.f, 1.f, 0.f);
     if (f) { c = ct2[i]; n = nrm2[i]; }
-    int bn = 0, bp = 0, tn = 0, tp = 0;
+    int bn = 0, tn = 0, tp = 0;
     for (int b = threadIdx.x; b < nb; b += kBlock) {
-        const int a0 = blk_cnt[2 * b], a1 = blk_cnt[2 * b + 1];
-        tn += a0; tp += a1;
-        if (b < me) { bn += a0; bp += a1; }
+        const int a0 = blk_cnt[2 * b];
+        tn += a0; tp += blk_cnt[2 * b + 1];
+        if (b < me) bn += a0;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        bn += __shfl_xor(bn, o); bp += __shfl_xor(bp, o); tn += __shfl_xor(tn, o); tp += __shfl_xor(tp, o);
-    }
-    int in = f, ip = sz;                             // inclusive scans inside the wave
+    for (int o = 32; o > 0; o >>= 1) { bn += __shfl_xor(bn, o); tn += __shfl_xor(tn, o); tp += __shfl_xor(tp, o); }
+    int in = f;                                      // inclusive scan inside the wave
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const int a0 = __shfl_up(in, o), a1 = __shfl_up(ip, o);
-        if (lane >= o) { in += a0; ip += a1; }
+        const int a0 = __shfl_up(in, o);
+        if (lane >= o) in += a0;
     }
-    if (lane == 0) { s_red[wave][0] = bn; s_red[wave][1] = bp; s_red[wave][2] = tn; s_red[wave][3] = tp; }
-    if (lane == 63) { s_w[wave][0] = in; s_w[wave][1] = ip; }
+    if (lane == 0) { s_red[wave][0] = bn; s_red[wave][1] = tn; s_red[wave][2] = tp; }
+    if (lane == 63) s_w[wave] = in;
     __syncthreads();
-    int base_n = 0, base_p = 0, tot_n = 0, tot_p = 0, on = 0, op = 0;
+    int base_n = 0, tot_n = 0, tot_p = 0, on = 0;
 #pragma unroll
     for (int w = 0; w < kBlock / 64; ++w) {
-        base_n += s_red[w][0]; base_p += s_red[w][1]; tot_n += s_red[w][2]; tot_p += s_red[w][3];
-        if (w < wave) { on += s_w[w][0]; op += s_w[w][1]; }
+        base_n += s_red[w][0]; tot_n += s_red[w][1]; tot_p += s_red[w][2];
+        if (w < wave) on += s_w[w];
     }
     if (f) {
-        const int pos = base_n + on + in - f, ppos = base_p + op + ip - sz;
+        const int pos = base_n + on + in - f;
         if (!(np > 6 && n.w != 0.0f)) n = make_float4(0.f, 0.f, 1.f, 0.f);
         n.w = 0.f;
-        list[pos] = i;
-        soff[pos] = ppos;
         stCT[pos] = c; stN[pos] = n;
         wsrc[pos] = c; wsrcn[pos] = n;
     }
     if (me == 0 && threadIdx.x == 0) {
-        soff[tot_n] = tot_p;
         scal[2] = (unsigned)tot_n;
         scal[3] = (unsigned)tot_p;
         for (int k = 0; k < 16; ++k) {
@@ -405,7 +398,7 @@ struct pwicp_pair {
     DevBuf<int> qorder;      // source patch points in Morton order of their initial target-grid cell
     DevBuf<int> all_stable;  // all-ones flags (bench replay over every patch)
     // per-iteration work
-    DevBuf<int> mCTBP, stable, list, soff, blk_cnt;   // matches of the 7*m2 centroid+boundary queries
+    DevBuf<int> mCTBP, stable, blk_cnt;   // matches of the 7*m2 centroid+boundary queries
     DevBuf<float> dCTBP, d2dense;
     DevBuf<float4> stCT, stN;
     IcpWork icp;
@@ -477,8 +470,6 @@ int finish_create(pwicp_pair* pr) {
     HIPCHK(ctx, pr->dCTBP.reserve(M2 * 7));
     HIPCHK(ctx, pr->stable.reserve(M2));
     HIPCHK(ctx, pr->blk_cnt.reserve(2 * (size_t)div_up((long long)M2, kBlock) + 2));
-    HIPCHK(ctx, pr->list.reserve(M2 + 1));
-    HIPCHK(ctx, pr->soff.reserve(M2 + 1));
     HIPCHK(ctx, pr->stable0.reserve(M2 + 1));
     HIPCHK(ctx, pr->stCT.reserve(M2));
     HIPCHK(ctx, pr->stN.reserve(M2));
@@ -724,8 +715,8 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                            pr->dCTBP.p, pr->mCTBP.p + m2, pr->dCTBP.p + m2, pr->P1.ctstd.p, pr->P2.bpstd.p, pr->nrm1.p,
                            pr->P1.ct.p, ct2, bp2, pr->P2.off.p, currDT, DTmin, DTctct, pr->stable.p, pr->blk_cnt.p, slot);
         hipLaunchKernelGGL(k_compact, dim3(div_up(m2, kBlock)), dim3(kBlock), 0, ctx->stream, m2, pr->stable.p, pr->P2.off.p,
-                           ct2, pr->nrm2.p, pr->blk_cnt.p, pr->list.p, pr->soff.p, pr->stCT.p, pr->stN.p, pr->icp.src.p,
-                           pr->icp.srcn.p, slot, pr->icp.state.p);
+                           ct2, pr->nrm2.p, pr->blk_cnt.p, pr->stCT.p, pr->stN.p, pr->icp.src.p, pr->icp.srcn.p, slot,
+                           pr->icp.state.p);
         // (5) R.cpp:875-877: inner ICP enqueued right behind, its point count read from the slot on the device;
         // ONE host round trip returns the counts, LoD_min and the ICP state together
         unsigned hs[kSlot], hb[6];

@@ -180,6 +180,25 @@ def test_loop_parity_with_oracle(ctx, oracle, n, which, epoch):
     pair.close()
 
 
+def test_loop_rockfall_scale_unreduced_coordinates(ctx, oracle):
+    """Stand-in for BASELINE configs[2] (rockfall data is not in the reference tree): spacing 0.3 m, patches 3 m,
+    coordinates offset by ~1e4 m and NOT reduced, so the float rounding slack of the cell assignment matters."""
+    import pwicp_amd as P
+    from pwicp_amd import synth
+    r = 0.3
+    tgt, _ = synth.make_tile(40000, r, offset=(1.0e4, -2.0e4, 1.5e3))
+    src, _ = synth.make_source(40000, r, epoch=4, offset=(1.0e4, -2.0e4, 1.5e3))
+    l1, n1 = synth.grid_labels(tgt, 10 * r)
+    l2, n2 = synth.grid_labels(src, 10 * r)
+    prm = P.Params(r, r, 10 * r, 10 * r, 1, 10 * r, 0.8 * r)
+    pair = P.Pair(ctx, tgt, l1, n1, src, l2, n2, prm)
+    res = pair.run(check=False)
+    io = oracle.run_loop(tgt, src, oracle.select_patches(tgt, l1, n1), oracle.select_patches(src, l2, n2), r, r, 10 * r, 10 * r,
+                         10 * r, 0.8 * r)
+    _assert_loop_parity(res, io)
+    pair.close()
+
+
 def test_loop_auto_dtinit(ctx, oracle):
     tgt, src, _ = _data.pair(30000)
     l1, n1 = _labels(tgt, "grid")

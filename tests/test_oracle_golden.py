@@ -96,3 +96,40 @@ def test_adaptive_pair_sequence_matches_reference_outputs(oracle):
                 break
         got[j + 1] = idx_target + 1
     assert got == expect
+
+
+AMAP = {2: 1, 3: 1, 4: 1, 5: 1, 6: 1, 7: 3, 8: 4, 9: 4, 10: 5, 11: 6, 12: 6, 13: 7, 14: 9, 15: 12, 16: 13, 17: 14, 18: 14,
+        19: 14, 20: 14}
+
+
+@pytest.mark.skipif(not os.path.isdir(G.REF_ROOT), reason="reference tree not mounted")
+def test_adaptive_pairs_match_reference_results(oracle):
+    """Second family of known answers: the reference's <e>_Adaptive_TransMatrix.txt files (source e registered to
+    the adaptive target AMAP[e], not to epoch 1).  Only pairs whose target differs from epoch 1 are new information."""
+    if not oracle.ref_frontend_available():
+        pytest.skip("oracle/_ref not built")
+    from pwicp_amd.pcd import read_pcd
+    prep = {}
+
+    def cloud(e):
+        if e not in prep:
+            prep[e] = G.preprocess_4d(oracle, read_pcd(G.epoch_path(e)))
+        return prep[e]
+
+    rows = {}
+    for e in (7, 9, 12, 14, 15, 17):
+        t = AMAP[e]
+        r1, r2, shift = G.reduce_pair(cloud(t), cloud(e))
+        l1, n1 = oracle.ref_frontend(r1, 0.05)
+        l2, n2 = oracle.ref_frontend(r2, 0.05)
+        io = oracle.run_loop(r1, r2, oracle.select_patches(r1, l1, n1), oracle.select_patches(r2, l2, n2),
+                             0.005, 0.005, 0.05, 0.05, 0.05, 0.004)
+        Tf = G.final_matrix(io.T16, shift)
+        Tg, Vg, stds = G.parse_transmatrix_file(os.path.join(G.GOLD, "reference_results", "%d_Adaptive_TransMatrix.txt" % e))
+        da = float(np.abs(G.euler(Tf) - G.euler(Tg)).max())
+        dt = float(np.abs(Tf[:3, 3].astype(float) - Tg[:3, 3]).max())
+        rows[e] = (da, dt)
+        assert io.status == 0
+    # all within registration-noise level, most at float print precision
+    assert all(v[0] < 1e-4 and v[1] < 2e-4 for v in rows.values()), rows
+    assert sum(1 for v in rows.values() if v[0] < 2e-6 and v[1] < 2e-6) >= 4, rows
