@@ -1,0 +1,205 @@
+// pwicp/Registration.h — C++ facade with the reference's own function names and argument meaning
+// (yihui4d/Piecewise-ICP include/Registration.h, include/CommonFunc.h), forwarding to the C ABI of pwicp.h.
+//
+// Two layers:
+//  * namespace pwicp: templates over "cloud-like" types (anything with a contiguous `.points` of 16-byte x,y,z,pad
+//    structs — pcl::PointCloud<pcl::PointXYZ> qualifies — and matrix types indexable as m(r, c)).  They compile
+//    without PCL (tests/facade_compile_check.cpp instantiates them with plain structs).
+//  * when PCL and Eigen are available at the user's site (`__has_include`), global functions with EXACTLY the
+//    reference's signatures (Registration.h:149-153, 213-214, 227-229, 116-129; CommonFunc.h) so that the reference's
+//    src/Registration.cpp can be replaced by this header plus libpwicp.so.
+// The context is per thread (the reference keeps module globals instead, Registration.cpp:11-14).
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../pwicp.h"
+
+namespace pwicp {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+// one context per thread, created on first use on device $PWICP_DEVICE / $LOCAL_RANK (default 0)
+inline pwicp_context* thread_context() {
+    struct Holder {
+        pwicp_context* ctx = nullptr;
+        ~Holder() { if (ctx) pwicp_destroy(ctx); }
+    };
+    static thread_local Holder h;
+    if (!h.ctx) {
+        const char* e = std::getenv("PWICP_DEVICE");
+        if (!e) e = std::getenv("LOCAL_RANK");
+        const int rc = pwicp_create(&h.ctx, e ? std::atoi(e) : 0);
+        if (rc != PWICP_OK) throw Error(rc, "pwicp: no usable HIP device (there is no CPU fallback)");
+    }
+    return h.ctx;
+}
+
+inline void check(int rc) {
+    if (rc != PWICP_OK) throw Error(rc, pwicp_last_error(thread_context()));
+}
+
+template <class Cloud>
+inline const float* xyz4(const Cloud& c) {
+    static_assert(sizeof(c.points[0]) == 16, "point type must be 16 bytes (x, y, z, pad) like pcl::PointXYZ");
+    return reinterpret_cast<const float*>(c.points.data());
+}
+
+// Piecewise_ICP (Registration.h:149-153) given the supervoxel labels of both clouds.
+// `labels*`: output of the segmentation front end (pwicp_frontend_segment_dev or the reference's own codelibrary).
+template <class Cloud, class Mat4, class MatX>
+void Piecewise_ICP_labelled(const Cloud& cloud1, Cloud& cloud2, const std::vector<int32_t>& labels1, int nsv1,
+                            const std::vector<int32_t>& labels2, int nsv2, float Res1, float Res2, float SVRes1,
+                            float SVRes2, bool isManualDTinit, float DTinit, float DTmin, std::vector<float>& DTseries,
+                            Mat4& transMat, MatX& VCM) {
+    pwicp_context* ctx = thread_context();
+    pwicp_params prm{Res1, Res2, SVRes1, SVRes2, isManualDTinit ? 1 : 0, DTinit, DTmin};
+    pwicp_pair* pair = nullptr;
+    check(pwicp_pair_create(ctx, xyz4(cloud1), (int)cloud1.points.size(), labels1.data(), nsv1, xyz4(cloud2),
+                            (int)cloud2.points.size(), labels2.data(), nsv2, &prm, &pair));
+    pwicp_result res;
+    const int rc = pwicp_pair_run(pair, &res);
+    if (rc == PWICP_OK)      // the reference transforms cloud2 in place (Registration.cpp:943-945)
+        pwicp_pair_download_source(pair, reinterpret_cast<float*>(cloud2.points.data()));
+    pwicp_pair_destroy(pair);
+    check(rc);
+    DTseries.assign(res.DTseries, res.DTseries + res.n_outer + 1);
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) transMat(r, c) = res.T16[4 * r + c];
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) VCM(r, c) = res.VCM[6 * r + c];
+}
+
+// Piecewise_ICP with the library's own front end (k-NN graph on the GPU + host fusion)
+template <class Cloud, class Mat4, class MatX>
+void Piecewise_ICP(const Cloud& cloud1, Cloud& cloud2, bool isSetResSVsize, float Res1, float Res2, float SVsize1,
+                   float SVsize2, bool isManualDTinit, float DTinit, float DTmin, std::vector<float>& DTseries,
+                   Mat4& transMat, MatX& VCM) {
+    const float SVRes1 = isSetResSVsize ? SVsize1 : Res1 * 10, SVRes2 = isSetResSVsize ? SVsize2 : Res2 * 10;   // R.cpp:635-640
+    pwicp_context* ctx = thread_context();
+    std::vector<int32_t> l1(cloud1.points.size()), l2(cloud2.points.size());
+    int n1 = 0, n2 = 0;
+    check(pwicp_frontend_segment_dev(ctx, xyz4(cloud1), (int)l1.size(), SVRes1, 45, Res1, l1.data(), &n1));
+    check(pwicp_frontend_segment_dev(ctx, xyz4(cloud2), (int)l2.size(), SVRes2, 45, Res2, l2.data(), &n2));
+    Piecewise_ICP_labelled(cloud1, cloud2, l1, n1, l2, n2, Res1, Res2, SVRes1, SVRes2, isManualDTinit, DTinit, DTmin,
+                           DTseries, transMat, VCM);
+}
+
+// calPercentileDistBetween2PC (CommonFunc.h; CommonFunc.cpp:266-281)
+template <class Cloud>
+double calPercentileDistBetween2PC(const Cloud& cloud1, const Cloud& cloud2, float percentile) {
+    double d = 0;
+    check(pwicp_percentile_dist(thread_context(), xyz4(cloud1), (int)cloud1.points.size(), xyz4(cloud2),
+                                (int)cloud2.points.size(), percentile, &d));
+    return d;
+}
+
+// calOverlapRatioByC2Cdist (Registration.h:116-129)
+template <class Cloud>
+float calOverlapRatioByC2Cdist(const Cloud& cloud1, const Cloud& cloud2, float DTinit) {
+    float r = 0;
+    check(pwicp_overlap_ratio(thread_context(), xyz4(cloud1), (int)cloud1.points.size(), xyz4(cloud2),
+                              (int)cloud2.points.size(), DTinit, &r));
+    return r;
+}
+
+// calPatchNormal (CommonFunc.h; CommonFunc.cpp:284-333) for ONE patch
+template <class Cloud>
+bool calPatchNormal(const Cloud& patch, float& nx, float& ny, float& nz) {
+    const int32_t off[2] = {0, (int32_t)patch.points.size()};
+    float n4[4] = {0, 0, 1, 0};
+    uint8_t ok = 0;
+    check(pwicp_patch_normals(thread_context(), xyz4(patch), off, 1, n4, &ok));
+    nx = n4[0]; ny = n4[1]; nz = n4[2];
+    return ok != 0;
+}
+
+// P2PICPwithPatchNormal / calTransParaVCM on PointNormal-like clouds (48-byte points: xyz pad | normal pad | curvature pad)
+template <class NCloud>
+inline void split_point_normal(const NCloud& c, std::vector<float>* xyz, std::vector<float>* nrm) {
+    static_assert(sizeof(c.points[0]) == 48, "point type must be 48 bytes like pcl::PointNormal");
+    const size_t n = c.points.size();
+    xyz->resize(4 * n); nrm->resize(4 * n);
+    const float* p = reinterpret_cast<const float*>(c.points.data());
+    for (size_t i = 0; i < n; ++i)
+        for (int k = 0; k < 4; ++k) { (*xyz)[4 * i + k] = p[12 * i + k]; (*nrm)[4 * i + k] = p[12 * i + 4 + k]; }
+}
+
+template <class NCloud, class Mat4>
+Mat4 P2PICPwithPatchNormal(const NCloud& cloudTarget, const NCloud& cloudSource, double EucldEpsilon) {
+    std::vector<float> t, tn, s, sn;
+    split_point_normal(cloudTarget, &t, &tn);
+    split_point_normal(cloudSource, &s, &sn);
+    float T[16];
+    check(pwicp_p2p_icp(thread_context(), t.data(), tn.data(), (int)(t.size() / 4), s.data(), sn.data(), (int)(s.size() / 4),
+                        EucldEpsilon, T, nullptr));
+    Mat4 M;
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) M(r, c) = T[4 * r + c];
+    return M;
+}
+
+template <class Cloud, class NCloud, class MatX>
+void calTransParaVCM(const Cloud& cloudTarget, const NCloud& cloudTargetwithNormals, const Cloud& cloudSourceStable, MatX& VCM) {
+    std::vector<float> t, tn;
+    split_point_normal(cloudTargetwithNormals, &t, &tn);
+    double V[36];
+    check(pwicp_trans_para_vcm(thread_context(), xyz4(cloudTarget), tn.data(), (int)cloudTarget.points.size(),
+                               xyz4(cloudSourceStable), (int)cloudSourceStable.points.size(), V));
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) VCM(r, c) = V[6 * r + c];
+}
+
+}  // namespace pwicp
+
+// ---- the reference's exact signatures, when PCL + Eigen are present ----------------------------------------------------
+#if defined(__has_include)
+#if __has_include(<pcl/point_types.h>) && __has_include(<pcl/point_cloud.h>) && __has_include(<Eigen/Dense>)
+#include <Eigen/Dense>
+#include <pcl/point_cloud.h>
+#include <pcl/point_types.h>
+#define PWICP_HAVE_PCL 1
+
+// Registration.h:149-153
+inline void Piecewise_ICP(pcl::PointCloud<pcl::PointXYZ>::Ptr cloud1, pcl::PointCloud<pcl::PointXYZ>::Ptr cloud2,
+                          bool isSetResSVsize, float Res1, float Res2, float SVsize1, float SVsize2, bool isManualDTinit,
+                          float DTinit, float DTmin, std::vector<float>& DTseries, Eigen::Matrix4f& transMat,
+                          Eigen::MatrixXd& VCM) {
+    VCM.resize(6, 6);
+    pwicp::Piecewise_ICP(*cloud1, *cloud2, isSetResSVsize, Res1, Res2, SVsize1, SVsize2, isManualDTinit, DTinit, DTmin,
+                         DTseries, transMat, VCM);
+}
+// Registration.h:213-214
+inline Eigen::Matrix4f P2PICPwithPatchNormal(pcl::PointCloud<pcl::PointNormal>::Ptr cloudTarget,
+                                             pcl::PointCloud<pcl::PointNormal>::Ptr cloudSource, double EucldEpsilon) {
+    return pwicp::P2PICPwithPatchNormal<pcl::PointCloud<pcl::PointNormal>, Eigen::Matrix4f>(*cloudTarget, *cloudSource, EucldEpsilon);
+}
+// Registration.h:227-229
+inline Eigen::MatrixXd calTransParaVCM(pcl::PointCloud<pcl::PointXYZ>::Ptr cloudTarget,
+                                       pcl::PointCloud<pcl::PointNormal>::Ptr cloudTargetwithNormals,
+                                       pcl::PointCloud<pcl::PointXYZ>::Ptr cloudSourceStable) {
+    Eigen::MatrixXd V(6, 6);
+    pwicp::calTransParaVCM(*cloudTarget, *cloudTargetwithNormals, *cloudSourceStable, V);
+    return V;
+}
+// Registration.h:116-129
+inline float calOverlapRatioByC2Cdist(pcl::PointCloud<pcl::PointXYZ>::Ptr cloud1, pcl::PointCloud<pcl::PointXYZ>::Ptr cloud2,
+                                      float DTinit) {
+    return pwicp::calOverlapRatioByC2Cdist(*cloud1, *cloud2, DTinit);
+}
+// CommonFunc.h
+inline double calPercentileDistBetween2PC(pcl::PointCloud<pcl::PointXYZ>::Ptr cloud1, pcl::PointCloud<pcl::PointXYZ>::Ptr cloud2,
+                                          float percentile) {
+    return pwicp::calPercentileDistBetween2PC(*cloud1, *cloud2, percentile);
+}
+inline bool calPatchNormal(pcl::PointCloud<pcl::PointXYZ> cloud, float& nx, float& ny, float& nz) {
+    return pwicp::calPatchNormal(cloud, nx, ny, nz);
+}
+#endif
+#endif

@@ -55,3 +55,28 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".hip", ".h", ".cpp", ".py", "Makefile")):
                 t = open(os.path.join(d, f), errors="replace").read()
                 assert "pwicp_oracle" not in t and "_oracle" not in t and "oracle/" not in t, os.path.join(d, f)
+
+
+def _build_facade_check(tmp_path):
+    import subprocess
+    import pwicp_amd
+    exe = str(tmp_path / "facade_check")
+    libdir = os.path.dirname(pwicp_amd.lib_path())
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "facade_compile_check.cpp"), "-L" + libdir, "-lpwicp",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+def test_cpp_facade_compiles_and_links(tmp_path):
+    """include/pwicp/Registration.h (the reference's function names over the C ABI) instantiates and links."""
+    import subprocess
+    out = subprocess.run([_build_facade_check(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "instantiated: 6" in out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_facade_runs_a_registration(tmp_path):
+    import subprocess
+    out = subprocess.run([_build_facade_check(tmp_path), "run"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "FACADE_OK" in out.stdout, out.stdout + out.stderr
