@@ -41,45 +41,64 @@ __device__ __forceinline__ void block_reduce_store(double* v, int nv, double* __
     }
 }
 
-__global__ void __launch_bounds__(kBlock) k_icp_accum(GridDesc g, const float4* __restrict__ tgt,
-                                                      const float4* __restrict__ tgt_n, float4* __restrict__ src,
-                                                      float4* __restrict__ srcn, int ns_host,
-                                                      const unsigned* __restrict__ ns_dev, const IcpState* st,
-                                                      double* __restrict__ partials) {
+// Group-cooperative accumulate: kGroup (8) consecutive lanes share one stable centroid.  They split the rows of its
+// nearest-neighbour search (nn_query_group: the search is a chain of dependent memory round trips at this size),
+// then each lane keeps 4 of the 28 sums of the point's LLS row, so the reduction over the wave's 8 points needs
+// 3 shuffle steps on 4 values instead of 6 steps on 28.
+constexpr int kAccBlock = 1024;                       // 128 points per block: few partials for the solve kernel
+constexpr int kAccPts = kAccBlock / kGroup;
+
+__global__ void __launch_bounds__(kAccBlock) k_icp_accum(GridDesc g, const float4* __restrict__ tgt,
+                                                         const float4* __restrict__ tgt_n, float4* __restrict__ src,
+                                                         float4* __restrict__ srcn, int ns_host,
+                                                         const unsigned* __restrict__ ns_dev, const IcpState* st,
+                                                         double* __restrict__ partials) {
+    __shared__ double sh[kAccBlock / 64][32];
     if (st->done) return;
     const int ns = ns_dev ? (int)*ns_dev : ns_host;          // the count may live on the device (no host sync)
-    if ((int)(blockIdx.x * blockDim.x) >= ns) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    double v[kNSums];
-#pragma unroll
-    for (int k = 0; k < kNSums; ++k) v[k] = 0.0;
+    if ((int)(blockIdx.x * kAccPts) >= ns) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = threadIdx.x % kGroup;
+    const int i = blockIdx.x * kAccPts + threadIdx.x / kGroup;
+    double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
     if (i < ns) {
         float4 p = src[i], nrm = srcn[i];
         if (st->iters > 0) {       // transformPointCloudWithNormals with the previous estimate
             p = xform_point(st->T, p);
             nrm = xform_normal(st->T, nrm);
-            src[i] = p;
-            srcn[i] = nrm;
+            if (sub == 0) { src[i] = p; srcn[i] = nrm; }
         }
-        unsigned ex;
-        NNBest b = nn_query(g, p.x, p.y, p.z, ex);
+        const NNBest b = nn_query_group(g, p.x, p.y, p.z, sub);
         const int bi = b.idx();
         const float4 t = tgt[bi], n = tgt_n[bi];
         const float sx = p.x, sy = p.y, sz = p.z, dx = t.x, dy = t.y, dz = t.z, nx = n.x, ny = n.y, nz = n.z;
         const double a = (double)(nz * sy - ny * sz);
         const double bb = (double)(nx * sz - nz * sx);
         const double c = (double)(ny * sx - nx * sy);
-        v[0] = a * a;   v[1] = a * bb;  v[2] = a * c;   v[3] = a * nx;  v[4] = a * ny;  v[5] = a * nz;
-        v[6] = bb * bb; v[7] = bb * c;  v[8] = bb * nx; v[9] = bb * ny; v[10] = bb * nz;
-        v[11] = c * c;  v[12] = c * nx; v[13] = c * ny; v[14] = c * nz;
-        v[15] = (double)(nx * nx); v[16] = (double)(nx * ny); v[17] = (double)(nx * nz);
-        v[18] = (double)(ny * ny); v[19] = (double)(ny * nz);
-        v[20] = (double)(nz * nz);
         const double d = (double)(nx * dx + ny * dy + nz * dz - nx * sx - ny * sy - nz * sz);
-        v[21] = a * d; v[22] = bb * d; v[23] = c * d; v[24] = nx * d; v[25] = ny * d; v[26] = nz * d;
-        v[27] = (double)b.d2();
+        // sum k (0..27) lives on lane sub = k % 8 as its (k / 8)-th value
+        switch (sub) {
+            case 0: w0 = a * a;   w1 = bb * nx;            w2 = (double)(nx * ny); w3 = nx * d; break;   // 0, 8, 16, 24
+            case 1: w0 = a * bb;  w1 = bb * ny;            w2 = (double)(nx * nz); w3 = ny * d; break;   // 1, 9, 17, 25
+            case 2: w0 = a * c;   w1 = bb * nz;            w2 = (double)(ny * ny); w3 = nz * d; break;   // 2, 10, 18, 26
+            case 3: w0 = a * nx;  w1 = c * c;              w2 = (double)(ny * nz); w3 = (double)b.d2(); break;   // 3, 11, 19, 27
+            case 4: w0 = a * ny;  w1 = c * nx;             w2 = (double)(nz * nz); break;                // 4, 12, 20
+            case 5: w0 = a * nz;  w1 = c * ny;             w2 = a * d; break;                            // 5, 13, 21
+            case 6: w0 = bb * bb; w1 = c * nz;             w2 = bb * d; break;                           // 6, 14, 22
+            default: w0 = bb * c; w1 = (double)(nx * nx);  w2 = c * d; break;                            // 7, 15, 23
+        }
     }
-    block_reduce_store(v, kNSums, partials + (size_t)blockIdx.x * kNSums);
+    // over the 8 points of the wave (lanes with equal `sub`), fixed order
+#pragma unroll
+    for (int o = kGroup; o < 64; o <<= 1) {
+        w0 += __shfl_xor(w0, o); w1 += __shfl_xor(w1, o); w2 += __shfl_xor(w2, o); w3 += __shfl_xor(w3, o);
+    }
+    if (lane < kGroup) { sh[wave][lane] = w0; sh[wave][8 + lane] = w1; sh[wave][16 + lane] = w2; sh[wave][24 + lane] = w3; }
+    __syncthreads();
+    if (threadIdx.x < kNSums) {
+        double acc = sh[0][threadIdx.x];
+        for (int w = 1; w < kAccBlock / 64; ++w) acc += sh[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * kNSums + threadIdx.x] = acc;
+    }
 }
 
 // 6x6 inverse by LU with partial pivoting on ONE wave, operands in LDS.  Element (i,j) is owned by lane 6*i+j; every
@@ -134,18 +153,21 @@ __global__ void __launch_bounds__(64) k_icp_solve(IcpState* st, const double* __
                                                   const unsigned* __restrict__ ns_dev, double mse_rel) {
     if (st->done) return;
     const int ns = ns_dev ? (int)*ns_dev : ns_host;
-    const int nblocks = (ns + kBlock - 1) / kBlock;
-    __shared__ double sums[kNSums];
+    const int nblocks = (ns + kAccPts - 1) / kAccPts;
+    __shared__ double sums[kNSums], half[2][kNSums];
     __shared__ double A[6][6], inv[6][6], x[6], sc[6];
     __shared__ int piv[8];
     __shared__ bool singular;
     __shared__ float T[16], F[16];
     const int t = threadIdx.x;
-    if (t < kNSums) {
+    if (t < 2 * kNSums) {      // two lanes per sum (even / odd blocks), then one add: a fixed summation order
+        const int k = t % kNSums, h = t / kNSums;
         double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * kNSums + t];
-        sums[t] = s;
+        for (int b = h; b < nblocks; b += 2) s += partials[(size_t)b * kNSums + k];
+        half[h][k] = s;
     }
+    __syncthreads();
+    if (t < kNSums) sums[t] = half[0][t] + half[1][t];
     __syncthreads();
     if (t < 36) {           // symmetric fill from the 21 upper-triangle sums
         const int i = t / 6, j = t % 6, r = min(i, j), c = max(i, j);
@@ -305,7 +327,7 @@ __global__ void __launch_bounds__(64) k_vcm_final(const double* __restrict__ par
 
 // ==========================================================================================================
 int IcpWork::reserve(pwicp_context* ctx, int ns_max) {
-    int nb = div_up(std::max(ns_max, 1), kBlock);
+    int nb = std::max(div_up(std::max(ns_max, 1), kBlock), div_up(std::max(ns_max, 1), kAccPts));
     HIPCHK(ctx, src.reserve((size_t)std::max(ns_max, 1)));
     HIPCHK(ctx, srcn.reserve((size_t)std::max(ns_max, 1)));
     HIPCHK(ctx, match.reserve((size_t)std::max(ns_max, 1)));
@@ -321,9 +343,9 @@ int IcpWork::reserve(pwicp_context* ctx, int ns_max) {
 int pw_icp_enqueue(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
                    int ns_max, const unsigned* ns_dev, double euclid_eps, int n_iter) {
     if (ns_max <= 0) return PWICP_OK;
-    const int nb = div_up(ns_max, kBlock);
+    const int nb = div_up(ns_max, kAccPts);
     for (int k = 0; k < n_iter; ++k) {
-        hipLaunchKernelGGL(k_icp_accum, dim3(nb), dim3(kBlock), 0, ctx->stream, g, d_tgt, d_tgt_n, w->src.p, w->srcn.p,
+        hipLaunchKernelGGL(k_icp_accum, dim3(nb), dim3(kAccBlock), 0, ctx->stream, g, d_tgt, d_tgt_n, w->src.p, w->srcn.p,
                            ns_max, ns_dev, w->state.p, w->partials.p);
         hipLaunchKernelGGL(k_icp_solve, dim3(1), dim3(64), 0, ctx->stream, w->state.p, w->partials.p, ns_max, ns_dev,
                            euclid_eps);
