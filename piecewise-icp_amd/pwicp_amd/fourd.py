@@ -60,9 +60,15 @@ def gather_records(local_records, n_pairs, world, dist=None, device=None):
         t = torch.from_numpy(buf.view(np.uint8).copy())
         if device is not None:
             t = t.to(device)
-        outs = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(outs, t)
-        allb = [o.cpu().numpy().view(_REC) for o in outs]
+        if t.is_cuda and hasattr(dist, "all_gather_into_tensor"):
+            # one flat RCCL all-gather (world * slots * 384 bytes)
+            flat = torch.empty(world * t.numel(), dtype=torch.uint8, device=t.device)
+            dist.all_gather_into_tensor(flat, t)
+            allb = [c.cpu().numpy().view(_REC) for c in flat.view(world, -1)]
+        else:
+            outs = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(outs, t)
+            allb = [o.cpu().numpy().view(_REC) for o in outs]
     table = {}
     for b in allb:
         for rec in b:
