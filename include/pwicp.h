@@ -194,6 +194,10 @@ PWICP_API int pwicp_frontend_segment_dev(pwicp_context* ctx, const float* cloud_
 /* PCpreprocessing(cloud, out, true, voxel_size, sor_k, sor_mult) (C.cpp:423-452). out_xyz4 holds n points. */
 PWICP_API int pwicp_preprocess(const float* cloud_xyz4, int n, float voxel_size, int sor_k, double sor_mult,
                                float* out_xyz4, int* n_out);
+/* pwicp_preprocess on the GPU (identical output): voxel keys + stable radix sort + per-voxel centroids, then the
+ * SOR mean-distance statistic from an exact float-metric k-NN on the uniform grid. */
+PWICP_API int pwicp_preprocess_dev(pwicp_context* ctx, const float* cloud_xyz4, int n, float voxel_size, int sor_k,
+                                   double sor_mult, float* out_xyz4, int* n_out);
 /* calPCresolution (C.cpp:239-263) */
 PWICP_API float pwicp_pc_resolution(const float* cloud_xyz4, int n);
 

@@ -517,14 +517,19 @@ __global__ void k_morton_keys(GridLevel g, const float4* __restrict__ p, int n, 
 // One lane per point, in cell order (neighbouring lanes scan the same cells).  The lane's sorted candidate list
 // lives in global memory in column layout (entry e of lane t at [e*n + t]: coalesced across the wave).
 // The (2r+1)^3 block is grown until the k-th distance is provably smaller than anything outside the block.
-__global__ void __launch_bounds__(kBlock) k_knn(GridLevel g, int k, double* __restrict__ nd, int* __restrict__ ni,
-                                                int* __restrict__ out_nb) {
+// Real = double: the front end's metric (codelibrary, squared distance in double).  Real = float: PCL's searches
+// (flann::L2_Simple<float>).  out_nb (optional): row `self` = the k neighbour indices.  out_mean (optional): the mean
+// of sqrt(d2) over neighbours 1..k-1 (the query itself is neighbour 0), accumulated in double and rounded to float —
+// the per-point statistic of pcl::StatisticalOutlierRemoval (filters/impl/statistical_outlier_removal.hpp).
+template <typename Real>
+__global__ void __launch_bounds__(kBlock) k_knn(GridLevel g, int k, Real* __restrict__ nd, int* __restrict__ ni,
+                                                int* __restrict__ out_nb, float* __restrict__ out_mean) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = g.n;
     if (t >= n) return;
     const float4 q = g.pts[t];
     const int self = __float_as_int(q.w);
-    const double qx = (double)q.x, qy = (double)q.y, qz = (double)q.z;
+    const Real qx = (Real)q.x, qy = (Real)q.y, qz = (Real)q.z;
     const int cx = cell_of(q.x, g.ox, g.inv_h), cy = cell_of(q.y, g.oy, g.inv_h), cz = cell_of(q.z, g.oz, g.inv_h);
     const int rcover = max(max(max(cx, g.nx - 1 - cx), max(cy, g.ny - 1 - cy)), max(cz, g.nz - 1 - cz));
     int cnt = 0;
@@ -536,20 +541,20 @@ __global__ void __launch_bounds__(kBlock) k_knn(GridLevel g, int k, double* __re
                 row_range(g, cy + dy, cz + dz, cx - r, cx + r, lo, hi);
                 for (int j = lo; j < hi; ++j) {
                     const float4 p = g.pts[j];
-                    const double dx = qx - (double)p.x, dy2 = qy - (double)p.y, dz2 = qz - (double)p.z;
-                    double d2 = dx * dx;
+                    const Real dx = qx - (Real)p.x, dy2 = qy - (Real)p.y, dz2 = qz - (Real)p.z;
+                    Real d2 = dx * dx;
                     d2 = d2 + dy2 * dy2;
                     d2 = d2 + dz2 * dz2;
                     const int id = __float_as_int(p.w);
                     // sorted insertion by (d2, id)
                     if (cnt == k) {
-                        const double wd = nd[(size_t)(k - 1) * n + t];
+                        const Real wd = nd[(size_t)(k - 1) * n + t];
                         const int wi = ni[(size_t)(k - 1) * n + t];
                         if (!(d2 < wd || (d2 == wd && id < wi))) continue;
                     }
                     int pos = cnt < k ? cnt : k - 1;
                     while (pos > 0) {
-                        const double pd = nd[(size_t)(pos - 1) * n + t];
+                        const Real pd = nd[(size_t)(pos - 1) * n + t];
                         const int pi = ni[(size_t)(pos - 1) * n + t];
                         if (!(d2 < pd || (d2 == pd && id < pi))) break;
                         nd[(size_t)pos * n + t] = pd;
@@ -564,10 +569,16 @@ __global__ void __launch_bounds__(kBlock) k_knn(GridLevel g, int k, double* __re
         if (r >= rcover) break;
         if (cnt == k) {
             const double bound = (double)r * (double)g.h - 2.0 * (double)g.slack;
-            if (bound > 0.0 && nd[(size_t)(k - 1) * n + t] < bound * bound * 0.99999) break;
+            if (bound > 0.0 && (double)nd[(size_t)(k - 1) * n + t] < bound * bound * 0.99999) break;
         }
     }
-    for (int e = 0; e < k; ++e) out_nb[(size_t)self * k + e] = (e < cnt) ? ni[(size_t)e * n + t] : -1;
+    if (out_nb)
+        for (int e = 0; e < k; ++e) out_nb[(size_t)self * k + e] = (e < cnt) ? ni[(size_t)e * n + t] : -1;
+    if (out_mean) {
+        double s = 0.0;
+        for (int e = 1; e < cnt; ++e) s += (double)sqrtf((float)nd[(size_t)e * n + t]);
+        out_mean[self] = (float)(s / (double)(k - 1));
+    }
 }
 
 // ---- k-th smallest of non-negative floats: 3-pass radix select on the bit pattern ---------------------
@@ -738,6 +749,26 @@ int build_level(pwicp_context* ctx, const float4* d_pts, int n, float h, const f
 
 }  // namespace
 
+// axis-aligned bounding box of n > 0 device points (synchronises the stream)
+int pw_bbox(pwicp_context* ctx, const float4* d_pts, int n, float mn[3], float mx[3]) {
+    DevBuf<unsigned> bb;
+    HIPCHK(ctx, bb.reserve(8));
+    static const unsigned init[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
+    HIPCHK(ctx, hipMemcpyAsync(bb.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    int nb = std::min(div_up(n, kBlock), ctx->n_cu * 4);
+    hipLaunchKernelGGL(k_bbox, dim3(nb), dim3(kBlock), 0, ctx->stream, d_pts, n, bb.p);
+    unsigned hb[8];
+    HIPCHK(ctx, hipMemcpyAsync(hb, bb.p, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 3; ++k) { mn[k] = ord2f(hb[k]); mx[k] = ord2f(hb[3 + k]); }
+    for (int k = 0; k < 3; ++k)
+        if (!(std::isfinite(mn[k]) && std::isfinite(mx[k]))) {
+            ctx->set_err("non-finite coordinates in the cloud");
+            return PWICP_E_INVALID;
+        }
+    return PWICP_OK;
+}
+
 int pw_grid_build(pwicp_context* ctx, const float4* d_pts, int n, float cell_edge, Grid* g) {
     GridDesc& d = g->d;
     memset(&d, 0, sizeof(d));
@@ -751,22 +782,8 @@ int pw_grid_build(pwicp_context* ctx, const float4* d_pts, int n, float cell_edg
         d.fine = e; d.coarse = e;
         return PWICP_OK;
     }
-    DevBuf<unsigned> bb;
-    HIPCHK(ctx, bb.reserve(8));
-    static const unsigned init[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
-    HIPCHK(ctx, hipMemcpyAsync(bb.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-    int nb = std::min(div_up(n, kBlock), ctx->n_cu * 4);
-    hipLaunchKernelGGL(k_bbox, dim3(nb), dim3(kBlock), 0, ctx->stream, d_pts, n, bb.p);
-    unsigned hb[8];
-    HIPCHK(ctx, hipMemcpyAsync(hb, bb.p, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     float mn[3], mx[3];
-    for (int k = 0; k < 3; ++k) { mn[k] = ord2f(hb[k]); mx[k] = ord2f(hb[3 + k]); }
-    for (int k = 0; k < 3; ++k)
-        if (!(std::isfinite(mn[k]) && std::isfinite(mx[k]))) {
-            ctx->set_err("pw_grid_build: non-finite coordinates in target cloud");
-            return PWICP_E_INVALID;
-        }
+    PWCHK(pw_bbox(ctx, d_pts, n, mn, mx));
     const float h = cell_edge > 0.f ? cell_edge : 1.f;
     PWCHK(build_level(ctx, d_pts, n, h, mn, mx, &d.fine, &g->cell_start, &g->pts));
     PWCHK(build_level(ctx, d_pts, n, 4.0f * d.fine.h, mn, mx, &d.coarse, &g->ccell_start, &g->cpts));
@@ -878,7 +895,24 @@ int pw_knn_launch(pwicp_context* ctx, const GridDesc& g, int k, int* d_nb) {
     DevBuf<int> ni;
     HIPCHK(ctx, nd.reserve((size_t)n * k));
     HIPCHK(ctx, ni.reserve((size_t)n * k));
-    hipLaunchKernelGGL(k_knn, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, g.fine, k, nd.p, ni.p, d_nb);
+    hipLaunchKernelGGL(k_knn<double>, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, g.fine, k, nd.p, ni.p, d_nb,
+                       (float*)nullptr);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipGetLastError());
+    return PWICP_OK;
+}
+
+// mean distance of every point to its mean_k nearest OTHER points (float metric), d_mean[i] for point i
+int pw_knn_mean_dist_launch(pwicp_context* ctx, const GridDesc& g, int mean_k, float* d_mean) {
+    const int n = g.fine.n;
+    if (n <= 0) return PWICP_OK;
+    const int k = mean_k + 1;
+    DevBuf<float> nd;
+    DevBuf<int> ni;
+    HIPCHK(ctx, nd.reserve((size_t)n * k));
+    HIPCHK(ctx, ni.reserve((size_t)n * k));
+    hipLaunchKernelGGL(k_knn<float>, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, g.fine, k, nd.p, ni.p,
+                       (int*)nullptr, d_mean);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;

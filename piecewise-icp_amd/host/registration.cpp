@@ -44,11 +44,13 @@ bool register_pair(pwicp_context* ctx, const std::vector<float>& cloud1, const s
     std::cout << "Original PC-1 point number: " << n1 << "\t Original PC-2 point number: " << n2 << std::endl;
     std::cout << "PC-1 avg. point spacing: " << Res1 << "\t PC-2 avg. point spacing: " << Res2 << std::endl << std::endl;
     // pre-process (R.cpp:412-416)
-    std::vector<float> p1((size_t)n1 * 4), p2((size_t)n2 * 4), tmp((size_t)std::max(n1, n2) * 4);
-    int m1 = voxel_grid(cloud1.data(), n1, Res1, tmp.data());
-    m1 = sor_filter(tmp.data(), m1, 14, sor_mult, p1.data());
-    int m2 = voxel_grid(cloud2.data(), n2, Res2, tmp.data());
-    m2 = sor_filter(tmp.data(), m2, 14, sor_mult, p2.data());
+    std::vector<float> p1((size_t)n1 * 4), p2((size_t)n2 * 4);
+    int m1 = 0, m2 = 0;
+    if (pwicp_preprocess_dev(ctx, cloud1.data(), n1, Res1, 14, sor_mult, p1.data(), &m1) != PWICP_OK ||
+        pwicp_preprocess_dev(ctx, cloud2.data(), n2, Res2, 14, sor_mult, p2.data(), &m2) != PWICP_OK) {
+        std::cerr << "Error: preprocessing failed: " << pwicp_last_error(ctx) << "\n";
+        return false;
+    }
     if (m1 < kNN + 1 || m2 < kNN + 1) { std::cerr << "Error: too few points after preprocessing.\n"; return false; }
     // reduction by the centroid of PC1 (R.cpp:419-436): pcl::compute3DCentroid float sums, float shift
     float acc[3] = {0, 0, 0};

@@ -85,6 +85,7 @@ def load_library():
     L.pwicp_frontend_segment.argtypes = [fp, C.c_int, C.c_float, C.c_int, ip, ip]
     L.pwicp_knn.argtypes = [vp, fp, C.c_int, C.c_int, C.c_float, ip]
     L.pwicp_frontend_segment_dev.argtypes = [vp, fp, C.c_int, C.c_float, C.c_int, C.c_float, ip, ip]
+    L.pwicp_preprocess_dev.argtypes = [vp, fp, C.c_int, C.c_float, C.c_int, C.c_double, fp, ip]
     L.pwicp_preprocess.argtypes = [fp, C.c_int, C.c_float, C.c_int, C.c_double, fp, ip]
     L.pwicp_pc_resolution.argtypes = [fp, C.c_int]
     L.pwicp_pc_resolution.restype = C.c_float
@@ -212,6 +213,15 @@ class Context:
         self._chk(self._L.pwicp_frontend_segment_dev(self._h, _p(c), len(c), float(sv_resolution), int(knn),
                                                       float(point_spacing), _p(lab, ip), C.byref(nsv)))
         return lab, nsv.value
+
+    def preprocess(self, cloud, voxel_size, sor_k=14, sor_mult=5.0):
+        """PCpreprocessing on the GPU (same output as the module-level preprocess)."""
+        c = f4(cloud)
+        out = np.empty_like(c)
+        m = C.c_int32()
+        self._chk(self._L.pwicp_preprocess_dev(self._h, _p(c), len(c), float(voxel_size), int(sor_k), float(sor_mult),
+                                               _p(out), C.byref(m)))
+        return out[:m.value].copy()
 
     def patchNormals(self, patch_xyz4, offsets):
         pat = f4(patch_xyz4)

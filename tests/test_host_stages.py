@@ -177,3 +177,26 @@ def test_gpu_knn_and_frontend_match_host(ctx, oracle):
     d2, i2 = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=45)
     dn2 = np.linalg.norm(pts[nb2].astype(np.float64) - pts[:, None, :].astype(np.float64), axis=2)
     assert np.allclose(dn2, d2, rtol=0, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_gpu_preprocess_matches_host(ctx, oracle):
+    """VoxelGrid + SOR on the GPU == host stage == oracle, point for point (order and bits)."""
+    import pwicp_amd as P
+    from pwicp_amd.pcd import read_pcd
+    cases = []
+    tgt, src, _ = _data.pair(60000)
+    rng = np.random.default_rng(11)
+    noisy = np.vstack([src[:, :3], src[:500, :3] + rng.normal(0, 0.3, (500, 3)).astype(np.float32)]).astype(np.float32)
+    cases.append((noisy, 1.5 * _data.R, 14, 2.7))
+    cases.append((tgt[:, :3] + np.float32(1234.5), 2.0 * _data.R, 14, 5.0))           # unreduced coordinates
+    g = os.path.join(os.path.dirname(__file__), "golden", "inputs", "Epoch_001.pcd")
+    cases.append((read_pcd(g)[:, :3], 0.02, 14, 5.0))
+    cases.append((rng.normal(0, 1, (40, 3)).astype(np.float32), 0.05, 14, 1.0))        # fewer voxels than a block
+    for cloud, leaf, k, mult in cases:
+        got = ctx.preprocess(cloud, leaf, k, mult)
+        want = P.preprocess(cloud, leaf, k, mult)
+        assert got.shape == want.shape and got.shape[0] > 0
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    o = oracle.sor(oracle.voxel_grid(cases[0][0], cases[0][1]), 14, 2.7)
+    assert np.array_equal(ctx.preprocess(*cases[0])[:, :3].view(np.uint32), np.ascontiguousarray(o[:, :3]).view(np.uint32))

@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-import os; R_=os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0,R_+'/tests'); sys.path.insert(0,R_+'/piecewise-icp_amd')
+import os; R_=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,R_+'/tests'); sys.path.insert(0,R_+'/piecewise-icp_amd')
 import pwicp_amd as P
 from pwicp_amd import synth
 ctx=P.Context(0); r=0.005; n=1000000
