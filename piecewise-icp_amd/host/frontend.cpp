@@ -11,7 +11,11 @@
 //
 // This is SURVEY.md §8 row f1 ("next"): it runs once per cloud on the host today; the registration loop itself
 // never touches it.
+#include <algorithm>
 #include <cfloat>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -20,29 +24,43 @@
 #include <vector>
 
 #include "kdtree.h"
+#include "parallel.h"
 #include "pwicp.h"
 
 namespace {
 
-struct V3 {
-    double x, y, z;
+// PWICP_TRACE=1: stage timings of the front end on stderr
+struct StageTimer {
+    const bool on = std::getenv("PWICP_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[pwicp front end] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
+// one cache line per point: position and PCA normal (double, as in the reference's front end)
+struct alignas(64) Pt {
+    double x, y, z, nx, ny, nz;
 };
 
 // pca_estimate_normals.h:42-108 with unit weights, points in the given order
-V3 pca_normal(const double* pts, const int* nb, int k) {
+void pca_normal(Pt* P, int self, const int32_t* nb, int k) {
     double cx = 0, cy = 0, cz = 0, sum = 0;
     for (int i = 0; i < k; ++i) {
-        const double* p = pts + 3 * (size_t)nb[i];
+        const Pt& p = P[nb[i]];
         const double w = 1.0;
-        cx += w * p[0]; cy += w * p[1]; cz += w * p[2];
+        cx += w * p.x; cy += w * p.y; cz += w * p.z;
         sum += w;
     }
     const double inv = 1.0 / sum;
     cx *= inv; cy *= inv; cz *= inv;
     double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0, s = 0;
     for (int i = 0; i < k; ++i) {
-        const double* p = pts + 3 * (size_t)nb[i];
-        const double x = p[0] - cx, y = p[1] - cy, z = p[2] - cz, w = 1.0;
+        const Pt& p = P[nb[i]];
+        const double x = p.x - cx, y = p.y - cy, z = p.z - cz, w = 1.0;
         a00 += w * x * x; a01 += w * x * y; a02 += w * x * z;
         a11 += w * y * y; a12 += w * y * z; a22 += w * z * z;
         s += w;
@@ -63,26 +81,23 @@ V3 pca_normal(const double* pts, const int* nb, int k) {
     else if (r >= 1.0) phi = 0.0;
     else phi = std::acos(r) / 3.0;
     const double eig = q + 2.0 * pq * std::cos(phi + M_PI * (2.0 / 3.0));
-    V3 n;
-    n.x = a01 * a12 - a02 * (a11 - eig);
-    n.y = a01 * a02 - a12 * (a00 - eig);
-    n.z = (a00 - eig) * (a11 - eig) - a01 * a01;
-    const double norm = std::sqrt(n.x * n.x + n.y * n.y + n.z * n.z);
-    if (norm == 0.0) return V3{0.0, 0.0, 1.0};
+    double nx = a01 * a12 - a02 * (a11 - eig);
+    double ny = a01 * a02 - a12 * (a00 - eig);
+    double nz = (a00 - eig) * (a11 - eig) - a01 * a01;
+    const double norm = std::sqrt(nx * nx + ny * ny + nz * nz);
+    Pt& o = P[self];
+    if (norm == 0.0) { o.nx = 0.0; o.ny = 0.0; o.nz = 1.0; return; }
     const double f = 1.0 / norm;
-    n.x *= f; n.y *= f; n.z *= f;
-    return n;
+    o.nx = nx * f; o.ny = ny * f; o.nz = nz * f;
 }
 
 struct Metric {      // Segmentation.h:362-375
-    const double* pts;
-    const V3* nrm;
+    const Pt* P;
     double resolution;
     double operator()(int a, int b) const {
-        const V3 &n1 = nrm[a], &n2 = nrm[b];
-        const double dot = n1.x * n2.x + n1.y * n2.y + n1.z * n2.z;
-        const double t1 = pts[3 * (size_t)a] - pts[3 * (size_t)b], t2 = pts[3 * (size_t)a + 1] - pts[3 * (size_t)b + 1],
-                     t3 = pts[3 * (size_t)a + 2] - pts[3 * (size_t)b + 2];
+        const Pt &p = P[a], &q = P[b];
+        const double dot = p.nx * q.nx + p.ny * q.ny + p.nz * q.nz;
+        const double t1 = p.x - q.x, t2 = p.y - q.y, t3 = p.z - q.z;
         const double dist = std::sqrt(t1 * t1 + t2 * t2 + t3 * t3);
         return 1.0 - std::fabs(dot) + dist / resolution * 0.4;
     }
@@ -102,83 +117,121 @@ struct DisjointSet {     // codelibrary/util/set/disjoint_set.h (path halving, L
 };
 
 // grid_sample.h:30-75: only the NUMBER of occupied cells is consumed by the segmentation
-int count_occupied_cells(const double* pts, int n, double resolution) {
+int count_occupied_cells(const Pt* P, int n, double resolution) {
     double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
-    for (int i = 0; i < n; ++i)
-        for (int d = 0; d < 3; ++d) {
-            mn[d] = std::min(mn[d], pts[3 * (size_t)i + d]);
-            mx[d] = std::max(mx[d], pts[3 * (size_t)i + d]);
-        }
+    for (int i = 0; i < n; ++i) {
+        const double c[3] = {P[i].x, P[i].y, P[i].z};
+        for (int d = 0; d < 3; ++d) { mn[d] = std::min(mn[d], c[d]); mx[d] = std::max(mx[d], c[d]); }
+    }
     const int size1 = (int)((mx[0] - mn[0]) / resolution + 1), size2 = (int)((mx[1] - mn[1]) / resolution + 1),
               size3 = (int)((mx[2] - mn[2]) / resolution + 1);
-    std::unordered_set<uint64_t> cells;
-    cells.reserve((size_t)n / 8 + 16);
-    for (int i = 0; i < n; ++i) {
-        int x = (int)((pts[3 * (size_t)i] - mn[0]) / resolution);
-        int y = (int)((pts[3 * (size_t)i + 1] - mn[1]) / resolution);
-        int z = (int)((pts[3 * (size_t)i + 2] - mn[2]) / resolution);
-        x = std::min(std::max(x, 0), size1 - 1);
-        y = std::min(std::max(y, 0), size2 - 1);
-        z = std::min(std::max(z, 0), size3 - 1);
-        cells.insert(((uint64_t)(uint32_t)x << 42) ^ ((uint64_t)(uint32_t)y << 21) ^ (uint64_t)(uint32_t)z);
-    }
-    return (int)cells.size();
+    std::vector<uint64_t> cells((size_t)n);
+    pwhost::parallel_for(n, [&](long long lo, long long hi) {
+        for (long long i = lo; i < hi; ++i) {
+            int x = (int)((P[i].x - mn[0]) / resolution);
+            int y = (int)((P[i].y - mn[1]) / resolution);
+            int z = (int)((P[i].z - mn[2]) / resolution);
+            x = std::min(std::max(x, 0), size1 - 1);
+            y = std::min(std::max(y, 0), size2 - 1);
+            z = std::min(std::max(z, 0), size3 - 1);
+            cells[(size_t)i] = ((uint64_t)(uint32_t)x << 42) ^ ((uint64_t)(uint32_t)y << 21) ^ (uint64_t)(uint32_t)z;
+        }
+    });
+    std::sort(cells.begin(), cells.end());
+    return (int)(std::unique(cells.begin(), cells.end()) - cells.begin());
 }
 
-// supervoxel_segmentation.h:65-248
-int supervoxel_segmentation(const Metric& metric, const std::vector<std::vector<int>>& neighbors, int n_points,
-                            int n_supervoxels, std::vector<int>* labels_out) {
+// supervoxel_segmentation.h:65-248.  nb: the k-NN graph, n_points rows of k indices.
+// Adjacency lists: a node that was never a fusion centre still reads its row of the k-NN graph; every list a round
+// writes is appended to one arena (list of node i = arena[off[i] .. off[i]+len[i])) which is compacted in place
+// between rounds.  The serial, order-dependent fusion pass therefore allocates nothing per supervoxel and touches
+// little fresh memory (first-touch page faults dominate this stage on virtualised hosts).
+int supervoxel_segmentation(const Metric& metric, const int32_t* nb, int k, int n_points, int n_supervoxels,
+                            std::vector<int>* labels_out) {
+    StageTimer tm;
     DisjointSet set(n_points);
     std::vector<int> supervoxels((size_t)n_points);
     for (int i = 0; i < n_points; ++i) supervoxels[(size_t)i] = i;
     std::vector<int> sizes((size_t)n_points, 1), queue((size_t)n_points);
-    std::vector<std::vector<int>> adjacents = neighbors;
+    constexpr size_t kInGraph = ~(size_t)0;                     // off[i]: the list is still row i of nb
+    std::vector<size_t> off((size_t)n_points, kInGraph);
+    std::vector<int> len((size_t)n_points, k);
+    std::vector<int> arena;
+    auto list_of = [&](int i) -> const int* {
+        return off[(size_t)i] == kInGraph ? nb + (size_t)i * (size_t)k : arena.data() + off[(size_t)i];
+    };
     int number_of_supervoxels = n_points;
     std::vector<char> visited((size_t)n_points, 0);
 
     // minimum value of lambda
     std::vector<double> dis((size_t)n_points, DBL_MAX);
-    for (int i = 0; i < n_points; ++i)
-        for (int j : adjacents[(size_t)i])
-            if (i != j) dis[(size_t)i] = std::min(dis[(size_t)i], metric(i, j));
+    pwhost::parallel_for(n_points, [&](long long lo, long long hi) {
+        for (long long i = lo; i < hi; ++i) {
+            double d = DBL_MAX;
+            const int32_t* row = nb + (size_t)i * (size_t)k;
+            for (int e = 0; e < k; ++e)
+                if (row[e] != (int)i) d = std::min(d, metric((int)i, row[e]));
+            dis[(size_t)i] = d;
+        }
+    });
     double lambda;
     {
         std::vector<double> v = dis;
         std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
         lambda = std::max(DBL_EPSILON, v[v.size() / 2]);
     }
+    tm.lap("  adjacency + lambda0");
 
     // ---- step 1: fusion with doubling lambda ---------------------------------------------------------------
+    std::vector<int> adjacent;
+    std::vector<double> loss_of((size_t)n_points);
     for (;; lambda *= 2.0) {
         if (supervoxels.size() <= 1) break;
         for (int i : supervoxels) {
-            if (adjacents[(size_t)i].empty()) continue;
+            if (len[(size_t)i] == 0) continue;
             visited[(size_t)i] = 1;
             int front = 0, back = 1;
             queue[(size_t)front++] = i;
-            for (int j : adjacents[(size_t)i]) {
-                j = set.find(j);
-                if (!visited[(size_t)j]) { visited[(size_t)j] = 1; queue[(size_t)back++] = j; }
-            }
-            std::vector<int> adjacent;
-            while (front < back) {
-                const int j = queue[(size_t)front++];
-                const double loss = sizes[(size_t)j] * metric(i, j);
-                const double improvement = lambda - loss;
-                if (improvement > 0.0) {
-                    set.link(j, i);
-                    sizes[(size_t)i] += sizes[(size_t)j];
-                    for (int k : adjacents[(size_t)j]) {
-                        k = set.find(k);
-                        if (!visited[(size_t)k]) { visited[(size_t)k] = 1; queue[(size_t)back++] = k; }
-                    }
-                    adjacents[(size_t)j].clear();
-                    if (--number_of_supervoxels == n_supervoxels) break;
-                } else {
-                    adjacent.push_back(j);
+            {
+                const int* a = list_of(i);
+                for (int e = 0, m = len[(size_t)i]; e < m; ++e) {
+                    const int j = set.find(a[e]);
+                    if (!visited[(size_t)j]) { visited[(size_t)j] = 1; queue[(size_t)back++] = j; }
                 }
             }
-            adjacents[(size_t)i].swap(adjacent);
+            adjacent.clear();
+            bool reached = false;
+            while (front < back && !reached) {
+                // losses of everything queued so far in one branch-free sweep (a candidate's size cannot change while
+                // it waits in the queue: only the centre i absorbs), then the FIFO decisions in the reference's order
+                const int stop = back;
+                for (int e = front; e < stop; ++e) {
+                    const int j = queue[(size_t)e];
+                    loss_of[(size_t)e] = sizes[(size_t)j] * metric(i, j);
+                }
+                while (front < stop) {
+                    const int j = queue[(size_t)front];
+                    const double loss = loss_of[(size_t)front];
+                    ++front;
+                    const double improvement = lambda - loss;
+                    if (improvement > 0.0) {
+                        set.link(j, i);
+                        sizes[(size_t)i] += sizes[(size_t)j];
+                        const int* a = list_of(j);
+                        for (int e = 0, m = len[(size_t)j]; e < m; ++e) {
+                            const int kk = set.find(a[e]);
+                            if (!visited[(size_t)kk]) { visited[(size_t)kk] = 1; queue[(size_t)back++] = kk; }
+                        }
+                        len[(size_t)j] = 0;
+                        if (--number_of_supervoxels == n_supervoxels) { reached = true; break; }
+                    } else {
+                        adjacent.push_back(j);
+                    }
+                }
+            }
+            off[(size_t)i] = arena.size();
+            len[(size_t)i] = (int)adjacent.size();
+            arena.insert(arena.end(), adjacent.begin(), adjacent.end());
             for (int j = 0; j < back; ++j) visited[(size_t)queue[(size_t)j]] = 0;
             if (number_of_supervoxels == n_supervoxels) break;
         }
@@ -187,36 +240,98 @@ int supervoxel_segmentation(const Metric& metric, const std::vector<std::vector<
             if (set.find(i) == i) supervoxels[(size_t)number_of_supervoxels++] = i;
         supervoxels.resize((size_t)number_of_supervoxels);
         if (number_of_supervoxels == n_supervoxels) break;
+        // compact the arena in place: every surviving non-empty list was appended this round, in supervoxel order
+        size_t w = 0;
+        for (int i : supervoxels) {
+            const int m = len[(size_t)i];
+            if (m) std::memmove(arena.data() + w, arena.data() + off[(size_t)i], (size_t)m * sizeof(int));
+            off[(size_t)i] = w;
+            w += (size_t)m;
+        }
+        arena.resize(w);
+        if (tm.on) { char b[64]; std::snprintf(b, sizeof b, "    round -> %d sv, arena %zu", number_of_supervoxels, arena.size()); tm.lap(b); }
     }
     std::vector<int>& labels = *labels_out;
     labels.resize((size_t)n_points);
     for (int i = 0; i < n_points; ++i) labels[(size_t)i] = set.find(i);
+    tm.lap("  fusion");
 
     // ---- step 2: boundary refinement -------------------------------------------------------------------------
-    for (int i = 0; i < n_points; ++i) dis[(size_t)i] = metric(i, labels[(size_t)i]);
-    std::queue<int> q;
+    pwhost::parallel_for(n_points, [&](long long lo, long long hi) {
+        for (long long i = lo; i < hi; ++i) dis[(size_t)i] = metric((int)i, labels[(size_t)i]);
+    });
+    std::vector<int> q((size_t)n_points);              // ring buffer: every point is queued at most once at a time
+    size_t qh = 0, qt = 0, qn = 0;
+    const size_t qcap = (size_t)n_points;
+    auto push = [&](int v) { q[qt] = v; qt = (qt + 1 == qcap) ? 0 : qt + 1; ++qn; };
     std::vector<char> in_q((size_t)n_points, 0);
-    for (int i = 0; i < n_points; ++i)
-        for (int j : neighbors[(size_t)i])
-            if (labels[(size_t)i] != labels[(size_t)j]) {
-                if (!in_q[(size_t)i]) { q.push(i); in_q[(size_t)i] = 1; }
-                if (!in_q[(size_t)j]) { q.push(j); in_q[(size_t)j] = 1; }
+    // seed: every point with a differently labelled neighbour, and that neighbour, in scan order.  The label
+    // comparisons (n*k random reads) run on all threads into one bit mask per point; the order-dependent pushes
+    // then only visit the boundary points.
+    if (k <= 64) {
+        std::vector<uint64_t> diff((size_t)n_points);
+        pwhost::parallel_for(n_points, [&](long long lo, long long hi) {
+            for (long long i = lo; i < hi; ++i) {
+                const int32_t* row = nb + (size_t)i * (size_t)k;
+                const int li = labels[(size_t)i];
+                uint64_t m = 0;
+                for (int e = 0; e < k; ++e) m |= (uint64_t)(labels[(size_t)row[e]] != li) << e;
+                diff[(size_t)i] = m;
             }
-    while (!q.empty()) {
-        const int i = q.front();
-        q.pop();
+        });
+        for (int i = 0; i < n_points; ++i) {
+            uint64_t m = diff[(size_t)i];
+            if (!m) continue;
+            const int32_t* row = nb + (size_t)i * (size_t)k;
+            if (!in_q[(size_t)i]) { push(i); in_q[(size_t)i] = 1; }
+            while (m) {
+                const int j = row[__builtin_ctzll(m)];
+                m &= m - 1;
+                if (!in_q[(size_t)j]) { push(j); in_q[(size_t)j] = 1; }
+            }
+        }
+    } else {
+        for (int i = 0; i < n_points; ++i) {
+            const int32_t* row = nb + (size_t)i * (size_t)k;
+            for (int e = 0; e < k; ++e) {
+                const int j = row[e];
+                if (labels[(size_t)i] != labels[(size_t)j]) {
+                    if (!in_q[(size_t)i]) { push(i); in_q[(size_t)i] = 1; }
+                    if (!in_q[(size_t)j]) { push(j); in_q[(size_t)j] = 1; }
+                }
+            }
+        }
+    }
+    if (tm.on) { char b[64]; std::snprintf(b, sizeof b, "    seeds: %zu", qn); tm.lap(b); }
+    size_t pops = 0;
+    while (qn) {
+        const int i = q[qh];
+        qh = (qh + 1 == qcap) ? 0 : qh + 1;
+        --qn;
+        ++pops;
         in_q[(size_t)i] = 0;
         bool change = false;
-        for (int j : neighbors[(size_t)i]) {
-            const int a = labels[(size_t)i], b = labels[(size_t)j];
+        const int32_t* row = nb + (size_t)i * (size_t)k;
+        // A label already tried during this visit cannot win later (dis[i] only decreases), so each distinct
+        // neighbouring label is evaluated once; the outcome is the reference's.
+        int tried[8], n_tried = 0;
+        for (int e = 0; e < k; ++e) {
+            const int a = labels[(size_t)i], b = labels[(size_t)row[e]];
             if (a == b) continue;
+            bool seen = false;
+            for (int t = 0; t < n_tried; ++t) seen |= (tried[t] == b);
+            if (seen) continue;
+            if (n_tried < 8) tried[n_tried++] = b;
             const double d = metric(i, b);
             if (d < dis[(size_t)i]) { labels[(size_t)i] = b; dis[(size_t)i] = d; change = true; }
         }
         if (change)
-            for (int j : neighbors[(size_t)i])
-                if (labels[(size_t)i] != labels[(size_t)j] && !in_q[(size_t)j]) { q.push(j); in_q[(size_t)j] = 1; }
+            for (int e = 0; e < k; ++e) {
+                const int j = row[e];
+                if (labels[(size_t)i] != labels[(size_t)j] && !in_q[(size_t)j]) { push(j); in_q[(size_t)j] = 1; }
+            }
     }
+    if (tm.on) { char b[64]; std::snprintf(b, sizeof b, "  boundary refinement (%zu pops)", pops); tm.lap(b); }
 
     // ---- step 3: relabel -----------------------------------------------------------------------------------------
     std::vector<int> map((size_t)n_points, 0);
@@ -225,16 +340,27 @@ int supervoxel_segmentation(const Metric& metric, const std::vector<std::vector<
     return (int)supervoxels.size();
 }
 
-// normals (S.cpp:39-44) + segmentation (S.cpp:51-67) from given neighbour lists
-int segment_from_neighbors(const std::vector<double>& pts, int n, const std::vector<std::vector<int>>& neighbors,
-                           float sv_resolution, int32_t* labels, int* n_supervoxels) {
-    std::vector<V3> normals((size_t)n);
-    for (int i = 0; i < n; ++i) normals[(size_t)i] = pca_normal(pts.data(), neighbors[(size_t)i].data(), (int)neighbors[(size_t)i].size());
+// normals (S.cpp:39-44) + segmentation (S.cpp:51-67) from the k-NN graph (n rows of k indices, the point itself first)
+int segment_from_neighbors(const float* cloud_xyz4, int n, const int32_t* nb, int k, float sv_resolution, int32_t* labels,
+                           int* n_supervoxels) {
+    StageTimer tm;
+    std::vector<Pt> P((size_t)n);
+    for (int i = 0; i < n; ++i) {                                            // S.cpp:18-22: float -> double
+        P[(size_t)i].x = (double)cloud_xyz4[4 * (size_t)i];
+        P[(size_t)i].y = (double)cloud_xyz4[4 * (size_t)i + 1];
+        P[(size_t)i].z = (double)cloud_xyz4[4 * (size_t)i + 2];
+    }
+    pwhost::parallel_for(n, [&](long long lo, long long hi) {
+        for (long long i = lo; i < hi; ++i) pca_normal(P.data(), (int)i, nb + (size_t)i * (size_t)k, k);
+    });
+    tm.lap("pca normals");
     const double res = (double)sv_resolution;
-    Metric metric{pts.data(), normals.data(), res};
-    const int n_sv = count_occupied_cells(pts.data(), n, res);
+    Metric metric{P.data(), res};
+    const int n_sv = count_occupied_cells(P.data(), n, res);
+    tm.lap("occupied cells");
     std::vector<int> lab;
-    const int got = supervoxel_segmentation(metric, neighbors, n, n_sv, &lab);
+    const int got = supervoxel_segmentation(metric, nb, k, n, n_sv, &lab);
+    tm.lap("segmentation total");
     for (int i = 0; i < n; ++i) labels[i] = lab[(size_t)i];
     *n_supervoxels = got;
     return PWICP_OK;
@@ -254,15 +380,15 @@ PWICP_API int pwicp_frontend_segment(const float* cloud_xyz4, int n, float sv_re
         for (int d = 0; d < 3; ++d) pts[3 * (size_t)i + d] = (double)cloud_xyz4[4 * (size_t)i + d];
     pwhost::KdTree<double> tree;
     tree.build(pts.data(), n, 3);
-    std::vector<std::vector<int>> neighbors((size_t)n);
-    std::vector<pwhost::KdTree<double>::Hit> hits((size_t)knn);
-    for (int i = 0; i < n; ++i) {                                             // S.cpp:37-41
-        const int c = tree.knn(pts.data() + 3 * (size_t)i, knn, hits.data());
-        std::vector<int>& nb = neighbors[(size_t)i];
-        nb.resize((size_t)c);
-        for (int k = 0; k < c; ++k) nb[(size_t)k] = hits[(size_t)k].idx;
-    }
-    return segment_from_neighbors(pts, n, neighbors, sv_resolution, labels, n_supervoxels);
+    std::vector<int32_t> nb((size_t)n * (size_t)knn);
+    pwhost::parallel_for(n, [&](long long lo, long long hi) {                // S.cpp:37-41
+        std::vector<pwhost::KdTree<double>::Hit> hits((size_t)knn);
+        for (long long i = lo; i < hi; ++i) {
+            const int c = tree.knn(pts.data() + 3 * (size_t)i, knn, hits.data());
+            for (int e = 0; e < knn; ++e) nb[(size_t)i * (size_t)knn + (size_t)e] = e < c ? hits[(size_t)e].idx : (int32_t)i;
+        }
+    });
+    return segment_from_neighbors(cloud_xyz4, n, nb.data(), knn, sv_resolution, labels, n_supervoxels);
 }
 
 // Same result, with the k-NN graph built on the GPU (pwicp_knn): the variant the entry points use.
@@ -273,12 +399,7 @@ PWICP_API int pwicp_frontend_segment_dev(pwicp_context* ctx, const float* cloud_
     std::vector<int32_t> nb((size_t)n * knn);
     const int rc = pwicp_knn(ctx, cloud_xyz4, n, knn, point_spacing > 0.f ? 2.0f * point_spacing : 0.f, nb.data());
     if (rc != PWICP_OK) return rc;
-    std::vector<double> pts((size_t)n * 3);
-    for (int i = 0; i < n; ++i)
-        for (int d = 0; d < 3; ++d) pts[3 * (size_t)i + d] = (double)cloud_xyz4[4 * (size_t)i + d];
-    std::vector<std::vector<int>> neighbors((size_t)n);
-    for (int i = 0; i < n; ++i) neighbors[(size_t)i].assign(nb.begin() + (size_t)i * knn, nb.begin() + (size_t)(i + 1) * knn);
-    return segment_from_neighbors(pts, n, neighbors, sv_resolution, labels, n_supervoxels);
+    return segment_from_neighbors(cloud_xyz4, n, nb.data(), knn, sv_resolution, labels, n_supervoxels);
 }
 
 }  // extern "C"

@@ -18,3 +18,6 @@ for name, fn in (("preprocess gpu", lambda: ctx.preprocess(t, r, 14, 5.0)), ("pr
     print("%-22s %8.3f s  -> %d points" % (name, dt, len(out)))
 a = ctx.preprocess(t, r, 14, 5.0); b = P.preprocess(t, r, 14, 5.0)
 print("identical:", a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)))
+for name, fn in (("front end gpu-knn", lambda: ctx.frontend_segment(a, 10 * r, 45, r)), ("front end host", lambda: P.frontend_segment(a, 10 * r))):
+    t0 = time.perf_counter(); lab, nsv = fn(); dt = time.perf_counter() - t0
+    print("%-22s %8.3f s  -> %d supervoxels" % (name, dt, nsv))
