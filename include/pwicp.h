@@ -200,6 +200,8 @@ PWICP_API int pwicp_preprocess_dev(pwicp_context* ctx, const float* cloud_xyz4, 
                                    double sor_mult, float* out_xyz4, int* n_out);
 /* calPCresolution (C.cpp:239-263) */
 PWICP_API float pwicp_pc_resolution(const float* cloud_xyz4, int n);
+/* the same value with the nearest-neighbour distances computed on the GPU */
+PWICP_API int pwicp_pc_resolution_dev(pwicp_context* ctx, const float* cloud_xyz4, int n, float* resolution);
 
 /* The reference's exported functions, same signatures (include/Registration.h:36, 49; python/main.py:15-18).
  * Device: $PWICP_DEVICE or $LOCAL_RANK (default 0).  Never exit(): false on any failure. */

@@ -167,6 +167,28 @@ int pwicp_knn(pwicp_context* ctx, const float* cloud_xyz4, int n, int k, float c
     return PWICP_OK;
 }
 
+// calPCresolution (C.cpp:239-263): float mean of the distance of every point to its nearest other point.  The
+// per-point distances come from the device (float-metric 2-NN, the point itself first); they are summed on the host
+// in point order, in float, as the reference does.
+int pwicp_pc_resolution_dev(pwicp_context* ctx, const float* cloud_xyz4, int n, float* resolution) {
+    if (!ctx) return PWICP_E_INVALID;
+    if (!cloud_xyz4 || !resolution || n < 2) { ctx->set_err("pwicp_pc_resolution_dev: invalid argument"); return PWICP_E_INVALID; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevBuf<float4> pts;
+    PWCHK(upload(ctx, cloud_xyz4, n, &pts));
+    Grid g;
+    PWCHK(pw_grid_build(ctx, pts.p, n, estimate_cell_edge(cloud_xyz4, n), &g));
+    DevBuf<float> d;
+    HIPCHK(ctx, d.reserve((size_t)n));
+    PWCHK(pw_knn_mean_dist_launch(ctx, g.d, 1, d.p));
+    std::vector<float> h((size_t)n);
+    HIPCHK(ctx, hipMemcpy(h.data(), d.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    float res = 0.0f;
+    for (int i = 0; i < n; ++i) res += h[(size_t)i];
+    *resolution = res / (float)n;
+    return PWICP_OK;
+}
+
 }  // extern "C"
 
 // ---- patch-level and ICP building blocks -------------------------------------------------------------------

@@ -37,26 +37,54 @@ struct PairOutput {
     pwicp_result res;
 };
 
+// Target-side setup that depends only on the target scan (preprocessed + centroid-reduced cloud, supervoxel labels).
+// In the Direct2Ref mode of a 4D series every pair has the same target (R.cpp:94-103), so it is prepared once.
+struct TargetCache {
+    int key = -1;                 // epoch index of the cached target, -1 = empty
+    float Res1 = 0.f, SVRes1 = 0.f;
+    double sor_mult = 0.0;
+    std::vector<float> p1;        // preprocessed, shifted by its own centroid
+    int m1 = 0;
+    float shift[3] = {0, 0, 0};
+    std::vector<int32_t> lab1;
+    int nsv1 = 0;
+};
+
 // Piecewise_ICP_4D without its file output (R.cpp:402-480); sor_mult 5.0 (4D) or 2.7 (pair)
 bool register_pair(pwicp_context* ctx, const std::vector<float>& cloud1, const std::vector<float>& cloud2,
-                   const ConfigPara& cfg, float Res1, float Res2, double sor_mult, PairOutput* out) {
+                   const ConfigPara& cfg, float Res1, float Res2, double sor_mult, PairOutput* out,
+                   TargetCache* cache = nullptr, int target_key = -1) {
     const int n1 = (int)(cloud1.size() / 4), n2 = (int)(cloud2.size() / 4);
     std::cout << "Original PC-1 point number: " << n1 << "\t Original PC-2 point number: " << n2 << std::endl;
     std::cout << "PC-1 avg. point spacing: " << Res1 << "\t PC-2 avg. point spacing: " << Res2 << std::endl << std::endl;
     // pre-process (R.cpp:412-416)
-    std::vector<float> p1((size_t)n1 * 4), p2((size_t)n2 * 4);
-    int m1 = 0, m2 = 0;
-    if (pwicp_preprocess_dev(ctx, cloud1.data(), n1, Res1, 14, sor_mult, p1.data(), &m1) != PWICP_OK ||
-        pwicp_preprocess_dev(ctx, cloud2.data(), n2, Res2, 14, sor_mult, p2.data(), &m2) != PWICP_OK) {
+    const float SVRes1 = cfg.isSetResSVsize ? cfg.SVsize1 : Res1 * 10, SVRes2 = cfg.isSetResSVsize ? cfg.SVsize2 : Res2 * 10;   // R.cpp:635-640
+    TargetCache local;
+    TargetCache& tc = cache ? *cache : local;
+    const bool hit = cache && target_key >= 0 && tc.key == target_key && tc.Res1 == Res1 && tc.SVRes1 == SVRes1 && tc.sor_mult == sor_mult;
+    std::vector<float> p2((size_t)n2 * 4);
+    int m2 = 0;
+    if (!hit) {
+        tc.key = -1;
+        tc.p1.resize((size_t)n1 * 4);
+        if (pwicp_preprocess_dev(ctx, cloud1.data(), n1, Res1, 14, sor_mult, tc.p1.data(), &tc.m1) != PWICP_OK) {
+            std::cerr << "Error: preprocessing failed: " << pwicp_last_error(ctx) << "\n";
+            return false;
+        }
+    }
+    if (pwicp_preprocess_dev(ctx, cloud2.data(), n2, Res2, 14, sor_mult, p2.data(), &m2) != PWICP_OK) {
         std::cerr << "Error: preprocessing failed: " << pwicp_last_error(ctx) << "\n";
         return false;
     }
+    const int m1 = tc.m1;
     if (m1 < kNN + 1 || m2 < kNN + 1) { std::cerr << "Error: too few points after preprocessing.\n"; return false; }
     // reduction by the centroid of PC1 (R.cpp:419-436): pcl::compute3DCentroid float sums, float shift
-    float acc[3] = {0, 0, 0};
-    for (int i = 0; i < m1; ++i) { acc[0] += p1[4 * (size_t)i]; acc[1] += p1[4 * (size_t)i + 1]; acc[2] += p1[4 * (size_t)i + 2]; }
-    float shift[3];
-    for (int d = 0; d < 3; ++d) shift[d] = -1 * (acc[d] / (float)m1);
+    if (!hit) {
+        float acc[3] = {0, 0, 0};
+        for (int i = 0; i < m1; ++i) { acc[0] += tc.p1[4 * (size_t)i]; acc[1] += tc.p1[4 * (size_t)i + 1]; acc[2] += tc.p1[4 * (size_t)i + 2]; }
+        for (int d = 0; d < 3; ++d) tc.shift[d] = -1 * (acc[d] / (float)m1);
+    }
+    const float* shift = tc.shift;
     const float S[16] = {1, 0, 0, shift[0], 0, 1, 0, shift[1], 0, 0, 1, shift[2], 0, 0, 0, 1};
     const float Sinv[16] = {1, 0, 0, -1 * shift[0], 0, 1, 0, -1 * shift[1], 0, 0, 1, -1 * shift[2], 0, 0, 0, 1};
     auto apply_shift = [&](std::vector<float>& p, int m) {       // pcl::transformPointCloud with a pure translation
@@ -68,19 +96,30 @@ bool register_pair(pwicp_context* ctx, const std::vector<float>& cloud1, const s
             q[2] = S[8] * x + S[9] * y + S[10] * z + S[11];
         }
     };
-    apply_shift(p1, m1);
+    if (!hit) apply_shift(tc.p1, m1);
     apply_shift(p2, m2);
     std::cout << "Preprocessed PC-1 point number: " << m1 << "\tPreprocessed PC-2 point number: " << m2 << std::endl << std::endl;
 
-    // supervoxel size (R.cpp:635-640) and labels (S.cpp:18-68)
-    const float SVRes1 = cfg.isSetResSVsize ? cfg.SVsize1 : Res1 * 10, SVRes2 = cfg.isSetResSVsize ? cfg.SVsize2 : Res2 * 10;
-    std::vector<int32_t> lab1((size_t)m1), lab2((size_t)m2);
-    int nsv1 = 0, nsv2 = 0;
-    if (pwicp_frontend_segment_dev(ctx, p1.data(), m1, SVRes1, kNN, Res1, lab1.data(), &nsv1) != PWICP_OK ||
-        pwicp_frontend_segment_dev(ctx, p2.data(), m2, SVRes2, kNN, Res2, lab2.data(), &nsv2) != PWICP_OK) {
+    // supervoxel labels (S.cpp:18-68)
+    std::vector<int32_t> lab2((size_t)m2);
+    int nsv2 = 0;
+    if (!hit) {
+        tc.lab1.resize((size_t)m1);
+        if (pwicp_frontend_segment_dev(ctx, tc.p1.data(), m1, SVRes1, kNN, Res1, tc.lab1.data(), &tc.nsv1) != PWICP_OK) {
+            std::cerr << "Error: supervoxel segmentation failed.\n";
+            return false;
+        }
+        tc.Res1 = Res1; tc.SVRes1 = SVRes1; tc.sor_mult = sor_mult; tc.key = target_key;
+    } else {
+        std::cout << "--->>> target epoch unchanged: preprocessed cloud and supervoxels reused." << std::endl;
+    }
+    if (pwicp_frontend_segment_dev(ctx, p2.data(), m2, SVRes2, kNN, Res2, lab2.data(), &nsv2) != PWICP_OK) {
         std::cerr << "Error: supervoxel segmentation failed.\n";
         return false;
     }
+    const std::vector<float>& p1 = tc.p1;
+    const std::vector<int32_t>& lab1 = tc.lab1;
+    const int nsv1 = tc.nsv1;
     std::cout << "--->>> " << nsv1 << " / " << nsv2 << " supervoxels are generated." << std::endl;
 
     pwicp_params prm{Res1, Res2, SVRes1, SVRes2, cfg.isSetDTinit ? 1 : 0, cfg.DTinit, cfg.DTmin};
@@ -234,10 +273,16 @@ PWICP_API bool PiecewiseICP_pair_call(const char* confile, const char* outfile) 
     if (!read_config(confile, &cfg)) { std::cerr << "Error: Cannot open configuration file! Aborting.\n\n"; return false; }
     std::vector<float> c1, c2;
     if (!load_pcd(cfg.FolderFilePath1, &c1) || !load_pcd(cfg.FolderFilePath2, &c2) || c1.empty() || c2.empty()) return false;   // R.cpp:252-256
-    float Res1 = cfg.PCres1, Res2 = cfg.PCres2;
-    if (!cfg.isSetResSVsize) { Res1 = pc_resolution(c1.data(), (int)(c1.size() / 4)); Res2 = pc_resolution(c2.data(), (int)(c2.size() / 4)); }
     pwicp_context* ctx = nullptr;
     if (pwicp_create(&ctx, env_device()) != PWICP_OK) { std::cerr << "Error: no usable HIP device (pwicp has no CPU fallback).\n"; return false; }
+    float Res1 = cfg.PCres1, Res2 = cfg.PCres2;
+    if (!cfg.isSetResSVsize &&
+        (pwicp_pc_resolution_dev(ctx, c1.data(), (int)(c1.size() / 4), &Res1) != PWICP_OK ||
+         pwicp_pc_resolution_dev(ctx, c2.data(), (int)(c2.size() / 4), &Res2) != PWICP_OK)) {
+        std::cerr << "Error: " << pwicp_last_error(ctx) << "\n";
+        pwicp_destroy(ctx);
+        return false;
+    }
     PairOutput out;
     const bool ok = register_pair(ctx, c1, c2, cfg, Res1, Res2, 2.7, &out);          // SOR multiplier 2.7 (R.cpp:272-273)
     pwicp_destroy(ctx);
@@ -305,6 +350,9 @@ PWICP_API bool PiecewiseICP_4D_call(const char* confile, int startEpoch, int epo
     std::vector<float> refCloud, c1, c2;
     load_pcd(files[(size_t)startEpoch], &refCloud);
     int done = 0;
+    TargetCache tcache;
+    int resKey = -1;
+    float resVal = 0.f;
     for (int i = startEpoch; i < epochNum - 1; ++i) {               // R.cpp:89-187
         const int step = i - startEpoch + 1;
         int refIdx = startEpoch;
@@ -318,9 +366,16 @@ PWICP_API bool PiecewiseICP_4D_call(const char* confile, int startEpoch, int epo
         load_pcd(files[(size_t)i + 1], &c2);
         if (c1.empty() || c2.empty()) { std::cerr << "Step " << step << " failed. Skipping to next.\n\n"; continue; }
         float Res1 = cfg.PCres1, Res2 = cfg.PCres2;
-        if (!cfg.isSetResSVsize) { Res1 = pc_resolution(c1.data(), (int)(c1.size() / 4)); Res2 = pc_resolution(c2.data(), (int)(c2.size() / 4)); }
+        if (!cfg.isSetResSVsize) {
+            if (refIdx != resKey) {
+                if (pwicp_pc_resolution_dev(ctx, c1.data(), (int)(c1.size() / 4), &resVal) != PWICP_OK) resVal = 0.f;
+                resKey = refIdx;
+            }
+            Res1 = resVal;
+            if (pwicp_pc_resolution_dev(ctx, c2.data(), (int)(c2.size() / 4), &Res2) != PWICP_OK) Res2 = 0.f;
+        }
         PairOutput out;
-        if (!register_pair(ctx, c1, c2, cfg, Res1, Res2, 5.0, &out) ||               // SOR multiplier 5.0 (R.cpp:415-416)
+        if (!register_pair(ctx, c1, c2, cfg, Res1, Res2, 5.0, &out, &tcache, refIdx) ||               // SOR multiplier 5.0 (R.cpp:415-416)
             !write_transmatrix_file(prefix + "TransMatrix.txt", out.T, out.VCM)) {
             std::cerr << "Step " << step << " failed. Skipping to next.\n\n";          // R.cpp:145-147
             continue;

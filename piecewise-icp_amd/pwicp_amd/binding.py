@@ -85,6 +85,7 @@ def load_library():
     L.pwicp_frontend_segment.argtypes = [fp, C.c_int, C.c_float, C.c_int, ip, ip]
     L.pwicp_knn.argtypes = [vp, fp, C.c_int, C.c_int, C.c_float, ip]
     L.pwicp_frontend_segment_dev.argtypes = [vp, fp, C.c_int, C.c_float, C.c_int, C.c_float, ip, ip]
+    L.pwicp_pc_resolution_dev.argtypes = [vp, fp, C.c_int, fp]
     L.pwicp_preprocess_dev.argtypes = [vp, fp, C.c_int, C.c_float, C.c_int, C.c_double, fp, ip]
     L.pwicp_preprocess.argtypes = [fp, C.c_int, C.c_float, C.c_int, C.c_double, fp, ip]
     L.pwicp_pc_resolution.argtypes = [fp, C.c_int]
@@ -128,6 +129,12 @@ def frontend_segment(cloud, sv_resolution, knn=45):
     if rc != 0:
         raise PwicpError(rc, "pwicp_frontend_segment")
     return lab, nsv.value
+
+
+def pc_resolution(cloud):
+    """calPCresolution (C.cpp:239-263) on the host."""
+    c = f4(cloud)
+    return float(load_library().pwicp_pc_resolution(_p(c), len(c)))
 
 
 def preprocess(cloud, voxel_size, sor_k=14, sor_mult=5.0):
@@ -222,6 +229,13 @@ class Context:
         self._chk(self._L.pwicp_preprocess_dev(self._h, _p(c), len(c), float(voxel_size), int(sor_k), float(sor_mult),
                                                _p(out), C.byref(m)))
         return out[:m.value].copy()
+
+    def pc_resolution(self, cloud):
+        """calPCresolution (C.cpp:239-263) with the nearest-neighbour search on the GPU."""
+        c = f4(cloud)
+        r = C.c_float()
+        self._chk(self._L.pwicp_pc_resolution_dev(self._h, _p(c), len(c), C.byref(r)))
+        return r.value
 
     def patchNormals(self, patch_xyz4, offsets):
         pat = f4(patch_xyz4)

@@ -208,6 +208,11 @@ def sor(cloud, k, mult):
     return out[:m].copy()
 
 
+def pc_resolution(cloud):
+    cloud = f4(cloud)
+    return float(lib().orc_pc_resolution(_p(cloud), len(cloud)))
+
+
 def matrix2angle(T):
     T = np.ascontiguousarray(T, np.float32).reshape(16)
     a = np.zeros(3, np.float32)

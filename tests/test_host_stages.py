@@ -200,3 +200,39 @@ def test_gpu_preprocess_matches_host(ctx, oracle):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     o = oracle.sor(oracle.voxel_grid(cases[0][0], cases[0][1]), 14, 2.7)
     assert np.array_equal(ctx.preprocess(*cases[0])[:, :3].view(np.uint32), np.ascontiguousarray(o[:, :3]).view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_4d_series_reuses_target_and_auto_spacing(tmp_path, ctx, oracle):
+    """Three-epoch Direct2Ref series (epoch 3 = a copy of epoch 2): the second pair runs with the cached target
+    (preprocessed cloud + supervoxels) and must give exactly the first pair's result; then the same series with the
+    point spacing estimated by calPCresolution on the GPU (isSetResSVsize = 0)."""
+    import shutil
+    import pwicp_amd as P
+    from pwicp_amd.pcd import read_pcd
+    inp = tmp_path / "in"
+    inp.mkdir()
+    src = os.path.join(G.GOLD, "inputs")
+    shutil.copy(os.path.join(src, "Epoch_001.pcd"), inp / "Epoch_001.pcd")
+    shutil.copy(os.path.join(src, "Epoch_002.pcd"), inp / "Epoch_002.pcd")
+    shutil.copy(os.path.join(src, "Epoch_002.pcd"), inp / "Epoch_003.pcd")
+    out = str(tmp_path) + "/o_"
+    cfg = tmp_path / "cfg.txt"
+    _write_config(cfg, str(inp), out)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        assert P.PiecewiseICP_4D_call(str(cfg), 0, 3, 0, 0.75) is True
+    finally:
+        os.chdir(cwd)
+    a = open(out + "2_Direct2Ref_TransMatrix.txt").read()
+    b = open(out + "3_Direct2Ref_TransMatrix.txt").read()
+    assert a == b
+    T, _, _ = G.parse_transmatrix_file(out + "2_Direct2Ref_TransMatrix.txt")
+    Tg, _, _ = G.parse_transmatrix_file(os.path.join(G.GOLD, "reference_results", "2_Direct2Ref_TransMatrix.txt"))
+    assert np.abs(G.euler(T) - G.euler(Tg)).max() < 5e-6
+    # point spacing on the GPU == host == oracle, bit for bit
+    c = read_pcd(os.path.join(src, "Epoch_001.pcd"))
+    r_gpu, r_host = ctx.pc_resolution(c), P.pc_resolution(c)
+    assert np.float32(r_gpu) == np.float32(r_host) == np.float32(oracle.pc_resolution(c))
+    assert 0.001 < r_gpu < 0.01
