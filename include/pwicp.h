@@ -208,6 +208,34 @@ PWICP_API int pwicp_pc_resolution_dev(pwicp_context* ctx, const float* cloud_xyz
 PWICP_API bool PiecewiseICP_pair_call(const char* confile, const char* outfile);
 PWICP_API bool PiecewiseICP_4D_call(const char* confile, int startEpoch, int epochNum, int pairMode, float overlapThd);
 
+/* ---- the 4D series as a handle: independent pairs on any GPU (R.cpp:89-187) -------------------------------
+ * PiecewiseICP_4D_call is open + run_pair over all pairs + write_results + close on one GPU.  On a multi-GPU node
+ * every rank opens the same configuration, runs the pairs p with p mod world == rank, the fixed-size records are
+ * all-gathered (RCCL) and rank 0 writes the files (pwicp_amd/series.py is the worked example). */
+typedef struct pwicp_series pwicp_series;
+typedef struct pwicp_pair_record {   /* 384 bytes, the unit of the all-gather */
+    int32_t pair;                    /* index in the series' pair order, -1 = empty slot */
+    int32_t status;                  /* PWICP_OK or the error code of the failed step */
+    int32_t n_outer, n_inner;
+    float T[16];                     /* T_final, row-major (R.cpp:461) */
+    double VCM[36];
+    int64_t n_corr;
+    float t_loop_ms, t_pair_ms;      /* registration loop / whole pair incl. file input and setup */
+} pwicp_pair_record;
+/* adaptive_targets (pairMode < 0 only): NULL = compute the pair map here (calAdaptivePairSequence, R.cpp:552-589,
+ * overlap ratios on the GPU) and write RegPairFile.txt; otherwise the map computed elsewhere, entry k = target of
+ * source k+1, both relative to startEpoch, n_adaptive = #scan files - startEpoch - 1. */
+PWICP_API int pwicp_series_open(const char* confile, int startEpoch, int epochNum, int pairMode, float overlapThd,
+                                int device, const int32_t* adaptive_targets, int n_adaptive, pwicp_series** out);
+PWICP_API void pwicp_series_close(pwicp_series* s);
+PWICP_API int pwicp_series_num_pairs(const pwicp_series* s);
+PWICP_API int pwicp_series_num_scans(const pwicp_series* s);     /* Epoch_### files found in the input folder */
+PWICP_API int pwicp_series_pair_epochs(const pwicp_series* s, int pair, int* target_index, int* source_index,
+                                       long* source_stamp);
+PWICP_API int pwicp_series_adaptive_targets(const pwicp_series* s, int32_t* targets, int n);
+PWICP_API int pwicp_series_run_pair(pwicp_series* s, int pair, pwicp_pair_record* rec);
+PWICP_API int pwicp_series_write_results(pwicp_series* s, const pwicp_pair_record* recs, int n_recs);
+
 /* ---- one dense NN launch on resident data, for roofline measurement (bench.py) --------------- */
 /* Runs the dense 1-NN kernel for all source patch points of `pair` against cloud1 `n_launches`
  * times on the pair's stream and returns the mean HIP-event time per launch, the number of queries

@@ -9,6 +9,7 @@
 // calTransToReferenceEpoch Registration.cpp:977-1153, calAbsErrorOfTransPara Registration.cpp:1157-1251.
 // Pipeline per pair: load PCD -> VoxelGrid + SOR -> subtract the target centroid -> supervoxel labels (host front
 // end) -> pwicp_pair_create / pwicp_pair_run (the fine-registration loop on the GPU) -> T_final = S^-1 T S -> files.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -16,6 +17,7 @@
 #include <iomanip>
 #include <iostream>
 #include <map>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -304,98 +306,215 @@ PWICP_API bool PiecewiseICP_pair_call(const char* confile, const char* outfile) 
     return true;
 }
 
-PWICP_API bool PiecewiseICP_4D_call(const char* confile, int startEpoch, int epochNum, int pairMode, float overlapThd) {
-    if (!confile) return false;
+// ---- 4D series as a handle: the pairs of R.cpp:89-187 are independent, so any subset can run on any GPU ---------
+}  // extern "C"
+
+struct pwicp_series {
     ConfigPara cfg;
-    std::cout << "Loading parameter configuration file: " << confile << "\n\n";
-    if (!read_config(confile, &cfg)) { std::cerr << "Error: Cannot open configuration file! Aborting.\n\n"; return false; }
-    const std::string inputFolder = cfg.FolderFilePath1, outputFolder = cfg.FolderFilePath2;
+    std::string outputFolder;
     std::vector<std::string> files;
     std::vector<long> times;
-    const int fileCount = extract_all_files(inputFolder, &files, &times);
-    std::cout << "--->>> " << fileCount << " scan files are successfully extracted. \n\n";
-    if (startEpoch < 0 || epochNum > fileCount || startEpoch >= epochNum) { std::cerr << "Error: epoch range outside the folder content.\n"; return false; }
-    pwicp_context* ctx = nullptr;
-    if (pwicp_create(&ctx, env_device()) != PWICP_OK) { std::cerr << "Error: no usable HIP device (pwicp has no CPU fallback).\n"; return false; }
+    int startEpoch = 0, epochNum = 0, pairMode = 0, device = 0;
+    std::map<int, int> regPairs;          // adaptive mode: source -> target, relative to startEpoch (R.cpp:570)
+    pwicp_context* ctx = nullptr;         // created by the first call that needs the GPU
+    TargetCache tcache;
+    int c1Key = -1, resKey = -1;
+    float resVal = 0.f;
+    std::vector<float> c1, c2;
 
-    // adaptive pair sequence (R.cpp:552-589), overlap ratio on the GPU (R.cpp:593-614)
-    std::map<int, int> regPairs;
-    const std::string adaptivePairFile = "RegPairFile.txt";
-    if (pairMode < 0) {
-        std::cout << "--->>> Adaptive pair sequence determination... \n";
-        int idxTarget = startEpoch;
-        std::vector<std::vector<float>> cache((size_t)fileCount);
-        auto cloud = [&](int i) -> std::vector<float>& { if (cache[(size_t)i].empty()) load_pcd(files[(size_t)i], &cache[(size_t)i]); return cache[(size_t)i]; };
-        for (int j = startEpoch + 1; j < fileCount; ++j) {
-            float ratio = 0;
-            for (int i = idxTarget; i < j; ++i) {
-                std::vector<float>&a = cloud(i), &b = cloud(j);
-                if (pwicp_overlap_ratio(ctx, a.data(), (int)(a.size() / 4), b.data(), (int)(b.size() / 4), cfg.DTinit, &ratio) != PWICP_OK) { pwicp_destroy(ctx); return false; }
-                idxTarget = i;
-                if (ratio > overlapThd) break;
-            }
-            regPairs[j - startEpoch] = idxTarget - startEpoch;
-            std::cout << "Pair: " << idxTarget - startEpoch << " - " << j - startEpoch << ";  Overlap ratio = " << 100 * ratio << "% \n";
-        }
-        std::ofstream pf(adaptivePairFile);
-        if (!pf) { std::cerr << "Error: Cannot open adaptivePairFile!\n"; pwicp_destroy(ctx); return false; }
-        for (auto& kv : regPairs) pf << kv.first << " " << kv.second << std::endl;
+    bool need_ctx() {
+        if (ctx) return true;
+        if (pwicp_create(&ctx, device) != PWICP_OK) { std::cerr << "Error: no usable HIP device (pwicp has no CPU fallback).\n"; ctx = nullptr; return false; }
+        return true;
     }
+    int num_pairs() const { return epochNum - startEpoch - 1; }
+    int ref_index(int pair) const {                   // R.cpp:94-103
+        const int i = startEpoch + pair, step = pair + 1;
+        if (pairMode > 0) return (pairMode >= step) ? startEpoch : (i + 1 - pairMode);
+        if (pairMode < 0) { auto it = regPairs.find(i + 1); return it == regPairs.end() ? -1 : it->second; }
+        return startEpoch;
+    }
+};
 
+namespace {
+
+// calAdaptivePairSequence (R.cpp:552-589) with the overlap ratio on the GPU (R.cpp:593-614)
+bool adaptive_pair_sequence(pwicp_series* s, float overlapThd, const std::string& pairFile) {
+    if (!s->need_ctx()) return false;
+    const int fileCount = (int)s->files.size(), startEpoch = s->startEpoch;
+    int idxTarget = startEpoch;
+    std::vector<std::vector<float>> cache((size_t)fileCount);
+    auto cloud = [&](int i) -> std::vector<float>& { if (cache[(size_t)i].empty()) load_pcd(s->files[(size_t)i], &cache[(size_t)i]); return cache[(size_t)i]; };
+    for (int j = startEpoch + 1; j < fileCount; ++j) {
+        float ratio = 0;
+        for (int i = idxTarget; i < j; ++i) {
+            std::vector<float>&a = cloud(i), &b = cloud(j);
+            if (pwicp_overlap_ratio(s->ctx, a.data(), (int)(a.size() / 4), b.data(), (int)(b.size() / 4), s->cfg.DTinit, &ratio) != PWICP_OK) return false;
+            idxTarget = i;
+            if (ratio > overlapThd) break;
+        }
+        s->regPairs[j - startEpoch] = idxTarget - startEpoch;
+        std::cout << "Pair: " << idxTarget - startEpoch << " - " << j - startEpoch << ";  Overlap ratio = " << 100 * ratio << "% \n";
+        if (idxTarget > startEpoch) cache[(size_t)idxTarget - 1].clear();        // scans before the current target are never read again
+    }
+    std::ofstream pf(pairFile);
+    if (!pf) { std::cerr << "Error: Cannot open adaptivePairFile!\n"; return false; }
+    for (auto& kv : s->regPairs) pf << kv.first << " " << kv.second << std::endl;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+PWICP_API int pwicp_series_open(const char* confile, int startEpoch, int epochNum, int pairMode, float overlapThd, int device,
+                                const int32_t* adaptive_targets, int n_adaptive, pwicp_series** out) {
+    if (!confile || !out) return PWICP_E_INVALID;
+    *out = nullptr;
+    std::unique_ptr<pwicp_series> s(new pwicp_series);
+    std::cout << "Loading parameter configuration file: " << confile << "\n\n";
+    if (!read_config(confile, &s->cfg)) { std::cerr << "Error: Cannot open configuration file! Aborting.\n\n"; return PWICP_E_INVALID; }
+    s->outputFolder = s->cfg.FolderFilePath2;
+    const int fileCount = extract_all_files(s->cfg.FolderFilePath1, &s->files, &s->times);
+    std::cout << "--->>> " << fileCount << " scan files are successfully extracted. \n\n";
+    if (startEpoch < 0 || epochNum > fileCount || startEpoch >= epochNum) { std::cerr << "Error: epoch range outside the folder content.\n"; return PWICP_E_INVALID; }
+    s->startEpoch = startEpoch; s->epochNum = epochNum; s->pairMode = pairMode; s->device = device;
+    if (pairMode < 0) {
+        if (adaptive_targets) {                       // map computed elsewhere (rank 0 of a multi-GPU run)
+            if (n_adaptive != fileCount - startEpoch - 1) { std::cerr << "Error: adaptive pair map has the wrong length.\n"; return PWICP_E_INVALID; }
+            for (int k = 0; k < n_adaptive; ++k) s->regPairs[k + 1] = adaptive_targets[k];
+        } else {
+            std::cout << "--->>> Adaptive pair sequence determination... \n";
+            if (!adaptive_pair_sequence(s.get(), overlapThd, "RegPairFile.txt")) { if (s->ctx) pwicp_destroy(s->ctx); return PWICP_E_INTERNAL; }
+        }
+    }
+    *out = s.release();
+    return PWICP_OK;
+}
+
+PWICP_API void pwicp_series_close(pwicp_series* s) {
+    if (!s) return;
+    if (s->ctx) pwicp_destroy(s->ctx);
+    delete s;
+}
+
+PWICP_API int pwicp_series_num_pairs(const pwicp_series* s) { return s ? s->num_pairs() : 0; }
+PWICP_API int pwicp_series_num_scans(const pwicp_series* s) { return s ? (int)s->files.size() : 0; }
+
+PWICP_API int pwicp_series_pair_epochs(const pwicp_series* s, int pair, int* target_index, int* source_index, long* source_stamp) {
+    if (!s || pair < 0 || pair >= s->num_pairs()) return PWICP_E_INVALID;
+    if (target_index) *target_index = s->ref_index(pair);
+    if (source_index) *source_index = s->startEpoch + pair + 1;
+    if (source_stamp) *source_stamp = s->times[(size_t)(s->startEpoch + pair + 1)];
+    return PWICP_OK;
+}
+
+// adaptive map as n = (#files - startEpoch - 1) targets, entry k = target of source k+1 (relative to startEpoch)
+PWICP_API int pwicp_series_adaptive_targets(const pwicp_series* s, int32_t* targets, int n) {
+    if (!s || !targets || n != (int)s->regPairs.size()) return PWICP_E_INVALID;
+    for (int k = 0; k < n; ++k) { auto it = s->regPairs.find(k + 1); targets[k] = it == s->regPairs.end() ? -1 : it->second; }
+    return PWICP_OK;
+}
+
+// one iteration of the pair loop R.cpp:89-150 (without its file output)
+PWICP_API int pwicp_series_run_pair(pwicp_series* s, int pair, pwicp_pair_record* rec) {
+    if (!s || !rec || pair < 0 || pair >= s->num_pairs()) return PWICP_E_INVALID;
+    std::memset(rec, 0, sizeof(*rec));
+    rec->pair = pair;
+    rec->status = PWICP_E_INTERNAL;
+    if (!s->need_ctx()) { rec->status = PWICP_E_NO_DEVICE; return PWICP_E_NO_DEVICE; }
+    const auto t0 = std::chrono::steady_clock::now();
+    const int i = s->startEpoch + pair, step = pair + 1, refIdx = s->ref_index(pair);
+    if (refIdx < 0 || refIdx >= (int)s->files.size()) return PWICP_E_INVALID;
+    std::cout << "\n//////////////////////  Process Pair_" << step << ":  Epoch-" << s->times[(size_t)refIdx] << " and Epoch-"
+              << s->times[(size_t)i + 1] << "   //////////////////////////////////////////// \n\n";
+    if (s->c1Key != refIdx) { load_pcd(s->files[(size_t)refIdx], &s->c1); s->c1Key = refIdx; }
+    load_pcd(s->files[(size_t)i + 1], &s->c2);
+    if (s->c1.empty() || s->c2.empty()) { std::cerr << "Step " << step << " failed. Skipping to next.\n\n"; return PWICP_E_INTERNAL; }
+    const ConfigPara& cfg = s->cfg;
+    float Res1 = cfg.PCres1, Res2 = cfg.PCres2;
+    if (!cfg.isSetResSVsize) {
+        if (refIdx != s->resKey) {
+            if (pwicp_pc_resolution_dev(s->ctx, s->c1.data(), (int)(s->c1.size() / 4), &s->resVal) != PWICP_OK) s->resVal = 0.f;
+            s->resKey = refIdx;
+        }
+        Res1 = s->resVal;
+        if (pwicp_pc_resolution_dev(s->ctx, s->c2.data(), (int)(s->c2.size() / 4), &Res2) != PWICP_OK) Res2 = 0.f;
+    }
+    PairOutput out;
+    if (!register_pair(s->ctx, s->c1, s->c2, cfg, Res1, Res2, 5.0, &out, &s->tcache, refIdx)) {       // SOR multiplier 5.0 (R.cpp:415-416)
+        std::cerr << "Step " << step << " failed. Skipping to next.\n\n";                             // R.cpp:145-147
+        rec->status = out.res.status != 0 ? out.res.status : PWICP_E_INTERNAL;
+        return rec->status;
+    }
+    rec->status = PWICP_OK;
+    rec->n_outer = out.res.n_outer;
+    rec->n_inner = out.res.n_inner_total;
+    std::memcpy(rec->T, out.T, sizeof(rec->T));
+    std::memcpy(rec->VCM, out.VCM, sizeof(rec->VCM));
+    rec->n_corr = out.res.n_corr;
+    rec->t_loop_ms = (float)out.res.t_loop_ms;
+    rec->t_pair_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return PWICP_OK;
+}
+
+// File output of the series from the records of all pairs (any order; failed or missing pairs are skipped as the
+// reference skips a failed step): per-pair TransMatrix files, TransMatrices.txt, TransParameters.txt (R.cpp:111-180),
+// then the composition to the reference epoch and the accuracy report (R.cpp:197-211).
+PWICP_API int pwicp_series_write_results(pwicp_series* s, const pwicp_pair_record* recs, int n_recs) {
+    if (!s || (!recs && n_recs > 0)) return PWICP_E_INVALID;
+    const int n = s->num_pairs();
+    std::vector<const pwicp_pair_record*> byPair((size_t)n, nullptr);
+    for (int k = 0; k < n_recs; ++k)
+        if (recs[k].pair >= 0 && recs[k].pair < n && recs[k].status == PWICP_OK) byPair[(size_t)recs[k].pair] = &recs[k];
+    const std::string& outputFolder = s->outputFolder;
     const std::string fTM = outputFolder + "TransMatrices.txt", fTP = outputFolder + "TransParameters.txt";
     std::ofstream oTM(fTM.c_str()), oTP(fTP.c_str());
-    if (!oTM || !oTP) { std::cerr << "Error: Unable to open output file(s).\n"; pwicp_destroy(ctx); return false; }
+    if (!oTM || !oTP) { std::cerr << "Error: Unable to open output file(s).\n"; return PWICP_E_INTERNAL; }
     oTP << trans_parameters_header() << std::endl;
-
-    std::vector<float> refCloud, c1, c2;
-    load_pcd(files[(size_t)startEpoch], &refCloud);
     int done = 0;
-    TargetCache tcache;
-    int resKey = -1;
-    float resVal = 0.f;
-    for (int i = startEpoch; i < epochNum - 1; ++i) {               // R.cpp:89-187
-        const int step = i - startEpoch + 1;
-        int refIdx = startEpoch;
-        if (pairMode > 0) refIdx = (pairMode >= step) ? startEpoch : (i + 1 - pairMode);
-        else if (pairMode < 0) refIdx = regPairs[i + 1];
-        std::cout << "\n//////////////////////  Process Pair_" << step << ":  Epoch-" << times[(size_t)refIdx] << " and Epoch-"
-                  << times[(size_t)i + 1] << "   //////////////////////////////////////////// \n\n";
-        std::string prefix = outputFolder + std::to_string(times[(size_t)i + 1]);
-        if (pairMode == 0) { prefix += "_Direct2Ref_"; c1 = refCloud; }
-        else { prefix += pairMode > 0 ? "_Fixed_" : "_Adaptive_"; load_pcd(files[(size_t)refIdx], &c1); }
-        load_pcd(files[(size_t)i + 1], &c2);
-        if (c1.empty() || c2.empty()) { std::cerr << "Step " << step << " failed. Skipping to next.\n\n"; continue; }
-        float Res1 = cfg.PCres1, Res2 = cfg.PCres2;
-        if (!cfg.isSetResSVsize) {
-            if (refIdx != resKey) {
-                if (pwicp_pc_resolution_dev(ctx, c1.data(), (int)(c1.size() / 4), &resVal) != PWICP_OK) resVal = 0.f;
-                resKey = refIdx;
-            }
-            Res1 = resVal;
-            if (pwicp_pc_resolution_dev(ctx, c2.data(), (int)(c2.size() / 4), &Res2) != PWICP_OK) Res2 = 0.f;
-        }
-        PairOutput out;
-        if (!register_pair(ctx, c1, c2, cfg, Res1, Res2, 5.0, &out, &tcache, refIdx) ||               // SOR multiplier 5.0 (R.cpp:415-416)
-            !write_transmatrix_file(prefix + "TransMatrix.txt", out.T, out.VCM)) {
-            std::cerr << "Step " << step << " failed. Skipping to next.\n\n";          // R.cpp:145-147
-            continue;
-        }
-        append_transmatrices(oTM, times[(size_t)i + 1], out.T, out.VCM);
-        append_transparameters(oTP, times[(size_t)i + 1], out.para, out.VCM);
+    for (int p = 0; p < n; ++p) {
+        const pwicp_pair_record* r = byPair[(size_t)p];
+        if (!r) continue;
+        const long stamp = s->times[(size_t)(s->startEpoch + p + 1)];
+        const std::string prefix = outputFolder + std::to_string(stamp) +
+                                   (s->pairMode == 0 ? "_Direct2Ref_" : s->pairMode > 0 ? "_Fixed_" : "_Adaptive_");
+        if (!write_transmatrix_file(prefix + "TransMatrix.txt", r->T, r->VCM)) continue;
+        float ang[3], para[6];
+        matrix2angle(r->T, ang);                                                  // R.cpp:464-480
+        para[0] = (float)(ang[0] * ARC_TO_GON); para[1] = (float)(ang[1] * ARC_TO_GON); para[2] = (float)(ang[2] * ARC_TO_GON);
+        para[3] = r->T[3]; para[4] = r->T[7]; para[5] = r->T[11];
+        append_transmatrices(oTM, stamp, r->T, r->VCM);
+        append_transparameters(oTP, stamp, para, r->VCM);
         ++done;
     }
     oTM.close();
     oTP.close();
-    pwicp_destroy(ctx);
-    const int n = epochNum - startEpoch - 1;
-    if (done != n) { std::cerr << "Warning: " << n - done << " pair(s) failed; composition to the reference epoch skipped.\n"; return done > 0; }
-    if (!trans_to_reference(fTM, pairMode, regPairs, n, outputFolder + "TransMatrices_toRef.txt", outputFolder + "TransParameters_toRef.txt"))
-        return false;
+    if (done != n) {
+        std::cerr << "Warning: " << n - done << " pair(s) failed; composition to the reference epoch skipped.\n";
+        return done > 0 ? PWICP_OK : PWICP_E_INTERNAL;
+    }
+    if (!trans_to_reference(fTM, s->pairMode, s->regPairs, n, outputFolder + "TransMatrices_toRef.txt", outputFolder + "TransParameters_toRef.txt"))
+        return PWICP_E_INTERNAL;
     // accuracy report only if the ground-truth file of the synthetic data set is present (the reference hard-codes
     // this path and exits when it is missing, R.cpp:207-211, 1189-1192)
-    abs_error_report(outputFolder + "TransMatrices_toRef.txt", "data/data_synthetic/defined_transformations.txt", epochNum, startEpoch,
+    abs_error_report(outputFolder + "TransMatrices_toRef.txt", "data/data_synthetic/defined_transformations.txt", s->epochNum, s->startEpoch,
                      outputFolder + "TransPara_AbsError.txt");
-    return true;
+    return PWICP_OK;
+}
+
+PWICP_API bool PiecewiseICP_4D_call(const char* confile, int startEpoch, int epochNum, int pairMode, float overlapThd) {
+    if (!confile) return false;
+    pwicp_series* s = nullptr;
+    if (pwicp_series_open(confile, startEpoch, epochNum, pairMode, overlapThd, env_device(), nullptr, 0, &s) != PWICP_OK) return false;
+    const int n = pwicp_series_num_pairs(s);
+    std::vector<pwicp_pair_record> recs((size_t)n);
+    bool device_ok = true;
+    for (int p = 0; p < n && device_ok; ++p)
+        if (pwicp_series_run_pair(s, p, &recs[(size_t)p]) == PWICP_E_NO_DEVICE) device_ok = false;
+    const bool ok = device_ok && pwicp_series_write_results(s, recs.data(), n) == PWICP_OK;
+    pwicp_series_close(s);
+    return ok;
 }
 
 }  // extern "C"

@@ -85,6 +85,15 @@ def load_library():
     L.pwicp_frontend_segment.argtypes = [fp, C.c_int, C.c_float, C.c_int, ip, ip]
     L.pwicp_knn.argtypes = [vp, fp, C.c_int, C.c_int, C.c_float, ip]
     L.pwicp_frontend_segment_dev.argtypes = [vp, fp, C.c_int, C.c_float, C.c_int, C.c_float, ip, ip]
+    L.pwicp_series_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, ip, C.c_int, C.POINTER(vp)]
+    L.pwicp_series_close.argtypes = [vp]
+    L.pwicp_series_close.restype = None
+    L.pwicp_series_num_pairs.argtypes = [vp]
+    L.pwicp_series_num_scans.argtypes = [vp]
+    L.pwicp_series_pair_epochs.argtypes = [vp, C.c_int, ip, ip, C.POINTER(C.c_long)]
+    L.pwicp_series_adaptive_targets.argtypes = [vp, ip, C.c_int]
+    L.pwicp_series_run_pair.argtypes = [vp, C.c_int, vp]
+    L.pwicp_series_write_results.argtypes = [vp, vp, C.c_int]
     L.pwicp_pc_resolution_dev.argtypes = [vp, fp, C.c_int, fp]
     L.pwicp_preprocess_dev.argtypes = [vp, fp, C.c_int, C.c_float, C.c_int, C.c_double, fp, ip]
     L.pwicp_preprocess.argtypes = [fp, C.c_int, C.c_float, C.c_int, C.c_double, fp, ip]
@@ -156,6 +165,86 @@ def PiecewiseICP_pair_call(confile, outfile):
 def PiecewiseICP_4D_call(confile, startEpoch, epochNum, pairMode, overlapThd=0.75):
     return bool(load_library().PiecewiseICP_4D_call(str(confile).encode(), int(startEpoch), int(epochNum), int(pairMode),
                                                     float(overlapThd)))
+
+
+class Series:
+    """A 4D series (PiecewiseICP_4D_call, R.cpp:17-215) as a handle whose pairs can be run one by one, on any GPU.
+    Records are rows of pwicp_amd.fourd.RECORD (= pwicp_pair_record, 384 bytes)."""
+
+    def __init__(self, confile, startEpoch, epochNum, pairMode, overlapThd=0.75, device=0, adaptive_targets=None):
+        self._L = load_library()
+        h = C.c_void_p()
+        at, n_at = None, 0
+        if adaptive_targets is not None:
+            self._at = np.ascontiguousarray(adaptive_targets, np.int32)
+            at, n_at = _p(self._at, ip), len(self._at)
+        rc = self._L.pwicp_series_open(str(confile).encode(), int(startEpoch), int(epochNum), int(pairMode),
+                                       float(overlapThd), int(device), at, n_at, C.byref(h))
+        if rc != 0:
+            raise PwicpError(rc, "pwicp_series_open")
+        self._h = h
+        self._start = int(startEpoch)
+        self.pair_mode = int(pairMode)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pwicp_series_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def num_pairs(self):
+        return int(self._L.pwicp_series_num_pairs(self._h))
+
+    def pair_epochs(self, pair):
+        """(target file index, source file index, source epoch stamp) of pair `pair`."""
+        t, s, st = C.c_int32(), C.c_int32(), C.c_long()
+        rc = self._L.pwicp_series_pair_epochs(self._h, int(pair), C.byref(t), C.byref(s), C.byref(st))
+        if rc != 0:
+            raise PwicpError(rc, "pwicp_series_pair_epochs")
+        return t.value, s.value, st.value
+
+    @property
+    def num_scans(self):
+        return int(self._L.pwicp_series_num_scans(self._h))
+
+    def adaptive_targets(self):
+        """Adaptive pair map: entry k = target of source k+1, both relative to startEpoch."""
+        n = self.num_scans - self._start - 1
+        out = np.empty(n, np.int32)
+        rc = self._L.pwicp_series_adaptive_targets(self._h, _p(out, ip), int(n))
+        if rc != 0:
+            raise PwicpError(rc, "pwicp_series_adaptive_targets")
+        return out
+
+    def run_pair(self, pair):
+        """One pair of the loop R.cpp:89-150 on this handle's GPU.  Returns a 1-element record array; a failed step
+        comes back with status != 0 (the reference skips it), a missing GPU raises."""
+        from .fourd import RECORD
+        rec = np.zeros(1, RECORD)
+        rc = self._L.pwicp_series_run_pair(self._h, int(pair), rec.ctypes.data_as(C.c_void_p))
+        if rc == -1:
+            raise PwicpError(rc, "pwicp_series_run_pair: no usable HIP device")
+        return rec
+
+    def write_results(self, records):
+        """records: structured array of RECORD rows (all pairs, any order).  Writes the reference's result files."""
+        from .fourd import RECORD
+        recs = np.ascontiguousarray(records, RECORD)
+        rc = self._L.pwicp_series_write_results(self._h, recs.ctypes.data_as(C.c_void_p), len(recs))
+        if rc != 0:
+            raise PwicpError(rc, "pwicp_series_write_results")
 
 
 class Context:

@@ -8,9 +8,11 @@ One process per GPU; the only exchange is an all-gather of a fixed 384-byte reco
 import numpy as np
 
 RECORD_BYTES = 384
+# = struct pwicp_pair_record of include/pwicp.h
 _REC = np.dtype([("pair", "<i4"), ("status", "<i4"), ("n_outer", "<i4"), ("n_inner", "<i4"),
-                 ("T", "<f4", (16,)), ("VCM", "<f8", (36,)), ("n_corr", "<i8"), ("pad", "u1", (8,))])
+                 ("T", "<f4", (16,)), ("VCM", "<f8", (36,)), ("n_corr", "<i8"), ("t_loop_ms", "<f4"), ("t_pair_ms", "<f4")])
 assert _REC.itemsize == RECORD_BYTES
+RECORD = _REC
 
 
 def pair_schedule(start_epoch, epoch_num, pair_mode, adaptive_pairs=None):

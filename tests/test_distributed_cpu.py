@@ -87,3 +87,80 @@ def test_shard_and_gather_world2_gloo(tmp_path):
 def test_record_is_384_bytes():
     r = fourd.pack_record(3, 0, 4, 9, np.eye(4), np.zeros((6, 6)), 12345)
     assert r.nbytes == 384 == fourd.RECORD_BYTES
+
+
+SERIES_WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(%(root)r, "piecewise-icp_amd"))
+    sys.path.insert(0, os.path.join(%(root)r, "tests"))
+    import pwicp_amd as P
+    from pwicp_amd import fourd
+    from test_distributed_cpu import _read_matrices, ADAPTIVE_REL
+    import _golden as G
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    targets = np.array([ADAPTIVE_REL[k] for k in range(1, 20)], np.int32)
+    # adaptive map handed over (as rank 0 would broadcast it): no GPU is needed to open the series or to write results
+    with P.Series(%(cfg)r, 0, 20, -1, 0.75, 0, targets) as s:
+        assert s.num_pairs == 19 and s.num_scans == 20
+        assert s.pair_epochs(6) == (int(targets[6]), 7, 8)
+        assert np.array_equal(s.adaptive_targets(), targets)
+        T, V = _read_matrices(os.path.join(G.GOLD, "reference_results", "TransMatrices.txt"), 19)
+        mine = [fourd.pack_record(p, 0, 5, 12, T[p], V[p], 1000) for p in range(19) if p %% world == rank]
+        table = fourd.gather_records(mine, 19, world, dist=dist)
+        if rank == 0:
+            recs = np.concatenate([table[p].reshape(1) for p in sorted(table)])
+            s.write_results(recs[::-1].copy())               # any order
+        try:
+            s.run_pair(0)
+            raise SystemExit("run_pair must fail without a GPU")
+        except P.PwicpError:
+            pass
+    dist.barrier()
+    if rank == 0:
+        print("SERIES_OK")
+    dist.destroy_process_group()
+''')
+
+ADAPTIVE_REL = {s - 1: t - 1 for s, t in {2: 1, 3: 1, 4: 1, 5: 1, 6: 1, 7: 3, 8: 4, 9: 4, 10: 5, 11: 6, 12: 6, 13: 7, 14: 9,
+                                          15: 12, 16: 13, 17: 14, 18: 14, 19: 14, 20: 14}.items()}
+
+
+def test_series_records_to_reference_files_world2_gloo(tmp_path):
+    """The multi-GPU series path without its GPU step: two ranks open the series, contribute the reference's own
+    pairwise results as records, rank 0 writes the files through libpwicp.so: TransMatrices.txt and the composition
+    TransMatrices_toRef.txt must reproduce the reference's checked-in files."""
+    from pwicp_amd.pcd import write_pcd_binary as write_pcd
+    inp = tmp_path / "scans"
+    inp.mkdir()
+    for e in range(1, 21):
+        write_pcd(str(inp / ("Epoch_%03d.pcd" % e)), np.zeros((3, 3), np.float32))
+    out = str(tmp_path) + "/res_"
+    cfg = tmp_path / "cfg.txt"
+    cfg.write_text("string FolderFilePath1: %s\nstring FolderFilePath2: %s\nbool isSetResSVsize (yes-1, no-0): 1\n"
+                   "float PCres1 (m): 0.005\nfloat PCres2 (m): 0.005\nfloat SVsize1 (m): 0.05\nfloat SVsize2 (m): 0.05\n"
+                   "bool isSetDTinit (yes-1, no-0): 1\nfloat DTinit (m): 0.05\nfloat DTmin (m): 0.004\n"
+                   "bool isVisual (yes-1, no-0): 0" % (str(inp), out))
+    script = tmp_path / "worker.py"
+    script.write_text(SERIES_WORKER % {"root": ROOT, "cfg": str(cfg)})
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "SERIES_OK" in res.stdout
+    gold = os.path.join(G.GOLD, "reference_results")
+    T, V = _read_matrices(out + "TransMatrices.txt", 19)
+    Tg, Vg = _read_matrices(os.path.join(gold, "TransMatrices.txt"), 19)
+    Tr, Vr = _read_matrices(out + "TransMatrices_toRef.txt", 19)
+    Trg, Vrg = _read_matrices(os.path.join(gold, "TransMatrices_toRef.txt"), 19)
+    for i in range(19):
+        assert np.array_equal(T[i], Tg[i]) and np.allclose(V[i], Vg[i], rtol=1e-9, atol=0)
+        assert np.abs(Tr[i] - Trg[i]).max() < 5e-6 and np.allclose(Vr[i], Vrg[i], rtol=2e-3, atol=3e-12)
+    assert os.path.exists(out + "8_Adaptive_TransMatrix.txt") and os.path.exists(out + "TransParameters_toRef.txt")
+    a = np.loadtxt(out + "TransParameters.txt", skiprows=1)
+    b = np.loadtxt(os.path.join(gold, "TransParameters.txt"), skiprows=1)
+    # the standard deviations come from the VCM as printed (12 decimals) in the reference's TransMatrices.txt
+    assert a.shape == b.shape and np.array_equal(a[:, :7], b[:, :7]) and np.allclose(a[:, 7:], b[:, 7:], rtol=1e-3)

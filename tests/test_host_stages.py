@@ -236,3 +236,56 @@ def test_4d_series_reuses_target_and_auto_spacing(tmp_path, ctx, oracle):
     r_gpu, r_host = ctx.pc_resolution(c), P.pc_resolution(c)
     assert np.float32(r_gpu) == np.float32(r_host) == np.float32(oracle.pc_resolution(c))
     assert 0.001 < r_gpu < 0.01
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pair_mode", [0, -1])
+def test_series_driver_two_ranks_matches_single_process(tmp_path, ctx, pair_mode):
+    """pwicp_amd.series (pairs sharded over two ranks, records all-gathered, rank 0 writes) produces the same files,
+    byte for byte, as the exported single-process PiecewiseICP_4D_call.  Both ranks share GPU 0 (gloo), which
+    exercises everything but the RCCL transport."""
+    import shutil
+    import socket
+    import subprocess
+    import sys
+    import pwicp_amd as P
+    inp = tmp_path / "in"
+    inp.mkdir()
+    src = os.path.join(G.GOLD, "inputs")
+    shutil.copy(os.path.join(src, "Epoch_001.pcd"), inp / "Epoch_001.pcd")
+    shutil.copy(os.path.join(src, "Epoch_002.pcd"), inp / "Epoch_002.pcd")
+    shutil.copy(os.path.join(src, "Epoch_002.pcd"), inp / "Epoch_003.pcd")
+    shutil.copy(os.path.join(src, "Epoch_001.pcd"), inp / "Epoch_004.pcd")
+    outs = []
+    for tag in ("single", "sharded"):
+        d = tmp_path / tag
+        d.mkdir()
+        out = str(d) + "/"
+        cfg = d / "cfg.txt"
+        _write_config(cfg, str(inp), out)
+        if tag == "single":
+            cwd = os.getcwd()
+            os.chdir(d)
+            try:
+                assert P.PiecewiseICP_4D_call(str(cfg), 0, 4, pair_mode, 0.75) is True
+            finally:
+                os.chdir(cwd)
+        else:
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+            env = dict(os.environ)
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            env["PYTHONPATH"] = os.path.join(root, "piecewise-icp_amd") + os.pathsep + env.get("PYTHONPATH", "")
+            res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "pwicp_amd.series",
+                                  str(cfg), "0", "4", str(pair_mode), "0.75", "--backend", "gloo", "--single-device"],
+                                 capture_output=True, text=True, timeout=600, cwd=str(d), env=env)
+            assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+        outs.append(out)
+    mode = "Direct2Ref" if pair_mode == 0 else "Adaptive"
+    names = ["TransMatrices.txt", "TransParameters.txt", "TransMatrices_toRef.txt", "TransParameters_toRef.txt"] + \
+            ["%d_%s_TransMatrix.txt" % (e, mode) for e in (2, 3, 4)]
+    for f in names:
+        a, b = open(outs[0] + f).read(), open(outs[1] + f).read()
+        assert a == b and len(a) > 50, f
+    if pair_mode < 0:
+        assert open(str(tmp_path / "single" / "RegPairFile.txt")).read() == open(str(tmp_path / "sharded" / "RegPairFile.txt")).read()
