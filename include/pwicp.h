@@ -236,6 +236,16 @@ PWICP_API int pwicp_series_adaptive_targets(const pwicp_series* s, int32_t* targ
 PWICP_API int pwicp_series_run_pair(pwicp_series* s, int pair, pwicp_pair_record* rec);
 PWICP_API int pwicp_series_write_results(pwicp_series* s, const pwicp_pair_record* recs, int n_recs);
 
+/* ---- measurement hooks ------------------------------------------------------------------------------------
+ * HIP events on the pair's stream feed pwicp_result.t_dense_nn_ms / t_inner_ms.  An event record costs a ~6 us
+ * bubble on the stream, so only the dense-NN pair is on by default. */
+enum {
+    PWICP_PROF_DENSE = 1,    /* events around every dense 1-NN launch   -> t_dense_nn_ms (default) */
+    PWICP_PROF_INNER = 2,    /* events around every inner-ICP batch     -> t_inner_ms */
+    PWICP_PROF_REPLAY = 4    /* keep the stable flags of the first dense launch for pwicp_pair_bench_dense_nn */
+};
+PWICP_API int pwicp_pair_set_profiling(pwicp_pair* pair, int flags);
+
 /* ---- one dense NN launch on resident data, for roofline measurement (bench.py) --------------- */
 /* Runs the dense 1-NN kernel for all source patch points of `pair` against cloud1 `n_launches`
  * times on the pair's stream and returns the mean HIP-event time per launch, the number of queries

@@ -186,11 +186,19 @@ constexpr int kBoxParts = 64;
 // (8) R.cpp:943-954 in ONE launch: blocks [0, nb_cloud) transform cloud2 and reduce its new bounding box (for the
 // next iteration's octree box, R.cpp:881-886); the remaining blocks transform centroids+boundary points and
 // the patch points.  min/max are exact whatever the reduction order.
+// The transformation is read from the ICP state on the device, so that the launch can be enqueued BEFORE the host
+// has seen the ICP result; it does nothing unless that ICP call has converged on >= 4 stable patches (the host then
+// takes the slow path and enqueues it again).
 __global__ void __launch_bounds__(kBlock) k_transform_all(float4* __restrict__ cloud, int n, int nb_cloud,
                                                           float4* __restrict__ ctbp, int n_ctbp,
-                                                          float4* __restrict__ pat, int n_pat, Mat4 T,
+                                                          float4* __restrict__ pat, int n_pat,
+                                                          const IcpState* __restrict__ st, const unsigned* __restrict__ ns_dev,
                                                           unsigned* __restrict__ bbox_part) {
     __shared__ float sh[kBlock / 64][6];
+    if (!st->done || *ns_dev < 4u) return;
+    Mat4 T;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) T.m[i] = st->Tfinal[i];
     if ((int)blockIdx.x >= nb_cloud) {
         const int nb = gridDim.x - nb_cloud, stride = nb * kBlock, ntot = n_ctbp + n_pat;
         for (int i = (blockIdx.x - nb_cloud) * kBlock + threadIdx.x; i < ntot; i += 4 * stride) {
@@ -250,8 +258,10 @@ __global__ void __launch_bounds__(kBlock) k_transform_all(float4* __restrict__ c
 }
 
 // folds the 64 partial boxes of the last transform into its slot and re-arms them (one wave)
-__global__ void __launch_bounds__(64) k_bbox_fold(unsigned* __restrict__ bbox_part, unsigned* __restrict__ slot) {
+__global__ void __launch_bounds__(64) k_bbox_fold(unsigned* __restrict__ bbox_part, unsigned* __restrict__ slot,
+                                                  const IcpState* __restrict__ st) {
     const int t = threadIdx.x;
+    if (st && (!st->done || slot[2] < 4u)) return;      // the transform before this launch did not run
     unsigned mn[3], mx[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) { mn[d] = bbox_part[t * 32 + d]; mx[d] = bbox_part[t * 32 + 3 + d]; }
@@ -296,8 +306,9 @@ __global__ void __launch_bounds__(64) k_fold_examined(unsigned long long* __rest
 // one 16-word scalar slot per outer iteration: [0] LoDmin [1] LoDmax [2] n stable [3] n stable points
 // [4..6] bbox min, [7..9] bbox max of cloud2 AFTER this iteration's transform (ordered-uint encoded)
 constexpr int kSlot = 16;
-__global__ void k_scal_init(unsigned* __restrict__ scal, int n_slots) {
+__global__ void k_scal_init(unsigned* __restrict__ scal, int n_slots, unsigned long long* __restrict__ zero, int n_zero) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_zero) zero[i] = 0ull;             // the run's diagnostic counters, re-armed in the same launch
     if (i >= n_slots * kSlot) return;
     const int w = i % kSlot;
     scal[i] = (w == 0 || (w >= 4 && w <= 6)) ? 0xffffffffu : 0u;
@@ -408,6 +419,7 @@ struct pwicp_pair {
     // stable flags of the first Stage-1 dense NN launch of the last run (replayed by bench_dense_nn)
     DevBuf<int> stable0;
     int ns0 = 0, nsp0 = 0;
+    int profiling = PWICP_PROF_DENSE;     // pwicp_pair_set_profiling
     std::vector<hipEvent_t> ev;
     // mailbox in pinned coherent host memory: [0] sequence word, [16..] payload
     unsigned* mail_h = nullptr;
@@ -476,9 +488,9 @@ int finish_create(pwicp_pair* pr) {
     HIPCHK(ctx, pr->d2dense.reserve((size_t)std::max(std::max(pr->P2.tot, pr->n2), 1)));
     HIPCHK(ctx, pr->scal.reserve((size_t)kSlot * (PWICP_MAX_OUTER + 1)));
     HIPCHK(ctx, pr->bbox_part.reserve((size_t)kBoxParts * 32));
-    hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(64), 0, ctx->stream, pr->bbox_part.p, (unsigned*)nullptr);   // arm
+    hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(64), 0, ctx->stream, pr->bbox_part.p, (unsigned*)nullptr, (const IcpState*)nullptr);   // arm
     {   // tight bbox of the uploaded source cloud (R.cpp:881-886 needs it in the first iteration)
-        hipLaunchKernelGGL(k_scal_init, dim3(1), dim3(64), 0, ctx->stream, pr->scal.p, 1);
+        hipLaunchKernelGGL(k_scal_init, dim3(1), dim3(64), 0, ctx->stream, pr->scal.p, 1, (unsigned long long*)nullptr, 0);
         Mat4 I{};
         hipLaunchKernelGGL(k_transform_bbox, dim3(std::min(div_up(pr->n2, kBlock), ctx->n_cu * 4)), dim3(kBlock), 0,
                            ctx->stream, pr->cloud2.p, pr->n2, I, 0, pr->scal.p);
@@ -644,7 +656,8 @@ static int mail_wait(pwicp_pair* pr, unsigned seq) {
 }
 
 // n_slots entries in d2dense of which n_valid are real distances (the rest carry the sentinel)
-static int select_p75(pwicp_pair* pr, int n_slots, int n_valid, double* out) {
+// 75th percentile of the dense distances (C.cpp:266-281): enqueue the selection and its mailbox message ...
+static int select_p75_enqueue(pwicp_pair* pr, int n_slots, int n_valid, unsigned* seq_out) {
     pwicp_context* ctx = pr->ctx;
     int k = (int)((float)n_valid * 0.75f);      // C.cpp:177
     if (k >= n_valid) k = n_valid - 1;
@@ -652,11 +665,23 @@ static int select_p75(pwicp_pair* pr, int n_slots, int n_valid, double* out) {
     const unsigned seq = ++pr->mail_seq;
     hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, ctx->stream, (const unsigned*)pr->sel_out.p, 1, (const unsigned*)nullptr, 0,
                        (const unsigned*)nullptr, 0, pr->mail_d + 16, pr->mail_d, seq);
+    *seq_out = seq;
+    return PWICP_OK;
+}
+
+// ... and pick the value up (work enqueued in between hides the round trip)
+static int select_p75_finish(pwicp_pair* pr, unsigned seq, double* out) {
     PWCHK(mail_wait(pr, seq));
     float v;
     memcpy(&v, pr->mail_h + 16, 4);
     *out = (double)sqrtf(v);                    // C.cpp:277
     return PWICP_OK;
+}
+
+static int select_p75(pwicp_pair* pr, int n_slots, int n_valid, double* out) {
+    unsigned seq = 0;
+    PWCHK(select_p75_enqueue(pr, n_slots, n_valid, &seq));
+    return select_p75_finish(pr, seq, out);
 }
 
 int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
@@ -689,13 +714,36 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     // tight bbox of the current source cloud: uploaded state now, then refreshed by every transform launch
     float bmin[3], bmax[3];
     for (int d = 0; d < 3; ++d) { bmin[d] = pr->bmin0[d]; bmax[d] = pr->bmax0[d]; }
-    hipLaunchKernelGGL(k_scal_init, dim3(div_up(kSlot * (PWICP_MAX_OUTER + 1), kBlock)), dim3(kBlock), 0, ctx->stream,
-                       pr->scal.p, PWICP_MAX_OUTER + 1);
-    HIPCHK(ctx, hipMemsetAsync(pr->examined.p, 0, (256 * 16 + 2) * sizeof(unsigned long long), ctx->stream));
+    {
+        const int n_zero = 256 * 16 + 2;
+        hipLaunchKernelGGL(k_scal_init, dim3(div_up(std::max(kSlot * (PWICP_MAX_OUTER + 1), n_zero), kBlock)), dim3(kBlock), 0,
+                           ctx->stream, pr->scal.p, PWICP_MAX_OUTER + 1, pr->examined.p, n_zero);
+    }
 
     int status = PWICP_OK;
     int prev_inner = 2;
     bool vcm_pending = false;
+    // Work that does not depend on the host's decisions is enqueued BEFORE the host waits for the mailbox, so that
+    // the device never idles during a round trip: the transform update (8) reads T from the ICP state, and the
+    // "front" of the next iteration (NN of centroids/boundary points + source patch normals) needs no threshold.
+    bool front_ready = false;                 // front of iteration k already enqueued by iteration k-1
+    float prev_lod = NAN;
+    auto enqueue_front = [&]() -> int {
+        // (1) R.cpp:737-747 — CT2 and BP2 queries in one launch; the target-centroid grid is static
+        PWCHK(pw_nn_launch(ctx, pr->g_ct1.d, pr->ctbp2.p, 7 * m2, pr->mCTBP.p, pr->dCTBP.p, nullptr));
+        // source patch normals for CTcloud2_withNorm (R.cpp:824): recomputed from the transformed patch points
+        PWCHK(pw_patch_normals_launch(ctx, pr->P2.pat.p, pr->P2.off.p, m2, pr->nrm2.p));
+        return PWICP_OK;
+    };
+    auto enqueue_transform = [&](unsigned* slot) {
+        // (8) R.cpp:943-954: cloud2 (+ its new bbox into this slot), centroids + boundary points, patch points
+        const int nb_cloud = std::min(div_up(pr->n2, kBlock), ctx->n_cu * 8);
+        const int nb_rest = std::min(div_up(7 * m2 + pr->P2.tot, kBlock), ctx->n_cu * 8);
+        hipLaunchKernelGGL(k_transform_all, dim3(nb_cloud + nb_rest), dim3(kBlock), 0, ctx->stream, pr->cloud2.p, pr->n2,
+                           nb_cloud, pr->ctbp2.p, 7 * m2, pr->P2.pat.p, pr->P2.tot, (const IcpState*)pr->icp.state.p,
+                           (const unsigned*)(slot + 2), pr->bbox_part.p);
+        hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(64), 0, ctx->stream, pr->bbox_part.p, slot, (const IcpState*)pr->icp.state.p);
+    };
     const auto t0 = std::chrono::steady_clock::now();
     while (!stage3) {                                                   // R.cpp:680
         const int k = res->n_outer;
@@ -704,11 +752,9 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         if (4 > m2) { status = PWICP_E_TOO_FEW_PATCHES; break; }        // R.cpp:728-731
         unsigned* const slot = pr->scal.p + (size_t)kSlot * k;
 
-        // (1) R.cpp:737-747 — CT2 and BP2 queries in one launch; the target-centroid grid is static
-        PWCHK(pw_nn_launch(ctx, pr->g_ct1.d, pr->ctbp2.p, 7 * m2, pr->mCTBP.p, pr->dCTBP.p, nullptr));
+        if (!front_ready) PWCHK(enqueue_front());
+        front_ready = false;
         res->n_corr += (long long)m2 + nbp2;
-        // source patch normals for CTcloud2_withNorm (R.cpp:824): recomputed from the transformed patch points
-        PWCHK(pw_patch_normals_launch(ctx, pr->P2.pat.p, pr->P2.off.p, m2, pr->nrm2.p));
         // (2)-(4)
         const float DTctct = currDT + 1 * (prm.SVRes1 + prm.SVRes2);   // R.cpp:817
         hipLaunchKernelGGL(k_classify, dim3(div_up(m2, kBlock)), dim3(kBlock), 0, ctx->stream, m2, pr->mCTBP.p,
@@ -718,17 +764,28 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                            ct2, pr->nrm2.p, pr->blk_cnt.p, pr->stCT.p, pr->stN.p, pr->icp.src.p, pr->icp.srcn.p, slot,
                            pr->icp.state.p);
         // (5) R.cpp:875-877: inner ICP enqueued right behind, its point count read from the slot on the device;
-        // ONE host round trip returns the counts, LoD_min and the ICP state together
+        // ONE host round trip returns the counts, LoD_min and the ICP state together.  Once Stage 2 is reached the
+        // dense search (7) cannot run any more, so the transform and — unless this looks like the last iteration
+        // (Stage 3 needs currDT == LoD_min, R.cpp:897) — the next front go out before the host waits.
+        const bool early_xf = stage2;
+        const bool early_front = stage2 && !(currDT == prev_lod);
+        bool xf_enqueued = false;
         unsigned hs[kSlot], hb[6];
         IcpState hst;
         {
-            hipEvent_t e0 = pr->event(n_ev), e1 = pr->event(n_ev + 1);
-            ev_kind.push_back({n_ev, 1});
-            n_ev += 2;
-            HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
             int batch = std::max(1, prev_inner);
             for (;;) {
+                // (an event record costs a ~6 us bubble on the stream: the inner-loop timing is opt-in)
+                const bool ev = (pr->profiling & PWICP_PROF_INNER) != 0;
+                if (ev) {
+                    ev_kind.push_back({n_ev, 1});
+                    HIPCHK(ctx, hipEventRecord(pr->event(n_ev), ctx->stream));
+                }
                 PWCHK(pw_icp_enqueue(ctx, pr->g_ct1.d, pr->P1.ct.p, pr->ct1n.p, &pr->icp, m2, slot + 2, 1e-6, batch));
+                if (ev) {
+                    HIPCHK(ctx, hipEventRecord(pr->event(n_ev + 1), ctx->stream));
+                    n_ev += 2;
+                }
                 // one mailbox message: this slot | bbox words of the PREVIOUS slot (cloud2 after the previous
                 // iteration's transform) | the ICP state
                 const unsigned seq = ++pr->mail_seq;
@@ -736,19 +793,23 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                                    (const unsigned*)(k > 0 ? slot - kSlot + 4 : slot + 4), 6,
                                    (const unsigned*)pr->icp.state.p, (int)(sizeof(IcpState) / 4), pr->mail_d + 16, pr->mail_d,
                                    seq);
+                if (early_xf) {
+                    enqueue_transform(slot);                 // no-op on the device while the ICP has not converged
+                    if (early_front) PWCHK(enqueue_front());
+                }
                 PWCHK(mail_wait(pr, seq));
                 memcpy(hs, pr->mail_h + 16, sizeof(hs));
                 memcpy(hb, pr->mail_h + 16 + kSlot, sizeof(hb));
                 memcpy(&hst, pr->mail_h + 16 + kSlot + 6, sizeof(IcpState));
-                if (hst.done || hst.iters >= 100) break;
+                if (hst.done || hst.iters >= 100) { xf_enqueued = early_xf; front_ready = early_xf && early_front; break; }
                 batch = 2;
             }
-            HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
         }
         if (k > 0)
             for (int d = 0; d < 3; ++d) { bmin[d] = ord2f_host(hb[d]); bmax[d] = ord2f_host(hb[3 + d]); }
         float LoDet_min;
         memcpy(&LoDet_min, &hs[0], 4);
+        prev_lod = LoDet_min;
         const int ns = (int)hs[2], nsp = (int)hs[3];
         res->n_stable[k] = ns; res->n_stable_pts[k] = nsp; res->LoDmin[k] = LoDet_min;
         if (4 > ns) { status = PWICP_E_TOO_FEW_STABLE; break; }        // R.cpp:864-867
@@ -773,19 +834,29 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         else if (currDT == LoDet_min) stage3 = true;
         if (!stage2) {
             // dense NN of the stable patches' points against the full target cloud (C.cpp:266-281)
-            hipEvent_t e0 = pr->event(n_ev), e1 = pr->event(n_ev + 1);
-            ev_kind.push_back({n_ev, 0});
-            n_ev += 2;
-            HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+            const bool ev = (pr->profiling & PWICP_PROF_DENSE) != 0;
+            if (ev) {
+                ev_kind.push_back({n_ev, 0});
+                HIPCHK(ctx, hipEventRecord(pr->event(n_ev), ctx->stream));
+            }
             PWCHK(pw_nn_dense_launch(ctx, pr->g_c1.d, pr->P2.pat.p, pr->qorder.p, pr->pt_patch2.p, pr->stable.p,
                                          pr->P2.tot, pr->d2dense.p, pr->examined.p));
-            HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
-            if (res->n_dense_nn_launches == 0) {      // remember the first launch for stand-alone replays
+            if (ev) {
+                HIPCHK(ctx, hipEventRecord(pr->event(n_ev + 1), ctx->stream));
+                n_ev += 2;
+            }
+            if (res->n_dense_nn_launches == 0 && (pr->profiling & PWICP_PROF_REPLAY)) {   // remember the first launch for stand-alone replays
                 HIPCHK(ctx, hipMemcpyAsync(pr->stable0.p, pr->stable.p, (size_t)m2 * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
                 pr->ns0 = ns; pr->nsp0 = nsp;
             }
+            unsigned sel_seq = 0;
+            PWCHK(select_p75_enqueue(pr, pr->P2.tot, nsp, &sel_seq));
+            // the percentile only steers the threshold: transform and next front go out while it travels
+            enqueue_transform(slot);
+            xf_enqueued = true;
+            if (!stage3) { PWCHK(enqueue_front()); front_ready = true; }
             double Dist75 = 0;
-            PWCHK(select_p75(pr, pr->P2.tot, nsp, &Dist75));
+            PWCHK(select_p75_finish(pr, sel_seq, &Dist75));
             res->n_corr += nsp; res->n_corr_dense += nsp; res->n_dense_nn_launches++;
             res->d75[k] = Dist75;
             if ((double)currDT > Dist75) currDT = (float)Dist75; else stage2 = true;
@@ -803,16 +874,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
             BB2 = BB1; BB1 = maxBB;
         }
 
-        // (8) R.cpp:943-954: cloud2 (+ its new bbox into this slot), centroids + boundary points, patch points
-        Mat4 T;
-        memcpy(T.m, Tk, sizeof(Tk));
-        {
-            const int nb_cloud = std::min(div_up(pr->n2, kBlock), ctx->n_cu * 8);
-            const int nb_rest = std::min(div_up(7 * m2 + pr->P2.tot, kBlock), ctx->n_cu * 8);
-            hipLaunchKernelGGL(k_transform_all, dim3(nb_cloud + nb_rest), dim3(kBlock), 0, ctx->stream, pr->cloud2.p, pr->n2,
-                               nb_cloud, pr->ctbp2.p, 7 * m2, pr->P2.pat.p, pr->P2.tot, T, pr->bbox_part.p);
-            hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(64), 0, ctx->stream, pr->bbox_part.p, slot);
-        }
+        if (!xf_enqueued) enqueue_transform(slot);                      // (8)
         // (9) R.cpp:958-961: stable centroids as copied BEFORE the update (R.cpp:868)
         if (stage3) {
             PWCHK(pw_vcm_enqueue(ctx, pr->g_ct1.d, pr->P1.ct.p, pr->ct1n.p, &pr->icp, pr->stCT.p, ns));
@@ -848,6 +910,12 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     res->status = status;
     HIPCHK(ctx, hipGetLastError());
     return status;
+}
+
+int pwicp_pair_set_profiling(pwicp_pair* pr, int flags) {
+    if (!pr) return PWICP_E_INVALID;
+    pr->profiling = flags;
+    return PWICP_OK;
 }
 
 int pwicp_pair_bench_dense_nn(pwicp_pair* pr, int n_launches, double* ms_per_launch, long long* n_queries,

@@ -79,6 +79,7 @@ def load_library():
         ("pwicp_pair_run", [vp, C.POINTER(Result)]),
         ("pwicp_pair_download_source", [vp, fp]),
         ("pwicp_pair_bench_dense_nn", [vp, C.c_int, dp, C.POINTER(C.c_longlong), dp, dp]),
+        ("pwicp_pair_set_profiling", [vp, C.c_int]),
     ]:
         if hasattr(L, name):
             getattr(L, name).argtypes = args
@@ -372,6 +373,9 @@ class Context:
         return V.reshape(6, 6)
 
 
+PROF_DENSE, PROF_INNER, PROF_REPLAY = 1, 2, 4
+
+
 class Pair:
     """A target/source pair resident in HBM; run() is the Piecewise_ICP while-loop."""
 
@@ -395,6 +399,10 @@ class Pair:
                                                             len(off1) - 1, _p(c2), len(c2), _p(pat2), _p(off2, ip),
                                                             len(off2) - 1, C.byref(params), C.byref(h)))
         self._h = h
+
+    def set_profiling(self, flags):
+        """PROF_DENSE = 1 (default), PROF_INNER = 2, PROF_REPLAY = 4 (include/pwicp.h)."""
+        self._ctx._chk(self._L.pwicp_pair_set_profiling(self._h, int(flags)))
 
     def close(self):
         if getattr(self, "_h", None):

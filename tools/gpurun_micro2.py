@@ -9,6 +9,6 @@ l1,n1=synth.grid_labels(t,10*r); l2,n2=synth.grid_labels(s,10*r)
 mode=sys.argv[1] if len(sys.argv)>1 else 'real'
 if mode=='near':
     s=t.copy(); s[:,2]+=np.float32(0.2*r); l2,n2=l1,n1
-pair=P.Pair(ctx,t,l1,n1,s,l2,n2,prm)
+pair=P.Pair(ctx,t,l1,n1,s,l2,n2,prm); pair.set_profiling(1|4)
 if mode=='real': res=pair.run()
 ms,nq,kb,edge=pair.bench_dense_nn(20); print(mode,'replay: %.3f ms/launch %d queries kbar %.1f'%(ms,nq,kb))
