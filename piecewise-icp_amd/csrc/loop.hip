@@ -729,11 +729,10 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     bool front_ready = false;                 // front of iteration k already enqueued by iteration k-1
     float prev_lod = NAN;
     auto enqueue_front = [&]() -> int {
-        // (1) R.cpp:737-747 — CT2 and BP2 queries in one launch; the target-centroid grid is static
-        PWCHK(pw_nn_launch(ctx, pr->g_ct1.d, pr->ctbp2.p, 7 * m2, pr->mCTBP.p, pr->dCTBP.p, nullptr));
-        // source patch normals for CTcloud2_withNorm (R.cpp:824): recomputed from the transformed patch points
-        PWCHK(pw_patch_normals_launch(ctx, pr->P2.pat.p, pr->P2.off.p, m2, pr->nrm2.p));
-        return PWICP_OK;
+        // (1) R.cpp:737-747 — CT2 and BP2 queries against the static target-centroid grid — and the source patch
+        // normals for CTcloud2_withNorm (R.cpp:824), recomputed from the transformed patch points: one launch
+        return pw_front_launch(ctx, pr->P2.pat.p, pr->P2.off.p, m2, pr->nrm2.p, pr->g_ct1.d, pr->ctbp2.p, 7 * m2,
+                               pr->mCTBP.p, pr->dCTBP.p);
     };
     auto enqueue_transform = [&](unsigned* slot) {
         // (8) R.cpp:943-954: cloud2 (+ its new bbox into this slot), centroids + boundary points, patch points

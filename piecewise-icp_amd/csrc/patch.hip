@@ -12,6 +12,7 @@
 
 #include "common.h"
 #include "devmath.h"
+#include "nn_device.h"
 #include "patch.h"
 
 using namespace pwdev;
@@ -19,6 +20,7 @@ using namespace pwdev;
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kFrontBlock = 256;     // a multiple of kGroup
 
 // pcl::computeMeanAndCovarianceMatrix (float, single pass) + solvePlaneParameters; false if n < 3
 __device__ inline bool point_normal(const float4* __restrict__ p, int n, float* nrm) {
@@ -147,10 +149,8 @@ __device__ inline void ct_bp(const float4* __restrict__ p, const unsigned char* 
 // pcl::computeMeanAndCovarianceMatrix exactly — but the loads are issued eight points ahead of the adds, so the
 // (inherently serial) accumulation no longer waits a full memory latency per point.  Each lane streams through
 // its own cache lines (8 points per 128-byte line).
-__global__ void __launch_bounds__(64) k_patch_normals(const float4* __restrict__ pat, const int* __restrict__ off, int m,
-                                                      float4* __restrict__ nrm_out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
+__device__ __forceinline__ void patch_normal_lane(const float4* __restrict__ pat, const int* __restrict__ off, int i,
+                                                  float4* __restrict__ nrm_out) {
     const int lo = off[i], hi = off[i + 1];
     float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
     int j = lo;
@@ -193,6 +193,37 @@ __global__ void __launch_bounds__(64) k_patch_normals(const float4* __restrict__
     }
     // w carries calPatchNormal's return value (1 / 0)
     nrm_out[i] = make_float4(nv[0], nv[1], nv[2], ok ? 1.0f : 0.0f);
+}
+
+__global__ void __launch_bounds__(64) k_patch_normals(const float4* __restrict__ pat, const int* __restrict__ off, int m,
+                                                      float4* __restrict__ nrm_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) patch_normal_lane(pat, off, i, nrm_out);
+}
+
+// The "front" of an outer iteration in ONE launch: blocks [0, nb_nrm) compute the source patch normals (R.cpp:824),
+// the remaining blocks the 1-NN of the source centroids and boundary points among the target centroids
+// (R.cpp:737-747), 8 lanes per query.  The two are independent, each is a chain of dependent memory round trips that
+// fills a fraction of the chip, and back to back they cost 16 + 17 us per iteration; side by side ~17 us.
+// The normal blocks come first in the grid so that the longer chain starts first.
+__global__ void __launch_bounds__(kFrontBlock) k_front(const float4* __restrict__ pat, const int* __restrict__ off, int m,
+                                                       float4* __restrict__ nrm_out, int nb_nrm, GridDesc g,
+                                                       const float4* __restrict__ q, int nq, int* __restrict__ idx,
+                                                       float* __restrict__ d2) {
+    if ((int)blockIdx.x < nb_nrm) {
+        const int i = blockIdx.x * kFrontBlock + threadIdx.x;
+        if (i < m) patch_normal_lane(pat, off, i, nrm_out);
+        return;
+    }
+    const int t = (blockIdx.x - nb_nrm) * kFrontBlock + threadIdx.x;
+    const int i = t / kGroup, sub = t % kGroup;
+    if (i >= nq) return;                        // a whole group is in or out of range together
+    const float4 v = q[i];
+    const NNBest b = nn_query_group(g, v.x, v.y, v.z, sub);
+    if (sub == 0) {
+        idx[i] = b.found() ? b.idx() : -1;
+        d2[i] = b.d2();
+    }
 }
 
 // CT / BP / sigma of already selected patches
@@ -330,6 +361,17 @@ __global__ void k_point_patch_ids(const int* __restrict__ off, int m, int* __res
 int pw_patch_normals_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, int m, float4* d_nrm) {
     if (m <= 0) return PWICP_OK;
     hipLaunchKernelGGL(k_patch_normals, dim3(div_up(m, 64)), dim3(64), 0, ctx->stream, d_pat, d_off, m, d_nrm);
+    HIPCHK(ctx, hipGetLastError());
+    return PWICP_OK;
+}
+
+int pw_front_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, int m, float4* d_nrm, const GridDesc& g,
+                    const float4* d_q, int nq, int* d_idx, float* d_d2) {
+    if (m <= 0 || nq <= 0) return PWICP_OK;
+    const int nb_nrm = div_up(m, kFrontBlock);
+    const int nb_nn = div_up((long long)nq * kGroup, kFrontBlock);
+    hipLaunchKernelGGL(k_front, dim3(nb_nrm + nb_nn), dim3(kFrontBlock), 0, ctx->stream, d_pat, d_off, m, d_nrm, nb_nrm, g,
+                       d_q, nq, d_idx, d_d2);
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }
