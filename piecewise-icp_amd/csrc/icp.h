@@ -12,17 +12,29 @@ struct IcpState {
     double prev_mse;
 };
 
+// optional mailbox message sent by the last launch of an ICP batch: a[0..na) | b[0..nb) | IcpState -> dst, then seq
+struct IcpMail {
+    const unsigned* a = nullptr;
+    int na = 0;
+    const unsigned* b = nullptr;
+    int nb = 0;
+    unsigned* dst = nullptr;        // nullptr: no message
+    unsigned* seq_ptr = nullptr;
+    unsigned seq = 0;
+};
+
 struct IcpWork {
     DevBuf<float4> src, srcn;      // working source centroids + normals (transformed in place)
     DevBuf<int> match;
     DevBuf<double> partials;
     DevBuf<IcpState> state;
+    DevBuf<unsigned> counter;      // blocks finished in the current launch (last one solves)
     DevBuf<double> qx, vcm;
     int reserve(pwicp_context* ctx, int ns_max);
 };
 
 int pw_icp_enqueue(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
-                   int ns_max, const unsigned* ns_dev, double euclid_eps, int n_iter);
+                   int ns_max, const unsigned* ns_dev, double euclid_eps, int n_iter, const IcpMail* mail = nullptr);
 int pw_icp_run(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w, int ns,
                double euclid_eps, float* T16, int* iters_out);
 int pw_vcm_enqueue(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,

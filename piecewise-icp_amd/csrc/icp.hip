@@ -41,6 +41,29 @@ __device__ __forceinline__ void block_reduce_store(double* v, int nv, double* __
     }
 }
 
+// Synchronisation inside ONE wave that communicates through LDS: the lanes run in lockstep and the LDS serves a wave's
+// requests in order, so a fence (waits + no compiler reordering) is enough; no s_barrier, hence usable by the first
+// wave of a larger block while its other waves have already left.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Device -> host mailbox message of an ICP batch (see k_mail in loop.hip): word ranges a | b | the ICP state, then the
+// sequence number with a system-scope release.  Executed by the first wave of one block.
+__device__ __forceinline__ void icp_send_mail(const IcpMail& m, const IcpState* st) {
+    const int t = threadIdx.x;
+    if (t >= 64) return;
+    const unsigned* c = (const unsigned*)st;
+    const int nc = (int)(sizeof(IcpState) / 4);
+    for (int i = t; i < m.na; i += 64) m.dst[i] = __hip_atomic_load(&m.a[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = t; i < m.nb; i += 64) m.dst[m.na + i] = __hip_atomic_load(&m.b[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = t; i < nc; i += 64) m.dst[m.na + m.nb + i] = __hip_atomic_load(&c[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    wave_sync();
+    if (t == 0) __hip_atomic_store(m.seq_ptr, m.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Group-cooperative accumulate: kGroup (8) consecutive lanes share one stable centroid.  They split the rows of its
 // nearest-neighbour search (nn_query_group: the search is a chain of dependent memory round trips at this size),
 // then each lane keeps 4 of the 28 sums of the point's LLS row, so the reduction over the wave's 8 points needs
@@ -48,14 +71,28 @@ __device__ __forceinline__ void block_reduce_store(double* v, int nv, double* __
 constexpr int kAccBlock = 1024;                       // 128 points per block: few partials for the solve kernel
 constexpr int kAccPts = kAccBlock / kGroup;
 
-__global__ void __launch_bounds__(kAccBlock) k_icp_accum(GridDesc g, const float4* __restrict__ tgt,
-                                                         const float4* __restrict__ tgt_n, float4* __restrict__ src,
-                                                         float4* __restrict__ srcn, int ns_host,
-                                                         const unsigned* __restrict__ ns_dev, const IcpState* st,
-                                                         double* __restrict__ partials) {
+__device__ void icp_solve_tail(IcpState* st, const double* partials, int ns, double mse_rel);
+
+// One inner iteration in ONE launch: every block accumulates its 128 points; the block that finishes last (device
+// counter) reduces the partials in a fixed order and solves the 6x6 system — the former second kernel, whose launch
+// and first dependent loads cost as much as its arithmetic.  `mail` (optional, last launch of a batch) publishes the
+// iteration record to the host mailbox from the same launch.
+__global__ void __launch_bounds__(kAccBlock) k_icp_iter(GridDesc g, const float4* __restrict__ tgt,
+                                                        const float4* __restrict__ tgt_n, float4* __restrict__ src,
+                                                        float4* __restrict__ srcn, int ns_host,
+                                                        const unsigned* __restrict__ ns_dev, IcpState* st,
+                                                        double* __restrict__ partials, unsigned* __restrict__ counter,
+                                                        double mse_rel, IcpMail mail) {
     __shared__ double sh[kAccBlock / 64][32];
-    if (st->done) return;
+    if (st->done) {                 // converged in an earlier launch of the batch: only the message is left to do
+        if (mail.dst && blockIdx.x == 0) icp_send_mail(mail, st);
+        return;
+    }
     const int ns = ns_dev ? (int)*ns_dev : ns_host;          // the count may live on the device (no host sync)
+    if (ns <= 0) {
+        if (mail.dst && blockIdx.x == 0) icp_send_mail(mail, st);
+        return;
+    }
     if ((int)(blockIdx.x * kAccPts) >= ns) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = threadIdx.x % kGroup;
     const int i = blockIdx.x * kAccPts + threadIdx.x / kGroup;
@@ -99,6 +136,25 @@ __global__ void __launch_bounds__(kAccBlock) k_icp_accum(GridDesc g, const float
         for (int w = 1; w < kAccBlock / 64; ++w) acc += sh[w][threadIdx.x];
         partials[(size_t)blockIdx.x * kNSums + threadIdx.x] = acc;
     }
+    // last active block -> solve.  Only wave 0 (which stored the partials) goes on: release fence, count, and if it
+    // is the last one the solve on that single wave (wave-level synchronisation only, see icp_solve_tail).
+    if (threadIdx.x >= 64) return;
+    __threadfence();
+    unsigned last = 0;
+    if (threadIdx.x == 0) {
+        const unsigned nact = (unsigned)((ns + kAccPts - 1) / kAccPts);
+        const unsigned prev = atomicAdd(counter, 1u);
+        last = (prev == nact - 1u) ? 1u : 0u;
+        if (last) *counter = 0u;                             // re-armed for the next launch
+    }
+    last = (unsigned)__shfl((int)last, 0);
+    if (!last) return;
+    __threadfence();
+    icp_solve_tail(st, partials, ns, mse_rel);
+    if (mail.dst) {
+        __threadfence();
+        icp_send_mail(mail, st);
+    }
 }
 
 // 6x6 inverse by LU with partial pivoting on ONE wave, operands in LDS.  Element (i,j) is owned by lane 6*i+j; every
@@ -108,7 +164,7 @@ __device__ __forceinline__ void inv6_wave(double (*A)[6], double (*inv)[6], int*
     const int t = threadIdx.x;
     if (t < 6) piv[t] = t;
     if (t == 0) *singular = false;
-    __syncthreads();
+    wave_sync();
     for (int k = 0; k < 6; ++k) {
         if (t == 0) {
             int p = k;
@@ -118,18 +174,18 @@ __device__ __forceinline__ void inv6_wave(double (*A)[6], double (*inv)[6], int*
             if (best == 0.0) *singular = true;
             piv[6] = p;                                   // scratch: pivot row of this step
         }
-        __syncthreads();
+        wave_sync();
         const int p = piv[6];
         if (p != k && t < 6) { const double tmp = A[k][t]; A[k][t] = A[p][t]; A[p][t] = tmp; }
         if (p != k && t == 6) { const int tp = piv[k]; piv[k] = piv[p]; piv[p] = tp; }
-        __syncthreads();
+        wave_sync();
         if (t > k && t < 6) A[t][k] = A[t][k] / A[k][k];
-        __syncthreads();
+        wave_sync();
         if (t < 36) {
             const int i = t / 6, j = t % 6;
             if (i > k && j > k) A[i][j] = A[i][j] - A[i][k] * A[k][j];
         }
-        __syncthreads();
+        wave_sync();
     }
     if (t < 6) {          // column t of the inverse: forward then back substitution (independent columns)
         double y[6];
@@ -144,15 +200,14 @@ __device__ __forceinline__ void inv6_wave(double (*A)[6], double (*inv)[6], int*
             inv[i][t] = s / A[i][i];
         }
     }
-    __syncthreads();
+    wave_sync();
     if (*singular && t < 36) inv[t / 6][t % 6] = NAN;
-    __syncthreads();
+    wave_sync();
 }
 
-__global__ void __launch_bounds__(64) k_icp_solve(IcpState* st, const double* __restrict__ partials, int ns_host,
-                                                  const unsigned* __restrict__ ns_dev, double mse_rel) {
-    if (st->done) return;
-    const int ns = ns_dev ? (int)*ns_dev : ns_host;
+// fixed-order sum of the block partials, 6x6 LU inverse, x = inv*ATb, T from (alpha,beta,gamma,t), convergence tests of
+// pcl::registration::DefaultConvergenceCriteria.  Runs on ONE wave (threadIdx.x < 64).
+__device__ void icp_solve_tail(IcpState* st, const double* partials, int ns, double mse_rel) {
     const int nblocks = (ns + kAccPts - 1) / kAccPts;
     __shared__ double sums[kNSums], half[2][kNSums];
     __shared__ double A[6][6], inv[6][6], x[6], sc[6];
@@ -163,26 +218,36 @@ __global__ void __launch_bounds__(64) k_icp_solve(IcpState* st, const double* __
     if (t < 2 * kNSums) {      // two lanes per sum (even / odd blocks), then one add: a fixed summation order
         const int k = t % kNSums, h = t / kNSums;
         double s = 0.0;
-        for (int b = h; b < nblocks; b += 2) s += partials[(size_t)b * kNSums + k];
+        // (written by other blocks of this launch: visible after the acquire fence in the caller.)  Eight loads in
+        // flight, then the adds in block order: the summation order stays fixed, the latency is paid once per eight
+        int b = h;
+        for (; b + 14 < nblocks; b += 16) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)(b + 2 * u) * kNSums + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < nblocks; b += 2) s += partials[(size_t)b * kNSums + k];
         half[h][k] = s;
     }
-    __syncthreads();
+    wave_sync();
     if (t < kNSums) sums[t] = half[0][t] + half[1][t];
-    __syncthreads();
+    wave_sync();
     if (t < 36) {           // symmetric fill from the 21 upper-triangle sums
         const int i = t / 6, j = t % 6, r = min(i, j), c = max(i, j);
         A[i][j] = sums[r * 6 - r * (r - 1) / 2 + (c - r)];
     }
-    __syncthreads();
+    wave_sync();
     inv6_wave(A, inv, piv, &singular);
     if (t < 6) {
         double s = 0.0;
         for (int c = 0; c < 6; ++c) s += inv[t][c] * sums[21 + c];
         x[t] = s;
     }
-    __syncthreads();
+    wave_sync();
     if (t < 3) { sc[t] = cos(x[t]); sc[3 + t] = sin(x[t]); }     // alpha, beta, gamma
-    __syncthreads();
+    wave_sync();
     if (t == 0) {
         const double ca = sc[0], cb = sc[1], cg = sc[2], sa = sc[3], sb = sc[4], sg = sc[5];
         T[0] = (float)(cg * cb);
@@ -198,7 +263,7 @@ __global__ void __launch_bounds__(64) k_icp_solve(IcpState* st, const double* __
         T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
     }
     if (t < 16) F[t] = st->Tfinal[t];
-    __syncthreads();
+    wave_sync();
     if (t < 16) {           // final = T * final (Eigen order), one element per lane
         const int i = t / 4, j = t % 4;
         float s = T[4 * i + 0] * F[0 + j];
@@ -333,6 +398,8 @@ int IcpWork::reserve(pwicp_context* ctx, int ns_max) {
     HIPCHK(ctx, match.reserve((size_t)std::max(ns_max, 1)));
     HIPCHK(ctx, partials.reserve((size_t)nb * kNSums));
     HIPCHK(ctx, state.reserve(1));
+    HIPCHK(ctx, counter.reserve(1));
+    HIPCHK(ctx, hipMemsetAsync(counter.p, 0, sizeof(unsigned), ctx->stream));
     HIPCHK(ctx, qx.reserve(48));
     HIPCHK(ctx, vcm.reserve(36));
     return PWICP_OK;
@@ -341,15 +408,14 @@ int IcpWork::reserve(pwicp_context* ctx, int ns_max) {
 // Enqueues n_iter inner iterations (accumulate + solve each) on the stream; no host synchronisation.  The number
 // of source points is ns_host, or *ns_dev when ns_dev != nullptr (then ns_max bounds the launch grid).
 int pw_icp_enqueue(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
-                   int ns_max, const unsigned* ns_dev, double euclid_eps, int n_iter) {
+                   int ns_max, const unsigned* ns_dev, double euclid_eps, int n_iter, const IcpMail* mail) {
     if (ns_max <= 0) return PWICP_OK;
     const int nb = div_up(ns_max, kAccPts);
-    for (int k = 0; k < n_iter; ++k) {
-        hipLaunchKernelGGL(k_icp_accum, dim3(nb), dim3(kAccBlock), 0, ctx->stream, g, d_tgt, d_tgt_n, w->src.p, w->srcn.p,
-                           ns_max, ns_dev, w->state.p, w->partials.p);
-        hipLaunchKernelGGL(k_icp_solve, dim3(1), dim3(64), 0, ctx->stream, w->state.p, w->partials.p, ns_max, ns_dev,
-                           euclid_eps);
-    }
+    IcpMail none{};
+    for (int k = 0; k < n_iter; ++k)
+        hipLaunchKernelGGL(k_icp_iter, dim3(nb), dim3(kAccBlock), 0, ctx->stream, g, d_tgt, d_tgt_n, w->src.p, w->srcn.p,
+                           ns_max, ns_dev, w->state.p, w->partials.p, w->counter.p, euclid_eps,
+                           (mail && k == n_iter - 1) ? *mail : none);
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }
@@ -363,7 +429,7 @@ int pw_icp_run(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const
     hipLaunchKernelGGL(k_icp_init, dim3(1), dim3(64), 0, ctx->stream, w->state.p);
     IcpState h;
     for (int done_iters = 0; done_iters < 100;) {
-        PWCHK(pw_icp_enqueue(ctx, g, d_tgt, d_tgt_n, w, ns, nullptr, euclid_eps, 4));
+        PWCHK(pw_icp_enqueue(ctx, g, d_tgt, d_tgt_n, w, ns, nullptr, euclid_eps, 4, nullptr));
         HIPCHK(ctx, hipMemcpyAsync(&h, w->state.p, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         done_iters = h.iters;

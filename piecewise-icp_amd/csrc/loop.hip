@@ -780,18 +780,18 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                     ev_kind.push_back({n_ev, 1});
                     HIPCHK(ctx, hipEventRecord(pr->event(n_ev), ctx->stream));
                 }
-                PWCHK(pw_icp_enqueue(ctx, pr->g_ct1.d, pr->P1.ct.p, pr->ct1n.p, &pr->icp, m2, slot + 2, 1e-6, batch));
+                // one mailbox message, sent by the batch's last launch: this slot | bbox words of the PREVIOUS slot
+                // (cloud2 after the previous iteration's transform) | the ICP state
+                const unsigned seq = ++pr->mail_seq;
+                IcpMail mail;
+                mail.a = slot; mail.na = kSlot;
+                mail.b = k > 0 ? slot - kSlot + 4 : slot + 4; mail.nb = 6;
+                mail.dst = pr->mail_d + 16; mail.seq_ptr = pr->mail_d; mail.seq = seq;
+                PWCHK(pw_icp_enqueue(ctx, pr->g_ct1.d, pr->P1.ct.p, pr->ct1n.p, &pr->icp, m2, slot + 2, 1e-6, batch, &mail));
                 if (ev) {
                     HIPCHK(ctx, hipEventRecord(pr->event(n_ev + 1), ctx->stream));
                     n_ev += 2;
                 }
-                // one mailbox message: this slot | bbox words of the PREVIOUS slot (cloud2 after the previous
-                // iteration's transform) | the ICP state
-                const unsigned seq = ++pr->mail_seq;
-                hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, ctx->stream, (const unsigned*)slot, kSlot,
-                                   (const unsigned*)(k > 0 ? slot - kSlot + 4 : slot + 4), 6,
-                                   (const unsigned*)pr->icp.state.p, (int)(sizeof(IcpState) / 4), pr->mail_d + 16, pr->mail_d,
-                                   seq);
                 if (early_xf) {
                     enqueue_transform(slot);                 // no-op on the device while the ICP has not converged
                     if (early_front) PWCHK(enqueue_front());

@@ -145,31 +145,37 @@ __device__ inline void ct_bp(const float4* __restrict__ p, const unsigned char* 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// One lane per patch.  A lane walks ITS patch in storage order — the nine float running sums are those of
-// pcl::computeMeanAndCovarianceMatrix exactly — but the loads are issued eight points ahead of the adds, so the
-// (inherently serial) accumulation no longer waits a full memory latency per point.  Each lane streams through
-// its own cache lines (8 points per 128-byte line).
-__device__ __forceinline__ void patch_normal_lane(const float4* __restrict__ pat, const int* __restrict__ off, int i,
-                                                  float4* __restrict__ nrm_out) {
+// Plane normal of patch i, computed by a group of kGroup (8) consecutive lanes.  The group loads 8 consecutive points
+// per request (one 128-byte line, up to kAhead requests in flight) and hands them round with lane shuffles; every lane
+// of the group then performs the SAME running sums over the points in storage order — the nine float accumulators are
+// those of pcl::computeMeanAndCovarianceMatrix exactly.  Compared with one lane per patch a wave touches 8 cache lines
+// per request instead of 64 and needs 1-2 memory round trips per patch instead of ~10.
+constexpr int kAhead = 8;
+__device__ __forceinline__ void patch_normal_group(const float4* __restrict__ pat, const int* __restrict__ off, int i, int sub,
+                                                   float4* __restrict__ nrm_out) {
     const int lo = off[i], hi = off[i + 1];
+    const int gbase = (threadIdx.x & 63) & ~(kGroup - 1);        // first lane of this group within the wave
     float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
-    int j = lo;
-    for (; j + 8 <= hi; j += 8) {
-        float4 v[8];
+    for (int base = lo; base < hi; base += kGroup * kAhead) {
+        float4 v[kAhead];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = pat[j + u];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            a0 += v[u].x * v[u].x; a1 += v[u].x * v[u].y; a2 += v[u].x * v[u].z;
-            a3 += v[u].y * v[u].y; a4 += v[u].y * v[u].z; a5 += v[u].z * v[u].z;
-            a6 += v[u].x; a7 += v[u].y; a8 += v[u].z;
+        for (int u = 0; u < kAhead; ++u) {
+            const int j = base + u * kGroup + sub;
+            v[u] = (j < hi) ? pat[j] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-    }
-    for (; j < hi; ++j) {
-        const float4 v = pat[j];
-        a0 += v.x * v.x; a1 += v.x * v.y; a2 += v.x * v.z;
-        a3 += v.y * v.y; a4 += v.y * v.z; a5 += v.z * v.z;
-        a6 += v.x; a7 += v.y; a8 += v.z;
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            if (base + u * kGroup >= hi) break;                  // uniform within the group
+#pragma unroll
+            for (int t = 0; t < kGroup; ++t) {
+                const float x = __shfl(v[u].x, gbase + t), y = __shfl(v[u].y, gbase + t), z = __shfl(v[u].z, gbase + t);
+                if (base + u * kGroup + t < hi) {
+                    a0 += x * x; a1 += x * y; a2 += x * z;
+                    a3 += y * y; a4 += y * z; a5 += z * z;
+                    a6 += x; a7 += y; a8 += z;
+                }
+            }
+        }
     }
     const int n = hi - lo;
     float nv[3] = {0.f, 0.f, 1.f};
@@ -192,13 +198,14 @@ __device__ __forceinline__ void patch_normal_lane(const float4* __restrict__ pat
         }
     }
     // w carries calPatchNormal's return value (1 / 0)
-    nrm_out[i] = make_float4(nv[0], nv[1], nv[2], ok ? 1.0f : 0.0f);
+    if (sub == 0) nrm_out[i] = make_float4(nv[0], nv[1], nv[2], ok ? 1.0f : 0.0f);
 }
 
-__global__ void __launch_bounds__(64) k_patch_normals(const float4* __restrict__ pat, const int* __restrict__ off, int m,
-                                                      float4* __restrict__ nrm_out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m) patch_normal_lane(pat, off, i, nrm_out);
+__global__ void __launch_bounds__(kFrontBlock) k_patch_normals(const float4* __restrict__ pat, const int* __restrict__ off,
+                                                               int m, float4* __restrict__ nrm_out) {
+    const int t = blockIdx.x * kFrontBlock + threadIdx.x;
+    const int i = t / kGroup;
+    if (i < m) patch_normal_group(pat, off, i, t % kGroup, nrm_out);      // a whole group is in or out of range together
 }
 
 // The "front" of an outer iteration in ONE launch: blocks [0, nb_nrm) compute the source patch normals (R.cpp:824),
@@ -211,8 +218,9 @@ __global__ void __launch_bounds__(kFrontBlock) k_front(const float4* __restrict_
                                                        const float4* __restrict__ q, int nq, int* __restrict__ idx,
                                                        float* __restrict__ d2) {
     if ((int)blockIdx.x < nb_nrm) {
-        const int i = blockIdx.x * kFrontBlock + threadIdx.x;
-        if (i < m) patch_normal_lane(pat, off, i, nrm_out);
+        const int t = blockIdx.x * kFrontBlock + threadIdx.x;
+        const int i = t / kGroup;
+        if (i < m) patch_normal_group(pat, off, i, t % kGroup, nrm_out);
         return;
     }
     const int t = (blockIdx.x - nb_nrm) * kFrontBlock + threadIdx.x;
@@ -360,7 +368,8 @@ __global__ void k_point_patch_ids(const int* __restrict__ off, int m, int* __res
 // ======================================================================================================
 int pw_patch_normals_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, int m, float4* d_nrm) {
     if (m <= 0) return PWICP_OK;
-    hipLaunchKernelGGL(k_patch_normals, dim3(div_up(m, 64)), dim3(64), 0, ctx->stream, d_pat, d_off, m, d_nrm);
+    hipLaunchKernelGGL(k_patch_normals, dim3(div_up((long long)m * kGroup, kFrontBlock)), dim3(kFrontBlock), 0, ctx->stream,
+                       d_pat, d_off, m, d_nrm);
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }
@@ -368,7 +377,7 @@ int pw_patch_normals_launch(pwicp_context* ctx, const float4* d_pat, const int* 
 int pw_front_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, int m, float4* d_nrm, const GridDesc& g,
                     const float4* d_q, int nq, int* d_idx, float* d_d2) {
     if (m <= 0 || nq <= 0) return PWICP_OK;
-    const int nb_nrm = div_up(m, kFrontBlock);
+    const int nb_nrm = div_up((long long)m * kGroup, kFrontBlock);
     const int nb_nn = div_up((long long)nq * kGroup, kFrontBlock);
     hipLaunchKernelGGL(k_front, dim3(nb_nrm + nb_nn), dim3(kFrontBlock), 0, ctx->stream, d_pat, d_off, m, d_nrm, nb_nrm, g,
                        d_q, nq, d_idx, d_d2);
