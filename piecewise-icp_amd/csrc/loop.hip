@@ -48,6 +48,7 @@ __global__ void __launch_bounds__(kBlock) k_classify(
     const float4* __restrict__ bp2, const int* __restrict__ off2, float currDT, float DTmin, float DTctct,
     int* __restrict__ stable, int* __restrict__ blk_cnt, unsigned* __restrict__ scal) {
     __shared__ int s_cnt[kBlock / 64][2];
+    __shared__ float s_lod[kBlock / 64][2];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float lod_min = INFINITY, lod_max = 0.0f;
     int st_flag = 0, st_pts = 0;
@@ -94,17 +95,24 @@ __global__ void __launch_bounds__(kBlock) k_classify(
         st_pts += __shfl_xor(st_pts, o);
     }
     // stable patches / points of this block, for the parallel compaction that follows
-    if ((threadIdx.x & 63) == 0) { s_cnt[threadIdx.x >> 6][0] = st_flag; s_cnt[threadIdx.x >> 6][1] = st_pts; }
+    if ((threadIdx.x & 63) == 0) {
+        s_cnt[threadIdx.x >> 6][0] = st_flag; s_cnt[threadIdx.x >> 6][1] = st_pts;
+        s_lod[threadIdx.x >> 6][0] = lod_min; s_lod[threadIdx.x >> 6][1] = lod_max;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         int a = 0, b = 0;
-        for (int w = 0; w < kBlock / 64; ++w) { a += s_cnt[w][0]; b += s_cnt[w][1]; }
+        float lo = INFINITY, hi = 0.0f;
+        for (int w = 0; w < kBlock / 64; ++w) {
+            a += s_cnt[w][0]; b += s_cnt[w][1];
+            lo = fminf(lo, s_lod[w][0]); hi = fmaxf(hi, s_lod[w][1]);
+        }
         blk_cnt[2 * blockIdx.x] = a;
         blk_cnt[2 * blockIdx.x + 1] = b;
-    }
-    if ((threadIdx.x & 63) == 0 && lod_max > 0.0f) {
-        atomicMin(&scal[0], __float_as_uint(lod_min));   // positive floats order like their bit patterns
-        atomicMax(&scal[1], __float_as_uint(lod_max));
+        if (hi > 0.0f) {                                  // one atomic pair per block: same-line atomics serialise
+            atomicMin(&scal[0], __float_as_uint(lo));     // positive floats order like their bit patterns
+            atomicMax(&scal[1], __float_as_uint(hi));
+        }
     }
 }
 
@@ -193,7 +201,7 @@ __global__ void __launch_bounds__(kBlock) k_transform_all(float4* __restrict__ c
                                                           float4* __restrict__ ctbp, int n_ctbp,
                                                           float4* __restrict__ pat, int n_pat,
                                                           const IcpState* __restrict__ st, const unsigned* __restrict__ ns_dev,
-                                                          unsigned* __restrict__ bbox_part) {
+                                                          unsigned* __restrict__ bbox_part, unsigned* __restrict__ slot) {
     __shared__ float sh[kBlock / 64][6];
     if (!st->done || *ns_dev < 4u) return;
     Mat4 T;
@@ -247,36 +255,63 @@ __global__ void __launch_bounds__(kBlock) k_transform_all(float4* __restrict__ c
 #pragma unroll
         for (int d = 0; d < 3; ++d) { sh[wave][d] = mn[d]; sh[wave][3 + d] = mx[d]; }
     __syncthreads();
+    if (threadIdx.x >= 64) return;
+    unsigned* part = bbox_part + (blockIdx.x & (kBoxParts - 1)) * 32;
     if (threadIdx.x < 3) {
         float a = sh[0][threadIdx.x], b = sh[0][3 + threadIdx.x];
         for (int w = 1; w < kBlock / 64; ++w) { a = fminf(a, sh[w][threadIdx.x]); b = fmaxf(b, sh[w][3 + threadIdx.x]); }
         // 64 partial boxes, one 128-byte line each: same-line atomics from all XCDs serialise (~5 ns apiece)
-        unsigned* part = bbox_part + (blockIdx.x & (kBoxParts - 1)) * 32;
         atomicMin(&part[threadIdx.x], f2ord_dev(a));
         atomicMax(&part[3 + threadIdx.x], f2ord_dev(b));
     }
-}
-
-// folds the 64 partial boxes of the last transform into its slot and re-arms them (one wave)
-__global__ void __launch_bounds__(64) k_bbox_fold(unsigned* __restrict__ bbox_part, unsigned* __restrict__ slot,
-                                                  const IcpState* __restrict__ st) {
+    // Fold in the same launch: the block that completes a partial box counts it, the block that completes the last
+    // partial box folds all of them into the slot and re-arms the buffer (two levels, so that no counter line sees
+    // more than ~nb_cloud/64 + 64 atomics).  The box atomics only have to be COMPLETE before the count (they are
+    // device-coherent read-modify-writes): a workgroup-scope release waits for them without the L2 write-back of a
+    // device-scope fence, which is ruinous in a launch that has just written the whole cloud.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    unsigned last = 0;
+    if (threadIdx.x == 0) {
+        const int pidx = blockIdx.x & (kBoxParts - 1);
+        const unsigned np = (unsigned)((nb_cloud - pidx + kBoxParts - 1) / kBoxParts);
+        if (atomicAdd(&part[8], 1u) == np - 1u) {
+            const unsigned nparts = (unsigned)min(nb_cloud, kBoxParts);
+            if (atomicAdd(&bbox_part[kBoxParts * 32], 1u) == nparts - 1u) last = 1u;
+        }
+    }
+    last = (unsigned)__shfl((int)last, 0);
+    if (!last) return;
     const int t = threadIdx.x;
-    if (st && (!st->done || slot[2] < 4u)) return;      // the transform before this launch did not run
-    unsigned mn[3], mx[3];
+    unsigned umn[3], umx[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { mn[d] = bbox_part[t * 32 + d]; mx[d] = bbox_part[t * 32 + 3 + d]; }
+    for (int d = 0; d < 3; ++d) {
+        umn[d] = __hip_atomic_load(&bbox_part[t * 32 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        umx[d] = __hip_atomic_load(&bbox_part[t * 32 + 3 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            mn[d] = min(mn[d], (unsigned)__shfl_xor((int)mn[d], o));
-            mx[d] = max(mx[d], (unsigned)__shfl_xor((int)mx[d], o));
+            umn[d] = min(umn[d], (unsigned)__shfl_xor((int)umn[d], o));
+            umx[d] = max(umx[d], (unsigned)__shfl_xor((int)umx[d], o));
         }
 #pragma unroll
     for (int d = 0; d < 3; ++d) { bbox_part[t * 32 + d] = 0xffffffffu; bbox_part[t * 32 + 3 + d] = 0u; }
-    if (t == 0 && slot)
+    bbox_part[t * 32 + 8] = 0u;
+    if (t == 0) {
+        bbox_part[kBoxParts * 32] = 0u;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { slot[4 + d] = mn[d]; slot[7 + d] = mx[d]; }
+        for (int d = 0; d < 3; ++d) { slot[4 + d] = umn[d]; slot[7 + d] = umx[d]; }
+    }
+}
+
+// arms the partial boxes and their counters (once, at pair creation; afterwards the folding block re-arms them)
+__global__ void __launch_bounds__(64) k_bbox_arm(unsigned* __restrict__ bbox_part) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { bbox_part[t * 32 + d] = 0xffffffffu; bbox_part[t * 32 + 3 + d] = 0u; }
+    bbox_part[t * 32 + 8] = 0u;
+    if (t == 0) bbox_part[kBoxParts * 32] = 0u;
 }
 
 // Device -> host mailbox: copies up to three word ranges into pinned, coherent host memory and then publishes a
@@ -487,8 +522,8 @@ int finish_create(pwicp_pair* pr) {
     HIPCHK(ctx, pr->stN.reserve(M2));
     HIPCHK(ctx, pr->d2dense.reserve((size_t)std::max(std::max(pr->P2.tot, pr->n2), 1)));
     HIPCHK(ctx, pr->scal.reserve((size_t)kSlot * (PWICP_MAX_OUTER + 1)));
-    HIPCHK(ctx, pr->bbox_part.reserve((size_t)kBoxParts * 32));
-    hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(64), 0, ctx->stream, pr->bbox_part.p, (unsigned*)nullptr, (const IcpState*)nullptr);   // arm
+    HIPCHK(ctx, pr->bbox_part.reserve((size_t)kBoxParts * 32 + 32));
+    hipLaunchKernelGGL(k_bbox_arm, dim3(1), dim3(64), 0, ctx->stream, pr->bbox_part.p);
     {   // tight bbox of the uploaded source cloud (R.cpp:881-886 needs it in the first iteration)
         hipLaunchKernelGGL(k_scal_init, dim3(1), dim3(64), 0, ctx->stream, pr->scal.p, 1, (unsigned long long*)nullptr, 0);
         Mat4 I{};
@@ -740,8 +775,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         const int nb_rest = std::min(div_up(7 * m2 + pr->P2.tot, kBlock), ctx->n_cu * 8);
         hipLaunchKernelGGL(k_transform_all, dim3(nb_cloud + nb_rest), dim3(kBlock), 0, ctx->stream, pr->cloud2.p, pr->n2,
                            nb_cloud, pr->ctbp2.p, 7 * m2, pr->P2.pat.p, pr->P2.tot, (const IcpState*)pr->icp.state.p,
-                           (const unsigned*)(slot + 2), pr->bbox_part.p);
-        hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(64), 0, ctx->stream, pr->bbox_part.p, slot, (const IcpState*)pr->icp.state.p);
+                           (const unsigned*)(slot + 2), pr->bbox_part.p, slot);
     };
     const auto t0 = std::chrono::steady_clock::now();
     while (!stage3) {                                                   // R.cpp:680
