@@ -113,7 +113,14 @@ int pw_bbox(pwicp_context* ctx, const float4* d_pts, int n, float mn[3], float m
 int pw_knn_launch(pwicp_context* ctx, const GridDesc& g, int k, int* d_nb);
 int pw_knn_mean_dist_launch(pwicp_context* ctx, const GridDesc& g, int mean_k, float* d_mean);
 // k-th smallest (0-based) of the non-sentinel entries of n non-negative floats; result written to d_out[0]; scratch >= 3*2048+8 uints
-int pw_select_kth_launch(pwicp_context* ctx, const float* d_vals, int n, int k, unsigned* d_scratch, float* d_out);
+// optional host-mailbox message of a selection: the selected value's bits -> dst[0], then seq (system-scope release)
+struct SelectMail {
+    unsigned* dst = nullptr;
+    unsigned* seq_ptr = nullptr;
+    unsigned seq = 0;
+};
+int pw_select_kth_launch(pwicp_context* ctx, const float* d_vals, int n, int k, unsigned* d_scratch, float* d_out,
+                         bool armed = false, const SelectMail* mail = nullptr);
 // count of values with sqrtf(v) < thr  -> d_count[0]
 int pw_count_below_launch(pwicp_context* ctx, const float* d_d2, int n, float thr, unsigned* d_count);
 // exclusive scan in place of n ints (n may be large); d_tmp >= div_up(n,4096)+1 ints

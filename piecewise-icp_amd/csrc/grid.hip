@@ -590,8 +590,13 @@ __global__ void k_select_init(unsigned* scratch, int k) {
     if (t < 8 + 3 * kSelBins) scratch[t] = (t == 1) ? (unsigned)k : 0u;
 }
 
+// Histogram pass + pick in ONE launch: the block that flushes its bins last (device counter in scratch[2]) scans the
+// 2048 bins on its first wave, narrows the prefix / rank for the next pass and re-arms the bins and the counter, so a
+// selection is three launches and the scratch buffer is ready for the next selection when the last one ends.
+// The final pass can publish the selected value to a host mailbox (see k_mail in loop.hip) from the same launch.
 template <int PASS>
-__global__ void k_select_hist(const float* __restrict__ v, int n, unsigned* __restrict__ scratch) {
+__global__ void k_select_pass(const float* __restrict__ v, int n, int k0, unsigned* __restrict__ scratch,
+                              float* __restrict__ out, SelectMail mail) {
     // 8 replicas of the histogram, chosen by lane: squared distances cluster in a few exponent bins, and same-bin
     // LDS atomics from the 64 lanes of a wave would serialise
     __shared__ unsigned h[8 * kSelBins];
@@ -618,40 +623,65 @@ __global__ void k_select_hist(const float* __restrict__ v, int n, unsigned* __re
         for (int r = 0; r < 8; ++r) s += h[r * kSelBins + t];
         if (s) atomicAdd(&gh[t], s);
     }
-}
-
-template <int PASS>
-__global__ void k_select_pick(unsigned* __restrict__ scratch, float* __restrict__ out) {
-    // one wave: each lane owns 32 consecutive bins
-    const unsigned* gh = scratch + 8 + PASS * kSelBins;
-    int lane = threadIdx.x;
+    // every thread waits for its own bin atomics (device-coherent RMWs; no cache write-back needed), then the count
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    unsigned last = 0;
+    if (threadIdx.x == 0) last = (atomicAdd(&scratch[2], 1u) == gridDim.x - 1u) ? 1u : 0u;
+    last = (unsigned)__shfl((int)last, 0);
+    if (!last) return;
+    // ---- pick (one wave: each lane owns 32 consecutive bins) ----
+    const int lane = threadIdx.x;
+    unsigned cnt[32];
     unsigned local = 0;
-    for (int b = 0; b < 32; ++b) local += gh[lane * 32 + b];
+#pragma unroll
+    for (int b = 0; b < 32; ++b) {
+        cnt[b] = __hip_atomic_load(&gh[lane * 32 + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        local += cnt[b];
+    }
     unsigned incl = local;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         unsigned t = __shfl_up(incl, o);
         if (lane >= o) incl += t;
     }
-    unsigned excl = incl - local;
-    unsigned k = scratch[1];
-    bool mine = (k >= excl) && (k < incl);
+    const unsigned excl = incl - local;
+    const unsigned k = (PASS == 0) ? (unsigned)k0 : scratch[1];
+    const bool mine = (k >= excl) && (k < incl);
+    unsigned value = 0;
     if (mine) {
         unsigned run = excl;
+#pragma unroll
         for (int b = 0; b < 32; ++b) {
-            unsigned c = gh[lane * 32 + b];
-            if (k < run + c) {
-                unsigned bin = (unsigned)(lane * 32 + b);
-                unsigned prefix = scratch[0];
-                if (PASS == 0) prefix = bin << 21;
-                else if (PASS == 1) prefix |= bin << 10;
-                else prefix |= bin;
-                scratch[0] = prefix;
+            const unsigned c = cnt[b];
+            if (k >= run && k < run + c) {
+                const unsigned bin = (unsigned)(lane * 32 + b);
+                unsigned pf = prefix;
+                if (PASS == 0) pf = bin << 21;
+                else if (PASS == 1) pf |= bin << 10;
+                else pf |= bin;
+                value = pf;
+                scratch[0] = (PASS == 2) ? 0u : pf;          // prefix for the next pass; cleared after the last one
                 scratch[1] = k - run;
-                if (PASS == 2) out[0] = __uint_as_float(prefix);
-                break;
+                if (PASS == 2) out[0] = __uint_as_float(pf);
             }
             run += c;
+        }
+    }
+    // re-arm this pass's bins and the counter
+#pragma unroll
+    for (int b = 0; b < 32; ++b) gh[lane * 32 + b] = 0u;
+    if (lane == 0) scratch[2] = 0u;
+    if (PASS == 2 && mail.dst) {
+        // exactly one lane found the value
+        const unsigned long long m = __ballot(mine);
+        const int src = m ? (int)__ffsll((long long)m) - 1 : 0;
+        value = (unsigned)__shfl((int)value, src);
+        if (lane == 0) {
+            mail.dst[0] = value;
+            __threadfence_system();
+            __hip_atomic_store(mail.seq_ptr, mail.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -818,18 +848,20 @@ int pw_nn_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_q, int n
     return PWICP_OK;
 }
 
-int pw_select_kth_launch(pwicp_context* ctx, const float* d_vals, int n, int k, unsigned* d_scratch, float* d_out) {
+int pw_select_kth_launch(pwicp_context* ctx, const float* d_vals, int n, int k, unsigned* d_scratch, float* d_out,
+                         bool armed, const SelectMail* mail) {
     if (n <= 0) return PWICP_E_INVALID;
     // few blocks: every block ends with one global atomic per non-empty bin, and same-address atomics serialise
     int nb = std::min(div_up(n, kBlock), std::max(ctx->n_cu / 2, 1));
-    hipLaunchKernelGGL(k_select_init, dim3(div_up(8 + 3 * kSelBins, kBlock)), dim3(kBlock), 0, ctx->stream,
-                       d_scratch, k);
-    hipLaunchKernelGGL(k_select_hist<0>, dim3(nb), dim3(kBlock), 0, ctx->stream, d_vals, n, d_scratch);
-    hipLaunchKernelGGL(k_select_pick<0>, dim3(1), dim3(64), 0, ctx->stream, d_scratch, d_out);
-    hipLaunchKernelGGL(k_select_hist<1>, dim3(nb), dim3(kBlock), 0, ctx->stream, d_vals, n, d_scratch);
-    hipLaunchKernelGGL(k_select_pick<1>, dim3(1), dim3(64), 0, ctx->stream, d_scratch, d_out);
-    hipLaunchKernelGGL(k_select_hist<2>, dim3(nb), dim3(kBlock), 0, ctx->stream, d_vals, n, d_scratch);
-    hipLaunchKernelGGL(k_select_pick<2>, dim3(1), dim3(64), 0, ctx->stream, d_scratch, d_out);
+    // `armed`: the scratch buffer was zeroed when it was allocated and only ever used by this function (every
+    // selection leaves it zeroed again)
+    if (!armed)
+        hipLaunchKernelGGL(k_select_init, dim3(div_up(8 + 3 * kSelBins, kBlock)), dim3(kBlock), 0, ctx->stream, d_scratch, k);
+    SelectMail none{};
+    hipLaunchKernelGGL(k_select_pass<0>, dim3(nb), dim3(kBlock), 0, ctx->stream, d_vals, n, k, d_scratch, d_out, none);
+    hipLaunchKernelGGL(k_select_pass<1>, dim3(nb), dim3(kBlock), 0, ctx->stream, d_vals, n, k, d_scratch, d_out, none);
+    hipLaunchKernelGGL(k_select_pass<2>, dim3(nb), dim3(kBlock), 0, ctx->stream, d_vals, n, k, d_scratch, d_out,
+                       mail ? *mail : none);
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }

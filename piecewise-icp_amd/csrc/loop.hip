@@ -535,6 +535,7 @@ int finish_create(pwicp_pair* pr) {
         for (int d = 0; d < 3; ++d) { pr->bmin0[d] = ord2f_host(hb[4 + d]); pr->bmax0[d] = ord2f_host(hb[7 + d]); }
     }
     HIPCHK(ctx, pr->sel_scratch.reserve(8 + 3 * 2048));
+    HIPCHK(ctx, hipMemsetAsync(pr->sel_scratch.p, 0, (8 + 3 * 2048) * sizeof(unsigned), ctx->stream));   // armed: see pw_select_kth_launch
     HIPCHK(ctx, pr->sel_out.reserve(1));
     HIPCHK(ctx, pr->examined.reserve(256 * 16 + 2));
     PWCHK(pr->icp.reserve(ctx, m2));
@@ -696,10 +697,10 @@ static int select_p75_enqueue(pwicp_pair* pr, int n_slots, int n_valid, unsigned
     pwicp_context* ctx = pr->ctx;
     int k = (int)((float)n_valid * 0.75f);      // C.cpp:177
     if (k >= n_valid) k = n_valid - 1;
-    PWCHK(pw_select_kth_launch(ctx, pr->d2dense.p, n_slots, k, pr->sel_scratch.p, pr->sel_out.p));
     const unsigned seq = ++pr->mail_seq;
-    hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, ctx->stream, (const unsigned*)pr->sel_out.p, 1, (const unsigned*)nullptr, 0,
-                       (const unsigned*)nullptr, 0, pr->mail_d + 16, pr->mail_d, seq);
+    SelectMail mail;
+    mail.dst = pr->mail_d + 16; mail.seq_ptr = pr->mail_d; mail.seq = seq;
+    PWCHK(pw_select_kth_launch(ctx, pr->d2dense.p, n_slots, k, pr->sel_scratch.p, pr->sel_out.p, /*armed*/ true, &mail));
     *seq_out = seq;
     return PWICP_OK;
 }
