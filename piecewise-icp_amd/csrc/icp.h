@@ -23,6 +23,14 @@ struct IcpMail {
     unsigned seq = 0;
 };
 
+// optional final message of a run, sent by the VCM's last launch: VCM (72 words) | diagnostic counter (2 words)
+struct VcmMail {
+    const unsigned long long* examined = nullptr;    // 256 partial counters, 16 words apart
+    unsigned* dst = nullptr;                          // nullptr: no message
+    unsigned* seq_ptr = nullptr;
+    unsigned seq = 0;
+};
+
 struct IcpWork {
     DevBuf<float4> src, srcn;      // working source centroids + normals (transformed in place)
     DevBuf<int> match;
@@ -38,6 +46,6 @@ int pw_icp_enqueue(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, c
 int pw_icp_run(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w, int ns,
                double euclid_eps, float* T16, int* iters_out);
 int pw_vcm_enqueue(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
-                   const float4* d_src, int ns);
+                   const float4* d_src, int ns, const VcmMail* mail = nullptr);
 int pw_vcm_run(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
                const float4* d_src, int ns, double* VCM36);

@@ -310,48 +310,82 @@ __device__ __forceinline__ void vcm_row(float4 q, float4 p, float4 n, double* a,
     *L = Nx * (Px - Qx) + Ny * (Py - Qy) + Nz * (Pz - Qz);
 }
 
-__global__ void __launch_bounds__(kBlock) k_vcm_accum(GridDesc g, const float4* __restrict__ tgt,
-                                                      const float4* __restrict__ tgt_n,
-                                                      const float4* __restrict__ src, int ns, int* __restrict__ match,
-                                                      double* __restrict__ partials) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    double v[kNSums];
-#pragma unroll
-    for (int k = 0; k < kNSums; ++k) v[k] = 0.0;
+// VCM step 1 in one launch: normal equations (group-cooperative like k_icp_iter: 8 lanes share a point's NN search and
+// each keeps 4 of the 27 sums) and, on the block that finishes last, Qxx = (A^T A)^-1 and x = Qxx A^T L.
+__global__ void __launch_bounds__(kAccBlock) k_vcm_normal(GridDesc g, const float4* __restrict__ tgt,
+                                                          const float4* __restrict__ tgt_n,
+                                                          const float4* __restrict__ src, int ns, int* __restrict__ match,
+                                                          double* __restrict__ partials, unsigned* __restrict__ counter,
+                                                          double* __restrict__ QX) {
+    __shared__ double sh[kAccBlock / 64][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = threadIdx.x % kGroup;
+    const int i = blockIdx.x * kAccPts + threadIdx.x / kGroup;
+    double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
     if (i < ns) {
-        float4 q = src[i];
-        unsigned ex;
-        NNBest b = nn_query(g, q.x, q.y, q.z, ex);
+        const float4 q = src[i];
+        const NNBest b = nn_query_group(g, q.x, q.y, q.z, sub);
         const int bi = b.idx();
-        match[i] = bi;
+        if (sub == 0) match[i] = bi;
         double a[6], L;
         vcm_row(q, tgt[bi], tgt_n[bi], a, &L);
-        int k = 0;
-        for (int r = 0; r < 6; ++r)
-            for (int c = r; c < 6; ++c) v[k++] = a[r] * a[c];
-        for (int r = 0; r < 6; ++r) v[21 + r] = a[r] * L;
+        // sum k (0..26; 21 upper-triangle products row by row, then a[r]*L) lives on lane sub = k % 8 as its (k / 8)-th value
+        switch (sub) {
+            case 0: w0 = a[0] * a[0]; w1 = a[1] * a[3]; w2 = a[3] * a[4]; w3 = a[3] * L; break;    // 0, 8, 16, 24
+            case 1: w0 = a[0] * a[1]; w1 = a[1] * a[4]; w2 = a[3] * a[5]; w3 = a[4] * L; break;    // 1, 9, 17, 25
+            case 2: w0 = a[0] * a[2]; w1 = a[1] * a[5]; w2 = a[4] * a[4]; w3 = a[5] * L; break;    // 2, 10, 18, 26
+            case 3: w0 = a[0] * a[3]; w1 = a[2] * a[2]; w2 = a[4] * a[5]; break;                   // 3, 11, 19
+            case 4: w0 = a[0] * a[4]; w1 = a[2] * a[3]; w2 = a[5] * a[5]; break;                   // 4, 12, 20
+            case 5: w0 = a[0] * a[5]; w1 = a[2] * a[4]; w2 = a[0] * L; break;                      // 5, 13, 21
+            case 6: w0 = a[1] * a[1]; w1 = a[2] * a[5]; w2 = a[1] * L; break;                      // 6, 14, 22
+            default: w0 = a[1] * a[2]; w1 = a[3] * a[3]; w2 = a[2] * L; break;                     // 7, 15, 23
+        }
     }
-    block_reduce_store(v, kVSums, partials + (size_t)blockIdx.x * kNSums);
-}
-
-// out: Q[36], X[6]
-__global__ void __launch_bounds__(64) k_vcm_solve(const double* __restrict__ partials, int nblocks, double* __restrict__ QX) {
+#pragma unroll
+    for (int o = kGroup; o < 64; o <<= 1) {
+        w0 += __shfl_xor(w0, o); w1 += __shfl_xor(w1, o); w2 += __shfl_xor(w2, o); w3 += __shfl_xor(w3, o);
+    }
+    if (lane < kGroup) { sh[wave][lane] = w0; sh[wave][8 + lane] = w1; sh[wave][16 + lane] = w2; sh[wave][24 + lane] = w3; }
+    __syncthreads();
+    if (threadIdx.x < kVSums) {
+        double acc = sh[0][threadIdx.x];
+        for (int w = 1; w < kAccBlock / 64; ++w) acc += sh[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * kNSums + threadIdx.x] = acc;
+    }
+    if (threadIdx.x >= 64) return;
+    __threadfence();
+    unsigned last = 0;
+    if (threadIdx.x == 0) {
+        last = (atomicAdd(counter, 1u) == gridDim.x - 1u) ? 1u : 0u;
+        if (last) *counter = 0u;
+    }
+    last = (unsigned)__shfl((int)last, 0);
+    if (!last) return;
+    __threadfence();
+    // ---- solve (one wave) ----
     __shared__ double sums[kVSums];
     __shared__ double A[6][6], Q[6][6];
     __shared__ int piv[8];
     __shared__ bool singular;
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, nblocks = gridDim.x;
     if (t < kVSums) {
         double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * kNSums + t];
+        int bk = 0;
+        for (; bk + 8 <= nblocks; bk += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)(bk + u) * kNSums + t];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; bk < nblocks; ++bk) s += partials[(size_t)bk * kNSums + t];
         sums[t] = s;
     }
-    __syncthreads();
+    wave_sync();
     if (t < 36) {
-        const int i = t / 6, j = t % 6, r = min(i, j), c = max(i, j);
-        A[i][j] = sums[r * 6 - r * (r - 1) / 2 + (c - r)];
+        const int r0 = t / 6, c0 = t % 6, r = min(r0, c0), c = max(r0, c0);
+        A[r0][c0] = sums[r * 6 - r * (r - 1) / 2 + (c - r)];
     }
-    __syncthreads();
+    wave_sync();
     inv6_wave(A, Q, piv, &singular);
     if (t < 36) QX[t] = Q[t / 6][t % 6];
     if (t < 6) {
@@ -361,10 +395,13 @@ __global__ void __launch_bounds__(64) k_vcm_solve(const double* __restrict__ par
     }
 }
 
-__global__ void __launch_bounds__(kBlock) k_vcm_resid(const float4* __restrict__ tgt, const float4* __restrict__ tgt_n,
-                                                      const float4* __restrict__ src, int ns,
-                                                      const int* __restrict__ match, const double* __restrict__ QX,
-                                                      double* __restrict__ partials) {
+// VCM step 2 in one launch: residuals v = A x - L, v^T v; the block that finishes last forms sigma0^2 * Qxx
+// (R.cpp:1330-1340) and, when asked, publishes it together with the run's diagnostic counter to the host mailbox.
+__global__ void __launch_bounds__(kBlock) k_vcm_finish(const float4* __restrict__ tgt, const float4* __restrict__ tgt_n,
+                                                       const float4* __restrict__ src, int ns,
+                                                       const int* __restrict__ match, const double* __restrict__ QX,
+                                                       double* __restrict__ partials, unsigned* __restrict__ counter,
+                                                       double* __restrict__ vcm, VcmMail mail) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     double v[kNSums];
     v[0] = 0.0;
@@ -377,15 +414,52 @@ __global__ void __launch_bounds__(kBlock) k_vcm_resid(const float4* __restrict__
         v[0] = r * r;
     }
     block_reduce_store(v, 1, partials + (size_t)blockIdx.x * kNSums);
-}
-
-__global__ void __launch_bounds__(64) k_vcm_final(const double* __restrict__ partials, int nblocks, int ns,
-                                                  const double* __restrict__ QX, double* __restrict__ vcm) {
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x >= 64) return;
+    __threadfence();
+    unsigned last = 0;
+    if (threadIdx.x == 0) {
+        last = (atomicAdd(counter, 1u) == gridDim.x - 1u) ? 1u : 0u;
+        if (last) *counter = 0u;
+    }
+    last = (unsigned)__shfl((int)last, 0);
+    if (!last) return;
+    __threadfence();
+    const int t = threadIdx.x, nblocks = gridDim.x;
     double vtpv = 0.0;
-    for (int b = 0; b < nblocks; ++b) vtpv += partials[(size_t)b * kNSums];
+    {   // block order, eight loads in flight; every lane computes the same sum
+        int bk = 0;
+        for (; bk + 8 <= nblocks; bk += 8) {
+            double w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = partials[(size_t)(bk + u) * kNSums];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vtpv += w[u];
+        }
+        for (; bk < nblocks; ++bk) vtpv += partials[(size_t)bk * kNSums];
+    }
     const double STD0 = sqrt(vtpv / (double)(ns - 6));
-    for (int i = 0; i < 36; ++i) vcm[i] = STD0 * STD0 * QX[i];
+    double out = 0.0;
+    if (t < 36) { out = STD0 * STD0 * QX[t]; vcm[t] = out; }
+    if (!mail.dst) return;
+    // message: 36 doubles | the folded diagnostic counter (256 partial counters, 128 bytes apart) | seq
+    unsigned long long ex = 0;
+    for (int k = t; k < 256; k += 64) ex += mail.examined[(size_t)k * 16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ex += __shfl_xor(ex, o);
+    if (t < 36) {
+        unsigned lo, hi;
+        memcpy(&lo, &out, 4);
+        memcpy(&hi, (const char*)&out + 4, 4);
+        mail.dst[2 * t] = lo;
+        mail.dst[2 * t + 1] = hi;
+    }
+    if (t == 0) {
+        mail.dst[72] = (unsigned)(ex & 0xffffffffull);
+        mail.dst[73] = (unsigned)(ex >> 32);
+    }
+    __threadfence_system();
+    wave_sync();
+    if (t == 0) __hip_atomic_store(mail.seq_ptr, mail.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace
@@ -443,15 +517,13 @@ int pw_icp_run(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const
 
 // enqueue only: the 6x6 result is left in w->vcm (device)
 int pw_vcm_enqueue(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
-                   const float4* d_src, int ns) {
+                   const float4* d_src, int ns, const VcmMail* mail) {
     if (ns <= 0) return PWICP_OK;
-    const int nb = div_up(ns, kBlock);
-    hipLaunchKernelGGL(k_vcm_accum, dim3(nb), dim3(kBlock), 0, ctx->stream, g, d_tgt, d_tgt_n, d_src, ns, w->match.p,
-                       w->partials.p);
-    hipLaunchKernelGGL(k_vcm_solve, dim3(1), dim3(64), 0, ctx->stream, w->partials.p, nb, w->qx.p);
-    hipLaunchKernelGGL(k_vcm_resid, dim3(nb), dim3(kBlock), 0, ctx->stream, d_tgt, d_tgt_n, d_src, ns, w->match.p,
-                       w->qx.p, w->partials.p);
-    hipLaunchKernelGGL(k_vcm_final, dim3(1), dim3(64), 0, ctx->stream, w->partials.p, nb, ns, w->qx.p, w->vcm.p);
+    VcmMail none{};
+    hipLaunchKernelGGL(k_vcm_normal, dim3(div_up(ns, kAccPts)), dim3(kAccBlock), 0, ctx->stream, g, d_tgt, d_tgt_n, d_src, ns,
+                       w->match.p, w->partials.p, w->counter.p, w->qx.p);
+    hipLaunchKernelGGL(k_vcm_finish, dim3(div_up(ns, kBlock)), dim3(kBlock), 0, ctx->stream, d_tgt, d_tgt_n, d_src, ns,
+                       w->match.p, w->qx.p, w->partials.p, w->counter.p, w->vcm.p, mail ? *mail : none);
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }
@@ -459,13 +531,7 @@ int pw_vcm_enqueue(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, c
 int pw_vcm_run(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
                const float4* d_src, int ns, double* VCM36) {
     if (ns <= 0) { for (int i = 0; i < 36; ++i) VCM36[i] = NAN; return PWICP_OK; }
-    const int nb = div_up(ns, kBlock);
-    hipLaunchKernelGGL(k_vcm_accum, dim3(nb), dim3(kBlock), 0, ctx->stream, g, d_tgt, d_tgt_n, d_src, ns, w->match.p,
-                       w->partials.p);
-    hipLaunchKernelGGL(k_vcm_solve, dim3(1), dim3(64), 0, ctx->stream, w->partials.p, nb, w->qx.p);
-    hipLaunchKernelGGL(k_vcm_resid, dim3(nb), dim3(kBlock), 0, ctx->stream, d_tgt, d_tgt_n, d_src, ns, w->match.p,
-                       w->qx.p, w->partials.p);
-    hipLaunchKernelGGL(k_vcm_final, dim3(1), dim3(64), 0, ctx->stream, w->partials.p, nb, ns, w->qx.p, w->vcm.p);
+    PWCHK(pw_vcm_enqueue(ctx, g, d_tgt, d_tgt_n, w, d_src, ns, nullptr));
     HIPCHK(ctx, hipMemcpyAsync(VCM36, w->vcm.p, 36 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipGetLastError());

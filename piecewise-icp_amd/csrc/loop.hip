@@ -759,6 +759,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     int status = PWICP_OK;
     int prev_inner = 2;
     bool vcm_pending = false;
+    unsigned vcm_seq = 0;
     // Work that does not depend on the host's decisions is enqueued BEFORE the host waits for the mailbox, so that
     // the device never idles during a round trip: the transform update (8) reads T from the ICP state, and the
     // "front" of the next iteration (NN of centroids/boundary points + source patch normals) needs no threshold.
@@ -911,7 +912,11 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         if (!xf_enqueued) enqueue_transform(slot);                      // (8)
         // (9) R.cpp:958-961: stable centroids as copied BEFORE the update (R.cpp:868)
         if (stage3) {
-            PWCHK(pw_vcm_enqueue(ctx, pr->g_ct1.d, pr->P1.ct.p, pr->ct1n.p, &pr->icp, pr->stCT.p, ns));
+            // last iteration: the VCM's final launch also sends the run's closing message (VCM | diagnostic counter)
+            VcmMail vm;
+            vm.examined = pr->examined.p;
+            vm.dst = pr->mail_d + 16; vm.seq_ptr = pr->mail_d; vm.seq = vcm_seq = ++pr->mail_seq;
+            PWCHK(pw_vcm_enqueue(ctx, pr->g_ct1.d, pr->P1.ct.p, pr->ct1n.p, &pr->icp, pr->stCT.p, ns, &vm));
             vcm_pending = true;
             res->n_corr += ns;
         }
@@ -920,17 +925,19 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         res->n_outer = k + 1;
         res->DTseries[k + 1] = currDT;
     }
-    // final message: the VCM (R.cpp:958-961) and the diagnostic counter; its arrival also means the stream is idle
+    // closing message: the VCM (R.cpp:958-961) and the diagnostic counter; its arrival also means the stream is idle
     unsigned long long ex = 0;
-    {
+    if (vcm_pending) {
+        PWCHK(mail_wait(pr, vcm_seq));
+        memcpy(res->VCM, pr->mail_h + 16, 36 * sizeof(double));
+        memcpy(&ex, pr->mail_h + 16 + 72, sizeof(ex));
+    } else {                                              // the loop ended without Stage 3 (error / iteration cap)
         hipLaunchKernelGGL(k_fold_examined, dim3(1), dim3(64), 0, ctx->stream, pr->examined.p);
         const unsigned seq = ++pr->mail_seq;
-        hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, ctx->stream, (const unsigned*)pr->icp.vcm.p, 72,
-                           (const unsigned*)(pr->examined.p + 256 * 16), 2, (const unsigned*)nullptr, 0, pr->mail_d + 16,
-                           pr->mail_d, seq);
+        hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, ctx->stream, (const unsigned*)(pr->examined.p + 256 * 16), 2,
+                           (const unsigned*)nullptr, 0, (const unsigned*)nullptr, 0, pr->mail_d + 16, pr->mail_d, seq);
         PWCHK(mail_wait(pr, seq));
-        if (vcm_pending) memcpy(res->VCM, pr->mail_h + 16, 36 * sizeof(double));
-        memcpy(&ex, pr->mail_h + 16 + 72, sizeof(ex));
+        memcpy(&ex, pr->mail_h + 16, sizeof(ex));
     }
     res->t_loop_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // events below must have completed
