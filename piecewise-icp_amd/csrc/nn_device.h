@@ -235,21 +235,38 @@ __device__ __forceinline__ void group_min(NNBest& b) {
     }
 }
 
-// rows (y in [y0,y1], z in [z0,z1]) x [x0,x1] dealt round-robin to the lanes of the group
+// up to four loads in flight per pass: a short range costs ONE memory round trip instead of one per two points
+__device__ __forceinline__ void scan_points4(const float4* __restrict__ pts, int lo, int hi, int step, float qx, float qy,
+                                             float qz, NNBest& b) {
+    for (int j = lo; j < hi; j += 4 * step) {
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (j + u * step < hi) p[u] = pts[j + u * step];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (j + u * step < hi) nn_consider(p[u], qx, qy, qz, b);
+    }
+}
+
+// rows (y in [y0,y1], z in [z0,z1]) x [x0,x1], shared by the group: the lanes fetch the begin/end words of eight rows
+// at once (one row each), hand them round with shuffles, and then walk every row TOGETHER, points interleaved over the
+// lanes, four loads in flight each.  The chain is 1 + sum_rows ceil(n_row / 32) round trips, whatever the shape of
+// the box (the coarse boxes of stage 2 have few, long rows).
 __device__ __forceinline__ void scan_box_group(const GridLevel& g, int x0, int x1, int y0, int y1, int z0, int z1, int sub,
                                                float qx, float qy, float qz, NNBest& b) {
     const int wy = y1 - y0 + 1;
     const int nrows = wy * (z1 - z0 + 1);
-    for (int t0 = sub; t0 < nrows; t0 += 2 * kGroup) {
-        int lo[2], hi[2];
+    const int gbase = (int)(__lane_id() & ~(unsigned)(kGroup - 1));
+    for (int t0 = 0; t0 < nrows; t0 += kGroup) {
+        int lo_s = 0, hi_s = 0;
+        const int t = t0 + sub;
+        if (t < nrows) row_range(g, y0 + t % wy, z0 + t / wy, x0, x1, lo_s, hi_s);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int t = t0 + k * kGroup;
-            lo[k] = hi[k] = 0;
-            if (t < nrows) row_range(g, y0 + t % wy, z0 + t / wy, x0, x1, lo[k], hi[k]);
+        for (int k = 0; k < kGroup; ++k) {
+            const int lo = __shfl(lo_s, gbase + k), hi = __shfl(hi_s, gbase + k);
+            scan_points4(g.pts, lo + sub, hi, kGroup, qx, qy, qz, b);
         }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) scan_points(g.pts, lo[k], hi[k], qx, qy, qz, b);
     }
 }
 
@@ -264,8 +281,8 @@ __device__ __forceinline__ NNBest nn_query_group(const GridDesc& gd, float qx, f
         int lo0, hi0, lo1 = 0, hi1 = 0;
         row_range(g, cy + (sub % 3) - 1, cz + (sub / 3) - 1, cx - 1, cx + 1, lo0, hi0);
         if (sub == 0) row_range(g, cy + 1, cz + 1, cx - 1, cx + 1, lo1, hi1);
-        scan_points(g.pts, lo0, hi0, qx, qy, qz, b);
-        scan_points(g.pts, lo1, hi1, qx, qy, qz, b);
+        scan_points4(g.pts, lo0, hi0, 1, qx, qy, qz, b);
+        scan_points4(g.pts, lo1, hi1, 1, qx, qy, qz, b);
         group_min(b);
         if (nn_resolved(g, 1, b)) return b;
     }
@@ -305,8 +322,8 @@ __device__ __forceinline__ NNBest nn_query_group(const GridDesc& gd, float qx, f
                     row_range(c, cy + dy, cz + dz, cx - r, cx - r, lo0, hi0);
                     row_range(c, cy + dy, cz + dz, cx + r, cx + r, lo1, hi1);
                 }
-                scan_points(c.pts, lo0, hi0, qx, qy, qz, b);
-                scan_points(c.pts, lo1, hi1, qx, qy, qz, b);
+                scan_points4(c.pts, lo0, hi0, 1, qx, qy, qz, b);
+                scan_points4(c.pts, lo1, hi1, 1, qx, qy, qz, b);
             }
             group_min(b);
         }

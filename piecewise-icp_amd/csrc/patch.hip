@@ -377,6 +377,12 @@ int pw_patch_normals_launch(pwicp_context* ctx, const float4* d_pat, const int* 
 int pw_front_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, int m, float4* d_nrm, const GridDesc& g,
                     const float4* d_q, int nq, int* d_idx, float* d_d2) {
     if (m <= 0 || nq <= 0) return PWICP_OK;
+    static int split = -1;               // PWICP_FRONT_SPLIT=1: two launches (A/B measurements only)
+    if (split < 0) { const char* e = getenv("PWICP_FRONT_SPLIT"); split = e ? atoi(e) : 0; }
+    if (split) {
+        PWCHK(pw_patch_normals_launch(ctx, d_pat, d_off, m, d_nrm));
+        return pw_nn_launch(ctx, g, d_q, nq, d_idx, d_d2, nullptr);
+    }
     const int nb_nrm = div_up((long long)m * kGroup, kFrontBlock);
     const int nb_nn = div_up((long long)nq * kGroup, kFrontBlock);
     hipLaunchKernelGGL(k_front, dim3(nb_nrm + nb_nn), dim3(kFrontBlock), 0, ctx->stream, d_pat, d_off, m, d_nrm, nb_nrm, g,
