@@ -145,38 +145,61 @@ __device__ inline void ct_bp(const float4* __restrict__ p, const unsigned char* 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Plane normal of patch i, computed by a group of kGroup (8) consecutive lanes.  The group loads 8 consecutive points
-// per request (one 128-byte line, up to kAhead requests in flight) and hands them round with lane shuffles; every lane
-// of the group then performs the SAME running sums over the points in storage order — the nine float accumulators are
-// those of pcl::computeMeanAndCovarianceMatrix exactly.  Compared with one lane per patch a wave touches 8 cache lines
-// per request instead of 64 and needs 1-2 memory round trips per patch instead of ~10.
-constexpr int kAhead = 8;
+// Plane normal of patch i, computed by a group of kGroup (8) consecutive lanes.  The group loads 64 consecutive points
+// per pass (8 coalesced requests in flight per lane) into its LDS tile; then every lane owns ONE of the nine running
+// sums of pcl::computeMeanAndCovarianceMatrix (lane 7 owns two) and adds the points' terms in storage order — the
+// same float operations in the same order as the serial loop, but ~7 instead of ~21 instructions per point and lane,
+// and 1-2 memory round trips per patch instead of ~10.
+//   lane:      0    1    2    3    4    5    6    7
+//   sum:       xx   xy   xz   yy   yz   zz   x    y (and z)
+constexpr int kAhead = 4;
+constexpr int kTilePts = kGroup * kAhead;            // 32 points per pass (16 KiB of LDS per 256-thread block)
+constexpr int kTileStride = kTilePts + 1;            // float4 units; +1: the 8 tiles of a wave start on different banks
 __device__ __forceinline__ void patch_normal_group(const float4* __restrict__ pat, const int* __restrict__ off, int i, int sub,
-                                                   float4* __restrict__ nrm_out) {
+                                                   float4* __restrict__ nrm_out, float4* __restrict__ tile) {
     const int lo = off[i], hi = off[i + 1];
-    const int gbase = (threadIdx.x & 63) & ~(kGroup - 1);        // first lane of this group within the wave
-    float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
-    for (int base = lo; base < hi; base += kGroup * kAhead) {
-        float4 v[kAhead];
+    const int gbase = (int)(__lane_id() & ~(unsigned)(kGroup - 1));       // first lane of this group within the wave
+    // operand components of this lane's sum (w = 1 turns a plain sum into the same mul-then-add)
+    const int c1 = sub < 3 ? 0 : (sub < 5 ? 1 : (sub == 5 ? 2 : (sub == 6 ? 0 : 1)));
+    const int c2 = sub == 0 ? 0 : (sub == 1 || sub == 3) ? 1 : (sub == 2 || sub == 4 || sub == 5) ? 2 : 3;
+    const float* tw = (const float*)tile;
+    float acc = 0.f, acc8 = 0.f;
+    float4 nxt[kAhead];                                // the next pass's points travel while this pass is summed
 #pragma unroll
-        for (int u = 0; u < kAhead; ++u) {
-            const int j = base + u * kGroup + sub;
-            v[u] = (j < hi) ? pat[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < kAhead; ++u) {
-            if (base + u * kGroup >= hi) break;                  // uniform within the group
-#pragma unroll
-            for (int t = 0; t < kGroup; ++t) {
-                const float x = __shfl(v[u].x, gbase + t), y = __shfl(v[u].y, gbase + t), z = __shfl(v[u].z, gbase + t);
-                if (base + u * kGroup + t < hi) {
-                    a0 += x * x; a1 += x * y; a2 += x * z;
-                    a3 += y * y; a4 += y * z; a5 += z * z;
-                    a6 += x; a7 += y; a8 += z;
-                }
-            }
-        }
+    for (int u = 0; u < kAhead; ++u) {
+        const int j = lo + u * kGroup + sub;
+        nxt[u] = (j < hi) ? pat[j] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    for (int base = lo; base < hi; base += kTilePts) {
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            float4 v = nxt[u];
+            v.w = 1.0f;
+            tile[u * kGroup + sub] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const int j = base + kTilePts + u * kGroup + sub;
+            nxt[u] = (j < hi) ? pat[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");          // the tile is private to this group (one wave)
+        __builtin_amdgcn_wave_barrier();
+        const int cnt = min(kTilePts, hi - base);
+        int t = 0;
+        for (; t + 8 <= cnt; t += 8) {
+            float p[8], q[8], z[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { p[u] = tw[(t + u) * 4 + c1]; q[u] = tw[(t + u) * 4 + c2]; z[u] = tw[(t + u) * 4 + 2]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc += p[u] * q[u]; acc8 += z[u]; }
+        }
+        for (; t < cnt; ++t) { acc += tw[t * 4 + c1] * tw[t * 4 + c2]; acc8 += tw[t * 4 + 2]; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    float a0 = __shfl(acc, gbase + 0), a1 = __shfl(acc, gbase + 1), a2 = __shfl(acc, gbase + 2), a3 = __shfl(acc, gbase + 3),
+          a4 = __shfl(acc, gbase + 4), a5 = __shfl(acc, gbase + 5), a6 = __shfl(acc, gbase + 6), a7 = __shfl(acc, gbase + 7),
+          a8 = __shfl(acc8, gbase + 7);
     const int n = hi - lo;
     float nv[3] = {0.f, 0.f, 1.f};
     bool ok = false;
@@ -203,9 +226,10 @@ __device__ __forceinline__ void patch_normal_group(const float4* __restrict__ pa
 
 __global__ void __launch_bounds__(kFrontBlock) k_patch_normals(const float4* __restrict__ pat, const int* __restrict__ off,
                                                                int m, float4* __restrict__ nrm_out) {
+    __shared__ float4 tiles[(kFrontBlock / kGroup) * kTileStride];
     const int t = blockIdx.x * kFrontBlock + threadIdx.x;
     const int i = t / kGroup;
-    if (i < m) patch_normal_group(pat, off, i, t % kGroup, nrm_out);      // a whole group is in or out of range together
+    if (i < m) patch_normal_group(pat, off, i, t % kGroup, nrm_out, tiles + (threadIdx.x / kGroup) * kTileStride);   // a whole group is in or out of range together
 }
 
 // The "front" of an outer iteration in ONE launch: blocks [0, nb_nrm) compute the source patch normals (R.cpp:824),
@@ -217,10 +241,11 @@ __global__ void __launch_bounds__(kFrontBlock) k_front(const float4* __restrict_
                                                        float4* __restrict__ nrm_out, int nb_nrm, GridDesc g,
                                                        const float4* __restrict__ q, int nq, int* __restrict__ idx,
                                                        float* __restrict__ d2) {
+    __shared__ float4 tiles[(kFrontBlock / kGroup) * kTileStride];
     if ((int)blockIdx.x < nb_nrm) {
         const int t = blockIdx.x * kFrontBlock + threadIdx.x;
         const int i = t / kGroup;
-        if (i < m) patch_normal_group(pat, off, i, t % kGroup, nrm_out);
+        if (i < m) patch_normal_group(pat, off, i, t % kGroup, nrm_out, tiles + (threadIdx.x / kGroup) * kTileStride);
         return;
     }
     const int t = (blockIdx.x - nb_nrm) * kFrontBlock + threadIdx.x;
