@@ -172,9 +172,10 @@ def main():
     if n_launch > 0 and t_dense_ms > 0:
         nq = sum(rr.n_corr_dense for rr in results) / n_launch
         kbar = res.dense_kbar
-        # algorithmic bytes per correspondence: query 16 + d2 out 4 + 9 stencil rows x
-        # (begin,end) 8 + 16 per target point examined
-        b_nn = 16.0 + 4.0 + 9 * 8.0 + 16.0 * kbar
+        # algorithmic bytes per correspondence: query 16 + d2 out 4 + stencil rows (9 for a
+        # grid of cells, 3 for a grid of columns) x (begin,end) 8 + 16 per target point examined
+        rows = int(res.dense_rows) or 9
+        b_nn = 16.0 + 4.0 + rows * 8.0 + 16.0 * kbar
         dur_s = (t_dense_ms / n_launch) * 1e-3
         achieved = b_nn * nq / dur_s / 1e9
         traffic = None
@@ -186,7 +187,7 @@ def main():
                 traffic = None
         roofline = {"bound": "hbm", "kernel": "k_nn_dense_direct", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "bytes_per_correspondence": round(b_nn, 1), "kbar": round(kbar, 2),
+                    "bytes_per_correspondence": round(b_nn, 1), "kbar": round(kbar, 2), "stencil_rows": rows,
                     "queries_per_launch": int(nq), "avg_launch_us": round(dur_s * 1e6, 2),
                     "compulsory_bytes_per_correspondence": round(16 + 4 + 16.0 * len(tgt) / max(nq, 1.0), 1),
                     # the algorithmic stream (every query re-reads its stencil) is mostly served by L1/L2: the bytes

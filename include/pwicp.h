@@ -148,6 +148,8 @@ typedef struct {
     int    n_dense_nn_launches;
     double t_inner_ms;                    /* HIP-event time of the inner-ICP launches        */
     double dense_kbar;                    /* mean target points examined per dense query     */
+    int32_t dense_rows;                   /* stencil rows per dense query: 9 (cells) or 3 (columns) */
+    int32_t reserved0;
 } pwicp_result;
 
 /* Uploads both clouds and their supervoxel labellings, runs patch selection/statistics and builds

@@ -58,6 +58,10 @@ struct DevBuf {
         p = nullptr;
         n = 0;
     }
+    void swap(DevBuf& o) {
+        T* tp = p; p = o.p; o.p = tp;
+        size_t tn = n; n = o.n; o.n = tn;
+    }
     // grows only; contents are NOT preserved
     hipError_t reserve(size_t count) {
         if (count <= n && p) return hipSuccess;
@@ -79,6 +83,7 @@ static inline int div_up(long long a, int b) { return (int)((a + b - 1) / b); }
 struct GridLevel {
     float ox, oy, oz;        // origin = min corner of the bounding box
     float h, inv_h;          // cell edge
+    float inv_hy, inv_hz;    // = inv_h, or 0 for a level of COLUMNS along that axis (ny or nz = 1), see pw_grid_build
     float slack;             // bound on |computed cell boundary - true boundary| (rounding)
     int nx, ny, nz;
     int n;                   // number of points

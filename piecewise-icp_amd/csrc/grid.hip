@@ -77,8 +77,8 @@ __global__ void k_cell_count(const float4* __restrict__ p, int n, GridLevel g, i
     if (i >= n) return;
     float4 v = p[i];
     int cx = min(max(cell_of(v.x, g.ox, g.inv_h), 0), g.nx - 1);
-    int cy = min(max(cell_of(v.y, g.oy, g.inv_h), 0), g.ny - 1);
-    int cz = min(max(cell_of(v.z, g.oz, g.inv_h), 0), g.nz - 1);
+    int cy = min(max(cell_of(v.y, g.oy, g.inv_hy), 0), g.ny - 1);
+    int cz = min(max(cell_of(v.z, g.oz, g.inv_hz), 0), g.nz - 1);
     int c = (cz * g.ny + cy) * g.nx + cx;
     cell_id[i] = c;
     rank[i] = atomicAdd(&cnt[c], 1);
@@ -217,8 +217,8 @@ __device__ __forceinline__ void nn_block_search(const GridDesc& gd, bool active,
             if (c.found()) {
                 const float rho = sqrtf(c.d2()) * 1.00001f + 2.0f * cl.slack;
                 x0 = max(cell_of(u.x - rho, cl.ox, cl.inv_h), 0); x1 = min(cell_of(u.x + rho, cl.ox, cl.inv_h), cl.nx - 1);
-                y0 = max(cell_of(u.y - rho, cl.oy, cl.inv_h), 0); y1 = min(cell_of(u.y + rho, cl.oy, cl.inv_h), cl.ny - 1);
-                z0 = max(cell_of(u.z - rho, cl.oz, cl.inv_h), 0); z1 = min(cell_of(u.z + rho, cl.oz, cl.inv_h), cl.nz - 1);
+                y0 = max(cell_of(u.y - rho, cl.oy, cl.inv_hy), 0); y1 = min(cell_of(u.y + rho, cl.oy, cl.inv_hy), cl.ny - 1);
+                z0 = max(cell_of(u.z - rho, cl.oz, cl.inv_hz), 0); z1 = min(cell_of(u.z + rho, cl.oz, cl.inv_hz), cl.nz - 1);
                 coop = (y1 - y0 + 1) * (z1 - z0 + 1) <= 64;
             }
             if (coop) {
@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_lds(GridDesc gd, const floa
     int cx = 0, cy = 0, cz = 0;
     bool ingrid = false;
     if (active) {
-        cx = cell_of(q.x, g.ox, g.inv_h); cy = cell_of(q.y, g.oy, g.inv_h); cz = cell_of(q.z, g.oz, g.inv_h);
+        cx = cell_of(q.x, g.ox, g.inv_h); cy = cell_of(q.y, g.oy, g.inv_hy); cz = cell_of(q.z, g.oz, g.inv_hz);
         ingrid = cx >= 0 && cx < g.nx && cy >= 0 && cy < g.ny && cz >= 0 && cz < g.nz;
     }
     // box of the block's in-grid query cells
@@ -445,8 +445,8 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_lds(GridDesc gd, const floa
                 const GridLevel& c = gd.coarse;
                 const float rho = sqrtf(b.d2()) * 1.00001f + 2.0f * c.slack;
                 const int a0 = max(cell_of(q.x - rho, c.ox, c.inv_h), 0), a1 = min(cell_of(q.x + rho, c.ox, c.inv_h), c.nx - 1);
-                const int b0 = max(cell_of(q.y - rho, c.oy, c.inv_h), 0), b1 = min(cell_of(q.y + rho, c.oy, c.inv_h), c.ny - 1);
-                const int c0 = max(cell_of(q.z - rho, c.oz, c.inv_h), 0), c1 = min(cell_of(q.z + rho, c.oz, c.inv_h), c.nz - 1);
+                const int b0 = max(cell_of(q.y - rho, c.oy, c.inv_hy), 0), b1 = min(cell_of(q.y + rho, c.oy, c.inv_hy), c.ny - 1);
+                const int c0 = max(cell_of(q.z - rho, c.oz, c.inv_hz), 0), c1 = min(cell_of(q.z + rho, c.oz, c.inv_hz), c.nz - 1);
                 if ((b1 - b0 + 1) * (c1 - c0 + 1) <= 64) {
                     if (a0 <= a1 && b0 <= b1 && c0 <= c1) ex = scan_box(c, a0, a1, b0, b1, c0, c1, q.x, q.y, q.z, b);
                 } else {
@@ -503,8 +503,8 @@ __global__ void k_morton_keys(GridLevel g, const float4* __restrict__ p, int n, 
     if (i >= n) return;
     const float4 v = p[i];
     const unsigned cx = (unsigned)min(max(cell_of(v.x, g.ox, g.inv_h), 0), g.nx - 1) >> shift;
-    const unsigned cy = (unsigned)min(max(cell_of(v.y, g.oy, g.inv_h), 0), g.ny - 1) >> shift;
-    const unsigned cz = (unsigned)min(max(cell_of(v.z, g.oz, g.inv_h), 0), g.nz - 1) >> shift;
+    const unsigned cy = (unsigned)min(max(cell_of(v.y, g.oy, g.inv_hy), 0), g.ny - 1) >> shift;
+    const unsigned cz = (unsigned)min(max(cell_of(v.z, g.oz, g.inv_hz), 0), g.nz - 1) >> shift;
     keys[i] = part1by2(cx) | (part1by2(cy) << 1) | (part1by2(cz) << 2);
     vals[i] = i;
 }
@@ -530,7 +530,7 @@ __global__ void __launch_bounds__(kBlock) k_knn(GridLevel g, int k, Real* __rest
     const float4 q = g.pts[t];
     const int self = __float_as_int(q.w);
     const Real qx = (Real)q.x, qy = (Real)q.y, qz = (Real)q.z;
-    const int cx = cell_of(q.x, g.ox, g.inv_h), cy = cell_of(q.y, g.oy, g.inv_h), cz = cell_of(q.z, g.oz, g.inv_h);
+    const int cx = cell_of(q.x, g.ox, g.inv_h), cy = cell_of(q.y, g.oy, g.inv_hy), cz = cell_of(q.z, g.oz, g.inv_hz);
     const int rcover = max(max(max(cx, g.nx - 1 - cx), max(cy, g.ny - 1 - cy)), max(cz, g.nz - 1 - cz));
     int cnt = 0;
     for (int r = 2;; ++r) {
@@ -738,11 +738,12 @@ namespace {
 
 // one level: counting sort of the points by cell of edge h over the bounding box [mn, mx]
 int build_level(pwicp_context* ctx, const float4* d_pts, int n, float h, const float* mn, const float* mx,
-                GridLevel* d, DevBuf<int>* cell_start, DevBuf<float4>* pts) {
+                GridLevel* d, DevBuf<int>* cell_start, DevBuf<float4>* pts, int flat_axis) {
     // cap the dense cell array at 2^28 cells (1 GiB of int32): coarser cells stay exact, only slower
     for (;;) {
         double cells = 1.0;
-        for (int k = 0; k < 3; ++k) cells *= std::floor((double)(mx[k] - mn[k]) / h) + 2.0;
+        for (int k = 0; k < 3; ++k)
+            if (k != flat_axis || flat_axis == 0) cells *= std::floor((double)(mx[k] - mn[k]) / h) + 2.0;
         if (cells <= 268435456.0) break;
         h *= 1.26f;
     }
@@ -753,6 +754,9 @@ int build_level(pwicp_context* ctx, const float4* d_pts, int n, float h, const f
     d->nx = (int)std::floor((mx[0] - mn[0]) * d->inv_h) + 1;
     d->ny = (int)std::floor((mx[1] - mn[1]) * d->inv_h) + 1;
     d->nz = (int)std::floor((mx[2] - mn[2]) * d->inv_h) + 1;
+    d->inv_hy = d->inv_hz = d->inv_h;
+    if (flat_axis == 1) { d->ny = 1; d->inv_hy = 0.0f; }       // columns along y
+    if (flat_axis == 2) { d->nz = 1; d->inv_hz = 0.0f; }       // columns along z
     float maxabs = 0.f;
     for (int k = 0; k < 3; ++k) maxabs = std::max(maxabs, std::max(std::fabs(mn[k]), std::fabs(mx[k])));
     const int maxdim = std::max(d->nx, std::max(d->ny, d->nz));
@@ -807,7 +811,7 @@ int pw_grid_build(pwicp_context* ctx, const float4* d_pts, int n, float cell_edg
         HIPCHK(ctx, hipMemsetAsync(g->cell_start.p, 0, 2 * sizeof(int), ctx->stream));
         HIPCHK(ctx, g->pts.reserve(1));
         GridLevel e{};
-        e.nx = e.ny = e.nz = 1; e.h = 1.f; e.inv_h = 1.f; e.n = 0;
+        e.nx = e.ny = e.nz = 1; e.h = 1.f; e.inv_h = 1.f; e.inv_hy = 1.f; e.inv_hz = 1.f; e.n = 0;
         e.cell_start = g->cell_start.p; e.pts = g->pts.p;
         d.fine = e; d.coarse = e;
         return PWICP_OK;
@@ -815,20 +819,56 @@ int pw_grid_build(pwicp_context* ctx, const float4* d_pts, int n, float cell_edg
     float mn[3], mx[3];
     PWCHK(pw_bbox(ctx, d_pts, n, mn, mx));
     const float h = cell_edge > 0.f ? cell_edge : 1.f;
-    PWCHK(build_level(ctx, d_pts, n, h, mn, mx, &d.fine, &g->cell_start, &g->pts));
-    PWCHK(build_level(ctx, d_pts, n, 4.0f * d.fine.h, mn, mx, &d.coarse, &g->ccell_start, &g->cpts));
-    // Kbar of the fine 27-cell stencil (reported with every run)
-    DevBuf<unsigned long long> acc;
-    HIPCHK(ctx, acc.reserve(1));
-    HIPCHK(ctx, hipMemsetAsync(acc.p, 0, sizeof(unsigned long long), ctx->stream));
-    const long long ncell = (long long)d.fine.nx * d.fine.ny * d.fine.nz;
-    int nbk = (int)std::min<long long>((ncell + kBlock - 1) / kBlock, (long long)ctx->n_cu * 16);
-    hipLaunchKernelGGL(k_kbar27, dim3(nbk), dim3(kBlock), 0, ctx->stream, d.fine, acc.p);
-    unsigned long long hacc = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&hacc, acc.p, sizeof(hacc), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // Layout of the levels: cells (3-D) or columns (cells in two axes, unbounded along y or z).  A search visits the
+    // 3 x 3 rows around the query's cell; with columns that is 3 rows instead of 9 — for surface-like clouds whose
+    // sheet is roughly normal to the collapsed axis the candidate set is the same, and a row costs about as much as
+    // kRowCost candidates (measured on the dense 1-NN kernel: 9 rows + 79 candidates 107 us, 3 rows + 81 candidates
+    // 73 us per 754 k queries).  The exactness bound r*h - 2*slack only uses the two gridded axes, so every layout
+    // gives the same (d2, index) minimum; the choice is purely a cost estimate from the measured stencil occupancy.
+    // PWICP_GRID_LAYOUT = 0 / 1 / 2 forces cells / y-columns / z-columns.
+    constexpr double kRowCost = 8.0;
+    static int forced = -2;
+    if (forced == -2) { const char* e = getenv("PWICP_GRID_LAYOUT"); forced = e ? atoi(e) : -1; }
+    auto kbar_of = [&](const GridLevel& lv, double* out) -> int {
+        DevBuf<unsigned long long> acc;
+        HIPCHK(ctx, acc.reserve(1));
+        HIPCHK(ctx, hipMemsetAsync(acc.p, 0, sizeof(unsigned long long), ctx->stream));
+        const long long ncell = (long long)lv.nx * lv.ny * lv.nz;
+        int nbk = (int)std::min<long long>((ncell + kBlock - 1) / kBlock, (long long)ctx->n_cu * 16);
+        hipLaunchKernelGGL(k_kbar27, dim3(nbk), dim3(kBlock), 0, ctx->stream, lv, acc.p);
+        unsigned long long hacc = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&hacc, acc.p, sizeof(hacc), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        *out = (double)hacc / (double)n;
+        return PWICP_OK;
+    };
+    int best_axis = 0;
+    double best_cost = 0.0;
+    {
+        // candidates: cells, and columns along the thinner of the y / z extents (x is the row direction)
+        int cand[2] = {0, (mx[1] - mn[1]) < (mx[2] - mn[2]) ? 1 : 2};
+        int ncand = 2;
+        if (forced >= 0 && forced <= 2) { cand[0] = forced; ncand = 1; }
+        for (int c = 0; c < ncand; ++c) {
+            GridLevel lv{};
+            DevBuf<int> cs;
+            DevBuf<float4> ps;
+            PWCHK(build_level(ctx, d_pts, n, h, mn, mx, &lv, &cs, &ps, cand[c]));
+            double kb = 0.0;
+            PWCHK(kbar_of(lv, &kb));
+            const double cost = kRowCost * (cand[c] ? 3.0 : 9.0) + kb;
+            if (c == 0 || cost < best_cost) {
+                best_cost = cost;
+                best_axis = cand[c];
+                d.fine = lv;
+                g->cell_start.swap(cs);
+                g->pts.swap(ps);
+                g->kbar27 = kb;
+            }
+        }
+    }
+    PWCHK(build_level(ctx, d_pts, n, 4.0f * d.fine.h, mn, mx, &d.coarse, &g->ccell_start, &g->cpts, best_axis));
     HIPCHK(ctx, hipGetLastError());
-    g->kbar27 = (double)hacc / (double)n;
     return PWICP_OK;
 }
 

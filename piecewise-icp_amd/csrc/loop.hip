@@ -948,6 +948,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         }
     }
     res->dense_kbar = res->n_corr_dense > 0 ? (double)ex / (double)res->n_corr_dense : 0.0;
+    res->dense_rows = (pr->g_c1.d.fine.ny == 1 || pr->g_c1.d.fine.nz == 1) ? 3 : 9;
     res->status = status;
     HIPCHK(ctx, hipGetLastError());
     return status;

@@ -161,7 +161,7 @@ __device__ __forceinline__ bool nn_resolved(const GridLevel& g, int r, const NNB
 
 // stage 3: block of radius r0 (where the grid starts) then shell by shell, on one level
 __device__ __forceinline__ unsigned nn_expand(const GridLevel& g, float qx, float qy, float qz, NNBest& b) {
-    const int cx = cell_of(qx, g.ox, g.inv_h), cy = cell_of(qy, g.oy, g.inv_h), cz = cell_of(qz, g.oz, g.inv_h);
+    const int cx = cell_of(qx, g.ox, g.inv_h), cy = cell_of(qy, g.oy, g.inv_hy), cz = cell_of(qz, g.oz, g.inv_hz);
     const int ex = max(0, max(-cx, cx - (g.nx - 1)));
     const int ey = max(0, max(-cy, cy - (g.ny - 1)));
     const int ez = max(0, max(-cz, cz - (g.nz - 1)));
@@ -180,7 +180,7 @@ __device__ __forceinline__ unsigned nn_expand(const GridLevel& g, float qx, floa
 // stage 1: fine 27-cell stencil; returns true when the result is final
 __device__ __forceinline__ bool nn_stage1(const GridDesc& gd, float qx, float qy, float qz, NNBest& b, unsigned& cnt) {
     const GridLevel& g = gd.fine;
-    const int cx = cell_of(qx, g.ox, g.inv_h), cy = cell_of(qy, g.oy, g.inv_h), cz = cell_of(qz, g.oz, g.inv_h);
+    const int cx = cell_of(qx, g.ox, g.inv_h), cy = cell_of(qy, g.oy, g.inv_hy), cz = cell_of(qz, g.oz, g.inv_hz);
     int lo[9], hi[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) row_range(g, cy + (k % 3) - 1, cz + (k / 3) - 1, cx - 1, cx + 1, lo[k], hi[k]);
@@ -199,8 +199,8 @@ __device__ __forceinline__ void nn_stage23(const GridDesc& gd, float qx, float q
         // candidate known -> scan the coarse cells touching the cube [q - rho, q + rho]
         const float rho = sqrtf(b.d2()) * 1.00001f + 2.0f * c.slack;
         const int x0 = max(cell_of(qx - rho, c.ox, c.inv_h), 0), x1 = min(cell_of(qx + rho, c.ox, c.inv_h), c.nx - 1);
-        const int y0 = max(cell_of(qy - rho, c.oy, c.inv_h), 0), y1 = min(cell_of(qy + rho, c.oy, c.inv_h), c.ny - 1);
-        const int z0 = max(cell_of(qz - rho, c.oz, c.inv_h), 0), z1 = min(cell_of(qz + rho, c.oz, c.inv_h), c.nz - 1);
+        const int y0 = max(cell_of(qy - rho, c.oy, c.inv_hy), 0), y1 = min(cell_of(qy + rho, c.oy, c.inv_hy), c.ny - 1);
+        const int z0 = max(cell_of(qz - rho, c.oz, c.inv_hz), 0), z1 = min(cell_of(qz + rho, c.oz, c.inv_hz), c.nz - 1);
         if ((y1 - y0 + 1) * (z1 - z0 + 1) <= 64) {
             if (x0 <= x1 && y0 <= y1 && z0 <= z1) cnt += scan_box(c, x0, x1, y0, y1, z0, z1, qx, qy, qz, b);
             return;
@@ -277,7 +277,7 @@ __device__ __forceinline__ NNBest nn_query_group(const GridDesc& gd, float qx, f
     if (g.n <= 0) return b;
     // stage 1: the 9 stencil rows over the 8 lanes (lane 0 also takes the ninth)
     {
-        const int cx = cell_of(qx, g.ox, g.inv_h), cy = cell_of(qy, g.oy, g.inv_h), cz = cell_of(qz, g.oz, g.inv_h);
+        const int cx = cell_of(qx, g.ox, g.inv_h), cy = cell_of(qy, g.oy, g.inv_hy), cz = cell_of(qz, g.oz, g.inv_hz);
         int lo0, hi0, lo1 = 0, hi1 = 0;
         row_range(g, cy + (sub % 3) - 1, cz + (sub / 3) - 1, cx - 1, cx + 1, lo0, hi0);
         if (sub == 0) row_range(g, cy + 1, cz + 1, cx - 1, cx + 1, lo1, hi1);
@@ -291,8 +291,8 @@ __device__ __forceinline__ NNBest nn_query_group(const GridDesc& gd, float qx, f
     if (b.found()) {
         const float rho = sqrtf(b.d2()) * 1.00001f + 2.0f * c.slack;
         const int x0 = max(cell_of(qx - rho, c.ox, c.inv_h), 0), x1 = min(cell_of(qx + rho, c.ox, c.inv_h), c.nx - 1);
-        const int y0 = max(cell_of(qy - rho, c.oy, c.inv_h), 0), y1 = min(cell_of(qy + rho, c.oy, c.inv_h), c.ny - 1);
-        const int z0 = max(cell_of(qz - rho, c.oz, c.inv_h), 0), z1 = min(cell_of(qz + rho, c.oz, c.inv_h), c.nz - 1);
+        const int y0 = max(cell_of(qy - rho, c.oy, c.inv_hy), 0), y1 = min(cell_of(qy + rho, c.oy, c.inv_hy), c.ny - 1);
+        const int z0 = max(cell_of(qz - rho, c.oz, c.inv_hz), 0), z1 = min(cell_of(qz + rho, c.oz, c.inv_hz), c.nz - 1);
         if ((y1 - y0 + 1) * (z1 - z0 + 1) <= 64) {
             if (x0 <= x1 && y0 <= y1 && z0 <= z1) scan_box_group(c, x0, x1, y0, y1, z0, z1, sub, qx, qy, qz, b);
             group_min(b);
@@ -301,7 +301,7 @@ __device__ __forceinline__ NNBest nn_query_group(const GridDesc& gd, float qx, f
     }
     // stage 3: block, then shells, on the coarse level; a group-min after every block/shell keeps the stop test uniform
     {
-        const int cx = cell_of(qx, c.ox, c.inv_h), cy = cell_of(qy, c.oy, c.inv_h), cz = cell_of(qz, c.oz, c.inv_h);
+        const int cx = cell_of(qx, c.ox, c.inv_h), cy = cell_of(qy, c.oy, c.inv_hy), cz = cell_of(qz, c.oz, c.inv_hz);
         const int ex = max(0, max(-cx, cx - (c.nx - 1)));
         const int ey = max(0, max(-cy, cy - (c.ny - 1)));
         const int ez = max(0, max(-cz, cz - (c.nz - 1)));
