@@ -283,6 +283,7 @@ __global__ void __launch_bounds__(kBlock) k_nn_points_group(GridDesc g, const fl
 // 5x5x5 shell, out of LDS.  Only queries that are still unresolved (farther than ~2 cell edges from any target
 // point), queries outside the grid, or blocks whose box does not fit the LDS budget take the global-memory
 // two-level path of nn_device.h.  Same arithmetic, same tie rule: results are bit-identical to k_nn_points.
+constexpr int kXcds = 8;           // accelerator complex dies of an MI355X (one L2 each)
 constexpr int kPtCap = 2048;      // staged points   (32 KiB)
 constexpr int kCsCap = 3072;      // staged begin/end words (12 KiB)
 constexpr int kRowCap = 256;      // staged cell rows
@@ -474,8 +475,12 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_direct(GridDesc gd, const f
                                                             const int* __restrict__ pt_patch,
                                                             const int* __restrict__ stable, int nq,
                                                             float* __restrict__ d2out,
-                                                            unsigned long long* __restrict__ examined) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+                                                            unsigned long long* __restrict__ examined, int chunk) {
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Workgroup b therefore
+    // takes tile (b % 8) * chunk + b / 8, so that every XCD walks ONE contiguous eighth of the Morton-ordered queries
+    // and its L2 only ever holds that eighth of the target cloud (chunk = ceil(#tiles / 8); chunk = 0: identity).
+    const int tile = chunk > 0 ? (int)(blockIdx.x % kXcds) * chunk + (int)(blockIdx.x / kXcds) : (int)blockIdx.x;
+    const int i = tile * kBlock + threadIdx.x;
     unsigned cnt = 0;
     bool active = false;
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -928,8 +933,14 @@ int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pa
         hipLaunchKernelGGL(k_nn_dense_lds, dim3(div_up(nq, kBlock)), dim3(kBlock), 0, ctx->stream, g, d_pat, d_qorder,
                            d_pt_patch, d_stable, nq, d_d2, d_examined);
     else
-        hipLaunchKernelGGL(k_nn_dense_direct, dim3(div_up(nq, kBlock)), dim3(kBlock), 0, ctx->stream, g, d_pat,
-                           variant == 1 ? d_qorder : (const int*)nullptr, d_pt_patch, d_stable, nq, d_d2, d_examined);
+    {
+        static int xcd = -1;                 // PWICP_DENSE_XCD=0: plain block order (A/B measurements only)
+        if (xcd < 0) { const char* e = getenv("PWICP_DENSE_XCD"); xcd = e ? atoi(e) : 1; }
+        const int tiles = div_up(nq, kBlock);
+        const int chunk = (xcd && variant == 1) ? div_up(tiles, kXcds) : 0;
+        hipLaunchKernelGGL(k_nn_dense_direct, dim3(chunk ? chunk * kXcds : tiles), dim3(kBlock), 0, ctx->stream, g, d_pat,
+                           variant == 1 ? d_qorder : (const int*)nullptr, d_pt_patch, d_stable, nq, d_d2, d_examined, chunk);
+    }
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }

@@ -177,6 +177,27 @@ __device__ __forceinline__ unsigned nn_expand(const GridLevel& g, float qx, floa
     return cnt;
 }
 
+// U loads in flight per pass.  The searches are bound by memory latency (SQ_WAIT_ANY ~78 % of the wave cycles of the
+// dense kernel with two loads in flight), not by issue: a row of a column grid holds ~27 points, so U = 2 means ~14
+// dependent round trips per row and U = 8 four.
+template <int U>
+__device__ __forceinline__ void scan_points_u(const float4* __restrict__ pts, int lo, int hi, float qx, float qy, float qz,
+                                              NNBest& b) {
+    for (int j = lo; j < hi; j += U) {
+        float4 p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (j + u < hi) p[u] = pts[j + u];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (j + u < hi) nn_consider(p[u], qx, qy, qz, b);
+    }
+}
+
+#ifndef PWICP_STAGE1_UNROLL
+#define PWICP_STAGE1_UNROLL 2
+#endif
+
 // stage 1: fine 27-cell stencil; returns true when the result is final
 __device__ __forceinline__ bool nn_stage1(const GridDesc& gd, float qx, float qy, float qz, NNBest& b, unsigned& cnt) {
     const GridLevel& g = gd.fine;
@@ -186,7 +207,7 @@ __device__ __forceinline__ bool nn_stage1(const GridDesc& gd, float qx, float qy
     for (int k = 0; k < 9; ++k) row_range(g, cy + (k % 3) - 1, cz + (k / 3) - 1, cx - 1, cx + 1, lo[k], hi[k]);
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-        scan_points(g.pts, lo[k], hi[k], qx, qy, qz, b);
+        scan_points_u<PWICP_STAGE1_UNROLL>(g.pts, lo[k], hi[k], qx, qy, qz, b);
         cnt += (unsigned)(hi[k] - lo[k]);
     }
     return nn_resolved(g, 1, b);

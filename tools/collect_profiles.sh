@@ -1,0 +1,20 @@
+#!/bin/bash
+# Run on the GPU box (gpurun): kernel trace + stats of bench.py, then one rocprofv3 --pmc pass per counter group
+# (counters never combined with sys/runtime traces).  Output under gpurun_out/prof_$TAG; summarise with
+# tools/summarize_pmc.py and copy the summaries into profiles/.
+TAG=${1:-final}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 10 --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $R/bench.py $ARGS > $OUT/bench_trace.log 2>&1
+for G in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" \
+         "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES"; do
+  N=$(echo $G | cut -d' ' -f1)
+  rocprofv3 --pmc $G --output-format csv -d $OUT/pmc -o $N -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_$N.log 2>&1
+done
+cd $R
+python bench.py --no-cpu-baseline > $OUT/bench_plain.log 2>&1
+python tools/summarize_pmc.py $OUT > $OUT/summary.log 2>&1
+tail -5 $OUT/summary.log
