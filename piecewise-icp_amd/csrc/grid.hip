@@ -622,14 +622,17 @@ __global__ void k_select_pass(const float* __restrict__ v, int n, int k0, unsign
     }
     __syncthreads();
     unsigned* gh = scratch + 8 + PASS * kSelBins;
+    unsigned seen = 0;
     for (int t = threadIdx.x; t < kSelBins; t += blockDim.x) {
         unsigned s = 0;
 #pragma unroll
         for (int r = 0; r < 8; ++r) s += h[r * kSelBins + t];
-        if (s) atomicAdd(&gh[t], s);
+        if (s) seen |= atomicAdd(&gh[t], s);
     }
-    // every thread waits for its own bin atomics (device-coherent RMWs; no cache write-back needed), then the count
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // The bin updates must have been PERFORMED before this block is counted.  They are device-coherent read-modify-
+    // writes, so waiting for their return values is enough (an acknowledged store is not: it may still be on its way
+    // to the coherence point — observed as a wrong percentile once in ~100 runs); no cache write-back is needed.
+    asm volatile("" ::"v"(seen));
     __syncthreads();
     if (threadIdx.x >= 64) return;
     unsigned last = 0;
@@ -897,7 +900,9 @@ int pw_select_kth_launch(pwicp_context* ctx, const float* d_vals, int n, int k, 
                          bool armed, const SelectMail* mail) {
     if (n <= 0) return PWICP_E_INVALID;
     // few blocks: every block ends with one global atomic per non-empty bin, and same-address atomics serialise
-    int nb = std::min(div_up(n, kBlock), std::max(ctx->n_cu / 2, 1));
+    static int nbl = -1;                 // PWICP_SELECT_BLOCKS: number of blocks (A/B measurements)
+    if (nbl < 0) { const char* e = getenv("PWICP_SELECT_BLOCKS"); nbl = e ? std::max(atoi(e), 1) : ctx->n_cu; }
+    int nb = std::min(div_up(n, kBlock), nbl);
     // `armed`: the scratch buffer was zeroed when it was allocated and only ever used by this function (every
     // selection leaves it zeroed again)
     if (!armed)

@@ -261,15 +261,16 @@ __global__ void __launch_bounds__(kBlock) k_transform_all(float4* __restrict__ c
         float a = sh[0][threadIdx.x], b = sh[0][3 + threadIdx.x];
         for (int w = 1; w < kBlock / 64; ++w) { a = fminf(a, sh[w][threadIdx.x]); b = fmaxf(b, sh[w][3 + threadIdx.x]); }
         // 64 partial boxes, one 128-byte line each: same-line atomics from all XCDs serialise (~5 ns apiece)
-        atomicMin(&part[threadIdx.x], f2ord_dev(a));
-        atomicMax(&part[3 + threadIdx.x], f2ord_dev(b));
+        const unsigned r0 = atomicMin(&part[threadIdx.x], f2ord_dev(a));
+        const unsigned r1 = atomicMax(&part[3 + threadIdx.x], f2ord_dev(b));
+        asm volatile("" ::"v"(r0), "v"(r1));      // wait until both have been PERFORMED (see below)
     }
     // Fold in the same launch: the block that completes a partial box counts it, the block that completes the last
     // partial box folds all of them into the slot and re-arms the buffer (two levels, so that no counter line sees
-    // more than ~nb_cloud/64 + 64 atomics).  The box atomics only have to be COMPLETE before the count (they are
-    // device-coherent read-modify-writes): a workgroup-scope release waits for them without the L2 write-back of a
-    // device-scope fence, which is ruinous in a launch that has just written the whole cloud.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // more than ~nb_cloud/64 + 64 atomics).  The box atomics have to be PERFORMED before the count: they are
+    // device-coherent read-modify-writes, so waiting for their return values (above) is enough.  A device-scope fence
+    // would also do, but it writes the L2 back, which is ruinous in a launch that has just written the whole cloud;
+    // a mere acknowledgement wait is NOT enough (the update may still be on its way to the coherence point).
     unsigned last = 0;
     if (threadIdx.x == 0) {
         const int pidx = blockIdx.x & (kBoxParts - 1);
@@ -808,7 +809,10 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         unsigned hs[kSlot], hb[6];
         IcpState hst;
         {
-            int batch = std::max(1, prev_inner);
+            // launches enqueued ahead: a launch after convergence is a ~4 us no-op, a missing one an exposed round trip
+            // (~15 us).  PCL's ICP needs 3-8 iterations in the first outer iteration and about half as many as the
+            // time before afterwards, hence 4, then half of the previous count, then 2 at a time.
+            int batch = (k == 0) ? 4 : std::max(1, (prev_inner + 1) / 2);
             for (;;) {
                 // (an event record costs a ~6 us bubble on the stream: the inner-loop timing is opt-in)
                 const bool ev = (pr->profiling & PWICP_PROF_INNER) != 0;
@@ -836,7 +840,8 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                 memcpy(hs, pr->mail_h + 16, sizeof(hs));
                 memcpy(hb, pr->mail_h + 16 + kSlot, sizeof(hb));
                 memcpy(&hst, pr->mail_h + 16 + kSlot + 6, sizeof(IcpState));
-                if (hst.done || hst.iters >= 100) { xf_enqueued = early_xf; front_ready = early_xf && early_front; break; }
+                // (fewer than 4 stable patches: R.cpp:864-867 stops below; the ICP state is then meaningless)
+                if (hst.done || hst.iters >= 100 || (int)hs[2] < 4) { xf_enqueued = early_xf; front_ready = early_xf && early_front; break; }
                 batch = 2;
             }
         }

@@ -287,3 +287,30 @@ def test_golden_epoch2_through_gpu(ctx, oracle):
     mine = np.concatenate([1000 * 63.6619772368 * np.sqrt(np.diag(V)[:3]), 1000 * np.sqrt(np.diag(V)[3:])])
     assert np.allclose(mine, stds, rtol=5e-3)
     pair.close()
+
+
+@pytest.mark.gpu
+def test_loop_is_deterministic_run_to_run(ctx):
+    """The same resident pair, run 80 times: one single result, bit for bit (T, VCM, thresholds, counts).  Guards the
+    'last block finishes the job' kernels (bounding-box fold, percentile pick, ICP / VCM solve), whose completion counts
+    rely on the partial results having been PERFORMED, not merely issued."""
+    import pwicp_amd as P
+    from pwicp_amd.pcd import read_pcd
+    g = os.path.join(os.path.dirname(__file__), "golden", "inputs")
+    p1 = ctx.preprocess(read_pcd(os.path.join(g, "Epoch_001.pcd")), 0.005, 14, 2.7)
+    p2 = ctx.preprocess(read_pcd(os.path.join(g, "Epoch_002.pcd")), 0.005, 14, 2.7)
+    cen = p1[:, :3].mean(0)
+    p1[:, :3] -= cen
+    p2[:, :3] -= cen
+    l1, n1 = ctx.frontend_segment(p1, 0.05, 45, 0.005)
+    l2, n2 = ctx.frontend_segment(p2, 0.05, 45, 0.005)
+    pair = P.Pair(ctx, p1, l1, n1, p2, l2, n2, P.Params(0.005, 0.005, 0.05, 0.05, 1, 0.05, 0.004))
+    seen = set()
+    for _ in range(80):
+        pair.reset()
+        r = pair.run()
+        seen.add((bytes(np.array(r.T16, np.float32)), bytes(np.array(r.VCM, np.float64)), tuple(r.n_inner[:r.n_outer]),
+                  tuple(r.n_stable[:r.n_outer]), bytes(np.array(r.DTseries[:r.n_outer + 1], np.float32)),
+                  bytes(np.array(r.maxBB[:r.n_outer], np.float32)), bytes(np.array(r.d75[:r.n_outer], np.float64))))
+    pair.close()
+    assert len(seen) == 1
