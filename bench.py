@@ -116,7 +116,6 @@ def main():
     t0 = time.time()
     pair = P.Pair(ctx, tgt, l1, n1, src, l2, n2, prm)
     t_setup = time.time() - t0
-    n_pairs = world
 
     def barrier():
         if dist is not None:
@@ -126,21 +125,32 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
+    # A step is one pair of the 4D series on this rank (pair index = step * world + rank).  The pairs are independent
+    # (R.cpp:89-187); the series' ONE exchange is the all-gather of the 384-byte result records once every rank has
+    # run its pairs (R.cpp:197-203 composes them afterwards), so it happens once per timed region, inside it.
+    def step(k, recs):
         pair.reset()
         res = pair.run()
         if dist is not None:
-            rec = fourd.pack_record(rank, res.status, res.n_outer, int(res.n_inner_total), res.T16, res.VCM, res.n_corr)
-            fourd.gather_records([rec], n_pairs, world, dist=dist, device=dev)
+            recs.append(fourd.pack_record(k * world + rank, res.status, res.n_outer, int(res.n_inner_total), res.T16, res.VCM,
+                                          res.n_corr))
         return res
 
-    for _ in range(args.warmup):
-        step()
+    def exchange(recs):
+        if dist is not None and recs:
+            table = fourd.gather_records(recs, len(recs) * world, world, dist=dist, device=dev)
+            assert len(table) == len(recs) * world, "record gather incomplete"
+
+    wrecs = []
+    for k in range(args.warmup):
+        step(k, wrecs)
+    exchange(wrecs)
     barrier()
     t0 = time.perf_counter()
-    results = []
-    for _ in range(args.steps):
-        results.append(step())
+    results, recs = [], []
+    for k in range(args.steps):
+        results.append(step(k, recs))
+    exchange(recs)
     barrier()
     elapsed = time.perf_counter() - t0
     tmax = elapsed
@@ -208,8 +218,8 @@ def main():
             "ms_per_step": round(1e3 * tmax / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "synthetic %d-pt source/target pair per GPU, full Piecewise-ICP loop to convergence "
-                                   "(BASELINE configs[1]; N>1: one independent pair per GPU of a 4D series, RCCL all-gather "
-                                   "of 384-byte result records)" % args.points,
+                                   "(BASELINE configs[1]; N>1: every step is one independent pair per GPU of a 4D series, the "
+                                   "384-byte result records of all steps are all-gathered over RCCL once, inside the timed region)" % args.points,
                        "points_per_cloud": args.points, "spacing_m": r, "patches_target_source": list(pair.num_patches()),
                        "outer_iterations": n_outer, "inner_iterations": n_inner,
                        "correspondences_per_step": int(res.n_corr), "parallelism": "pair-per-gpu x%d" % world,
