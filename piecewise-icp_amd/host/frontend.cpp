@@ -368,6 +368,14 @@ int segment_from_neighbors(const float* cloud_xyz4, int n, const int32_t* nb, in
 
 }  // namespace
 
+namespace pwhost {
+// host part of the front end from a given k-NN graph (thread-safe: no shared state), see io.h
+int segment_from_knn(const float* cloud_xyz4, int n, const int32_t* nb, int k, float sv_resolution, int32_t* labels,
+                     int* n_supervoxels) {
+    return segment_from_neighbors(cloud_xyz4, n, nb, k, sv_resolution, labels, n_supervoxels);
+}
+}  // namespace pwhost
+
 extern "C" {
 
 // kNN = 45 in the reference (include/CommonFunc.h:41).  Host-only variant: k-NN with the host KD-tree.

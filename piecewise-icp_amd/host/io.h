@@ -33,6 +33,9 @@ bool read_transmatrices(const std::string& path, int n, std::vector<int>* stamps
                         std::vector<std::array<double, 36>>* Vs);
 
 // preprocess.cpp
+// PCA normals + supervoxel fusion + boundary refinement from a k-NN graph (n rows of k indices, the point itself first)
+int segment_from_knn(const float* cloud_xyz4, int n, const int32_t* nb, int k, float sv_resolution, int32_t* labels,
+                     int* n_supervoxels);
 int voxel_grid(const float* in4, int n, float leaf, float* out4);
 int sor_filter(const float* in4, int n, int mean_k, double std_mul, float* out4);
 float pc_resolution(const float* c4, int n);

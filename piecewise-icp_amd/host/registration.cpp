@@ -20,6 +20,7 @@
 #include <memory>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "io.h"
@@ -102,22 +103,33 @@ bool register_pair(pwicp_context* ctx, const std::vector<float>& cloud1, const s
     apply_shift(p2, m2);
     std::cout << "Preprocessed PC-1 point number: " << m1 << "\tPreprocessed PC-2 point number: " << m2 << std::endl << std::endl;
 
-    // supervoxel labels (S.cpp:18-68)
+    // supervoxel labels (S.cpp:18-68): the k-NN graphs on the GPU, one after the other; then the order-dependent host
+    // passes (fusion, boundary refinement) of the two clouds side by side on two host threads
     std::vector<int32_t> lab2((size_t)m2);
     int nsv2 = 0;
-    if (!hit) {
-        tc.lab1.resize((size_t)m1);
-        if (pwicp_frontend_segment_dev(ctx, tc.p1.data(), m1, SVRes1, kNN, Res1, tc.lab1.data(), &tc.nsv1) != PWICP_OK) {
-            std::cerr << "Error: supervoxel segmentation failed.\n";
+    {
+        std::vector<int32_t> nb1, nb2((size_t)m2 * kNN);
+        if (!hit) {
+            nb1.resize((size_t)m1 * kNN);
+            tc.lab1.resize((size_t)m1);
+            if (pwicp_knn(ctx, tc.p1.data(), m1, kNN, 2.0f * Res1, nb1.data()) != PWICP_OK) {
+                std::cerr << "Error: supervoxel segmentation failed: " << pwicp_last_error(ctx) << "\n";
+                return false;
+            }
+        } else {
+            std::cout << "--->>> target epoch unchanged: preprocessed cloud and supervoxels reused." << std::endl;
+        }
+        if (pwicp_knn(ctx, p2.data(), m2, kNN, 2.0f * Res2, nb2.data()) != PWICP_OK) {
+            std::cerr << "Error: supervoxel segmentation failed: " << pwicp_last_error(ctx) << "\n";
             return false;
         }
-        tc.Res1 = Res1; tc.SVRes1 = SVRes1; tc.sor_mult = sor_mult; tc.key = target_key;
-    } else {
-        std::cout << "--->>> target epoch unchanged: preprocessed cloud and supervoxels reused." << std::endl;
-    }
-    if (pwicp_frontend_segment_dev(ctx, p2.data(), m2, SVRes2, kNN, Res2, lab2.data(), &nsv2) != PWICP_OK) {
-        std::cerr << "Error: supervoxel segmentation failed.\n";
-        return false;
+        int rc1 = PWICP_OK, rc2 = PWICP_OK;
+        std::thread t1;
+        if (!hit) t1 = std::thread([&] { rc1 = segment_from_knn(tc.p1.data(), m1, nb1.data(), kNN, SVRes1, tc.lab1.data(), &tc.nsv1); });
+        rc2 = segment_from_knn(p2.data(), m2, nb2.data(), kNN, SVRes2, lab2.data(), &nsv2);
+        if (t1.joinable()) t1.join();
+        if (rc1 != PWICP_OK || rc2 != PWICP_OK) { std::cerr << "Error: supervoxel segmentation failed.\n"; return false; }
+        if (!hit) { tc.Res1 = Res1; tc.SVRes1 = SVRes1; tc.sor_mult = sor_mult; tc.key = target_key; }
     }
     const std::vector<float>& p1 = tc.p1;
     const std::vector<int32_t>& lab1 = tc.lab1;
