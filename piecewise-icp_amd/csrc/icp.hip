@@ -4,14 +4,16 @@
 // align: correspondence search, TransformationEstimationPointToPlaneLLS, transformPointCloudWithNormals,
 // DefaultConvergenceCriteria) and calTransParaVCM Registration.cpp:1273-1343.
 //
-// One inner iteration = two launches on one stream, no host round trip:
-//   k_icp_accum  (grid over the S stable centroids): applies the previous incremental transform to the
-//                working source (points + normals), exact 1-NN in the target-centroid grid, forms the row
+// One inner iteration = ONE launch (k_icp_iter), no host round trip:
+//   accumulate (grid over the S stable centroids, 8 lanes per centroid): applies the previous incremental transform to
+//                the working source (points + normals), exact 1-NN in the target-centroid grid, forms the row
 //                [a b c nx ny nz | d] in float exactly as PCL does, widens to double and reduces the 21+6
 //                sums (+ sum of d2 for the MSE test) with wave shuffles -> LDS -> one partial per block;
-//   k_icp_solve  (one wave): fixed-order sum of the block partials, 6x6 LU inverse, x = inv*ATb,
-//                Rz*Ry*Rx matrix in double -> float, final = T*final, convergence tests, done flag.
+//   solve      (first wave of the block that finishes last): fixed-order sum of the block partials, 6x6 LU inverse,
+//                x = inv*ATb, Rz*Ry*Rx matrix in double -> float, final = T*final, convergence tests, done flag,
+//                and — in the last launch of a batch — the iteration record to the host mailbox.
 // Launches after convergence are no-ops (done flag), so iterations are enqueued in small batches.
+// calTransParaVCM is two launches of the same shape (k_vcm_normal, k_vcm_finish).
 #include "common.h"
 #include "devmath.h"
 #include "icp.h"
