@@ -3,10 +3,26 @@
 
 #include <array>
 #include <ostream>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
 namespace pwhost {
+
+// PWICP_TRACE=1: wall time of the stages of an entry point on stderr
+struct StageTimer {
+    const bool on = std::getenv("PWICP_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[pwicp entry point] %-34s %9.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 
 constexpr double ARC_TO_GON = 63.6619772368;       // include/CommonFunc.h:40
 

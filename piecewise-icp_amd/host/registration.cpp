@@ -57,6 +57,7 @@ struct TargetCache {
 bool register_pair(pwicp_context* ctx, const std::vector<float>& cloud1, const std::vector<float>& cloud2,
                    const ConfigPara& cfg, float Res1, float Res2, double sor_mult, PairOutput* out,
                    TargetCache* cache = nullptr, int target_key = -1) {
+    StageTimer tm;
     const int n1 = (int)(cloud1.size() / 4), n2 = (int)(cloud2.size() / 4);
     std::cout << "Original PC-1 point number: " << n1 << "\t Original PC-2 point number: " << n2 << std::endl;
     std::cout << "PC-1 avg. point spacing: " << Res1 << "\t PC-2 avg. point spacing: " << Res2 << std::endl << std::endl;
@@ -79,6 +80,7 @@ bool register_pair(pwicp_context* ctx, const std::vector<float>& cloud1, const s
         std::cerr << "Error: preprocessing failed: " << pwicp_last_error(ctx) << "\n";
         return false;
     }
+    tm.lap("voxel grid + SOR (GPU)");
     const int m1 = tc.m1;
     if (m1 < kNN + 1 || m2 < kNN + 1) { std::cerr << "Error: too few points after preprocessing.\n"; return false; }
     // reduction by the centroid of PC1 (R.cpp:419-436): pcl::compute3DCentroid float sums, float shift
@@ -123,6 +125,7 @@ bool register_pair(pwicp_context* ctx, const std::vector<float>& cloud1, const s
             std::cerr << "Error: supervoxel segmentation failed: " << pwicp_last_error(ctx) << "\n";
             return false;
         }
+        tm.lap("k-NN graphs (GPU)");
         int rc1 = PWICP_OK, rc2 = PWICP_OK;
         std::thread t1;
         if (!hit) t1 = std::thread([&] { rc1 = segment_from_knn(tc.p1.data(), m1, nb1.data(), kNN, SVRes1, tc.lab1.data(), &tc.nsv1); });
@@ -130,6 +133,7 @@ bool register_pair(pwicp_context* ctx, const std::vector<float>& cloud1, const s
         if (t1.joinable()) t1.join();
         if (rc1 != PWICP_OK || rc2 != PWICP_OK) { std::cerr << "Error: supervoxel segmentation failed.\n"; return false; }
         if (!hit) { tc.Res1 = Res1; tc.SVRes1 = SVRes1; tc.sor_mult = sor_mult; tc.key = target_key; }
+        tm.lap("normals + supervoxels (host)");
     }
     const std::vector<float>& p1 = tc.p1;
     const std::vector<int32_t>& lab1 = tc.lab1;
@@ -142,10 +146,12 @@ bool register_pair(pwicp_context* ctx, const std::vector<float>& cloud1, const s
         std::cerr << "Error: " << pwicp_last_error(ctx) << "\n";
         return false;
     }
+    tm.lap("upload, patches, grids (GPU)");
     int M1 = 0, M2 = 0;
     pwicp_pair_num_patches(pair, &M1, &M2);
     std::cout << "PC-1 selected patch number: " << M1 << "\tPC-2 selected patch number: " << M2 << std::endl;
     const int rc = pwicp_pair_run(pair, &out->res);
+    tm.lap("registration loop (GPU)");
     pwicp_pair_destroy(pair);
     if (rc != PWICP_OK) {
         std::cerr << "Error: registration failed (status " << rc << "): " << pwicp_last_error(ctx) << "\n";
