@@ -13,6 +13,9 @@
 // never touches it.
 #include <algorithm>
 #include <cfloat>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -102,6 +105,35 @@ struct Metric {      // Segmentation.h:362-375
         return 1.0 - std::fabs(dot) + dist / resolution * 0.4;
     }
 };
+
+// bit e set <=> labels[row[e]] != mine, for k <= 64 neighbours: the hot loop of the boundary refinement
+uint64_t differing_labels_scalar(const int* labels, const int32_t* row, int k, int mine) {
+    uint64_t m = 0;
+    for (int e = 0; e < k; ++e) m |= (uint64_t)(labels[(size_t)row[e]] != mine) << e;
+    return m;
+}
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) uint64_t differing_labels_avx2(const int* labels, const int32_t* row, int k, int mine) {
+    const __m256i me = _mm256_set1_epi32(mine);
+    uint64_t m = 0;
+    int e = 0;
+    for (; e + 8 <= k; e += 8) {
+        const __m256i idx = _mm256_loadu_si256((const __m256i*)(row + e));
+        const __m256i lab = _mm256_i32gather_epi32(labels, idx, 4);
+        const unsigned eq = (unsigned)_mm256_movemask_ps(_mm256_castsi256_ps(_mm256_cmpeq_epi32(lab, me)));
+        m |= (uint64_t)(~eq & 0xffu) << e;
+    }
+    for (; e < k; ++e) m |= (uint64_t)(labels[(size_t)row[e]] != mine) << e;
+    return m;
+}
+#endif
+typedef uint64_t (*DifferingFn)(const int*, const int32_t*, int, int);
+DifferingFn pick_differing() {
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("avx2")) return differing_labels_avx2;
+#endif
+    return differing_labels_scalar;
+}
 
 struct DisjointSet {     // codelibrary/util/set/disjoint_set.h (path halving, Link(i -> j))
     mutable std::vector<int> parent;
@@ -304,6 +336,7 @@ int supervoxel_segmentation(const Metric& metric, const int32_t* nb, int k, int 
     }
     if (tm.on) { char b[64]; std::snprintf(b, sizeof b, "    seeds: %zu", qn); tm.lap(b); }
     size_t pops = 0;
+    const DifferingFn differing = pick_differing();
     while (qn) {
         const int i = q[qh];
         qh = (qh + 1 == qcap) ? 0 : qh + 1;
@@ -312,24 +345,48 @@ int supervoxel_segmentation(const Metric& metric, const int32_t* nb, int k, int 
         in_q[(size_t)i] = 0;
         bool change = false;
         const int32_t* row = nb + (size_t)i * (size_t)k;
-        // A label already tried during this visit cannot win later (dis[i] only decreases), so each distinct
-        // neighbouring label is evaluated once; the outcome is the reference's.
-        int tried[8], n_tried = 0;
-        for (int e = 0; e < k; ++e) {
-            const int a = labels[(size_t)i], b = labels[(size_t)row[e]];
-            if (a == b) continue;
-            bool seen = false;
-            for (int t = 0; t < n_tried; ++t) seen |= (tried[t] == b);
-            if (seen) continue;
-            if (n_tried < 8) tried[n_tried++] = b;
-            const double d = metric(i, b);
-            if (d < dis[(size_t)i]) { labels[(size_t)i] = b; dis[(size_t)i] = d; change = true; }
-        }
-        if (change)
-            for (int e = 0; e < k; ++e) {
-                const int j = row[e];
-                if (labels[(size_t)i] != labels[(size_t)j] && !in_q[(size_t)j]) { push(j); in_q[(size_t)j] = 1; }
+        // Only neighbours whose label differs from the point's label at the START of the visit can matter (a label the
+        // point switches to during the visit is skipped from then on, its old label can never win again), and a label
+        // already tried cannot win later either (dis[i] only decreases): each distinct neighbouring label is evaluated
+        // once, in the order of its first occurrence; the outcome is the reference's.
+        if (k <= 64) {
+            uint64_t m = differing(labels.data(), row, k, labels[(size_t)i]);
+            int tried[8], n_tried = 0;
+            while (m) {
+                const int e = __builtin_ctzll(m);
+                m &= m - 1;
+                const int a = labels[(size_t)i], b = labels[(size_t)row[e]];
+                if (a == b) continue;
+                bool seen = false;
+                for (int t = 0; t < n_tried; ++t) seen |= (tried[t] == b);
+                if (seen) continue;
+                if (n_tried < 8) tried[n_tried++] = b;
+                const double d = metric(i, b);
+                if (d < dis[(size_t)i]) { labels[(size_t)i] = b; dis[(size_t)i] = d; change = true; }
             }
+        } else {
+            for (int e = 0; e < k; ++e) {
+                const int a = labels[(size_t)i], b = labels[(size_t)row[e]];
+                if (a == b) continue;
+                const double d = metric(i, b);
+                if (d < dis[(size_t)i]) { labels[(size_t)i] = b; dis[(size_t)i] = d; change = true; }
+            }
+        }
+        if (change) {
+            if (k <= 64) {
+                uint64_t m = differing(labels.data(), row, k, labels[(size_t)i]);
+                while (m) {
+                    const int j = row[__builtin_ctzll(m)];
+                    m &= m - 1;
+                    if (!in_q[(size_t)j]) { push(j); in_q[(size_t)j] = 1; }
+                }
+            } else {
+                for (int e = 0; e < k; ++e) {
+                    const int j = row[e];
+                    if (labels[(size_t)i] != labels[(size_t)j] && !in_q[(size_t)j]) { push(j); in_q[(size_t)j] = 1; }
+                }
+            }
+        }
     }
     if (tm.on) { char b[64]; std::snprintf(b, sizeof b, "  boundary refinement (%zu pops)", pops); tm.lap(b); }
 
