@@ -314,3 +314,42 @@ def test_loop_is_deterministic_run_to_run(ctx):
                   bytes(np.array(r.maxBB[:r.n_outer], np.float32)), bytes(np.array(r.d75[:r.n_outer], np.float64))))
     pair.close()
     assert len(seen) == 1
+
+
+LAYOUT_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(%(root)r, "piecewise-icp_amd")); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import pwicp_amd as P
+import _oracle, _data
+ctx = P.Context(0)
+tgt, src, _ = _data.pair(40000)
+rng = np.random.default_rng(5)
+far = (src[:2000] + rng.normal(0, 0.5, (2000, 3))).astype(np.float32)          # queries far from the surface too
+q = np.vstack([src, far]).astype(np.float32)
+idx, d2 = ctx.determineCorrespondences(tgt, q)
+oi, od = _oracle.nn1(tgt, q)
+assert np.array_equal(idx, oi) and np.array_equal(d2.view(np.uint32), od.view(np.uint32))
+nb = ctx.knn(src, 20)
+from scipy.spatial import cKDTree
+d, ii = cKDTree(src.astype(np.float64)).query(src.astype(np.float64), k=20)
+dn = np.linalg.norm(src[nb].astype(np.float64) - src[:, None, :].astype(np.float64), axis=2)
+assert np.allclose(dn, d, rtol=0, atol=1e-12)
+print("LAYOUT_OK")
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["0", "1", "2"])
+def test_every_grid_layout_gives_the_exact_minimum(tmp_path, layout):
+    """Cells, y-columns and z-columns (PWICP_GRID_LAYOUT, read once per process) return the oracle's (index, d2) for
+    every query and the exact k-NN lists — the layout is a cost choice only."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text(LAYOUT_WORKER % {"root": root})
+    env = dict(os.environ)
+    env["PWICP_GRID_LAYOUT"] = layout
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "LAYOUT_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
