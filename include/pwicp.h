@@ -236,6 +236,9 @@ PWICP_API int pwicp_series_pair_epochs(const pwicp_series* s, int pair, int* tar
                                        long* source_stamp);
 PWICP_API int pwicp_series_adaptive_targets(const pwicp_series* s, int32_t* targets, int n);
 PWICP_API int pwicp_series_run_pair(pwicp_series* s, int pair, pwicp_pair_record* rec);
+/* Any subset of the pairs, pipelined: scans read and supervoxels computed on host threads for several pairs at once,
+ * GPU stages one after the other.  Same records as n calls of pwicp_series_run_pair. */
+PWICP_API int pwicp_series_run_pairs(pwicp_series* s, const int32_t* pairs, int n_pairs, pwicp_pair_record* recs);
 PWICP_API int pwicp_series_write_results(pwicp_series* s, const pwicp_pair_record* recs, int n_recs);
 
 /* ---- measurement hooks ------------------------------------------------------------------------------------

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "io.h"
+#include "parallel.h"
 #include "pwicp.h"
 
 
@@ -40,109 +41,74 @@ struct PairOutput {
     pwicp_result res;
 };
 
-// Target-side setup that depends only on the target scan (preprocessed + centroid-reduced cloud, supervoxel labels).
-// In the Direct2Ref mode of a 4D series every pair has the same target (R.cpp:94-103), so it is prepared once.
-struct TargetCache {
-    int key = -1;                 // epoch index of the cached target, -1 = empty
-    float Res1 = 0.f, SVRes1 = 0.f;
+// One preprocessed, centroid-reduced cloud with its supervoxel labels.  Preparing it has a GPU part (VoxelGrid + SOR,
+// k-NN graph) and a host part (PCA normals, supervoxel fusion, boundary refinement: serial per cloud, ~1.2 s per 1 M
+// points) — kept apart so that the host parts of several clouds can run side by side on host threads.
+struct Prepared {
+    std::vector<float> p;          // preprocessed points, shifted
+    int m = 0;
+    float shift[3] = {0, 0, 0};    // the translation that was applied (minus the centroid of the pair's target)
+    float Res = 0.f, SVRes = 0.f;
     double sor_mult = 0.0;
-    std::vector<float> p1;        // preprocessed, shifted by its own centroid
-    int m1 = 0;
-    float shift[3] = {0, 0, 0};
-    std::vector<int32_t> lab1;
-    int nsv1 = 0;
+    std::vector<int32_t> nb;       // k-NN graph (released by prepare_host)
+    std::vector<int32_t> lab;
+    int nsv = 0;
 };
 
-// Piecewise_ICP_4D without its file output (R.cpp:402-480); sor_mult 5.0 (4D) or 2.7 (pair)
-bool register_pair(pwicp_context* ctx, const std::vector<float>& cloud1, const std::vector<float>& cloud2,
-                   const ConfigPara& cfg, float Res1, float Res2, double sor_mult, PairOutput* out,
-                   TargetCache* cache = nullptr, int target_key = -1) {
-    StageTimer tm;
-    const int n1 = (int)(cloud1.size() / 4), n2 = (int)(cloud2.size() / 4);
-    std::cout << "Original PC-1 point number: " << n1 << "\t Original PC-2 point number: " << n2 << std::endl;
-    std::cout << "PC-1 avg. point spacing: " << Res1 << "\t PC-2 avg. point spacing: " << Res2 << std::endl << std::endl;
-    // pre-process (R.cpp:412-416)
-    const float SVRes1 = cfg.isSetResSVsize ? cfg.SVsize1 : Res1 * 10, SVRes2 = cfg.isSetResSVsize ? cfg.SVsize2 : Res2 * 10;   // R.cpp:635-640
-    TargetCache local;
-    TargetCache& tc = cache ? *cache : local;
-    const bool hit = cache && target_key >= 0 && tc.key == target_key && tc.Res1 == Res1 && tc.SVRes1 == SVRes1 && tc.sor_mult == sor_mult;
-    std::vector<float> p2((size_t)n2 * 4);
-    int m2 = 0;
-    if (!hit) {
-        tc.key = -1;
-        tc.p1.resize((size_t)n1 * 4);
-        if (pwicp_preprocess_dev(ctx, cloud1.data(), n1, Res1, 14, sor_mult, tc.p1.data(), &tc.m1) != PWICP_OK) {
-            std::cerr << "Error: preprocessing failed: " << pwicp_last_error(ctx) << "\n";
-            return false;
-        }
-    }
-    if (pwicp_preprocess_dev(ctx, cloud2.data(), n2, Res2, 14, sor_mult, p2.data(), &m2) != PWICP_OK) {
+// GPU part.  shift_in == nullptr: the cloud is a target and is reduced by its own centroid (R.cpp:419-436:
+// pcl::compute3DCentroid float sums, float shift); otherwise the target's shift is applied.
+bool prepare_gpu(pwicp_context* ctx, const std::vector<float>& raw, float Res, float SVRes, double sor_mult, const float* shift_in,
+                 Prepared* c) {
+    const int n = (int)(raw.size() / 4);
+    c->Res = Res; c->SVRes = SVRes; c->sor_mult = sor_mult;
+    c->p.resize((size_t)std::max(n, 1) * 4);
+    if (pwicp_preprocess_dev(ctx, raw.data(), n, Res, 14, sor_mult, c->p.data(), &c->m) != PWICP_OK) {      // R.cpp:412-416
         std::cerr << "Error: preprocessing failed: " << pwicp_last_error(ctx) << "\n";
         return false;
     }
-    tm.lap("voxel grid + SOR (GPU)");
-    const int m1 = tc.m1;
-    if (m1 < kNN + 1 || m2 < kNN + 1) { std::cerr << "Error: too few points after preprocessing.\n"; return false; }
-    // reduction by the centroid of PC1 (R.cpp:419-436): pcl::compute3DCentroid float sums, float shift
-    if (!hit) {
+    const int m = c->m;
+    c->p.resize((size_t)std::max(m, 1) * 4);
+    if (m < kNN + 1) { std::cerr << "Error: too few points after preprocessing.\n"; return false; }
+    if (shift_in) {
+        for (int d = 0; d < 3; ++d) c->shift[d] = shift_in[d];
+    } else {
         float acc[3] = {0, 0, 0};
-        for (int i = 0; i < m1; ++i) { acc[0] += tc.p1[4 * (size_t)i]; acc[1] += tc.p1[4 * (size_t)i + 1]; acc[2] += tc.p1[4 * (size_t)i + 2]; }
-        for (int d = 0; d < 3; ++d) tc.shift[d] = -1 * (acc[d] / (float)m1);
+        for (int i = 0; i < m; ++i) { acc[0] += c->p[4 * (size_t)i]; acc[1] += c->p[4 * (size_t)i + 1]; acc[2] += c->p[4 * (size_t)i + 2]; }
+        for (int d = 0; d < 3; ++d) c->shift[d] = -1 * (acc[d] / (float)m);
     }
-    const float* shift = tc.shift;
-    const float S[16] = {1, 0, 0, shift[0], 0, 1, 0, shift[1], 0, 0, 1, shift[2], 0, 0, 0, 1};
-    const float Sinv[16] = {1, 0, 0, -1 * shift[0], 0, 1, 0, -1 * shift[1], 0, 0, 1, -1 * shift[2], 0, 0, 0, 1};
-    auto apply_shift = [&](std::vector<float>& p, int m) {       // pcl::transformPointCloud with a pure translation
-        for (int i = 0; i < m; ++i) {
-            float* q = p.data() + 4 * (size_t)i;
-            const float x = q[0], y = q[1], z = q[2];
-            q[0] = S[0] * x + S[1] * y + S[2] * z + S[3];
-            q[1] = S[4] * x + S[5] * y + S[6] * z + S[7];
-            q[2] = S[8] * x + S[9] * y + S[10] * z + S[11];
-        }
-    };
-    if (!hit) apply_shift(tc.p1, m1);
-    apply_shift(p2, m2);
-    std::cout << "Preprocessed PC-1 point number: " << m1 << "\tPreprocessed PC-2 point number: " << m2 << std::endl << std::endl;
-
-    // supervoxel labels (S.cpp:18-68): the k-NN graphs on the GPU, one after the other; then the order-dependent host
-    // passes (fusion, boundary refinement) of the two clouds side by side on two host threads
-    std::vector<int32_t> lab2((size_t)m2);
-    int nsv2 = 0;
-    {
-        std::vector<int32_t> nb1, nb2((size_t)m2 * kNN);
-        if (!hit) {
-            nb1.resize((size_t)m1 * kNN);
-            tc.lab1.resize((size_t)m1);
-            if (pwicp_knn(ctx, tc.p1.data(), m1, kNN, 2.0f * Res1, nb1.data()) != PWICP_OK) {
-                std::cerr << "Error: supervoxel segmentation failed: " << pwicp_last_error(ctx) << "\n";
-                return false;
-            }
-        } else {
-            std::cout << "--->>> target epoch unchanged: preprocessed cloud and supervoxels reused." << std::endl;
-        }
-        if (pwicp_knn(ctx, p2.data(), m2, kNN, 2.0f * Res2, nb2.data()) != PWICP_OK) {
-            std::cerr << "Error: supervoxel segmentation failed: " << pwicp_last_error(ctx) << "\n";
-            return false;
-        }
-        tm.lap("k-NN graphs (GPU)");
-        int rc1 = PWICP_OK, rc2 = PWICP_OK;
-        std::thread t1;
-        if (!hit) t1 = std::thread([&] { rc1 = segment_from_knn(tc.p1.data(), m1, nb1.data(), kNN, SVRes1, tc.lab1.data(), &tc.nsv1); });
-        rc2 = segment_from_knn(p2.data(), m2, nb2.data(), kNN, SVRes2, lab2.data(), &nsv2);
-        if (t1.joinable()) t1.join();
-        if (rc1 != PWICP_OK || rc2 != PWICP_OK) { std::cerr << "Error: supervoxel segmentation failed.\n"; return false; }
-        if (!hit) { tc.Res1 = Res1; tc.SVRes1 = SVRes1; tc.sor_mult = sor_mult; tc.key = target_key; }
-        tm.lap("normals + supervoxels (host)");
+    const float* sh = c->shift;
+    const float S[16] = {1, 0, 0, sh[0], 0, 1, 0, sh[1], 0, 0, 1, sh[2], 0, 0, 0, 1};
+    for (int i = 0; i < m; ++i) {                                  // pcl::transformPointCloud with a pure translation
+        float* q = c->p.data() + 4 * (size_t)i;
+        const float x = q[0], y = q[1], z = q[2];
+        q[0] = S[0] * x + S[1] * y + S[2] * z + S[3];
+        q[1] = S[4] * x + S[5] * y + S[6] * z + S[7];
+        q[2] = S[8] * x + S[9] * y + S[10] * z + S[11];
     }
-    const std::vector<float>& p1 = tc.p1;
-    const std::vector<int32_t>& lab1 = tc.lab1;
-    const int nsv1 = tc.nsv1;
-    std::cout << "--->>> " << nsv1 << " / " << nsv2 << " supervoxels are generated." << std::endl;
+    c->nb.resize((size_t)m * kNN);
+    if (pwicp_knn(ctx, c->p.data(), m, kNN, 2.0f * Res, c->nb.data()) != PWICP_OK) {                          // S.cpp:30-41
+        std::cerr << "Error: supervoxel segmentation failed: " << pwicp_last_error(ctx) << "\n";
+        return false;
+    }
+    return true;
+}
 
-    pwicp_params prm{Res1, Res2, SVRes1, SVRes2, cfg.isSetDTinit ? 1 : 0, cfg.DTinit, cfg.DTmin};
+// host part (thread-safe): supervoxel labels (S.cpp:42-68)
+bool prepare_host(Prepared* c) {
+    c->lab.resize((size_t)c->m);
+    const int rc = segment_from_knn(c->p.data(), c->m, c->nb.data(), kNN, c->SVRes, c->lab.data(), &c->nsv);
+    std::vector<int32_t>().swap(c->nb);
+    return rc == PWICP_OK;
+}
+
+// the registration of two prepared clouds: Piecewise_ICP (R.cpp:618-700) on the GPU, then T_final = S^-1 T S (R.cpp:461)
+bool run_prepared(pwicp_context* ctx, const Prepared& t, const Prepared& s, const ConfigPara& cfg, PairOutput* out) {
+    StageTimer tm;
+    std::cout << "Preprocessed PC-1 point number: " << t.m << "\tPreprocessed PC-2 point number: " << s.m << std::endl << std::endl;
+    std::cout << "--->>> " << t.nsv << " / " << s.nsv << " supervoxels are generated." << std::endl;
+    pwicp_params prm{t.Res, s.Res, t.SVRes, s.SVRes, cfg.isSetDTinit ? 1 : 0, cfg.DTinit, cfg.DTmin};
     pwicp_pair* pair = nullptr;
-    if (pwicp_pair_create(ctx, p1.data(), m1, lab1.data(), nsv1, p2.data(), m2, lab2.data(), nsv2, &prm, &pair) != PWICP_OK) {
+    if (pwicp_pair_create(ctx, t.p.data(), t.m, t.lab.data(), t.nsv, s.p.data(), s.m, s.lab.data(), s.nsv, &prm, &pair) != PWICP_OK) {
         std::cerr << "Error: " << pwicp_last_error(ctx) << "\n";
         return false;
     }
@@ -159,16 +125,38 @@ bool register_pair(pwicp_context* ctx, const std::vector<float>& cloud1, const s
     }
     for (int k = 0; k < out->res.n_outer; ++k)
         std::cout << "--->>> Iteration No." << k + 1 << " | Current DT = " << out->res.DTseries[k + 1] * 100 << " cm. \n";
-    // T_final = S^-1 * T * S (R.cpp:461), parameters (R.cpp:464-480)
+    const float* sh = t.shift;
+    const float S[16] = {1, 0, 0, sh[0], 0, 1, 0, sh[1], 0, 0, 1, sh[2], 0, 0, 0, 1};
+    const float Sinv[16] = {1, 0, 0, -1 * sh[0], 0, 1, 0, -1 * sh[1], 0, 0, 1, -1 * sh[2], 0, 0, 0, 1};
     float tmpM[16];
     mat4_mul(Sinv, out->res.T16, tmpM);
     mat4_mul(tmpM, S, out->T);
     float ang[3];
-    matrix2angle(out->T, ang);
+    matrix2angle(out->T, ang);                                                     // R.cpp:464-480
     out->para[0] = (float)(ang[0] * ARC_TO_GON); out->para[1] = (float)(ang[1] * ARC_TO_GON); out->para[2] = (float)(ang[2] * ARC_TO_GON);
     out->para[3] = out->T[3]; out->para[4] = out->T[7]; out->para[5] = out->T[11];
     std::memcpy(out->VCM, out->res.VCM, sizeof(out->VCM));
     return true;
+}
+
+// Piecewise_ICP_4D without its file output (R.cpp:402-480) for ONE pair; sor_mult 5.0 (4D) or 2.7 (pair)
+bool register_pair(pwicp_context* ctx, const std::vector<float>& cloud1, const std::vector<float>& cloud2,
+                   const ConfigPara& cfg, float Res1, float Res2, double sor_mult, PairOutput* out) {
+    StageTimer tm;
+    std::cout << "Original PC-1 point number: " << cloud1.size() / 4 << "\t Original PC-2 point number: " << cloud2.size() / 4 << std::endl;
+    std::cout << "PC-1 avg. point spacing: " << Res1 << "\t PC-2 avg. point spacing: " << Res2 << std::endl << std::endl;
+    const float SVRes1 = cfg.isSetResSVsize ? cfg.SVsize1 : Res1 * 10, SVRes2 = cfg.isSetResSVsize ? cfg.SVsize2 : Res2 * 10;   // R.cpp:635-640
+    Prepared t, s;
+    if (!prepare_gpu(ctx, cloud1, Res1, SVRes1, sor_mult, nullptr, &t) || !prepare_gpu(ctx, cloud2, Res2, SVRes2, sor_mult, t.shift, &s))
+        return false;
+    tm.lap("voxel grid + SOR, k-NN graphs (GPU)");
+    bool ok1 = true, ok2 = true;
+    std::thread th([&] { ok1 = prepare_host(&t); });            // the two clouds side by side
+    ok2 = prepare_host(&s);
+    th.join();
+    tm.lap("normals + supervoxels (host)");
+    if (!ok1 || !ok2) { std::cerr << "Error: supervoxel segmentation failed.\n"; return false; }
+    return run_prepared(ctx, t, s, cfg, out);
 }
 
 // calTransToReferenceEpoch, R.cpp:977-1153 (re-reads the pairwise file, exactly as the reference does)
@@ -335,10 +323,9 @@ struct pwicp_series {
     int startEpoch = 0, epochNum = 0, pairMode = 0, device = 0;
     std::map<int, int> regPairs;          // adaptive mode: source -> target, relative to startEpoch (R.cpp:570)
     pwicp_context* ctx = nullptr;         // created by the first call that needs the GPU
-    TargetCache tcache;
-    int c1Key = -1, resKey = -1;
-    float resVal = 0.f;
-    std::vector<float> c1, c2;
+    // prepared target clouds by epoch index (in the Direct2Ref mode every pair has the same target, R.cpp:94-103; in the
+    // adaptive mode runs of pairs share one): prepared once, kept while the following pairs use them
+    std::map<int, std::shared_ptr<Prepared>> targets;
 
     bool need_ctx() {
         if (ctx) return true;
@@ -434,46 +421,134 @@ PWICP_API int pwicp_series_adaptive_targets(const pwicp_series* s, int32_t* targ
     return PWICP_OK;
 }
 
-// one iteration of the pair loop R.cpp:89-150 (without its file output)
+// Iterations of the pair loop R.cpp:89-150 (without their file output) for any subset of the pairs.  The pairs are
+// independent, and so are the setup stages of their clouds: the pairs are taken in windows; within a window the scans
+// are read on host threads, the GPU parts of the preparation run one after the other (tens of ms each), the serial
+// host parts (~1.2 s per 1 M points and cloud) run side by side on host threads, then the registrations run on the
+// GPU.  The results do not depend on the window (every stage is a pure function of its cloud).
+PWICP_API int pwicp_series_run_pairs(pwicp_series* s, const int32_t* pairs, int n_pairs, pwicp_pair_record* recs) {
+    if (!s || !pairs || !recs || n_pairs < 0) return PWICP_E_INVALID;
+    for (int k = 0; k < n_pairs; ++k) {
+        std::memset(&recs[k], 0, sizeof(recs[k]));
+        recs[k].pair = pairs[k];
+        recs[k].status = PWICP_E_INTERNAL;
+        if (pairs[k] < 0 || pairs[k] >= s->num_pairs()) return PWICP_E_INVALID;
+    }
+    if (n_pairs == 0) return PWICP_OK;
+    if (!s->need_ctx()) { for (int k = 0; k < n_pairs; ++k) recs[k].status = PWICP_E_NO_DEVICE; return PWICP_E_NO_DEVICE; }
+    const ConfigPara& cfg = s->cfg;
+    const double sor_mult = 5.0;                                           // R.cpp:415-416
+    int window = std::max(1, std::min(host_threads() - 1, 16));
+    if (const char* e = std::getenv("PWICP_SERIES_WINDOW")) window = std::max(1, atoi(e));
+    for (int w0 = 0; w0 < n_pairs; w0 += window) {
+        const int w1 = std::min(n_pairs, w0 + window), nw = w1 - w0;
+        const auto t0 = std::chrono::steady_clock::now();
+        StageTimer tm;
+        // ---- scans of this window: sources, and targets that are not prepared yet -------------------------------
+        std::vector<int> refIdx((size_t)nw);
+        std::vector<std::vector<float>> raw2((size_t)nw);
+        std::map<int, std::vector<float>> raw1;
+        for (int k = 0; k < nw; ++k) {
+            refIdx[(size_t)k] = s->ref_index(pairs[w0 + k]);
+            if (refIdx[(size_t)k] < 0 || refIdx[(size_t)k] >= (int)s->files.size()) return PWICP_E_INVALID;
+            if (!s->targets.count(refIdx[(size_t)k])) raw1[refIdx[(size_t)k]];
+        }
+        {
+            std::vector<std::thread> th;
+            for (int k = 0; k < nw; ++k)
+                th.emplace_back([&, k] { load_pcd(s->files[(size_t)(s->startEpoch + pairs[w0 + k] + 1)], &raw2[(size_t)k]); });
+            for (auto& kv : raw1) th.emplace_back([&s, &kv] { load_pcd(s->files[(size_t)kv.first], &kv.second); });
+            for (auto& t : th) t.join();
+        }
+        tm.lap("read scans (host threads)");
+        // ---- GPU parts, one after the other -------------------------------------------------------------------------
+        std::vector<char> ok((size_t)nw, 1);
+        for (auto& kv : raw1) {
+            auto t = std::make_shared<Prepared>();
+            float Res1 = cfg.PCres1;
+            bool good = !kv.second.empty();
+            if (good && !cfg.isSetResSVsize && pwicp_pc_resolution_dev(s->ctx, kv.second.data(), (int)(kv.second.size() / 4), &Res1) != PWICP_OK) good = false;
+            const float SVRes1 = cfg.isSetResSVsize ? cfg.SVsize1 : Res1 * 10;                       // R.cpp:635-640
+            if (good) good = prepare_gpu(s->ctx, kv.second, Res1, SVRes1, sor_mult, nullptr, t.get());
+            if (good) s->targets[kv.first] = t;
+            std::vector<float>().swap(kv.second);
+        }
+        std::vector<Prepared> src((size_t)nw);
+        for (int k = 0; k < nw; ++k) {
+            auto it = s->targets.find(refIdx[(size_t)k]);
+            float Res2 = cfg.PCres2;
+            bool good = it != s->targets.end() && !raw2[(size_t)k].empty();
+            if (good && !cfg.isSetResSVsize && pwicp_pc_resolution_dev(s->ctx, raw2[(size_t)k].data(), (int)(raw2[(size_t)k].size() / 4), &Res2) != PWICP_OK) good = false;
+            const float SVRes2 = cfg.isSetResSVsize ? cfg.SVsize2 : Res2 * 10;
+            if (good) good = prepare_gpu(s->ctx, raw2[(size_t)k], Res2, SVRes2, sor_mult, it->second->shift, &src[(size_t)k]);
+            ok[(size_t)k] = good ? 1 : 0;
+            std::vector<float>().swap(raw2[(size_t)k]);
+        }
+        tm.lap("voxel grid + SOR, k-NN graphs (GPU)");
+        // ---- host parts side by side ---------------------------------------------------------------------------------
+        {
+            std::vector<std::thread> th;
+            std::vector<char> okt(raw1.size(), 1);
+            size_t ti = 0;
+            for (auto& kv : raw1) {
+                auto it = s->targets.find(kv.first);
+                if (it != s->targets.end() && it->second->lab.empty()) {
+                    Prepared* p = it->second.get();
+                    char* flag = &okt[ti];
+                    th.emplace_back([p, flag] { *flag = prepare_host(p) ? 1 : 0; });
+                }
+                ++ti;
+            }
+            for (int k = 0; k < nw; ++k)
+                if (ok[(size_t)k]) th.emplace_back([&, k] { ok[(size_t)k] = prepare_host(&src[(size_t)k]) ? 1 : 0; });
+            for (auto& t : th) t.join();
+            ti = 0;
+            for (auto& kv : raw1) { if (!okt[ti]) s->targets.erase(kv.first); ++ti; }
+        }
+        tm.lap("normals + supervoxels (host threads)");
+        // ---- registrations ---------------------------------------------------------------------------------------------
+        const double t_setup_each = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / nw;
+        for (int k = 0; k < nw; ++k) {
+            pwicp_pair_record* rec = &recs[w0 + k];
+            const int pair = pairs[w0 + k], step = pair + 1, i = s->startEpoch + pair;
+            const auto tp = std::chrono::steady_clock::now();
+            std::cout << "\n//////////////////////  Process Pair_" << step << ":  Epoch-" << s->times[(size_t)refIdx[(size_t)k]] << " and Epoch-"
+                      << s->times[(size_t)i + 1] << "   //////////////////////////////////////////// \n\n";
+            auto it = s->targets.find(refIdx[(size_t)k]);
+            PairOutput out;
+            std::memset(&out, 0, sizeof(out));
+            if (!ok[(size_t)k] || it == s->targets.end() || !run_prepared(s->ctx, *it->second, src[(size_t)k], cfg, &out)) {
+                std::cerr << "Step " << step << " failed. Skipping to next.\n\n";                          // R.cpp:145-147
+                rec->status = out.res.status != 0 ? out.res.status : PWICP_E_INTERNAL;
+                continue;
+            }
+            rec->status = PWICP_OK;
+            rec->n_outer = out.res.n_outer;
+            rec->n_inner = out.res.n_inner_total;
+            std::memcpy(rec->T, out.T, sizeof(rec->T));
+            std::memcpy(rec->VCM, out.VCM, sizeof(rec->VCM));
+            rec->n_corr = out.res.n_corr;
+            rec->t_loop_ms = (float)out.res.t_loop_ms;
+            rec->t_pair_ms = (float)(t_setup_each + std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp).count());
+            Prepared().p.swap(src[(size_t)k].p);                                                             // release early
+        }
+        tm.lap("registrations (GPU)");
+        // keep the reference epoch and the targets of this window, drop older ones
+        for (auto it = s->targets.begin(); it != s->targets.end();) {
+            bool used = it->first == s->startEpoch;
+            for (int k = 0; k < nw; ++k) used = used || refIdx[(size_t)k] == it->first;
+            if (used) ++it; else it = s->targets.erase(it);
+        }
+    }
+    return PWICP_OK;
+}
+
+// one iteration of the pair loop
 PWICP_API int pwicp_series_run_pair(pwicp_series* s, int pair, pwicp_pair_record* rec) {
     if (!s || !rec || pair < 0 || pair >= s->num_pairs()) return PWICP_E_INVALID;
-    std::memset(rec, 0, sizeof(*rec));
-    rec->pair = pair;
-    rec->status = PWICP_E_INTERNAL;
-    if (!s->need_ctx()) { rec->status = PWICP_E_NO_DEVICE; return PWICP_E_NO_DEVICE; }
-    const auto t0 = std::chrono::steady_clock::now();
-    const int i = s->startEpoch + pair, step = pair + 1, refIdx = s->ref_index(pair);
-    if (refIdx < 0 || refIdx >= (int)s->files.size()) return PWICP_E_INVALID;
-    std::cout << "\n//////////////////////  Process Pair_" << step << ":  Epoch-" << s->times[(size_t)refIdx] << " and Epoch-"
-              << s->times[(size_t)i + 1] << "   //////////////////////////////////////////// \n\n";
-    if (s->c1Key != refIdx) { load_pcd(s->files[(size_t)refIdx], &s->c1); s->c1Key = refIdx; }
-    load_pcd(s->files[(size_t)i + 1], &s->c2);
-    if (s->c1.empty() || s->c2.empty()) { std::cerr << "Step " << step << " failed. Skipping to next.\n\n"; return PWICP_E_INTERNAL; }
-    const ConfigPara& cfg = s->cfg;
-    float Res1 = cfg.PCres1, Res2 = cfg.PCres2;
-    if (!cfg.isSetResSVsize) {
-        if (refIdx != s->resKey) {
-            if (pwicp_pc_resolution_dev(s->ctx, s->c1.data(), (int)(s->c1.size() / 4), &s->resVal) != PWICP_OK) s->resVal = 0.f;
-            s->resKey = refIdx;
-        }
-        Res1 = s->resVal;
-        if (pwicp_pc_resolution_dev(s->ctx, s->c2.data(), (int)(s->c2.size() / 4), &Res2) != PWICP_OK) Res2 = 0.f;
-    }
-    PairOutput out;
-    if (!register_pair(s->ctx, s->c1, s->c2, cfg, Res1, Res2, 5.0, &out, &s->tcache, refIdx)) {       // SOR multiplier 5.0 (R.cpp:415-416)
-        std::cerr << "Step " << step << " failed. Skipping to next.\n\n";                             // R.cpp:145-147
-        rec->status = out.res.status != 0 ? out.res.status : PWICP_E_INTERNAL;
-        return rec->status;
-    }
-    rec->status = PWICP_OK;
-    rec->n_outer = out.res.n_outer;
-    rec->n_inner = out.res.n_inner_total;
-    std::memcpy(rec->T, out.T, sizeof(rec->T));
-    std::memcpy(rec->VCM, out.VCM, sizeof(rec->VCM));
-    rec->n_corr = out.res.n_corr;
-    rec->t_loop_ms = (float)out.res.t_loop_ms;
-    rec->t_pair_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    return PWICP_OK;
+    const int32_t p = pair;
+    const int rc = pwicp_series_run_pairs(s, &p, 1, rec);
+    return rc != PWICP_OK ? rc : rec->status;
 }
 
 // File output of the series from the records of all pairs (any order; failed or missing pairs are skipped as the
@@ -526,10 +601,10 @@ PWICP_API bool PiecewiseICP_4D_call(const char* confile, int startEpoch, int epo
     pwicp_series* s = nullptr;
     if (pwicp_series_open(confile, startEpoch, epochNum, pairMode, overlapThd, env_device(), nullptr, 0, &s) != PWICP_OK) return false;
     const int n = pwicp_series_num_pairs(s);
-    std::vector<pwicp_pair_record> recs((size_t)n);
-    bool device_ok = true;
-    for (int p = 0; p < n && device_ok; ++p)
-        if (pwicp_series_run_pair(s, p, &recs[(size_t)p]) == PWICP_E_NO_DEVICE) device_ok = false;
+    std::vector<pwicp_pair_record> recs((size_t)std::max(n, 1));
+    std::vector<int32_t> all((size_t)std::max(n, 1));
+    for (int p = 0; p < n; ++p) all[(size_t)p] = p;
+    const bool device_ok = pwicp_series_run_pairs(s, all.data(), n, recs.data()) != PWICP_E_NO_DEVICE;
     const bool ok = device_ok && pwicp_series_write_results(s, recs.data(), n) == PWICP_OK;
     pwicp_series_close(s);
     return ok;

@@ -95,6 +95,7 @@ def load_library():
     L.pwicp_series_pair_epochs.argtypes = [vp, C.c_int, ip, ip, C.POINTER(C.c_long)]
     L.pwicp_series_adaptive_targets.argtypes = [vp, ip, C.c_int]
     L.pwicp_series_run_pair.argtypes = [vp, C.c_int, vp]
+    L.pwicp_series_run_pairs.argtypes = [vp, ip, C.c_int, vp]
     L.pwicp_series_write_results.argtypes = [vp, vp, C.c_int]
     L.pwicp_pc_resolution_dev.argtypes = [vp, fp, C.c_int, fp]
     L.pwicp_preprocess_dev.argtypes = [vp, fp, C.c_int, C.c_float, C.c_int, C.c_double, fp, ip]
@@ -239,6 +240,21 @@ class Series:
         if rc == -1:
             raise PwicpError(rc, "pwicp_series_run_pair: no usable HIP device")
         return rec
+
+    def run_pairs(self, pairs):
+        """Several pairs, pipelined (scans read and supervoxels computed on host threads for a window of pairs at once).
+        Returns a record array with one row per requested pair, in the order given."""
+        from .fourd import RECORD
+        ids = np.ascontiguousarray(pairs, np.int32)
+        recs = np.zeros(len(ids), RECORD)
+        if len(ids) == 0:
+            return recs
+        rc = self._L.pwicp_series_run_pairs(self._h, _p(ids, ip), len(ids), recs.ctypes.data_as(C.c_void_p))
+        if rc == -1:
+            raise PwicpError(rc, "pwicp_series_run_pairs: no usable HIP device")
+        if rc != 0:
+            raise PwicpError(rc, "pwicp_series_run_pairs")
+        return recs
 
     def write_results(self, records):
         """records: structured array of RECORD rows (all pairs, any order).  Writes the reference's result files."""

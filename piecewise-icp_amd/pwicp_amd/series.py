@@ -59,7 +59,8 @@ def run_series(confile, start_epoch, epoch_num, pair_mode, overlap_thd=0.75, bac
             series = Series(confile, start_epoch, epoch_num, pair_mode, overlap_thd, device)
         with series:
             n = series.num_pairs
-            mine = [series.run_pair(p) for p in range(n) if p % world == rank]
+            done = series.run_pairs([p for p in range(n) if p % world == rank])
+            mine = [done[k:k + 1] for k in range(len(done))]
             table = fourd.gather_records(mine, n, world, dist=dist, device=dev)
             if rank == 0:
                 recs = np.concatenate([table[p].reshape(1) for p in sorted(table)]) if table else np.zeros(0, fourd.RECORD)
