@@ -86,6 +86,7 @@ int nn_host_clouds(pwicp_context* ctx, const float* t4, int nt, const float* q4,
     Grid g;
     const float edge = estimate_cell_edge(t4, nt);
     PWCHK(pw_grid_build(ctx, dt.p, nt, edge, &g));
+    PWCHK(pw_check_finite(ctx, dq.p, nq));
     HIPCHK(ctx, d2->reserve((size_t)(nq > 0 ? nq : 1)));
     if (idx) HIPCHK(ctx, idx->reserve((size_t)(nq > 0 ? nq : 1)));
     PWCHK(pw_nn_launch(ctx, g.d, dq.p, nq, idx ? idx->p : nullptr, d2->p, nullptr));

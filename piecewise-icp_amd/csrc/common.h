@@ -115,6 +115,7 @@ int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pa
                            unsigned long long* d_examined);
 int pw_morton_order(pwicp_context* ctx, const GridDesc& g, const float4* d_pts, int n, DevBuf<int>* order);
 int pw_bbox(pwicp_context* ctx, const float4* d_pts, int n, float mn[3], float mx[3]);
+int pw_check_finite(pwicp_context* ctx, const float4* d_pts, int n);
 int pw_knn_launch(pwicp_context* ctx, const GridDesc& g, int k, int* d_nb);
 int pw_knn_mean_dist_launch(pwicp_context* ctx, const GridDesc& g, int mean_k, float* d_mean);
 // k-th smallest (0-based) of the non-sentinel entries of n non-negative floats; result written to d_out[0]; scratch >= 3*2048+8 uints

@@ -39,16 +39,19 @@ __host__ __device__ __forceinline__ float ord2f(unsigned u) {
 }
 
 // ---- bounding box ------------------------------------------------------------------------------
-// out[0..2] = min (ordered-uint encoded), out[3..5] = max, out[6] = max |coord|
+// out[0..2] = min (ordered-uint encoded), out[3..5] = max, out[6] = 1 if any coordinate is not finite
 __global__ void __launch_bounds__(kBlock) k_bbox(const float4* __restrict__ p, int n, unsigned* __restrict__ out) {
     __shared__ float sh[kBlock / 64][6];
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    bool bad = false;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float4 v = p[i];
         mn[0] = fminf(mn[0], v.x); mx[0] = fmaxf(mx[0], v.x);
         mn[1] = fminf(mn[1], v.y); mx[1] = fmaxf(mx[1], v.y);
         mn[2] = fminf(mn[2], v.z); mx[2] = fmaxf(mx[2], v.z);
+        bad = bad || !(isfinite(v.x) && isfinite(v.y) && isfinite(v.z));     // fminf/fmaxf silently drop NaN
     }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(&out[6], 1u);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll
@@ -803,12 +806,24 @@ int pw_bbox(pwicp_context* ctx, const float4* d_pts, int n, float mn[3], float m
     HIPCHK(ctx, hipMemcpyAsync(hb, bb.p, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < 3; ++k) { mn[k] = ord2f(hb[k]); mx[k] = ord2f(hb[3 + k]); }
+    if (hb[6]) {
+        ctx->set_err("non-finite coordinates in the cloud");
+        return PWICP_E_INVALID;
+    }
     for (int k = 0; k < 3; ++k)
         if (!(std::isfinite(mn[k]) && std::isfinite(mx[k]))) {
             ctx->set_err("non-finite coordinates in the cloud");
             return PWICP_E_INVALID;
         }
     return PWICP_OK;
+}
+
+// PWICP_E_INVALID if any coordinate of the n device points is NaN or infinite (queries as well as targets must be finite:
+// a NaN query has no nearest neighbour)
+int pw_check_finite(pwicp_context* ctx, const float4* d_pts, int n) {
+    if (n <= 0) return PWICP_OK;
+    float mn[3], mx[3];
+    return pw_bbox(ctx, d_pts, n, mn, mx);
 }
 
 int pw_grid_build(pwicp_context* ctx, const float4* d_pts, int n, float cell_edge, Grid* g) {

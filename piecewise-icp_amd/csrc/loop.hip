@@ -494,6 +494,7 @@ int finish_create(pwicp_pair* pr) {
     float f_dense = 3.0f, f_ct = 1.0f;
     if (const char* e = getenv("PWICP_DENSE_CELL_FACTOR")) { float v = (float)atof(e); if (v > 0.f) f_dense = v; }
     if (const char* e = getenv("PWICP_CT_CELL_FACTOR")) { float v = (float)atof(e); if (v > 0.f) f_ct = v; }
+    PWCHK(pw_check_finite(ctx, pr->cloud2.p, pr->n2));
     PWCHK(pw_grid_build(ctx, pr->cloud1.p, pr->n1, f_dense * pr->prm.Res1, &pr->g_c1));
     PWCHK(pw_grid_build(ctx, pr->P1.ct.p, m1, f_ct * pr->prm.SVRes1, &pr->g_ct1));
     // dense-query order (one-off): Morton order of the source patch points in the target grid
@@ -596,6 +597,8 @@ int pwicp_pair_create(pwicp_context* ctx, const float* cloud1, int n1, const int
     do {
         if ((rc = upload4(ctx, cloud1, n1, &pr->cloud1)) != PWICP_OK) break;
         if ((rc = upload4(ctx, cloud2, n2, &pr->cloud2)) != PWICP_OK) break;
+        if ((rc = pw_check_finite(ctx, pr->cloud1.p, n1)) != PWICP_OK) break;      // before anything walks the points
+        if ((rc = pw_check_finite(ctx, pr->cloud2.p, n2)) != PWICP_OK) break;
         if (l1.reserve((size_t)n1) != hipSuccess || l2.reserve((size_t)n2) != hipSuccess) { rc = PWICP_E_NOMEM; break; }
         if (hipMemcpyAsync(l1.p, labels1, (size_t)n1 * sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
             hipMemcpyAsync(l2.p, labels2, (size_t)n2 * sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {

@@ -353,3 +353,40 @@ def test_every_grid_layout_gives_the_exact_minimum(tmp_path, layout):
     env["PWICP_GRID_LAYOUT"] = layout
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "LAYOUT_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_too_few_stable_patches_is_an_error_code_and_the_pair_stays_usable(ctx, oracle):
+    """Source shifted far beyond the distance threshold: no stable patch (reference: std::exit, R.cpp:864-867) ->
+    PWICP_E_TOO_FEW_STABLE, no hang; the same context then registers a proper pair bit-identically to a fresh one."""
+    import pwicp_amd as P
+    tgt, src, _ = _data.pair(30000)
+    l1, n1 = _labels(tgt, "grid")
+    l2, n2 = _labels(src, "grid")
+    far = src.copy()
+    far[:, 2] += np.float32(1.0)                       # 1 m off, DTinit = 5 cm
+    bad = P.Pair(ctx, tgt, l1, n1, far, l2, n2, _data.params())
+    res = bad.run(check=False)
+    assert res.status == -4                            # PWICP_E_TOO_FEW_STABLE
+    bad.close()
+    good = P.Pair(ctx, tgt, l1, n1, src, l2, n2, _data.params())
+    r1 = good.run()
+    io = oracle.run_loop(tgt, src, oracle.select_patches(tgt, l1, n1), oracle.select_patches(src, l2, n2),
+                         _data.R, _data.R, 10 * _data.R, 10 * _data.R, 10 * _data.R, 0.8 * _data.R)
+    assert r1.status == 0 and r1.n_outer == io.n_outer
+    assert np.abs(np.array(r1.T16, np.float64) - np.array(io.T16, np.float64)).max() < 1e-6
+    good.close()
+
+
+@pytest.mark.gpu
+def test_non_finite_input_is_rejected(ctx):
+    import pwicp_amd as P
+    tgt, src, _ = _data.pair(20000)
+    l1, n1 = _labels(tgt, "grid")
+    l2, n2 = _labels(src, "grid")
+    broken = tgt.copy()
+    broken[123, 1] = np.nan
+    with pytest.raises(P.PwicpError):
+        P.Pair(ctx, broken, l1, n1, src, l2, n2, _data.params())
+    with pytest.raises(P.PwicpError):
+        ctx.determineCorrespondences(broken, src)
