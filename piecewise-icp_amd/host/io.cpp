@@ -146,14 +146,35 @@ bool load_pcd(const std::string& path, std::vector<float>* xyz4) {
         }
     } else if (mode == "ascii") {
         std::vector<double> row((size_t)ncol);
+        std::string tok;
         for (long i = 0; i < npts; ++i) {
-            for (int c = 0; c < ncol; ++c) if (!(in >> row[(size_t)c])) return false;
+            for (int c = 0; c < ncol; ++c) {                 // via strtod: "nan" / "inf" are legal values in PCL's ascii files
+                if (!(in >> tok)) return false;
+                char* end = nullptr;
+                row[(size_t)c] = std::strtod(tok.c_str(), &end);
+                if (end == tok.c_str()) return false;
+            }
             float* o = xyz4->data() + 4 * (size_t)i;
             for (int d = 0; d < 3; ++d) o[d] = (float)row[(size_t)col[d]];
             o[3] = 1.0f;
         }
     } else {
         return false;                                       // binary_compressed is not produced by the reference
+    }
+    // PCL keeps non-finite points of a file and makes every consumer on this path skip them (VoxelGrid, getMinMax3D,
+    // KdTreeFLANN::setInputCloud and calPCresolution test pcl_isfinite when !is_dense); dropping them here is equivalent
+    // for the registration (only RegisteredSourceCloud.pcd of the pair entry point loses those points)
+    {
+        size_t w = 0;
+        const size_t np = xyz4->size() / 4;
+        for (size_t i = 0; i < np; ++i) {
+            const float* q = xyz4->data() + 4 * i;
+            if (std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2])) {
+                if (w != i) std::memcpy(xyz4->data() + 4 * w, q, 16);
+                ++w;
+            }
+        }
+        xyz4->resize(4 * w);
     }
     return true;
 }
