@@ -5,6 +5,9 @@
  * reference does).  Citations "R.cpp", "C.cpp", "S.cpp" are src/Registration.cpp,
  * src/CommonFunc.cpp, src/Segmentation.cpp of the reference; "PCL:" cites PCL 1.8.1.
  */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include "pwicp_oracle.h"
 
 #include <float.h>
@@ -206,8 +209,30 @@ void orc_kdtree_knn(const orc_kdtree* t, const float* q3, int k, int* idx, float
     kd_search_rec(t, 0, q3, &r, md, dists);
 }
 
+/* Number of host threads of the batch searches below.  1 (default) = the faithful single-threaded cost of the
+ * reference (PCL 1.8.1's CorrespondenceEstimation and ICP are single-threaded, the reference has no threads); > 1 =
+ * the "OpenMP over all host cores" variant of SURVEY 8d, timed beside it by bench.py.  The queries are independent, so
+ * the results are the same whatever the thread count; tree builds and all reductions stay serial. */
+static int g_orc_threads = 1;
+void orc_set_num_threads(int n) { g_orc_threads = n > 0 ? n : 1; }
+int orc_get_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_num_procs();
+#else
+    return 1;
+#endif
+}
+
 void orc_kdtree_nn1(const orc_kdtree* t, const float* qry4, int nq, int* idx, float* d2)
 {
+#ifdef _OPENMP
+    if (g_orc_threads > 1 && nq >= 4096) {
+#pragma omp parallel for schedule(dynamic, 2048) num_threads(g_orc_threads)
+        for (int i = 0; i < nq; ++i) orc_kdtree_knn(t, qry4 + 4 * (size_t)i, 1, idx + i, d2 + i);
+        return;
+    }
+#endif
     for (int i = 0; i < nq; ++i) orc_kdtree_knn(t, qry4 + 4 * (size_t)i, 1, idx + i, d2 + i);
 }
 

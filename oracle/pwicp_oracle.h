@@ -43,6 +43,9 @@ void orc_kdtree_nn1(const orc_kdtree* t, const float* qry4, int nq, int* idx, fl
 void orc_kdtree_knn(const orc_kdtree* t, const float* q3, int k, int* idx, float* d2);
 /* pcl::registration::CorrespondenceEstimation::determineCorrespondences(.., DBL_MAX):
    builds the tree on the target (as the reference does at every call site) and searches. */
+/* host threads of the batch nearest-neighbour searches (1 = faithful single-threaded cost, the default) */
+void orc_set_num_threads(int n);
+int orc_get_max_threads(void);
 void orc_determine_correspondences(const float* tgt4, int nt, const float* src4, int ns,
                                    int* idx, float* d2);
 

@@ -213,6 +213,20 @@ def pc_resolution(cloud):
     return float(lib().orc_pc_resolution(_p(cloud), len(cloud)))
 
 
+def set_num_threads(n):
+    """Host threads of the oracle's batch NN searches (1 = the faithful single-threaded cost)."""
+    L = lib()
+    L.orc_set_num_threads.argtypes = [C.c_int]
+    L.orc_set_num_threads.restype = None
+    L.orc_set_num_threads(int(n))
+
+
+def max_threads():
+    L = lib()
+    L.orc_get_max_threads.restype = C.c_int
+    return int(L.orc_get_max_threads())
+
+
 def matrix2angle(T):
     T = np.ascontiguousarray(T, np.float32).reshape(16)
     a = np.zeros(3, np.float32)
