@@ -496,6 +496,38 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_direct(GridDesc gd, const f
     add_examined(examined, cnt);
 }
 
+// Dense 1-NN with the group-cooperative query: 8 lanes share one query, take every 8th point of a stencil row (one
+// coalesced 128-byte request per row pass) and split the far path.  The dense search is bound by the length of the
+// per-query chain of dependent memory round trips at full occupancy (SQ_WAIT_ANY ~75 %), not by issue: a row of a
+// column grid holds ~27 points, i.e. ~14 dependent passes for one lane and 1-2 for a group.  Same XCD-aware tile order.
+__global__ void __launch_bounds__(kBlock) k_nn_dense_group(GridDesc gd, const float4* __restrict__ pat,
+                                                           const int* __restrict__ qorder,
+                                                           const int* __restrict__ pt_patch,
+                                                           const int* __restrict__ stable, int nq,
+                                                           float* __restrict__ d2out,
+                                                           unsigned long long* __restrict__ examined, int chunk) {
+    constexpr int kQ = kBlock / kGroup;                   // queries per block
+    const int tile = chunk > 0 ? (int)(blockIdx.x % kXcds) * chunk + (int)(blockIdx.x / kXcds) : (int)blockIdx.x;
+    const int i = tile * kQ + (int)(threadIdx.x / kGroup), sub = threadIdx.x % kGroup;
+    if (i >= nq) return;
+    const int p = qorder ? qorder[i] : i;
+    if (!stable[pt_patch[p]]) {
+        if (sub == 0) d2out[i] = __uint_as_float(kSentinel);
+        return;
+    }
+    const float4 q = pat[p];
+    unsigned cnt = 0;
+    const NNBest b = nn_query_group_counted(gd, q.x, q.y, q.z, sub, cnt);
+    if (sub == 0) d2out[i] = b.d2();
+    if (examined) {
+        // points examined by this group's lanes, summed over the wave, one atomic per wave on a spread counter
+        unsigned long long c = cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if ((threadIdx.x & 63) == 0 && c) atomicAdd(&examined[(blockIdx.x & 255) * 16], c);
+    }
+}
+
 // Morton code (10 bits per axis) of the fine cell of each point, for the one-off query ordering
 __device__ __forceinline__ unsigned part1by2(unsigned x) {
     x &= 0x3ffu;
@@ -956,10 +988,17 @@ int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pa
     {
         static int xcd = -1;                 // PWICP_DENSE_XCD=0: plain block order (A/B measurements only)
         if (xcd < 0) { const char* e = getenv("PWICP_DENSE_XCD"); xcd = e ? atoi(e) : 1; }
-        const int tiles = div_up(nq, kBlock);
-        const int chunk = (xcd && variant == 1) ? div_up(tiles, kXcds) : 0;
-        hipLaunchKernelGGL(k_nn_dense_direct, dim3(chunk ? chunk * kXcds : tiles), dim3(kBlock), 0, ctx->stream, g, d_pat,
-                           variant == 1 ? d_qorder : (const int*)nullptr, d_pt_patch, d_stable, nq, d_d2, d_examined, chunk);
+        if (variant == 3) {                  // group-cooperative queries
+            const int tiles = div_up(nq, kBlock / kGroup);
+            const int chunk = xcd ? div_up(tiles, kXcds) : 0;
+            hipLaunchKernelGGL(k_nn_dense_group, dim3(chunk ? chunk * kXcds : tiles), dim3(kBlock), 0, ctx->stream, g, d_pat,
+                               d_qorder, d_pt_patch, d_stable, nq, d_d2, d_examined, chunk);
+        } else {
+            const int tiles = div_up(nq, kBlock);
+            const int chunk = (xcd && variant == 1) ? div_up(tiles, kXcds) : 0;
+            hipLaunchKernelGGL(k_nn_dense_direct, dim3(chunk ? chunk * kXcds : tiles), dim3(kBlock), 0, ctx->stream, g, d_pat,
+                               variant == 1 ? d_qorder : (const int*)nullptr, d_pt_patch, d_stable, nq, d_d2, d_examined, chunk);
+        }
     }
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;

@@ -257,8 +257,9 @@ __device__ __forceinline__ void group_min(NNBest& b) {
 }
 
 // up to four loads in flight per pass: a short range costs ONE memory round trip instead of one per two points
-__device__ __forceinline__ void scan_points4(const float4* __restrict__ pts, int lo, int hi, int step, float qx, float qy,
-                                             float qz, NNBest& b) {
+__device__ __forceinline__ unsigned scan_points4(const float4* __restrict__ pts, int lo, int hi, int step, float qx, float qy,
+                                                 float qz, NNBest& b) {
+    unsigned cnt = 0;
     for (int j = lo; j < hi; j += 4 * step) {
         float4 p[4];
 #pragma unroll
@@ -266,16 +267,18 @@ __device__ __forceinline__ void scan_points4(const float4* __restrict__ pts, int
             if (j + u * step < hi) p[u] = pts[j + u * step];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (j + u * step < hi) nn_consider(p[u], qx, qy, qz, b);
+            if (j + u * step < hi) { nn_consider(p[u], qx, qy, qz, b); ++cnt; }
     }
+    return cnt;
 }
 
 // rows (y in [y0,y1], z in [z0,z1]) x [x0,x1], shared by the group: the lanes fetch the begin/end words of eight rows
 // at once (one row each), hand them round with shuffles, and then walk every row TOGETHER, points interleaved over the
 // lanes, four loads in flight each.  The chain is 1 + sum_rows ceil(n_row / 32) round trips, whatever the shape of
 // the box (the coarse boxes of stage 2 have few, long rows).
-__device__ __forceinline__ void scan_box_group(const GridLevel& g, int x0, int x1, int y0, int y1, int z0, int z1, int sub,
-                                               float qx, float qy, float qz, NNBest& b) {
+__device__ __forceinline__ unsigned scan_box_group(const GridLevel& g, int x0, int x1, int y0, int y1, int z0, int z1, int sub,
+                                                   float qx, float qy, float qz, NNBest& b) {
+    unsigned cnt = 0;
     const int wy = y1 - y0 + 1;
     const int nrows = wy * (z1 - z0 + 1);
     const int gbase = (int)(__lane_id() & ~(unsigned)(kGroup - 1));
@@ -286,9 +289,10 @@ __device__ __forceinline__ void scan_box_group(const GridLevel& g, int x0, int x
 #pragma unroll
         for (int k = 0; k < kGroup; ++k) {
             const int lo = __shfl(lo_s, gbase + k), hi = __shfl(hi_s, gbase + k);
-            scan_points4(g.pts, lo + sub, hi, kGroup, qx, qy, qz, b);
+            cnt += scan_points4(g.pts, lo + sub, hi, kGroup, qx, qy, qz, b);
         }
     }
+    return cnt;
 }
 
 __device__ __forceinline__ NNBest nn_query_group(const GridDesc& gd, float qx, float qy, float qz, int sub) {
@@ -345,6 +349,62 @@ __device__ __forceinline__ NNBest nn_query_group(const GridDesc& gd, float qx, f
                 }
                 scan_points4(c.pts, lo0, hi0, 1, qx, qy, qz, b);
                 scan_points4(c.pts, lo1, hi1, 1, qx, qy, qz, b);
+            }
+            group_min(b);
+        }
+    }
+    return b;
+}
+
+// The same exact search for LONG stencil rows (dense cloud-to-cloud queries): in stage 1 all lanes of the group walk every
+// row together (nn_query_group gives each lane a row of its own, which suits the 1-3 point rows of the centroid grids).
+// `cnt` receives the points this lane examined.
+__device__ __forceinline__ NNBest nn_query_group_counted(const GridDesc& gd, float qx, float qy, float qz, int sub, unsigned& cnt) {
+    NNBest b;
+    b.key = kKeyInit;
+    const GridLevel& g = gd.fine;
+    if (g.n <= 0) return b;
+    {
+        const int cx = cell_of(qx, g.ox, g.inv_h), cy = cell_of(qy, g.oy, g.inv_hy), cz = cell_of(qz, g.oz, g.inv_hz);
+        cnt += scan_box_group(g, cx - 1, cx + 1, cy - 1, cy + 1, cz - 1, cz + 1, sub, qx, qy, qz, b);
+        group_min(b);
+        if (nn_resolved(g, 1, b)) return b;
+    }
+    const GridLevel& c = gd.coarse;
+    if (b.found()) {
+        const float rho = sqrtf(b.d2()) * 1.00001f + 2.0f * c.slack;
+        const int x0 = max(cell_of(qx - rho, c.ox, c.inv_h), 0), x1 = min(cell_of(qx + rho, c.ox, c.inv_h), c.nx - 1);
+        const int y0 = max(cell_of(qy - rho, c.oy, c.inv_hy), 0), y1 = min(cell_of(qy + rho, c.oy, c.inv_hy), c.ny - 1);
+        const int z0 = max(cell_of(qz - rho, c.oz, c.inv_hz), 0), z1 = min(cell_of(qz + rho, c.oz, c.inv_hz), c.nz - 1);
+        if ((y1 - y0 + 1) * (z1 - z0 + 1) <= 64) {
+            if (x0 <= x1 && y0 <= y1 && z0 <= z1) cnt += scan_box_group(c, x0, x1, y0, y1, z0, z1, sub, qx, qy, qz, b);
+            group_min(b);
+            return b;
+        }
+    }
+    {
+        const int cx = cell_of(qx, c.ox, c.inv_h), cy = cell_of(qy, c.oy, c.inv_hy), cz = cell_of(qz, c.oz, c.inv_hz);
+        const int ex = max(0, max(-cx, cx - (c.nx - 1)));
+        const int ey = max(0, max(-cy, cy - (c.ny - 1)));
+        const int ez = max(0, max(-cz, cz - (c.nz - 1)));
+        int r = max(max(ex, ey), max(ez, 1));
+        const int rcover = max(max(max(cx, c.nx - 1 - cx), max(cy, c.ny - 1 - cy)), max(cz, c.nz - 1 - cz));
+        cnt += scan_box_group(c, cx - r, cx + r, cy - r, cy + r, cz - r, cz + r, sub, qx, qy, qz, b);
+        group_min(b);
+        while (!nn_resolved(c, r, b) && r < rcover) {
+            ++r;
+            const int w = 2 * r + 1;
+            for (int t = sub; t < w * w; t += kGroup) {
+                const int dz = t / w - r, dy = t % w - r;
+                int lo0, hi0, lo1 = 0, hi1 = 0;
+                if (dz == -r || dz == r || dy == -r || dy == r) {
+                    row_range(c, cy + dy, cz + dz, cx - r, cx + r, lo0, hi0);
+                } else {
+                    row_range(c, cy + dy, cz + dz, cx - r, cx - r, lo0, hi0);
+                    row_range(c, cy + dy, cz + dz, cx + r, cx + r, lo1, hi1);
+                }
+                cnt += scan_points4(c.pts, lo0, hi0, 1, qx, qy, qz, b);
+                cnt += scan_points4(c.pts, lo1, hi1, 1, qx, qy, qz, b);
             }
             group_min(b);
         }
