@@ -72,15 +72,22 @@ __global__ void __launch_bounds__(kBlock) k_classify(
         // (4) R.cpp:826-862; `thr < dist` fails, exactly the reference's comparisons
         const float thr = (currDT <= LoD) ? LoD : currDT;
         bool pass = !(thr < resCT);
+        // the six boundary points: all index loads, then all gathers, in flight together (the kernel is a chain of
+        // dependent round trips, not throughput)
+        int jb[6];
+        float4 b[6], nn[6], tt[6];
+        float db[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { jb[k] = mBP[6 * i + k]; b[k] = bp2[6 * i + k]; db[k] = dBP[6 * i + k]; }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { nn[k] = nrm1[jb[k]]; tt[k] = ct1[jb[k]]; }
+#pragma unroll
         for (int k = 0; k < 6; ++k) {
-            const int jb = mBP[6 * i + k];
-            const float4 b = bp2[6 * i + k];
-            n = nrm1[jb]; t = ct1[jb];
             float res;
-            if (n.w != 0.0f) {
-                const float dx = t.x - b.x, dy = t.y - b.y, dz = t.z - b.z;
-                res = fabsf(dx * n.x + dy * n.y + dz * n.z);
-            } else res = sqrtf(dBP[6 * i + k]);
+            if (nn[k].w != 0.0f) {
+                const float dx = tt[k].x - b[k].x, dy = tt[k].y - b[k].y, dz = tt[k].z - b[k].z;
+                res = fabsf(dx * nn[k].x + dy * nn[k].y + dz * nn[k].z);
+            } else res = sqrtf(db[k]);
             if (thr < res) pass = false;
         }
         st_flag = (pass && (p2pt < DTctct)) ? 1 : 0;
