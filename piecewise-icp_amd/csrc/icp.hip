@@ -220,17 +220,17 @@ __device__ void icp_solve_tail(IcpState* st, const double* partials, int ns, dou
     if (t < 2 * kNSums) {      // two lanes per sum (even / odd blocks), then one add: a fixed summation order
         const int k = t % kNSums, h = t / kNSums;
         double s = 0.0;
-        // (written by other blocks of this launch: visible after the acquire fence in the caller.)  Eight loads in
-        // flight, then the adds in block order: the summation order stays fixed, the latency is paid once per eight
+        // (written by other blocks of this launch: visible after the acquire fence in the caller.)  Many loads in
+        // flight, then the adds in block order: the summation order stays fixed, the latency is paid once per pass
         int b = h;
-        for (; b + 14 < nblocks; b += 16) {
-            double v[8];
+        for (; b < nblocks; b += 64) {            // 32 guarded loads in flight (typical launches: one pass)
+            double v[32];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)(b + 2 * u) * kNSums + k];
+            for (int u = 0; u < 32; ++u) v[u] = (b + 2 * u < nblocks) ? partials[(size_t)(b + 2 * u) * kNSums + k] : 0.0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
+            for (int u = 0; u < 32; ++u)
+                if (b + 2 * u < nblocks) s += v[u];
         }
-        for (; b < nblocks; b += 2) s += partials[(size_t)b * kNSums + k];
         half[h][k] = s;
     }
     wave_sync();
