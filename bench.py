@@ -216,8 +216,8 @@ def main():
                     "hbm_measured_gbs": (round(traffic / dur_s / 1e9, 1) if traffic else None),
                     "hbm_measured_frac": (round(traffic / dur_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
                     "note": "achieved = algorithmic bytes (SURVEY 8d model, measured Kbar) / HIP-event time; a value above "
-                            "peak means cache reuse, not HBM speed: the kernel is bound by memory latency at full occupancy "
-                            "(SQ_WAIT_ANY 75 %, profiles/README.md)"}
+                            "peak means cache reuse, not HBM speed: the traffic is already compulsory; the kernel is bound by VALU "
+                            "issue (44 % busy) and load latency at full occupancy (profiles/README.md)"}
 
     if rank == 0:
         value = corr_total / tmax
