@@ -91,7 +91,7 @@ struct GridLevel {
     const float4* pts;       // sorted by cell; w = __int_as_float(original index)
 };
 
-// Two levels over the same points: `fine` serves the common 27-cell stencil, `coarse` (4x the edge) resolves
+// Two levels over the same points: `fine` serves the common 27-cell stencil, `coarse` (2x the edge) resolves
 // far queries without walking many empty fine cells.
 struct GridDesc {
     GridLevel fine, coarse;

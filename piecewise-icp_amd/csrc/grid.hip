@@ -922,7 +922,9 @@ int pw_grid_build(pwicp_context* ctx, const float4* d_pts, int n, float cell_edg
             }
         }
     }
-    PWCHK(build_level(ctx, d_pts, n, 4.0f * d.fine.h, mn, mx, &d.coarse, &g->ccell_start, &g->cpts, best_axis));
+    static float coarse_factor = 0.f;          // PWICP_COARSE_FACTOR: coarse edge / fine edge (default 2: measured best of 1.5 / 2 / 2.5 / 3 / 4)
+    if (coarse_factor == 0.f) { const char* e = getenv("PWICP_COARSE_FACTOR"); coarse_factor = e ? (float)atof(e) : 2.0f; if (!(coarse_factor > 1.f)) coarse_factor = 2.0f; }
+    PWCHK(build_level(ctx, d_pts, n, coarse_factor * d.fine.h, mn, mx, &d.coarse, &g->ccell_start, &g->cpts, best_axis));
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }

@@ -496,7 +496,7 @@ int finish_create(pwicp_pair* pr) {
                            pr->nrm1.p, pr->ct1n.p);
     // cell edges: dense cloud grid = 3 x point spacing (27-cell stencil ~ 80 points; measured optimum: most first-
     // iteration queries, 1-2 spacings from the target, still resolve in the stencil); centroid grid = 1 x patch
-    // size (its 4x coarse level resolves the far queries of displaced, unstable patches).
+    // size (its 2x coarse level resolves the far queries of displaced, unstable patches).
     // Tuning knobs for experiments only (results do not depend on them; the search is exact for any edge).
     float f_dense = 3.0f, f_ct = 1.0f;
     if (const char* e = getenv("PWICP_DENSE_CELL_FACTOR")) { float v = (float)atof(e); if (v > 0.f) f_dense = v; }
