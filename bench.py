@@ -217,7 +217,7 @@ def main():
                     "hbm_measured_frac": (round(traffic / dur_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
                     "note": "achieved = algorithmic bytes (SURVEY 8d model, measured Kbar) / HIP-event time; a value above "
                             "peak means cache reuse, not HBM speed: the traffic is already compulsory; the kernel is bound by VALU "
-                            "issue (44 % busy) and load latency at full occupancy (profiles/README.md)"}
+                            "issue (~50 % busy) and load latency at full occupancy (profiles/README.md)"}
 
     if rank == 0:
         value = corr_total / tmax
