@@ -239,7 +239,7 @@ def test_4d_series_reuses_target_and_auto_spacing(tmp_path, ctx, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pair_mode", [0, -1])
+@pytest.mark.parametrize("pair_mode", [0, -1, 2])
 def test_series_driver_two_ranks_matches_single_process(tmp_path, ctx, pair_mode):
     """pwicp_amd.series (pairs sharded over two ranks, records all-gathered, rank 0 writes) produces the same files,
     byte for byte, as the exported single-process PiecewiseICP_4D_call.  Both ranks share GPU 0 (gloo), which
@@ -281,7 +281,7 @@ def test_series_driver_two_ranks_matches_single_process(tmp_path, ctx, pair_mode
                                  capture_output=True, text=True, timeout=600, cwd=str(d), env=env)
             assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
         outs.append(out)
-    mode = "Direct2Ref" if pair_mode == 0 else "Adaptive"
+    mode = "Direct2Ref" if pair_mode == 0 else ("Adaptive" if pair_mode < 0 else "Fixed")
     names = ["TransMatrices.txt", "TransParameters.txt", "TransMatrices_toRef.txt", "TransParameters_toRef.txt"] + \
             ["%d_%s_TransMatrix.txt" % (e, mode) for e in (2, 3, 4)]
     for f in names:
