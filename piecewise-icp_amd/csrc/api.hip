@@ -3,6 +3,9 @@
 #include <cmath>
 #include <new>
 
+#include <chrono>
+#include <cstdio>
+
 #include "common.h"
 #include "icp.h"
 #include "patch.h"
@@ -157,14 +160,27 @@ int pwicp_knn(pwicp_context* ctx, const float* cloud_xyz4, int n, int k, float c
     if (!ctx) return PWICP_E_INVALID;
     if (!cloud_xyz4 || !neighbors || n <= 0 || k <= 0 || k > n) { ctx->set_err("pwicp_knn: invalid argument"); return PWICP_E_INVALID; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    const bool trace = getenv("PWICP_TRACE") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[pwicp knn] %-24s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    };
     DevBuf<float4> pts;
     PWCHK(upload(ctx, cloud_xyz4, n, &pts));
+    lap("upload");
     Grid g;
     PWCHK(pw_grid_build(ctx, pts.p, n, cell_edge > 0.f ? cell_edge : estimate_cell_edge(cloud_xyz4, n), &g));
+    lap("grid");
     DevBuf<int> nb;
     HIPCHK(ctx, nb.reserve((size_t)n * k));
     PWCHK(pw_knn_launch(ctx, g.d, k, nb.p));
+    lap("alloc + kernel");
     HIPCHK(ctx, hipMemcpy(neighbors, nb.p, (size_t)n * k * sizeof(int), hipMemcpyDeviceToHost));
+    lap("download");
     return PWICP_OK;
 }
 

@@ -26,6 +26,7 @@
 #include <unordered_set>
 #include <vector>
 
+#include "hostbuf.h"
 #include "kdtree.h"
 #include "parallel.h"
 #include "pwicp.h"
@@ -401,11 +402,12 @@ int supervoxel_segmentation(const Metric& metric, const int32_t* nb, int k, int 
 int segment_from_neighbors(const float* cloud_xyz4, int n, const int32_t* nb, int k, float sv_resolution, int32_t* labels,
                            int* n_supervoxels) {
     StageTimer tm;
-    std::vector<Pt> P((size_t)n);
+    pwhost::HostBuf<Pt> P;
+    if (!P.reserve((size_t)n)) return PWICP_E_NOMEM;
     for (int i = 0; i < n; ++i) {                                            // S.cpp:18-22: float -> double
-        P[(size_t)i].x = (double)cloud_xyz4[4 * (size_t)i];
-        P[(size_t)i].y = (double)cloud_xyz4[4 * (size_t)i + 1];
-        P[(size_t)i].z = (double)cloud_xyz4[4 * (size_t)i + 2];
+        P.p[(size_t)i].x = (double)cloud_xyz4[4 * (size_t)i];
+        P.p[(size_t)i].y = (double)cloud_xyz4[4 * (size_t)i + 1];
+        P.p[(size_t)i].z = (double)cloud_xyz4[4 * (size_t)i + 2];
     }
     pwhost::parallel_for(n, [&](long long lo, long long hi) {
         for (long long i = lo; i < hi; ++i) pca_normal(P.data(), (int)i, nb + (size_t)i * (size_t)k, k);
@@ -461,7 +463,8 @@ PWICP_API int pwicp_frontend_segment_dev(pwicp_context* ctx, const float* cloud_
                                          float point_spacing, int32_t* labels, int* n_supervoxels) {
     if (!ctx || !cloud_xyz4 || !labels || !n_supervoxels || n <= 0 || knn <= 0 || knn >= n || !(sv_resolution > 0.f))
         return PWICP_E_INVALID;
-    std::vector<int32_t> nb((size_t)n * knn);
+    pwhost::HostBuf<int32_t> nb;
+    if (!nb.reserve((size_t)n * knn)) return PWICP_E_NOMEM;
     const int rc = pwicp_knn(ctx, cloud_xyz4, n, knn, point_spacing > 0.f ? 2.0f * point_spacing : 0.f, nb.data());
     if (rc != PWICP_OK) return rc;
     return segment_from_neighbors(cloud_xyz4, n, nb.data(), knn, sv_resolution, labels, n_supervoxels);

@@ -23,6 +23,7 @@
 #include <thread>
 #include <vector>
 
+#include "hostbuf.h"
 #include "io.h"
 #include "parallel.h"
 #include "pwicp.h"
@@ -50,7 +51,7 @@ struct Prepared {
     float shift[3] = {0, 0, 0};    // the translation that was applied (minus the centroid of the pair's target)
     float Res = 0.f, SVRes = 0.f;
     double sor_mult = 0.0;
-    std::vector<int32_t> nb;       // k-NN graph (released by prepare_host)
+    HostBuf<int32_t> nb;           // k-NN graph, m x kNN (released by prepare_host)
     std::vector<int32_t> lab;
     int nsv = 0;
 };
@@ -85,7 +86,7 @@ bool prepare_gpu(pwicp_context* ctx, const std::vector<float>& raw, float Res, f
         q[1] = S[4] * x + S[5] * y + S[6] * z + S[7];
         q[2] = S[8] * x + S[9] * y + S[10] * z + S[11];
     }
-    c->nb.resize((size_t)m * kNN);
+    if (!c->nb.reserve((size_t)m * kNN)) { std::cerr << "Error: out of host memory.\n"; return false; }
     if (pwicp_knn(ctx, c->p.data(), m, kNN, 2.0f * Res, c->nb.data()) != PWICP_OK) {                          // S.cpp:30-41
         std::cerr << "Error: supervoxel segmentation failed: " << pwicp_last_error(ctx) << "\n";
         return false;
@@ -97,7 +98,7 @@ bool prepare_gpu(pwicp_context* ctx, const std::vector<float>& raw, float Res, f
 bool prepare_host(Prepared* c) {
     c->lab.resize((size_t)c->m);
     const int rc = segment_from_knn(c->p.data(), c->m, c->nb.data(), kNN, c->SVRes, c->lab.data(), &c->nsv);
-    std::vector<int32_t>().swap(c->nb);
+    c->nb.release();
     return rc == PWICP_OK;
 }
 
