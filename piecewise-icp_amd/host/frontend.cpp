@@ -189,7 +189,9 @@ int supervoxel_segmentation(const Metric& metric, const int32_t* nb, int k, int 
     constexpr size_t kInGraph = ~(size_t)0;                     // off[i]: the list is still row i of nb
     std::vector<size_t> off((size_t)n_points, kInGraph);
     std::vector<int> len((size_t)n_points, k);
-    std::vector<int> arena;
+    pwhost::HostBuf<int> arena;                 // huge-page backed; grows by doubling (rare: one round appends < n*k entries)
+    size_t arena_size = 0;
+    if (!arena.reserve((size_t)n_points * (size_t)k)) return -1;
     auto list_of = [&](int i) -> const int* {
         return off[(size_t)i] == kInGraph ? nb + (size_t)i * (size_t)k : arena.data() + off[(size_t)i];
     };
@@ -262,9 +264,16 @@ int supervoxel_segmentation(const Metric& metric, const int32_t* nb, int k, int 
                     }
                 }
             }
-            off[(size_t)i] = arena.size();
+            off[(size_t)i] = arena_size;
             len[(size_t)i] = (int)adjacent.size();
-            arena.insert(arena.end(), adjacent.begin(), adjacent.end());
+            if (arena_size + adjacent.size() > arena.n) {
+                pwhost::HostBuf<int> bigger;
+                if (!bigger.reserve(std::max(2 * arena.n, arena_size + adjacent.size()))) return -1;
+                std::memcpy(bigger.p, arena.p, arena_size * sizeof(int));
+                arena.swap(bigger);
+            }
+            if (!adjacent.empty()) std::memcpy(arena.p + arena_size, adjacent.data(), adjacent.size() * sizeof(int));
+            arena_size += adjacent.size();
             for (int j = 0; j < back; ++j) visited[(size_t)queue[(size_t)j]] = 0;
             if (number_of_supervoxels == n_supervoxels) break;
         }
@@ -281,8 +290,8 @@ int supervoxel_segmentation(const Metric& metric, const int32_t* nb, int k, int 
             off[(size_t)i] = w;
             w += (size_t)m;
         }
-        arena.resize(w);
-        if (tm.on) { char b[64]; std::snprintf(b, sizeof b, "    round -> %d sv, arena %zu", number_of_supervoxels, arena.size()); tm.lap(b); }
+        arena_size = w;
+        if (tm.on) { char b[64]; std::snprintf(b, sizeof b, "    round -> %d sv, arena %zu", number_of_supervoxels, arena_size); tm.lap(b); }
     }
     std::vector<int>& labels = *labels_out;
     labels.resize((size_t)n_points);
@@ -420,6 +429,7 @@ int segment_from_neighbors(const float* cloud_xyz4, int n, const int32_t* nb, in
     std::vector<int> lab;
     const int got = supervoxel_segmentation(metric, nb, k, n, n_sv, &lab);
     tm.lap("segmentation total");
+    if (got < 0) return PWICP_E_NOMEM;
     for (int i = 0; i < n; ++i) labels[i] = lab[(size_t)i];
     *n_supervoxels = got;
     return PWICP_OK;
