@@ -178,8 +178,11 @@ PWICP_API int pwicp_pair_run(pwicp_pair* pair, pwicp_result* result);
 PWICP_API int pwicp_pair_download_source(pwicp_pair* pair, float* cloud2_xyz4);
 
 /* ---- host-side setup stages and the reference's file-in / file-out entry points -------------------------------- */
-/* These run on the HOST today ("next" for the GPU); they are what the reference does
- * before and after the loop, exported so that the two entry points below are a complete drop-in. */
+/* The stages the reference runs before the loop, exported so that the two entry points below
+ * are a complete drop-in.  The *_dev functions (and pwicp_knn) run on the GPU and are what the entry points use; the
+ * functions without a context are host implementations of the SAME stage with identical output, kept as separate,
+ * explicitly named entry points (the tests cross-check the two; nothing ever selects them as a fallback).  The serial
+ * passes of the supervoxel front end (fusion, boundary refinement) are host code in both variants. */
 
 /* Supervoxel label of every point.  Replaces the first half of PatchGenerationAndRefinement (S.cpp:18-68):
  * k-NN (knn = 45 in the reference, C.h:41, query point included), PCA normals, boundary-preserving supervoxel
