@@ -166,6 +166,17 @@ PWICP_API int pwicp_pair_create_from_patches(pwicp_context* ctx,
                                 const float* cloud2_xyz4, int n2,
                                 const float* patch2_xyz4, const int32_t* off2, int m2,
                                 const pwicp_params* params, pwicp_pair** pair);
+/* The static target side of a pair as a handle of its own: cloud, patches, normals, search grids.  Every pair of a
+ * Direct2Ref series registers against the same target scan (R.cpp:94-103; the reference rebuilds all of it per pair,
+ * R.cpp:653): build it once, create the pairs with it.  params->Res1 / SVRes1 of those pairs must be the target's.
+ * The target must outlive the pairs created with it. */
+typedef struct pwicp_target pwicp_target;
+PWICP_API int pwicp_target_create(pwicp_context* ctx, const float* cloud1_xyz4, int n1, const int32_t* labels1,
+                                  int n_supervoxels1, float Res1, float SVRes1, pwicp_target** out);
+PWICP_API void pwicp_target_destroy(pwicp_target* target);
+PWICP_API int pwicp_pair_create_with_target(pwicp_target* target, const float* cloud2_xyz4, int n2,
+                                            const int32_t* labels2, int n_supervoxels2, const pwicp_params* params,
+                                            pwicp_pair** out);
 PWICP_API void pwicp_pair_destroy(pwicp_pair* pair);
 PWICP_API int  pwicp_pair_num_patches(const pwicp_pair* pair, int* m1, int* m2);
 /* Restores the source-side arrays to their uploaded state (the loop transforms them in place,

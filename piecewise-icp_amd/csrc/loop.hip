@@ -430,16 +430,24 @@ float bb_corner_change(const double* bb, const float* T) {
 }  // namespace
 
 // ==========================================================================================================
-struct pwicp_pair {
+// The static target side of a pair: cloud, patches, normals and the two search grids.  Shareable between pairs with the
+// same target scan (every pair of a Direct2Ref series, R.cpp:94-103): built once, read-only afterwards.
+struct pwicp_target {
     pwicp_context* ctx = nullptr;
-    pwicp_params prm{};
-    // target (static)
+    float Res1 = 0.f, SVRes1 = 0.f;
     int n1 = 0;
     DevBuf<float4> cloud1;
     Grid g_c1, g_ct1;
     PatchSet P1;
     DevBuf<float4> nrm1;    // calPatchNormal per target patch, w = ok
     DevBuf<float4> ct1n;    // normals of CTcloud1_withNorm
+};
+
+struct pwicp_pair {
+    pwicp_context* ctx = nullptr;
+    pwicp_params prm{};
+    pwicp_target* tgt = nullptr;     // target side
+    bool owns_tgt = false;           // created by pwicp_pair_create (destroyed with the pair) or borrowed
     // source (transformed in place by the loop) + pristine copies for reset
     int n2 = 0;
     DevBuf<float4> cloud2, cloud2_0;
@@ -471,6 +479,7 @@ struct pwicp_pair {
     ~pwicp_pair() {
         for (auto e : ev) (void)hipEventDestroy(e);
         if (mail_h) (void)hipHostFree(mail_h);
+        if (owns_tgt) delete tgt;
     }
     hipEvent_t event(size_t i) {
         while (ev.size() <= i) {
@@ -484,16 +493,16 @@ struct pwicp_pair {
 
 namespace {
 
-int finish_create(pwicp_pair* pr) {
-    pwicp_context* ctx = pr->ctx;
-    const int m1 = pr->P1.m, m2 = pr->P2.m;
-    // static target side: patch normals, centroid normals, grids
-    HIPCHK(ctx, pr->nrm1.reserve((size_t)std::max(m1, 1)));
-    HIPCHK(ctx, pr->ct1n.reserve((size_t)std::max(m1, 1)));
-    PWCHK(pw_patch_normals_launch(ctx, pr->P1.pat.p, pr->P1.off.p, m1, pr->nrm1.p));
+// static target side once its cloud and patches are on the device: patch normals, centroid normals, grids
+int finish_target(pwicp_target* t) {
+    pwicp_context* ctx = t->ctx;
+    const int m1 = t->P1.m;
+    HIPCHK(ctx, t->nrm1.reserve((size_t)std::max(m1, 1)));
+    HIPCHK(ctx, t->ct1n.reserve((size_t)std::max(m1, 1)));
+    PWCHK(pw_patch_normals_launch(ctx, t->P1.pat.p, t->P1.off.p, m1, t->nrm1.p));
     if (m1 > 0)
-        hipLaunchKernelGGL(k_with_norm, dim3(div_up(m1, kBlock)), dim3(kBlock), 0, ctx->stream, m1, pr->P1.off.p,
-                           pr->nrm1.p, pr->ct1n.p);
+        hipLaunchKernelGGL(k_with_norm, dim3(div_up(m1, kBlock)), dim3(kBlock), 0, ctx->stream, m1, t->P1.off.p,
+                           t->nrm1.p, t->ct1n.p);
     // cell edges: dense cloud grid = 3 x point spacing (27-cell stencil ~ 80 points; measured optimum: most first-
     // iteration queries, 1-2 spacings from the target, still resolve in the stencil); centroid grid = 1 x patch
     // size (its 2x coarse level resolves the far queries of displaced, unstable patches).
@@ -501,13 +510,20 @@ int finish_create(pwicp_pair* pr) {
     float f_dense = 3.0f, f_ct = 1.0f;
     if (const char* e = getenv("PWICP_DENSE_CELL_FACTOR")) { float v = (float)atof(e); if (v > 0.f) f_dense = v; }
     if (const char* e = getenv("PWICP_CT_CELL_FACTOR")) { float v = (float)atof(e); if (v > 0.f) f_ct = v; }
+    PWCHK(pw_grid_build(ctx, t->cloud1.p, t->n1, f_dense * t->Res1, &t->g_c1));
+    PWCHK(pw_grid_build(ctx, t->P1.ct.p, m1, f_ct * t->SVRes1, &t->g_ct1));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PWICP_OK;
+}
+
+int finish_create(pwicp_pair* pr) {
+    pwicp_context* ctx = pr->ctx;
+    const int m2 = pr->P2.m;
     PWCHK(pw_check_finite(ctx, pr->cloud2.p, pr->n2));
-    PWCHK(pw_grid_build(ctx, pr->cloud1.p, pr->n1, f_dense * pr->prm.Res1, &pr->g_c1));
-    PWCHK(pw_grid_build(ctx, pr->P1.ct.p, m1, f_ct * pr->prm.SVRes1, &pr->g_ct1));
     // dense-query order (one-off): Morton order of the source patch points in the target grid
     HIPCHK(ctx, pr->pt_patch2.reserve((size_t)std::max(pr->P2.tot, 1)));
     PWCHK(pw_point_patch_ids_launch(ctx, pr->P2.off.p, m2, pr->pt_patch2.p));
-    PWCHK(pw_morton_order(ctx, pr->g_c1.d, pr->P2.pat.p, pr->P2.tot, &pr->qorder));
+    PWCHK(pw_morton_order(ctx, pr->tgt->g_c1.d, pr->P2.pat.p, pr->P2.tot, &pr->qorder));
     // pristine source copies; centroids and boundary points live in ONE buffer so that a single NN launch and a
     // single transform launch serve both (R.cpp:737-747, 946-949)
     HIPCHK(ctx, pr->cloud2_0.reserve((size_t)std::max(pr->n2, 1)));
@@ -585,6 +601,69 @@ bool params_ok(const pwicp_params* p) {
 
 extern "C" {
 
+int pwicp_target_create(pwicp_context* ctx, const float* cloud1, int n1, const int32_t* labels1, int nsv1, float Res1,
+                        float SVRes1, pwicp_target** out) {
+    if (!ctx) return PWICP_E_INVALID;
+    if (!out || !cloud1 || !labels1 || n1 <= 0 || nsv1 < 0 || !(Res1 > 0.f) || !(SVRes1 > 0.f)) {
+        ctx->set_err("pwicp_target_create: invalid argument");
+        return PWICP_E_INVALID;
+    }
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    pwicp_target* t = new (std::nothrow) pwicp_target();
+    if (!t) return PWICP_E_NOMEM;
+    t->ctx = ctx; t->n1 = n1; t->Res1 = Res1; t->SVRes1 = SVRes1;
+    int rc = PWICP_OK;
+    DevBuf<int> l1;
+    do {
+        if ((rc = upload4(ctx, cloud1, n1, &t->cloud1)) != PWICP_OK) break;
+        if ((rc = pw_check_finite(ctx, t->cloud1.p, n1)) != PWICP_OK) break;       // before anything walks the points
+        if (l1.reserve((size_t)n1) != hipSuccess) { rc = PWICP_E_NOMEM; break; }
+        if (hipMemcpyAsync(l1.p, labels1, (size_t)n1 * sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = PWICP_E_NO_DEVICE; break; }
+        if ((rc = pw_select_patches_dev(ctx, t->cloud1.p, n1, l1.p, nsv1, &t->P1)) != PWICP_OK) break;
+        rc = finish_target(t);
+    } while (0);
+    if (rc != PWICP_OK) { delete t; return rc; }
+    *out = t;
+    return PWICP_OK;
+}
+
+void pwicp_target_destroy(pwicp_target* t) {
+    if (!t) return;
+    (void)hipSetDevice(t->ctx->device);
+    (void)hipStreamSynchronize(t->ctx->stream);
+    delete t;
+}
+
+int pwicp_pair_create_with_target(pwicp_target* t, const float* cloud2, int n2, const int32_t* labels2, int nsv2,
+                                  const pwicp_params* params, pwicp_pair** out) {
+    if (!t) return PWICP_E_INVALID;
+    pwicp_context* ctx = t->ctx;
+    if (!out || !cloud2 || !labels2 || n2 <= 0 || nsv2 < 0 || !params_ok(params) || params->Res1 != t->Res1 ||
+        params->SVRes1 != t->SVRes1) {
+        ctx->set_err("pwicp_pair_create_with_target: invalid argument (Res1 / SVRes1 must be the target's)");
+        return PWICP_E_INVALID;
+    }
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    pwicp_pair* pr = new (std::nothrow) pwicp_pair();
+    if (!pr) return PWICP_E_NOMEM;
+    pr->ctx = ctx; pr->prm = *params; pr->tgt = t; pr->owns_tgt = false; pr->n2 = n2;
+    int rc = PWICP_OK;
+    DevBuf<int> l2;
+    do {
+        if ((rc = upload4(ctx, cloud2, n2, &pr->cloud2)) != PWICP_OK) break;
+        if ((rc = pw_check_finite(ctx, pr->cloud2.p, n2)) != PWICP_OK) break;
+        if (l2.reserve((size_t)n2) != hipSuccess) { rc = PWICP_E_NOMEM; break; }
+        if (hipMemcpyAsync(l2.p, labels2, (size_t)n2 * sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = PWICP_E_NO_DEVICE; break; }
+        if ((rc = pw_select_patches_dev(ctx, pr->cloud2.p, n2, l2.p, nsv2, &pr->P2)) != PWICP_OK) break;
+        rc = finish_create(pr);
+    } while (0);
+    if (rc != PWICP_OK) { delete pr; return rc; }
+    *out = pr;
+    return PWICP_OK;
+}
+
 int pwicp_pair_create(pwicp_context* ctx, const float* cloud1, int n1, const int32_t* labels1, int nsv1,
                       const float* cloud2, int n2, const int32_t* labels2, int nsv2, const pwicp_params* params,
                       pwicp_pair** out) {
@@ -595,28 +674,11 @@ int pwicp_pair_create(pwicp_context* ctx, const float* cloud1, int n1, const int
         return PWICP_E_INVALID;
     }
     *out = nullptr;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    pwicp_pair* pr = new (std::nothrow) pwicp_pair();
-    if (!pr) return PWICP_E_NOMEM;
-    pr->ctx = ctx; pr->prm = *params; pr->n1 = n1; pr->n2 = n2;
-    int rc = PWICP_OK;
-    DevBuf<int> l1, l2;
-    do {
-        if ((rc = upload4(ctx, cloud1, n1, &pr->cloud1)) != PWICP_OK) break;
-        if ((rc = upload4(ctx, cloud2, n2, &pr->cloud2)) != PWICP_OK) break;
-        if ((rc = pw_check_finite(ctx, pr->cloud1.p, n1)) != PWICP_OK) break;      // before anything walks the points
-        if ((rc = pw_check_finite(ctx, pr->cloud2.p, n2)) != PWICP_OK) break;
-        if (l1.reserve((size_t)n1) != hipSuccess || l2.reserve((size_t)n2) != hipSuccess) { rc = PWICP_E_NOMEM; break; }
-        if (hipMemcpyAsync(l1.p, labels1, (size_t)n1 * sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-            hipMemcpyAsync(l2.p, labels2, (size_t)n2 * sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
-            rc = PWICP_E_NO_DEVICE; break;
-        }
-        if ((rc = pw_select_patches_dev(ctx, pr->cloud1.p, n1, l1.p, nsv1, &pr->P1)) != PWICP_OK) break;
-        if ((rc = pw_select_patches_dev(ctx, pr->cloud2.p, n2, l2.p, nsv2, &pr->P2)) != PWICP_OK) break;
-        rc = finish_create(pr);
-    } while (0);
-    if (rc != PWICP_OK) { delete pr; return rc; }
-    *out = pr;
+    pwicp_target* t = nullptr;
+    PWCHK(pwicp_target_create(ctx, cloud1, n1, labels1, nsv1, params->Res1, params->SVRes1, &t));
+    const int rc = pwicp_pair_create_with_target(t, cloud2, n2, labels2, nsv2, params, out);
+    if (rc != PWICP_OK) { pwicp_target_destroy(t); return rc; }
+    (*out)->owns_tgt = true;
     return PWICP_OK;
 }
 
@@ -632,14 +694,18 @@ int pwicp_pair_create_from_patches(pwicp_context* ctx, const float* cloud1, int 
     *out = nullptr;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     pwicp_pair* pr = new (std::nothrow) pwicp_pair();
-    if (!pr) return PWICP_E_NOMEM;
-    pr->ctx = ctx; pr->prm = *params; pr->n1 = n1; pr->n2 = n2;
+    pwicp_target* t = new (std::nothrow) pwicp_target();
+    if (!pr || !t) { delete pr; delete t; return PWICP_E_NOMEM; }
+    t->ctx = ctx; t->n1 = n1; t->Res1 = params->Res1; t->SVRes1 = params->SVRes1;
+    pr->ctx = ctx; pr->prm = *params; pr->tgt = t; pr->owns_tgt = true; pr->n2 = n2;
     int rc = PWICP_OK;
     do {
-        if ((rc = upload4(ctx, cloud1, n1, &pr->cloud1)) != PWICP_OK) break;
+        if ((rc = upload4(ctx, cloud1, n1, &t->cloud1)) != PWICP_OK) break;
         if ((rc = upload4(ctx, cloud2, n2, &pr->cloud2)) != PWICP_OK) break;
-        if ((rc = upload_patches(ctx, patch1, off1, m1, &pr->P1)) != PWICP_OK) break;
+        if ((rc = pw_check_finite(ctx, t->cloud1.p, n1)) != PWICP_OK) break;
+        if ((rc = upload_patches(ctx, patch1, off1, m1, &t->P1)) != PWICP_OK) break;
         if ((rc = upload_patches(ctx, patch2, off2, m2, &pr->P2)) != PWICP_OK) break;
+        if ((rc = finish_target(t)) != PWICP_OK) break;
         rc = finish_create(pr);
     } while (0);
     if (rc != PWICP_OK) { delete pr; return rc; }
@@ -656,7 +722,7 @@ void pwicp_pair_destroy(pwicp_pair* pr) {
 
 int pwicp_pair_num_patches(const pwicp_pair* pr, int* m1, int* m2) {
     if (!pr) return PWICP_E_INVALID;
-    if (m1) *m1 = pr->P1.m;
+    if (m1) *m1 = pr->tgt->P1.m;
     if (m2) *m2 = pr->P2.m;
     return PWICP_OK;
 }
@@ -747,7 +813,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     // R.cpp:626-631
     float DTinit = prm.DTinit;
     if (!prm.isManualDTinit) {
-        PWCHK(pw_nn_launch(ctx, pr->g_c1.d, pr->cloud2.p, pr->n2, nullptr, pr->d2dense.p, nullptr));
+        PWCHK(pw_nn_launch(ctx, pr->tgt->g_c1.d, pr->cloud2.p, pr->n2, nullptr, pr->d2dense.p, nullptr));
         double d75 = 0;
         PWCHK(select_p75(pr, pr->n2, pr->n2, &d75));
         DTinit = (float)(d75 * 3.0);
@@ -779,7 +845,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     auto enqueue_front = [&]() -> int {
         // (1) R.cpp:737-747 — CT2 and BP2 queries against the static target-centroid grid — and the source patch
         // normals for CTcloud2_withNorm (R.cpp:824), recomputed from the transformed patch points: one launch
-        return pw_front_launch(ctx, pr->P2.pat.p, pr->P2.off.p, m2, pr->nrm2.p, pr->g_ct1.d, pr->ctbp2.p, 7 * m2,
+        return pw_front_launch(ctx, pr->P2.pat.p, pr->P2.off.p, m2, pr->nrm2.p, pr->tgt->g_ct1.d, pr->ctbp2.p, 7 * m2,
                                pr->mCTBP.p, pr->dCTBP.p);
     };
     auto enqueue_transform = [&](unsigned* slot) {
@@ -804,8 +870,8 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         // (2)-(4)
         const float DTctct = currDT + 1 * (prm.SVRes1 + prm.SVRes2);   // R.cpp:817
         hipLaunchKernelGGL(k_classify, dim3(div_up(m2, kBlock)), dim3(kBlock), 0, ctx->stream, m2, pr->mCTBP.p,
-                           pr->dCTBP.p, pr->mCTBP.p + m2, pr->dCTBP.p + m2, pr->P1.ctstd.p, pr->P2.bpstd.p, pr->nrm1.p,
-                           pr->P1.ct.p, ct2, bp2, pr->P2.off.p, currDT, DTmin, DTctct, pr->stable.p, pr->blk_cnt.p, slot);
+                           pr->dCTBP.p, pr->mCTBP.p + m2, pr->dCTBP.p + m2, pr->tgt->P1.ctstd.p, pr->P2.bpstd.p, pr->tgt->nrm1.p,
+                           pr->tgt->P1.ct.p, ct2, bp2, pr->P2.off.p, currDT, DTmin, DTctct, pr->stable.p, pr->blk_cnt.p, slot);
         hipLaunchKernelGGL(k_compact, dim3(div_up(m2, kBlock)), dim3(kBlock), 0, ctx->stream, m2, pr->stable.p, pr->P2.off.p,
                            ct2, pr->nrm2.p, pr->blk_cnt.p, pr->stCT.p, pr->stN.p, pr->icp.src.p, pr->icp.srcn.p, slot,
                            pr->icp.state.p);
@@ -837,7 +903,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                 mail.a = slot; mail.na = kSlot;
                 mail.b = k > 0 ? slot - kSlot + 4 : slot + 4; mail.nb = 6;
                 mail.dst = pr->mail_d + 16; mail.seq_ptr = pr->mail_d; mail.seq = seq;
-                PWCHK(pw_icp_enqueue(ctx, pr->g_ct1.d, pr->P1.ct.p, pr->ct1n.p, &pr->icp, m2, slot + 2, 1e-6, batch, &mail));
+                PWCHK(pw_icp_enqueue(ctx, pr->tgt->g_ct1.d, pr->tgt->P1.ct.p, pr->tgt->ct1n.p, &pr->icp, m2, slot + 2, 1e-6, batch, &mail));
                 if (ev) {
                     HIPCHK(ctx, hipEventRecord(pr->event(n_ev + 1), ctx->stream));
                     n_ev += 2;
@@ -889,7 +955,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                 ev_kind.push_back({n_ev, 0});
                 HIPCHK(ctx, hipEventRecord(pr->event(n_ev), ctx->stream));
             }
-            PWCHK(pw_nn_dense_launch(ctx, pr->g_c1.d, pr->P2.pat.p, pr->qorder.p, pr->pt_patch2.p, pr->stable.p,
+            PWCHK(pw_nn_dense_launch(ctx, pr->tgt->g_c1.d, pr->P2.pat.p, pr->qorder.p, pr->pt_patch2.p, pr->stable.p,
                                          pr->P2.tot, pr->d2dense.p, pr->examined.p));
             if (ev) {
                 HIPCHK(ctx, hipEventRecord(pr->event(n_ev + 1), ctx->stream));
@@ -931,7 +997,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
             VcmMail vm;
             vm.examined = pr->examined.p;
             vm.dst = pr->mail_d + 16; vm.seq_ptr = pr->mail_d; vm.seq = vcm_seq = ++pr->mail_seq;
-            PWCHK(pw_vcm_enqueue(ctx, pr->g_ct1.d, pr->P1.ct.p, pr->ct1n.p, &pr->icp, pr->stCT.p, ns, &vm));
+            PWCHK(pw_vcm_enqueue(ctx, pr->tgt->g_ct1.d, pr->tgt->P1.ct.p, pr->tgt->ct1n.p, &pr->icp, pr->stCT.p, ns, &vm));
             vcm_pending = true;
             res->n_corr += ns;
         }
@@ -963,7 +1029,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         }
     }
     res->dense_kbar = res->n_corr_dense > 0 ? (double)ex / (double)res->n_corr_dense : 0.0;
-    res->dense_rows = (pr->g_c1.d.fine.ny == 1 || pr->g_c1.d.fine.nz == 1) ? 3 : 9;
+    res->dense_rows = (pr->tgt->g_c1.d.fine.ny == 1 || pr->tgt->g_c1.d.fine.nz == 1) ? 3 : 9;
     res->status = status;
     HIPCHK(ctx, hipGetLastError());
     return status;
@@ -995,7 +1061,7 @@ int pwicp_pair_bench_dense_nn(pwicp_pair* pr, int n_launches, double* ms_per_lau
     }
     HIPCHK(ctx, hipMemsetAsync(pr->examined.p, 0, 256 * 16 * sizeof(unsigned long long), ctx->stream));
     // warm-up launch (also measures Kbar)
-    PWCHK(pw_nn_dense_launch(ctx, pr->g_c1.d, pr->pat2_0.p, pr->qorder.p, pr->pt_patch2.p, flags, tot,
+    PWCHK(pw_nn_dense_launch(ctx, pr->tgt->g_c1.d, pr->pat2_0.p, pr->qorder.p, pr->pt_patch2.p, flags, tot,
                                  pr->d2dense.p, pr->examined.p));
     unsigned long long ex = 0;
     {
@@ -1007,7 +1073,7 @@ int pwicp_pair_bench_dense_nn(pwicp_pair* pr, int n_launches, double* ms_per_lau
     hipEvent_t e0 = pr->event(0), e1 = pr->event(1);
     HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
     for (int i = 0; i < n_launches; ++i)
-        PWCHK(pw_nn_dense_launch(ctx, pr->g_c1.d, pr->pat2_0.p, pr->qorder.p, pr->pt_patch2.p, flags, tot,
+        PWCHK(pw_nn_dense_launch(ctx, pr->tgt->g_c1.d, pr->pat2_0.p, pr->qorder.p, pr->pt_patch2.p, flags, tot,
                                      pr->d2dense.p, nullptr));
     HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1016,7 +1082,7 @@ int pwicp_pair_bench_dense_nn(pwicp_pair* pr, int n_launches, double* ms_per_lau
     if (ms_per_launch) *ms_per_launch = (double)ms / n_launches;
     if (n_queries) *n_queries = npts;
     if (kbar) *kbar = (double)ex / (double)npts;
-    if (cell_edge) *cell_edge = pr->g_c1.d.fine.h;
+    if (cell_edge) *cell_edge = pr->tgt->g_c1.d.fine.h;
     return PWICP_OK;
 }
 

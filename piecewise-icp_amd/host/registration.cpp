@@ -54,6 +54,11 @@ struct Prepared {
     HostBuf<int32_t> nb;           // k-NN graph, m x kNN (released by prepare_host)
     std::vector<int32_t> lab;
     int nsv = 0;
+    pwicp_target* dev = nullptr;   // device side of a TARGET (cloud, patches, normals, grids), built at its first pair
+    Prepared() = default;
+    Prepared(const Prepared&) = delete;
+    Prepared& operator=(const Prepared&) = delete;
+    ~Prepared() { if (dev) pwicp_target_destroy(dev); }
 };
 
 // GPU part.  shift_in == nullptr: the cloud is a target and is reduced by its own centroid (R.cpp:419-436:
@@ -103,13 +108,18 @@ bool prepare_host(Prepared* c) {
 }
 
 // the registration of two prepared clouds: Piecewise_ICP (R.cpp:618-700) on the GPU, then T_final = S^-1 T S (R.cpp:461)
-bool run_prepared(pwicp_context* ctx, const Prepared& t, const Prepared& s, const ConfigPara& cfg, PairOutput* out) {
+bool run_prepared(pwicp_context* ctx, Prepared& t, const Prepared& s, const ConfigPara& cfg, PairOutput* out) {
     StageTimer tm;
     std::cout << "Preprocessed PC-1 point number: " << t.m << "\tPreprocessed PC-2 point number: " << s.m << std::endl << std::endl;
     std::cout << "--->>> " << t.nsv << " / " << s.nsv << " supervoxels are generated." << std::endl;
     pwicp_params prm{t.Res, s.Res, t.SVRes, s.SVRes, cfg.isSetDTinit ? 1 : 0, cfg.DTinit, cfg.DTmin};
     pwicp_pair* pair = nullptr;
-    if (pwicp_pair_create(ctx, t.p.data(), t.m, t.lab.data(), t.nsv, s.p.data(), s.m, s.lab.data(), s.nsv, &prm, &pair) != PWICP_OK) {
+    // the target's device side is built once and shared by all pairs with this target (R.cpp:653 rebuilds it per pair)
+    if (!t.dev && pwicp_target_create(ctx, t.p.data(), t.m, t.lab.data(), t.nsv, t.Res, t.SVRes, &t.dev) != PWICP_OK) {
+        std::cerr << "Error: " << pwicp_last_error(ctx) << "\n";
+        return false;
+    }
+    if (pwicp_pair_create_with_target(t.dev, s.p.data(), s.m, s.lab.data(), s.nsv, &prm, &pair) != PWICP_OK) {
         std::cerr << "Error: " << pwicp_last_error(ctx) << "\n";
         return false;
     }
@@ -400,6 +410,7 @@ PWICP_API int pwicp_series_open(const char* confile, int startEpoch, int epochNu
 
 PWICP_API void pwicp_series_close(pwicp_series* s) {
     if (!s) return;
+    s->targets.clear();                          // device-side targets go before their context
     if (s->ctx) pwicp_destroy(s->ctx);
     delete s;
 }
@@ -531,7 +542,7 @@ PWICP_API int pwicp_series_run_pairs(pwicp_series* s, const int32_t* pairs, int 
             rec->n_corr = out.res.n_corr;
             rec->t_loop_ms = (float)out.res.t_loop_ms;
             rec->t_pair_ms = (float)(t_setup_each + std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp).count());
-            Prepared().p.swap(src[(size_t)k].p);                                                             // release early
+            std::vector<float>().swap(src[(size_t)k].p);                                                     // release early
         }
         tm.lap("registrations (GPU)");
         // keep the reference epoch and the targets of this window, drop older ones

@@ -81,6 +81,9 @@ def load_library():
         ("pwicp_pair_download_source", [vp, fp]),
         ("pwicp_pair_bench_dense_nn", [vp, C.c_int, dp, C.POINTER(C.c_longlong), dp, dp]),
         ("pwicp_pair_set_profiling", [vp, C.c_int]),
+        ("pwicp_target_create", [vp, fp, C.c_int, ip, C.c_int, C.c_float, C.c_float, C.POINTER(vp)]),
+        ("pwicp_target_destroy", [vp]),
+        ("pwicp_pair_create_with_target", [vp, fp, C.c_int, ip, C.c_int, C.POINTER(Params), C.POINTER(vp)]),
     ]:
         if hasattr(L, name):
             getattr(L, name).argtypes = args
@@ -393,15 +396,49 @@ class Context:
 PROF_DENSE, PROF_INNER, PROF_REPLAY = 1, 2, 4
 
 
+class Target:
+    """The static target side of a pair (cloud, patches, normals, grids), shareable by all pairs with this target scan
+    (every pair of a Direct2Ref series).  Must outlive the pairs created with it."""
+
+    def __init__(self, ctx, cloud1, labels1, nsv1, Res1, SVRes1):
+        self._ctx = ctx
+        self._L = ctx._L
+        c1 = f4(cloud1)
+        l1 = np.ascontiguousarray(labels1, np.int32)
+        h = C.c_void_p()
+        ctx._chk(self._L.pwicp_target_create(ctx._h, _p(c1), len(c1), _p(l1, ip), int(nsv1), float(Res1), float(SVRes1),
+                                             C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pwicp_target_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Pair:
     """A target/source pair resident in HBM; run() is the Piecewise_ICP while-loop."""
 
-    def __init__(self, ctx, cloud1, labels1, nsv1, cloud2, labels2, nsv2, params, patches=None):
+    def __init__(self, ctx, cloud1, labels1, nsv1, cloud2, labels2, nsv2, params, patches=None, target=None):
         self._ctx = ctx
         self._L = ctx._L
         self.n2 = len(cloud2)
-        c1, c2 = f4(cloud1), f4(cloud2)
         h = C.c_void_p()
+        if target is not None:                      # cloud1 / labels1 / nsv1 are ignored: the target handle carries them
+            self._target = target                   # keep it alive
+            c2 = f4(cloud2)
+            l2 = np.ascontiguousarray(labels2, np.int32)
+            ctx._chk(self._L.pwicp_pair_create_with_target(target._h, _p(c2), len(c2), _p(l2, ip), int(nsv2),
+                                                           C.byref(params), C.byref(h)))
+            self._h = h
+            return
+        c1, c2 = f4(cloud1), f4(cloud2)
         if patches is None:
             l1 = np.ascontiguousarray(labels1, np.int32)
             l2 = np.ascontiguousarray(labels2, np.int32)

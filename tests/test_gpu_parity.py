@@ -390,3 +390,29 @@ def test_non_finite_input_is_rejected(ctx):
         P.Pair(ctx, broken, l1, n1, src, l2, n2, _data.params())
     with pytest.raises(P.PwicpError):
         ctx.determineCorrespondences(broken, src)
+
+
+@pytest.mark.gpu
+def test_shared_target_gives_the_same_results(ctx):
+    """Two source epochs registered against ONE device-side target (pwicp_target) == each registered with its own
+    pwicp_pair_create, bit for bit; the target is not modified by a run."""
+    import pwicp_amd as P
+    tgt, src1, _ = _data.pair(40000, epoch=1)
+    _, src2, _ = _data.pair(40000, epoch=2)
+    l1, n1 = _labels(tgt, "grid")
+    prm = _data.params()
+    T = P.Target(ctx, tgt, l1, n1, prm.Res1, prm.SVRes1)
+    outs = []
+    for src in (src1, src2, src1):
+        l2, n2 = _labels(src, "grid")
+        a = P.Pair(ctx, None, None, 0, src, l2, n2, prm, target=T)
+        ra = a.run()
+        b = P.Pair(ctx, tgt, l1, n1, src, l2, n2, prm)
+        rb = b.run()
+        assert ra.status == 0 and list(ra.T16) == list(rb.T16) and list(ra.VCM) == list(rb.VCM)
+        assert list(ra.DTseries[:ra.n_outer + 1]) == list(rb.DTseries[:rb.n_outer + 1])
+        outs.append(list(ra.T16))
+        a.close()
+        b.close()
+    assert outs[0] == outs[2] and outs[0] != outs[1]
+    T.close()
