@@ -473,19 +473,32 @@ PWICP_API int pwicp_series_run_pairs(pwicp_series* s, const int32_t* pairs, int 
             for (auto& t : th) t.join();
         }
         tm.lap("read scans (host threads)");
-        // ---- GPU parts, one after the other -------------------------------------------------------------------------
+        // ---- GPU parts one after the other; the host part of a cloud starts on its own thread as soon as its k-NN graph
+        //      is down, so the serial host passes of earlier clouds run while the GPU prepares the later ones -------------
         std::vector<char> ok((size_t)nw, 1);
-        for (auto& kv : raw1) {
-            auto t = std::make_shared<Prepared>();
-            float Res1 = cfg.PCres1;
-            bool good = !kv.second.empty();
-            if (good && !cfg.isSetResSVsize && pwicp_pc_resolution_dev(s->ctx, kv.second.data(), (int)(kv.second.size() / 4), &Res1) != PWICP_OK) good = false;
-            const float SVRes1 = cfg.isSetResSVsize ? cfg.SVsize1 : Res1 * 10;                       // R.cpp:635-640
-            if (good) good = prepare_gpu(s->ctx, kv.second, Res1, SVRes1, sor_mult, nullptr, t.get());
-            if (good) s->targets[kv.first] = t;
-            std::vector<float>().swap(kv.second);
-        }
+        std::vector<std::thread> th;
+        std::vector<char> okt(raw1.size(), 1);
         std::vector<Prepared> src((size_t)nw);
+        th.reserve(raw1.size() + (size_t)nw);
+        {
+            size_t ti = 0;
+            for (auto& kv : raw1) {
+                auto t = std::make_shared<Prepared>();
+                float Res1 = cfg.PCres1;
+                bool good = !kv.second.empty();
+                if (good && !cfg.isSetResSVsize && pwicp_pc_resolution_dev(s->ctx, kv.second.data(), (int)(kv.second.size() / 4), &Res1) != PWICP_OK) good = false;
+                const float SVRes1 = cfg.isSetResSVsize ? cfg.SVsize1 : Res1 * 10;                       // R.cpp:635-640
+                if (good) good = prepare_gpu(s->ctx, kv.second, Res1, SVRes1, sor_mult, nullptr, t.get());
+                if (good) {
+                    s->targets[kv.first] = t;
+                    Prepared* p = t.get();
+                    char* flag = &okt[ti];
+                    th.emplace_back([p, flag] { *flag = prepare_host(p) ? 1 : 0; });
+                }
+                std::vector<float>().swap(kv.second);
+                ++ti;
+            }
+        }
         for (int k = 0; k < nw; ++k) {
             auto it = s->targets.find(refIdx[(size_t)k]);
             float Res2 = cfg.PCres2;
@@ -494,30 +507,16 @@ PWICP_API int pwicp_series_run_pairs(pwicp_series* s, const int32_t* pairs, int 
             const float SVRes2 = cfg.isSetResSVsize ? cfg.SVsize2 : Res2 * 10;
             if (good) good = prepare_gpu(s->ctx, raw2[(size_t)k], Res2, SVRes2, sor_mult, it->second->shift, &src[(size_t)k]);
             ok[(size_t)k] = good ? 1 : 0;
+            if (good) th.emplace_back([&ok, &src, k] { ok[(size_t)k] = prepare_host(&src[(size_t)k]) ? 1 : 0; });
             std::vector<float>().swap(raw2[(size_t)k]);
         }
         tm.lap("voxel grid + SOR, k-NN graphs (GPU)");
-        // ---- host parts side by side ---------------------------------------------------------------------------------
+        for (auto& t : th) t.join();
         {
-            std::vector<std::thread> th;
-            std::vector<char> okt(raw1.size(), 1);
             size_t ti = 0;
-            for (auto& kv : raw1) {
-                auto it = s->targets.find(kv.first);
-                if (it != s->targets.end() && it->second->lab.empty()) {
-                    Prepared* p = it->second.get();
-                    char* flag = &okt[ti];
-                    th.emplace_back([p, flag] { *flag = prepare_host(p) ? 1 : 0; });
-                }
-                ++ti;
-            }
-            for (int k = 0; k < nw; ++k)
-                if (ok[(size_t)k]) th.emplace_back([&, k] { ok[(size_t)k] = prepare_host(&src[(size_t)k]) ? 1 : 0; });
-            for (auto& t : th) t.join();
-            ti = 0;
             for (auto& kv : raw1) { if (!okt[ti]) s->targets.erase(kv.first); ++ti; }
         }
-        tm.lap("normals + supervoxels (host threads)");
+        tm.lap("normals + supervoxels (host threads, rest)");
         // ---- registrations ---------------------------------------------------------------------------------------------
         const double t_setup_each = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / nw;
         for (int k = 0; k < nw; ++k) {
