@@ -158,14 +158,12 @@ bool register_pair(pwicp_context* ctx, const std::vector<float>& cloud1, const s
     std::cout << "PC-1 avg. point spacing: " << Res1 << "\t PC-2 avg. point spacing: " << Res2 << std::endl << std::endl;
     const float SVRes1 = cfg.isSetResSVsize ? cfg.SVsize1 : Res1 * 10, SVRes2 = cfg.isSetResSVsize ? cfg.SVsize2 : Res2 * 10;   // R.cpp:635-640
     Prepared t, s;
-    if (!prepare_gpu(ctx, cloud1, Res1, SVRes1, sor_mult, nullptr, &t) || !prepare_gpu(ctx, cloud2, Res2, SVRes2, sor_mult, t.shift, &s))
-        return false;
-    tm.lap("voxel grid + SOR, k-NN graphs (GPU)");
-    bool ok1 = true, ok2 = true;
-    std::thread th([&] { ok1 = prepare_host(&t); });            // the two clouds side by side
-    ok2 = prepare_host(&s);
+    if (!prepare_gpu(ctx, cloud1, Res1, SVRes1, sor_mult, nullptr, &t)) return false;
+    bool ok1 = true;
+    std::thread th([&] { ok1 = prepare_host(&t); });            // the target's host passes run beside the source's GPU part
+    const bool ok2 = prepare_gpu(ctx, cloud2, Res2, SVRes2, sor_mult, t.shift, &s) && prepare_host(&s);
     th.join();
-    tm.lap("normals + supervoxels (host)");
+    tm.lap("preparation (GPU: voxel grid, SOR, k-NN; host: supervoxels)");
     if (!ok1 || !ok2) { std::cerr << "Error: supervoxel segmentation failed.\n"; return false; }
     return run_prepared(ctx, t, s, cfg, out);
 }
