@@ -14,6 +14,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <cstring>
 #include <vector>
 
 #include "../pwicp.h"
@@ -156,6 +157,68 @@ void calTransParaVCM(const Cloud& cloudTarget, const NCloud& cloudTargetwithNorm
         for (int c = 0; c < 6; ++c) VCM(r, c) = V[6 * r + c];
 }
 
+// ---- the stages before the loop -------------------------------------------------------------------------------------
+
+// PCpreprocessing (CommonFunc.h:196-198; CommonFunc.cpp:423-452): VoxelGrid + SOR, on the GPU
+template <class Cloud>
+void PCpreprocessing(const Cloud& cloud_in, Cloud& cloud_out, bool isDownSamp, float voxelSize, int SOR_NeighborNum,
+                     double SOR_StdMult) {
+    const int n = (int)cloud_in.points.size();
+    std::vector<float> out((size_t)(n > 0 ? n : 1) * 4);
+    int m = 0;
+    // (every caller on this path down-samples; the SOR-only variant of the reference is not offered by the GPU stage)
+    if (!isDownSamp) throw Error(PWICP_E_INVALID, "PCpreprocessing: isDownSamp = false is not supported by the GPU stage");
+    check(pwicp_preprocess_dev(thread_context(), xyz4(cloud_in), n, voxelSize, SOR_NeighborNum, SOR_StdMult, out.data(), &m));
+    cloud_out.points.resize((size_t)m);
+    if (m) std::memcpy(static_cast<void*>(cloud_out.points.data()), out.data(), (size_t)m * 16);
+}
+
+// calPCresolution (CommonFunc.h:116; CommonFunc.cpp:239-263)
+template <class Cloud>
+float calPCresolution(const Cloud& cloud) {
+    float r = 0.f;
+    check(pwicp_pc_resolution_dev(thread_context(), xyz4(cloud), (int)cloud.points.size(), &r));
+    return r;
+}
+
+// PatchGenerationAndRefinement (Segmentation.h:399-403; Segmentation.cpp:11-192) + calBPandCTSTD (Segmentation.h:451-452):
+// supervoxels (GPU k-NN graph + host passes), then patch extraction / refinement / selection and the per-patch
+// centroids, boundary points and sigmas on the GPU.  `pointSpacing` replaces the reference's global resolution; the
+// patches come back as a vector instead of a new[]-ed array (S.cpp:84), the sigmas of calBPandCTSTD with them.
+template <class Cloud>
+int PatchGenerationAndRefinement(const Cloud& cloud, float svResolution, float pointSpacing, Cloud& cloudCentroid,
+                                 Cloud& cloudBoundary, std::vector<Cloud>& cloudPatches, std::vector<float>& stdBP,
+                                 std::vector<float>& stdCT) {
+    pwicp_context* ctx = thread_context();
+    const int n = (int)cloud.points.size();
+    std::vector<int32_t> lab((size_t)(n > 0 ? n : 1));
+    int nsv = 0;
+    check(pwicp_frontend_segment_dev(ctx, xyz4(cloud), n, svResolution, 45, pointSpacing, lab.data(), &nsv));
+    int m = 0, tot = 0;
+    check(pwicp_select_patches(ctx, xyz4(cloud), n, lab.data(), nsv, &m, &tot, nullptr, nullptr, nullptr, nullptr, nullptr,
+                               nullptr, nullptr));
+    std::vector<float> pat((size_t)(tot > 0 ? tot : 1) * 4);
+    std::vector<int32_t> off((size_t)m + 1);
+    cloudCentroid.points.resize((size_t)m);
+    cloudBoundary.points.resize((size_t)m * 6);
+    stdBP.resize((size_t)(m > 0 ? m : 1));
+    stdCT.resize((size_t)(m > 0 ? m : 1));
+    std::vector<float> ct((size_t)(m > 0 ? m : 1) * 4), bp((size_t)(m > 0 ? m : 1) * 24);
+    check(pwicp_select_patches(ctx, xyz4(cloud), n, lab.data(), nsv, &m, &tot, pat.data(), off.data(), nullptr, ct.data(),
+                               bp.data(), stdBP.data(), stdCT.data()));
+    stdBP.resize((size_t)m);
+    stdCT.resize((size_t)m);
+    if (m) std::memcpy(static_cast<void*>(cloudCentroid.points.data()), ct.data(), (size_t)m * 16);
+    if (m) std::memcpy(static_cast<void*>(cloudBoundary.points.data()), bp.data(), (size_t)m * 96);
+    cloudPatches.assign((size_t)m, Cloud());
+    for (int k = 0; k < m; ++k) {
+        const int cnt = off[(size_t)k + 1] - off[(size_t)k];
+        cloudPatches[(size_t)k].points.resize((size_t)cnt);
+        if (cnt) std::memcpy(static_cast<void*>(cloudPatches[(size_t)k].points.data()), pat.data() + 4 * (size_t)off[(size_t)k], (size_t)cnt * 16);
+    }
+    return m;
+}
+
 }  // namespace pwicp
 
 // ---- the reference's exact signatures, when PCL + Eigen are present ----------------------------------------------------
@@ -201,5 +264,13 @@ inline double calPercentileDistBetween2PC(pcl::PointCloud<pcl::PointXYZ>::Ptr cl
 inline bool calPatchNormal(pcl::PointCloud<pcl::PointXYZ> cloud, float& nx, float& ny, float& nz) {
     return pwicp::calPatchNormal(cloud, nx, ny, nz);
 }
+// CommonFunc.h:196-198
+inline void PCpreprocessing(pcl::PointCloud<pcl::PointXYZ>::Ptr cloud_in, pcl::PointCloud<pcl::PointXYZ>::Ptr cloud_out,
+                            bool isDownSamp, float voxelSize, int SOR_NeighborNum, double SOR_StdMult) {
+    pwicp::PCpreprocessing(*cloud_in, *cloud_out, isDownSamp, voxelSize, SOR_NeighborNum, SOR_StdMult);
+    cloud_out->width = (uint32_t)cloud_out->points.size(); cloud_out->height = 1; cloud_out->is_dense = true;
+}
+// CommonFunc.h:116
+inline float calPCresolution(pcl::PointCloud<pcl::PointXYZ>::Ptr cloud) { return pwicp::calPCresolution(*cloud); }
 #endif
 #endif

@@ -39,7 +39,11 @@ int main(int argc, char** argv) {
         Mat<4, 4, float> (*f5)(const Cloud<PointNormal>&, const Cloud<PointNormal>&, double) =
             &pwicp::P2PICPwithPatchNormal<Cloud<PointNormal>, Mat<4, 4, float>>;
         void (*f6)(const Cloud<PointXYZ>&, const Cloud<PointNormal>&, const Cloud<PointXYZ>&, Mat<6, 6, double>&) = &pwicp::calTransParaVCM;
-        std::printf("facade templates instantiated: %d\n", (f1 && f2 && f3 && f4 && f5 && f6) ? 6 : 0);
+        void (*f7)(const Cloud<PointXYZ>&, Cloud<PointXYZ>&, bool, float, int, double) = &pwicp::PCpreprocessing;
+        float (*f8)(const Cloud<PointXYZ>&) = &pwicp::calPCresolution;
+        int (*f9)(const Cloud<PointXYZ>&, float, float, Cloud<PointXYZ>&, Cloud<PointXYZ>&, std::vector<Cloud<PointXYZ>>&,
+                  std::vector<float>&, std::vector<float>&) = &pwicp::PatchGenerationAndRefinement;
+        std::printf("facade templates instantiated: %d\n", (f1 && f2 && f3 && f4 && f5 && f6 && f7 && f8 && f9) ? 9 : 0);
         return 0;
     }
     std::vector<float> DT;
@@ -48,6 +52,17 @@ int main(int argc, char** argv) {
     pwicp::Piecewise_ICP(a, b, true, 0.005f, 0.005f, 0.05f, 0.05f, true, 0.05f, 0.004f, DT, T, V);
     std::printf("facade run: outer iterations %d, t = (%g %g %g)\n", (int)DT.size() - 1, T(0, 3), T(1, 3), T(2, 3));
     const bool ok = std::fabs(T(0, 3) + 0.002f) < 5e-4f && std::fabs(T(1, 3) - 0.001f) < 5e-4f && std::fabs(T(2, 3) + 0.0015f) < 5e-4f;
-    std::printf(ok ? "FACADE_OK\n" : "FACADE_MISMATCH\n");
-    return ok ? 0 : 1;
+    // the stages before the loop through the facade
+    Cloud<PointXYZ> pre, ct, bpc;
+    pwicp::PCpreprocessing(a, pre, true, 0.005f, 14, 5.0);
+    const float spacing = pwicp::calPCresolution(pre);
+    std::vector<Cloud<PointXYZ>> patches;
+    std::vector<float> sbp, sct;
+    const int m = pwicp::PatchGenerationAndRefinement(pre, 0.05f, 0.005f, ct, bpc, patches, sbp, sct);
+    std::printf("facade stages: %zu -> %zu points, spacing %g, %d patches\n", a.points.size(), pre.points.size(), (double)spacing, m);
+    const bool ok2 = pre.points.size() > 1000 && pre.points.size() <= a.points.size() && spacing > 0.003f && spacing < 0.008f &&
+                     m > 20 && (int)ct.points.size() == m && (int)bpc.points.size() == 6 * m && (int)patches.size() == m &&
+                     patches[0].points.size() > 4 && (int)sbp.size() == m;
+    std::printf((ok && ok2) ? "FACADE_OK\n" : "FACADE_MISMATCH\n");
+    return (ok && ok2) ? 0 : 1;
 }
