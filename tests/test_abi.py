@@ -80,3 +80,18 @@ def test_cpp_facade_runs_a_registration(tmp_path):
     import subprocess
     out = subprocess.run([_build_facade_check(tmp_path), "run"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "FACADE_OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_header_is_plain_c99(tmp_path):
+    """include/pwicp.h compiles as strict C99 (-pedantic), links against libpwicp.so and the 384-byte record has the
+    size the all-gather assumes; without a GPU pwicp_create reports PWICP_E_NO_DEVICE (-1), never a fallback."""
+    import subprocess
+    import pwicp_amd
+    exe = str(tmp_path / "c_abi_check")
+    libdir = os.path.dirname(pwicp_amd.lib_path())
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_abi_check.c"), "-L" + libdir, "-lpwicp", "-Wl,-rpath," + libdir,
+                           "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "record 384 B" in out.stdout
+    assert ("-> -1" in out.stdout) or ("-> 0" in out.stdout)
