@@ -1,7 +1,8 @@
 /* TEST INFRASTRUCTURE — NOT PRODUCT CODE.
  *
  * CPU oracle for the Piecewise-ICP fine-registration loop: a plain-C restatement (single-threaded unless
- * orc_set_num_threads asks for the OpenMP variant of its batch nearest-neighbour queries; same results) of the reference's algorithm (yihui4d/Piecewise-ICP @ 2025-09-05) for the
+ * orc_set_num_threads asks for the OpenMP variant of its batch nearest-neighbour queries; same results)
+ * of the reference's algorithm (yihui4d/Piecewise-ICP @ 2025-09-05) for the
  * path src/Registration.cpp:618-972, 1255-1343, src/CommonFunc.cpp:145-179, 266-452,
  * src/Segmentation.cpp:97-150, 195-321 and of the PCL 1.8.1 / FLANN routines those lines
  * call (PCL is a third-party dependency that is NOT vendored in the reference tree and
