@@ -5,7 +5,7 @@ correspondences/s and ms per ICP iteration on a synthetic 1 M-point pair).
   python bench.py --gpus N --steps K --warmup W
   (N > 1: launched by torch.distributed.run, one rank per GPU; every rank registers its own source epoch of a
    synthetic 4D series against the shared reference epoch — independent pairs, weak scaling — and the 384-byte
-   result records are all-gathered over RCCL.)
+   result records of all steps are all-gathered over RCCL once, inside the timed region: the series' one exchange.)
 
 A "step" = one complete Piecewise-ICP loop (Piecewise_ICP's while-loop, reference src/Registration.cpp:680-694)
 on data already resident in HBM: pwicp_pair_reset (device-to-device restore of the source arrays) +
