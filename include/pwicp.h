@@ -40,7 +40,9 @@ typedef enum {
     PWICP_E_TOO_FEW_PATCHES = -3, /* < 4 source patches            (R.cpp:728-731) */
     PWICP_E_TOO_FEW_STABLE = -4,  /* < 4 stable patches            (R.cpp:864-867) */
     PWICP_E_NOMEM = -5,
-    PWICP_E_INTERNAL = -6
+    PWICP_E_INTERNAL = -6,
+    PWICP_E_NOT_CONVERGED = -7    /* PWICP_MAX_OUTER outer iterations without reaching Stage 3 (the reference would keep
+                                     iterating, R.cpp:680): T16 is the last estimate, VCM was never computed */
 } pwicp_status;
 
 typedef struct pwicp_context pwicp_context;   /* one per GPU / per thread; replaces the reference's
@@ -207,13 +209,21 @@ PWICP_API int pwicp_knn(pwicp_context* ctx, const float* cloud_xyz4, int n, int 
 /* pwicp_frontend_segment with the k-NN graph built on the GPU (identical labels). point_spacing <= 0: estimated. */
 PWICP_API int pwicp_frontend_segment_dev(pwicp_context* ctx, const float* cloud_xyz4, int n, float sv_resolution,
                                          int knn, float point_spacing, int32_t* labels, int* n_supervoxels);
-/* PCpreprocessing(cloud, out, true, voxel_size, sor_k, sor_mult) (C.cpp:423-452). out_xyz4 holds n points. */
+/* PCpreprocessing(cloud, out, true, voxel_size, sor_k, sor_mult) (C.cpp:423-452). out_xyz4 holds n points.
+ * As pcl::VoxelGrid does, a leaf size whose voxel indices would overflow int32 makes the voxel stage a pass-through (warning
+ * on stderr) and the SOR stage runs on the full cloud. */
 PWICP_API int pwicp_preprocess(const float* cloud_xyz4, int n, float voxel_size, int sor_k, double sor_mult,
                                float* out_xyz4, int* n_out);
 /* pwicp_preprocess on the GPU (identical output): voxel keys + stable radix sort + per-voxel centroids, then the
  * SOR mean-distance statistic from an exact float-metric k-NN on the uniform grid. */
 PWICP_API int pwicp_preprocess_dev(pwicp_context* ctx, const float* cloud_xyz4, int n, float voxel_size, int sor_k,
                                    double sor_mult, float* out_xyz4, int* n_out);
+/* SORfilter (C.cpp:441-452; decl C.h:209) = PCpreprocessing(..., isDownSamp = false, ...): pcl::StatisticalOutlierRemoval
+ * (mean_k = sor_k, stddev multiplier sor_mult) alone.  _dev: the k-NN statistic on the GPU (identical output); spacing_hint > 0
+ * sizes the search grid only (<= 0: estimated), it never changes the result. */
+PWICP_API int pwicp_sor_filter(const float* cloud_xyz4, int n, int sor_k, double sor_mult, float* out_xyz4, int* n_out);
+PWICP_API int pwicp_sor_filter_dev(pwicp_context* ctx, const float* cloud_xyz4, int n, int sor_k, double sor_mult,
+                                   float spacing_hint, float* out_xyz4, int* n_out);
 /* calPCresolution (C.cpp:239-263) */
 PWICP_API float pwicp_pc_resolution(const float* cloud_xyz4, int n);
 /* the same value with the nearest-neighbour distances computed on the GPU */

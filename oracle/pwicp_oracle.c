@@ -988,6 +988,14 @@ int orc_voxel_grid(const float* in4, int n, float leaf, float* out4)
             if (v < mn[d]) mn[d] = v;
             if (v > mx[d]) mx[d] = v;
         }
+    {   /* PCL 1.8.1 voxel_grid.hpp: integer index overflow -> warning and output = input */
+        long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1,
+                  dz = (long long)((mx[2] - mn[2]) * inv) + 1;
+        if ((double)dx * (double)dy * (double)dz > 2147483647.0) {
+            memcpy(out4, in4, (size_t)n * 16);
+            return n;
+        }
+    }
     int minb[3], maxb[3], divb[3];
     for (int d = 0; d < 3; ++d) {
         minb[d] = (int)floorf(mn[d] * inv);

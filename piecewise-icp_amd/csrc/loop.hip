@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(kBlock) k_classify(
     if (i < m2) {
         // (2) level of detection, R.cpp:756-766
         const float maxLoD = DTmin * 2.0f, minLoD = DTmin;
-        const int j = mCT[i];
+        const int j = max(mCT[i], 0);                  // (-1 = empty target: rejected on the host before the launch)
         const float s1 = ctstd1[j], s2 = bpstd2[i];
         float LoD = (float)(1.96 * (double)sqrtf(s1 * s1 + s2 * s2));
         if (LoD > maxLoD) LoD = maxLoD; else if (LoD < minLoD) LoD = minLoD;
@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(kBlock) k_classify(
         float4 b[6], nn[6], tt[6];
         float db[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { jb[k] = mBP[6 * i + k]; b[k] = bp2[6 * i + k]; db[k] = dBP[6 * i + k]; }
+        for (int k = 0; k < 6; ++k) { jb[k] = max(mBP[6 * i + k], 0); b[k] = bp2[6 * i + k]; db[k] = dBP[6 * i + k]; }
 #pragma unroll
         for (int k = 0; k < 6; ++k) { nn[k] = nrm1[jb[k]]; tt[k] = ct1[jb[k]]; }
 #pragma unroll
@@ -876,9 +876,9 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     const auto t0 = std::chrono::steady_clock::now();
     while (!stage3) {                                                   // R.cpp:680
         const int k = res->n_outer;
-        if (k >= PWICP_MAX_OUTER) break;
+        if (k >= PWICP_MAX_OUTER) { status = PWICP_E_NOT_CONVERGED; break; }     // Stage 3 never reached: no VCM, not a success
         if (currDT <= DTmin) currDT = DTmin;                            // R.cpp:724-725
-        if (4 > m2) { status = PWICP_E_TOO_FEW_PATCHES; break; }        // R.cpp:728-731
+        if (4 > m2 || 1 > pr->tgt->P1.m) { status = PWICP_E_TOO_FEW_PATCHES; break; }   // R.cpp:728-731; an empty target has no match
         unsigned* const slot = pr->scal.p + (size_t)kSlot * k;
 
         if (!front_ready) PWCHK(enqueue_front());

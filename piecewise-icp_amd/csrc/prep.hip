@@ -75,28 +75,54 @@ __global__ void k_sor_emit(const float4* __restrict__ p, const float* __restrict
 
 }  // namespace
 
+// pcl::VoxelGrid's index-overflow test (filters/impl/voxel_grid.hpp, PCL 1.8.1): per axis (int64)((max - min) * inverse_leaf)
+// + 1 in float arithmetic, product > INT_MAX -> warning, and the filter hands the INPUT cloud through unchanged.
+static bool voxel_index_overflows(const float* mn, const float* mx, float inv) {
+    const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1,
+                    dz = (long long)((mx[2] - mn[2]) * inv) + 1;
+    return (double)dx * (double)dy * (double)dz > 2147483647.0;
+}
+
 // d_in: n points on the device.  d_out receives the filtered cloud (m points), *m_out its size.
-int pw_preprocess_dev(pwicp_context* ctx, const float4* d_in, int n, float leaf, int sor_k, double sor_mult,
+// downsample = false: PCpreprocessing(..., isDownSamp = false, ...) = SORfilter alone (C.cpp:436-452); `leaf` then only
+// sizes the search grid (<= 0: estimated from the cloud).
+int pw_preprocess_dev(pwicp_context* ctx, const float4* d_in, int n, bool downsample, float leaf, int sor_k, double sor_mult,
                       DevBuf<float4>* d_out, int* m_out) {
     *m_out = 0;
     if (n <= 0) return PWICP_OK;
-    // ---- voxel grid -----------------------------------------------------------------------------------------------
     float mn[3], mx[3];
     PWCHK(pw_bbox(ctx, d_in, n, mn, mx));
+    DevBuf<float4> vox;
+    DevBuf<int> tmp;
+    const float4* sor_in = d_in;
+    int m = n;
+    if (downsample && voxel_index_overflows(mn, mx, 1.0f / leaf)) {
+        fprintf(stderr, "[pwicp] Leaf size is too small for the input dataset. Integer indices would overflow: the cloud is passed on "
+                        "unfiltered (pcl::VoxelGrid semantics).\n");
+        downsample = false;
+    }
+    if (!downsample && !(leaf > 0.f)) {
+        // grid edge for the SOR search only (any edge is exact): ~2 mean spacings of a surface-like cloud in its bounding box
+        const double ex = (double)mx[0] - mn[0], ey = (double)mx[1] - mn[1], ez = (double)mx[2] - mn[2];
+        const double a = std::max(ex * ey, std::max(ex * ez, ey * ez));
+        leaf = (float)std::max(std::sqrt(std::max(a, 1e-12) / (double)n), 1e-6);
+    }
+    if (downsample) {
+    // ---- voxel grid -----------------------------------------------------------------------------------------------
     const float inv = 1.0f / leaf;
     VgParams v;
     v.inv = inv;
     int divb[3];
     const int minb[3] = {(int)std::floor(mn[0] * inv), (int)std::floor(mn[1] * inv), (int)std::floor(mn[2] * inv)};
     for (int k = 0; k < 3; ++k) divb[k] = (int)std::floor(mx[k] * inv) - minb[k] + 1;
-    if ((double)divb[0] * divb[1] * divb[2] > 2147483647.0) {
-        ctx->set_err("pwicp_preprocess: leaf size too small for the cloud extent (voxel index overflows int32, as in PCL)");
+    if ((double)divb[0] * divb[1] * divb[2] > 2147483647.0) {      // (unreachable after the test above save for rounding at the edge)
+        ctx->set_err("pwicp_preprocess: leaf size too small for the cloud extent (voxel index overflows int32)");
         return PWICP_E_INVALID;
     }
     v.minb0 = minb[0]; v.minb1 = minb[1]; v.minb2 = minb[2];
     v.mul1 = divb[0]; v.mul2 = divb[0] * divb[1];
     DevBuf<unsigned> keys, keys_s;
-    DevBuf<int> vals, order, head, start, tmp;
+    DevBuf<int> vals, order, head, start;
     HIPCHK(ctx, keys.reserve((size_t)n));
     HIPCHK(ctx, keys_s.reserve((size_t)n));
     HIPCHK(ctx, vals.reserve((size_t)n));
@@ -112,17 +138,19 @@ int pw_preprocess_dev(pwicp_context* ctx, const float4* d_in, int n, float leaf,
     HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(tsort.p, tb, keys.p, keys_s.p, vals.p, order.p, n, 0, end_bit, ctx->stream));
     hipLaunchKernelGGL(k_vg_heads, dim3(div_up(n + 1, kBlock)), dim3(kBlock), 0, ctx->stream, keys_s.p, n, head.p);
     PWCHK(pw_exclusive_scan(ctx, head.p, (long long)n + 1, &tmp));
-    int m = 0;
+    m = 0;
     HIPCHK(ctx, hipMemcpyAsync(&m, head.p + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, start.reserve((size_t)m + 1));
-    DevBuf<float4> vox;
     HIPCHK(ctx, vox.reserve((size_t)m));
     hipLaunchKernelGGL(k_vg_starts, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, keys_s.p, head.p, n, start.p);
     hipLaunchKernelGGL(k_vg_centroids, dim3(div_up(m, kBlock)), dim3(kBlock), 0, ctx->stream, d_in, order.p, start.p, m, n, vox.p);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));          // the sort temporaries die with this scope
+    sor_in = vox.p;
+    }
     // ---- statistical outlier removal ---------------------------------------------------------------------------------
     Grid g;
-    PWCHK(pw_grid_build(ctx, vox.p, m, 2.0f * leaf, &g));
+    PWCHK(pw_grid_build(ctx, sor_in, m, 2.0f * leaf, &g));
     DevBuf<float> dist;
     HIPCHK(ctx, dist.reserve((size_t)m));
     PWCHK(pw_knn_mean_dist_launch(ctx, g.d, sor_k, dist.p));
@@ -143,7 +171,7 @@ int pw_preprocess_dev(pwicp_context* ctx, const float4* d_in, int n, float leaf,
     HIPCHK(ctx, hipMemcpyAsync(&kept, keep.p + m, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, d_out->reserve((size_t)std::max(kept, 1)));
-    hipLaunchKernelGGL(k_sor_emit, dim3(div_up(m, kBlock)), dim3(kBlock), 0, ctx->stream, vox.p, dist.p, m, thr, keep.p, d_out->p);
+    hipLaunchKernelGGL(k_sor_emit, dim3(div_up(m, kBlock)), dim3(kBlock), 0, ctx->stream, sor_in, dist.p, m, thr, keep.p, d_out->p);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipGetLastError());
     *m_out = kept;
@@ -162,7 +190,27 @@ extern "C" int pwicp_preprocess_dev(pwicp_context* ctx, const float* cloud_xyz4,
     HIPCHK(ctx, in.reserve((size_t)std::max(n, 1)));
     if (n > 0) HIPCHK(ctx, hipMemcpyAsync(in.p, cloud_xyz4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
     int m = 0;
-    PWCHK(pw_preprocess_dev(ctx, in.p, n, voxel_size, sor_k, sor_mult, &out, &m));
+    PWCHK(pw_preprocess_dev(ctx, in.p, n, true, voxel_size, sor_k, sor_mult, &out, &m));
+    if (m > 0) HIPCHK(ctx, hipMemcpy(out_xyz4, out.p, (size_t)m * sizeof(float4), hipMemcpyDeviceToHost));
+    *n_out = m;
+    return PWICP_OK;
+}
+
+// SORfilter (C.cpp:441-452; decl C.h) = PCpreprocessing with isDownSamp = false: pcl::StatisticalOutlierRemoval alone.
+// spacing_hint (> 0) only sizes the search grid.
+extern "C" int pwicp_sor_filter_dev(pwicp_context* ctx, const float* cloud_xyz4, int n, int sor_k, double sor_mult,
+                                    float spacing_hint, float* out_xyz4, int* n_out) {
+    if (!ctx) return PWICP_E_INVALID;
+    if (!cloud_xyz4 || !out_xyz4 || !n_out || n < 0 || sor_k <= 0) {
+        ctx->set_err("pwicp_sor_filter_dev: invalid argument");
+        return PWICP_E_INVALID;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevBuf<float4> in, out;
+    HIPCHK(ctx, in.reserve((size_t)std::max(n, 1)));
+    if (n > 0) HIPCHK(ctx, hipMemcpyAsync(in.p, cloud_xyz4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    int m = 0;
+    PWCHK(pw_preprocess_dev(ctx, in.p, n, false, spacing_hint, sor_k, sor_mult, &out, &m));
     if (m > 0) HIPCHK(ctx, hipMemcpy(out_xyz4, out.p, (size_t)m * sizeof(float4), hipMemcpyDeviceToHost));
     *n_out = m;
     return PWICP_OK;

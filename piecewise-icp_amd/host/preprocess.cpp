@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <cstdio>
 #include <vector>
 
 #include "kdtree.h"
@@ -30,6 +31,16 @@ int voxel_grid(const float* in4, int n, float leaf, float* out4) {
             mn[d] = std::min(mn[d], v);
             mx[d] = std::max(mx[d], v);
         }
+    {   // pcl::VoxelGrid (PCL 1.8.1 voxel_grid.hpp): index overflow -> warning, output = input
+        const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1,
+                        dz = (long long)((mx[2] - mn[2]) * inv) + 1;
+        if ((double)dx * (double)dy * (double)dz > 2147483647.0) {
+            std::fprintf(stderr, "[pwicp] Leaf size is too small for the input dataset. Integer indices would overflow: the cloud is "
+                                 "passed on unfiltered (pcl::VoxelGrid semantics).\n");
+            std::memcpy(out4, in4, (size_t)n * 16);
+            return n;
+        }
+    }
     int minb[3], divb[3];
     for (int d = 0; d < 3; ++d) {
         minb[d] = (int)std::floor(mn[d] * inv);
@@ -113,6 +124,13 @@ PWICP_API int pwicp_preprocess(const float* cloud_xyz4, int n, float voxel_size,
     std::vector<float> tmp((size_t)std::max(n, 1) * 4);
     const int m = pwhost::voxel_grid(cloud_xyz4, n, voxel_size, tmp.data());
     *n_out = pwhost::sor_filter(tmp.data(), m, sor_k, sor_mult, out_xyz4);
+    return PWICP_OK;
+}
+
+// SORfilter (C.cpp:441-452) on the host
+PWICP_API int pwicp_sor_filter(const float* cloud_xyz4, int n, int sor_k, double sor_mult, float* out_xyz4, int* n_out) {
+    if (!cloud_xyz4 || !out_xyz4 || !n_out || n < 0 || sor_k <= 0) return PWICP_E_INVALID;
+    *n_out = pwhost::sor_filter(cloud_xyz4, n, sor_k, sor_mult, out_xyz4);
     return PWICP_OK;
 }
 

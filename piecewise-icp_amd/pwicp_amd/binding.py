@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PWICP_MAX_OUTER = 256
 
 STATUS = {0: "OK", -1: "NO_DEVICE", -2: "INVALID", -3: "TOO_FEW_PATCHES", -4: "TOO_FEW_STABLE",
-          -5: "NOMEM", -6: "INTERNAL"}
+          -5: "NOMEM", -6: "INTERNAL", -7: "NOT_CONVERGED"}
 
 
 class PwicpError(RuntimeError):
@@ -103,6 +103,8 @@ def load_library():
     L.pwicp_pc_resolution_dev.argtypes = [vp, fp, C.c_int, fp]
     L.pwicp_preprocess_dev.argtypes = [vp, fp, C.c_int, C.c_float, C.c_int, C.c_double, fp, ip]
     L.pwicp_preprocess.argtypes = [fp, C.c_int, C.c_float, C.c_int, C.c_double, fp, ip]
+    L.pwicp_sor_filter.argtypes = [fp, C.c_int, C.c_int, C.c_double, fp, ip]
+    L.pwicp_sor_filter_dev.argtypes = [vp, fp, C.c_int, C.c_int, C.c_double, C.c_float, fp, ip]
     L.pwicp_pc_resolution.argtypes = [fp, C.c_int]
     L.pwicp_pc_resolution.restype = C.c_float
     L.PiecewiseICP_pair_call.argtypes = [C.c_char_p, C.c_char_p]
@@ -161,6 +163,18 @@ def preprocess(cloud, voxel_size, sor_k=14, sor_mult=5.0):
     rc = L.pwicp_preprocess(_p(c), len(c), float(voxel_size), int(sor_k), float(sor_mult), _p(out), C.byref(m))
     if rc != 0:
         raise PwicpError(rc, "pwicp_preprocess")
+    return out[:m.value].copy()
+
+
+def sor_filter(cloud, sor_k=14, sor_mult=5.0):
+    """SORfilter (C.cpp:441-452) = PCpreprocessing with isDownSamp = false, host version."""
+    L = load_library()
+    c = f4(cloud)
+    out = np.empty_like(c)
+    m = C.c_int32()
+    rc = L.pwicp_sor_filter(_p(c), len(c), int(sor_k), C.c_double(sor_mult), _p(out), C.byref(m))
+    if rc != 0:
+        raise PwicpError(rc, "pwicp_sor_filter")
     return out[:m.value].copy()
 
 
@@ -338,6 +352,15 @@ class Context:
         m = C.c_int32()
         self._chk(self._L.pwicp_preprocess_dev(self._h, _p(c), len(c), float(voxel_size), int(sor_k), float(sor_mult),
                                                _p(out), C.byref(m)))
+        return out[:m.value].copy()
+
+    def sor_filter(self, cloud, sor_k=14, sor_mult=5.0, spacing_hint=0.0):
+        """SORfilter (C.cpp:441-452) with the k-NN statistic on the GPU (same output as the module-level sor_filter)."""
+        c = f4(cloud)
+        out = np.empty_like(c)
+        m = C.c_int32()
+        self._chk(self._L.pwicp_sor_filter_dev(self._h, _p(c), len(c), int(sor_k), C.c_double(sor_mult),
+                                               C.c_float(spacing_hint), _p(out), C.byref(m)))
         return out[:m.value].copy()
 
     def pc_resolution(self, cloud):

@@ -19,34 +19,59 @@ from . import fourd
 from .binding import Series
 
 
-def run_series(confile, start_epoch, epoch_num, pair_mode, overlap_thd=0.75, backend="nccl", single_device=False):
-    """Returns True on success (on every rank).  Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment."""
+def _agree(dist, dev, ok):
+    """All ranks learn whether EVERY rank got here in good order (all-reduce MIN of a flag) — called before each
+    data collective so that a rank that failed locally (bad configuration, no device, a raised error) makes all ranks
+    leave together instead of leaving the others blocked in a broadcast / all-gather."""
+    if dist is None:
+        return bool(ok)
+    import torch
+    f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(f, op=dist.ReduceOp.MIN)
+    return bool(f.item())
+
+
+def run_series(confile, start_epoch, epoch_num, pair_mode, overlap_thd=0.75, backend="nccl", single_device=False,
+               timeout_s=1800):
+    """Returns True on success (on every rank).  Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
+    A failure on any rank is agreed on by all ranks before the next collective: every rank returns False, none hangs
+    (and the process group carries a timeout as the last line of defence)."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     device = 0 if single_device else local_rank
     dist, dev = None, None
     if world > 1:
+        import datetime
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        tmo = datetime.timedelta(seconds=timeout_s)
         if backend == "nccl":
             torch.cuda.set_device(device)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device), timeout=tmo)
             dev = torch.device("cuda", device)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=tmo)
             dev = torch.device("cpu")
     ok = False
+    series = None
     try:
-        targets = None
+        # ---- phase 1: open the series (adaptive mode: rank 0 determines the pair map, the others receive it) -----
+        targets, good = None, True
         if pair_mode < 0 and world > 1:
-            # rank 0 computes the adaptive pair map and writes RegPairFile.txt; the others receive it
             import torch
-            s0 = Series(confile, start_epoch, epoch_num, pair_mode, overlap_thd, device) if rank == 0 else None
+            if rank == 0:
+                try:
+                    series = Series(confile, start_epoch, epoch_num, pair_mode, overlap_thd, device)
+                    targets = series.adaptive_targets()
+                except Exception as e:                      # noqa: BLE001 - reported, then agreed on by all ranks
+                    print("pwicp series: rank 0 failed to open the series: %s" % e, file=sys.stderr)
+                    good = False
+            if not _agree(dist, dev, good):
+                return False
             n_t = torch.zeros(1, dtype=torch.int32, device=dev)
             if rank == 0:
-                targets = s0.adaptive_targets()
                 n_t[0] = len(targets)
             dist.broadcast(n_t, src=0)
             t = torch.zeros(int(n_t.item()), dtype=torch.int32, device=dev)
@@ -54,26 +79,40 @@ def run_series(confile, start_epoch, epoch_num, pair_mode, overlap_thd=0.75, bac
                 t.copy_(torch.from_numpy(targets))
             dist.broadcast(t, src=0)
             targets = t.cpu().numpy()
-            series = s0 if rank == 0 else Series(confile, start_epoch, epoch_num, pair_mode, overlap_thd, device, targets)
-        else:
-            series = Series(confile, start_epoch, epoch_num, pair_mode, overlap_thd, device)
-        with series:
-            n = series.num_pairs
+        if series is None:
+            try:
+                series = Series(confile, start_epoch, epoch_num, pair_mode, overlap_thd, device, targets)
+            except Exception as e:                          # noqa: BLE001
+                print("pwicp series: rank %d failed to open the series: %s" % (rank, e), file=sys.stderr)
+                good = False
+        if not _agree(dist, dev, good):
+            return False
+        # ---- phase 2: this rank's pairs, then the series' one exchange ---------------------------------------
+        n = series.num_pairs
+        mine = []
+        try:
             done = series.run_pairs([p for p in range(n) if p % world == rank])
             mine = [done[k:k + 1] for k in range(len(done))]
-            table = fourd.gather_records(mine, n, world, dist=dist, device=dev)
-            if rank == 0:
+        except Exception as e:                              # noqa: BLE001
+            print("pwicp series: rank %d failed while running its pairs: %s" % (rank, e), file=sys.stderr)
+            good = False
+        if not _agree(dist, dev, good):
+            return False
+        table = fourd.gather_records(mine, n, world, dist=dist, device=dev)
+        if rank == 0:
+            try:
                 recs = np.concatenate([table[p].reshape(1) for p in sorted(table)]) if table else np.zeros(0, fourd.RECORD)
                 series.write_results(recs)
                 ok = len(recs) == n and bool(np.all(recs["status"] == 0))
-            else:
-                ok = True
-        if dist is not None:
-            import torch
-            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-            dist.broadcast(flag, src=0)
-            ok = bool(flag.item())
+            except Exception as e:                          # noqa: BLE001
+                print("pwicp series: writing the results failed: %s" % e, file=sys.stderr)
+                ok = False
+        else:
+            ok = True
+        ok = _agree(dist, dev, ok)
     finally:
+        if series is not None:
+            series.close()
         if dist is not None and dist.is_initialized():
             dist.destroy_process_group()
     return ok

@@ -164,3 +164,38 @@ def test_series_records_to_reference_files_world2_gloo(tmp_path):
     b = np.loadtxt(os.path.join(gold, "TransParameters.txt"), skiprows=1)
     # the standard deviations come from the VCM as printed (12 decimals) in the reference's TransMatrices.txt
     assert a.shape == b.shape and np.array_equal(a[:, :7], b[:, :7]) and np.allclose(a[:, 7:], b[:, 7:], rtol=1e-3)
+
+
+def test_series_driver_failure_on_one_rank_ends_every_rank(tmp_path):
+    """a rank that fails before a collective (here: the configuration file is unreadable on every rank, and
+    in a second run only rank 1 fails) must not leave the others blocked in a broadcast / all-gather: every rank agrees
+    on the failure (all-reduce MIN) and returns False."""
+    worker = tmp_path / "w.py"
+    worker.write_text(textwrap.dedent('''
+        import os, sys
+        sys.path.insert(0, os.path.join(%r, "piecewise-icp_amd"))
+        from pwicp_amd import series
+        rank = int(os.environ["RANK"])
+        cfg = sys.argv[1] if (sys.argv[2] == "all" or rank == 1) else sys.argv[3]
+        ok = series.run_series(cfg, 0, 3, int(sys.argv[4]), 0.75, backend="gloo", single_device=True, timeout_s=60)
+        print("RANK%%d_RETURNED_%%s" %% (rank, ok))
+        sys.exit(0 if not ok else 3)
+    ''' % ROOT))
+    from pwicp_amd.pcd import write_pcd_binary as write_pcd
+    inp = tmp_path / "scans"
+    inp.mkdir()
+    for e in range(1, 4):
+        write_pcd(str(inp / ("Epoch_%03d.pcd" % e)), np.zeros((3, 3), np.float32))
+    good = tmp_path / "cfg.txt"
+    good.write_text("string FolderFilePath1: %s\nstring FolderFilePath2: %s\nbool isSetResSVsize (yes-1, no-0): 1\n"
+                    "float PCres1 (m): 0.005\nfloat PCres2 (m): 0.005\nfloat SVsize1 (m): 0.05\nfloat SVsize2 (m): 0.05\n"
+                    "bool isSetDTinit (yes-1, no-0): 1\nfloat DTinit (m): 0.05\nfloat DTmin (m): 0.004\n"
+                    "bool isVisual (yes-1, no-0): 0" % (str(inp), str(tmp_path) + "/res_"))
+    for who, mode in (("all", 0), ("one", 0), ("all", -1)):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                              "--master-addr", "127.0.0.1", "--master-port", str(port), str(worker),
+                              str(tmp_path / "missing.txt"), who, str(good), str(mode)],
+                             capture_output=True, text=True, timeout=240, cwd=str(tmp_path))
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        assert "RANK0_RETURNED_False" in res.stdout and "RANK1_RETURNED_False" in res.stdout

@@ -1,0 +1,171 @@
+"""BASELINE.json configs on the GPU, each against the oracle (through the C ABI):
+  configs[1]  1 M-point pair, product supervoxel labels        -> bit-exact loop parity with the oracle
+  configs[0]+ the flip-sensitive golden pairs e8/e11/e13/e19   -> GPU == oracle, GPU vs the reference's result files
+  configs[3]  8 pairs x 1 M points against one shared target   -> every record == stand-alone pair == oracle
+  configs[4]  one 5 M-point pair                               -> oracle loop parity + sampled brute-force NN
+"""
+import os
+
+import numpy as np
+import pytest
+
+import _data
+import _golden as G
+from test_gpu_parity import _assert_loop_parity
+
+pytestmark = pytest.mark.gpu
+
+R = _data.R
+
+
+def _oracle_loop(oracle, tgt, l1, n1, src, l2, n2, r=R, sv=10 * R, dtinit=10 * R, dtmin=0.8 * R):
+    P1 = oracle.select_patches(tgt, l1, n1)
+    P2 = oracle.select_patches(src, l2, n2)
+    return oracle.run_loop(tgt, src, P1, P2, r, r, sv, sv, dtinit, dtmin)
+
+
+def test_loop_parity_1m_supervoxel_labels(ctx, oracle):
+    """BASELINE configs[1] at full size with the PRODUCT's supervoxel labels (what bench.py runs): DT series, stable
+    counts, d75, LoD, maxBB, inner-iteration counts bit-exact against the oracle; T within north_star's tolerance."""
+    import pwicp_amd as P
+    tgt, src, _ = _data.pair(1000000)
+    l1, n1 = ctx.frontend_segment(tgt, 10 * R, 45, R)
+    l2, n2 = ctx.frontend_segment(src, 10 * R, 45, R)
+    pair = P.Pair(ctx, tgt, l1, n1, src, l2, n2, _data.params())
+    res = pair.run(check=False)
+    io = _oracle_loop(oracle, tgt, l1, n1, src, l2, n2)
+    _assert_loop_parity(res, io)
+    assert res.n_dense_nn_launches >= 1 and res.n_corr_dense > 500000
+    moved = pair.download_source()
+    c2 = oracle.f4(src).copy()
+    for i in range(io.n_outer):
+        oracle.lib().orc_transform_points(oracle._p(c2), len(c2), oracle._p(np.array(io.Tk[i], np.float32)))
+    assert np.array_equal(moved[:, :3], c2[:, :3])
+    pair.close()
+
+
+# tolerance vs the reference's result file, as tests/test_oracle_golden.py (rad, m)
+GOLD_TOL = {8: (5e-5, 5e-5), 11: (5e-6, 5e-6), 13: (5e-6, 5e-6), 19: (2e-3, 3e-3)}
+
+
+@pytest.mark.parametrize("epoch", [8, 11, 13, 19])
+def test_flip_sensitive_golden_pairs_through_gpu(ctx, oracle, epoch):
+    """The pairs of the reference's synthetic series that end with <= 65-300 stable patches: one patch
+    classified differently moves the result.  GPU == oracle on every discrete quantity, and the GPU result is as close
+    to the reference's own file as the oracle's."""
+    if not oracle.ref_frontend_available():
+        pytest.skip("oracle/_ref not built")
+    import pwicp_amd as P
+    from pwicp_amd.pcd import read_pcd
+    p1 = G.preprocess_4d(oracle, read_pcd(G.epoch_path(1)))
+    p2 = G.preprocess_4d(oracle, read_pcd(G.epoch_path(epoch)))
+    r1, r2, shift = G.reduce_pair(p1, p2)
+    l1, n1 = oracle.ref_frontend(r1, 0.05)
+    l2, n2 = oracle.ref_frontend(r2, 0.05)
+    pair = P.Pair(ctx, r1, l1, n1, r2, l2, n2, P.Params(0.005, 0.005, 0.05, 0.05, 1, 0.05, 0.004))
+    res = pair.run(check=False)
+    io = _oracle_loop(oracle, r1, l1, n1, r2, l2, n2, r=0.005, sv=0.05, dtinit=0.05, dtmin=0.004)
+    _assert_loop_parity(res, io)
+    Tf = G.final_matrix(res.T16, shift)
+    Tg, _, _ = G.parse_transmatrix_file(os.path.join(G.GOLD, "reference_results", "%d_Direct2Ref_TransMatrix.txt" % epoch))
+    assert np.abs(G.euler(Tf) - G.euler(Tg)).max() < GOLD_TOL[epoch][0]
+    assert np.abs(Tf[:3, 3].astype(float) - Tg[:3, 3]).max() < GOLD_TOL[epoch][1]
+    pair.close()
+
+
+def _mat4_mul_f32(A, B):
+    """float 4x4 product in the element order of the product's mat4_mul (Eigen's order for Matrix4f)."""
+    A = np.asarray(A, np.float32).reshape(4, 4)
+    B = np.asarray(B, np.float32).reshape(4, 4)
+    out = np.zeros((4, 4), np.float32)
+    for i in range(4):
+        for j in range(4):
+            s = np.float32(A[i, 0] * B[0, j])
+            for k in range(1, 4):
+                s = np.float32(s + np.float32(A[i, k] * B[k, j]))
+            out[i, j] = s
+    return out
+
+
+def _final_matrix_exact(T16, shift):
+    """T_final = S^-1 * T * S (R.cpp:461) with sequential float sums."""
+    S = np.eye(4, dtype=np.float32); S[:3, 3] = shift
+    Si = np.eye(4, dtype=np.float32); Si[:3, 3] = np.float32(-1) * shift
+    return _mat4_mul_f32(_mat4_mul_f32(Si, T16), S)
+
+
+def _write_series_config(path, p1, p2, res=R, sv=10 * R, dtinit=10 * R, dtmin=0.8 * R):
+    with open(path, "w") as f:      # layout of configuration_files/configuration_4d.txt (11 positional lines)
+        f.write("string FolderFilePath1: %s\nstring FolderFilePath2: %s\nbool isSetResSVsize (yes-1, no-0): 1\n"
+                "float PCres1 (m): %.9g\nfloat PCres2 (m): %.9g\nfloat SVsize1 (m): %.9g\nfloat SVsize2 (m): %.9g\n"
+                "bool isSetDTinit (yes-1, no-0): 1\nfloat DTinit (m): %.9g\nfloat DTmin (m): %.9g\nbool isVisual (yes-1, no-0): 0"
+                % (p1, p2, res, res, sv, sv, dtinit, dtmin))
+
+
+def test_series_8_pairs_1m_shared_target(tmp_path, ctx, oracle):
+    """BASELINE configs[3] on one GPU: reference epoch + 8 source epochs of 1 M points (SURVEY 8d cfg 4), Direct2Ref,
+    through pwicp_series_run_pairs with the device-side target shared by all pairs.  Every record must equal a
+    stand-alone pwicp_pair_create run on the same preprocessed clouds, which must match the oracle."""
+    import pwicp_amd as P
+    from pwicp_amd import synth
+    from pwicp_amd.pcd import write_pcd_binary
+    n = 1000000
+    inp = tmp_path / "scans"
+    inp.mkdir()
+    tgt, _ = synth.make_tile(n, R)
+    write_pcd_binary(str(inp / "Epoch_001.pcd"), tgt)
+    srcs = []
+    for e in range(1, 9):
+        s, _ = synth.make_source(n, R, epoch=e)
+        srcs.append(s)
+        write_pcd_binary(str(inp / ("Epoch_%03d.pcd" % (e + 1))), s)
+    out = str(tmp_path) + "/res_"
+    cfg = tmp_path / "cfg.txt"
+    _write_series_config(cfg, str(inp), out)
+    with P.Series(str(cfg), 0, 9, 0, 0.75, 0) as series:
+        assert series.num_pairs == 8
+        recs = series.run_pairs(list(range(8)))
+        series.write_results(recs)
+    assert np.all(recs["status"] == 0) and list(recs["pair"]) == list(range(8))
+    assert os.path.exists(out + "TransMatrices_toRef.txt") and os.path.exists(out + "9_Direct2Ref_TransMatrix.txt")
+    # stand-alone: the same preprocessing (VoxelGrid + SOR 5.0), reduction, labels; a pair of its own per source epoch
+    p1 = ctx.preprocess(tgt, R, 14, 5.0)
+    r1, _, shift = G.reduce_pair(p1, p1)
+    l1, n1 = ctx.frontend_segment(r1, 10 * R, 45, R)
+    for k in (0, 3, 7):
+        p2 = ctx.preprocess(srcs[k], R, 14, 5.0)
+        r2 = p2.copy()
+        r2[:, :3] = (p2[:, :3] + shift[None, :]).astype(np.float32)
+        l2, n2 = ctx.frontend_segment(r2, 10 * R, 45, R)
+        pair = P.Pair(ctx, r1, l1, n1, r2, l2, n2, _data.params())
+        res = pair.run()
+        pair.close()
+        Tf = _final_matrix_exact(res.T16, shift)
+        assert np.array_equal(Tf.reshape(16), recs["T"][k])                         # shared target == own target, bit for bit
+        assert np.array_equal(np.array(res.VCM), recs["VCM"][k])
+        assert int(recs["n_outer"][k]) == res.n_outer and int(recs["n_corr"][k]) == res.n_corr
+        io = _oracle_loop(oracle, r1, l1, n1, r2, l2, n2)
+        _assert_loop_parity(res, io)
+
+
+def test_pair_5m_points(ctx, oracle):
+    """BASELINE configs[4] point count (5 M points per cloud, L = 11.2 m): the cell tables of this size, oracle loop
+    parity, sampled brute-force NN at full size."""
+    import pwicp_amd as P
+    from pwicp_amd import synth
+    n = 5000000
+    tgt, src, Tgt = _data.pair(n)
+    l1, n1 = synth.grid_labels(tgt, 10 * R)
+    l2, n2 = synth.grid_labels(src, 10 * R)
+    pair = P.Pair(ctx, tgt, l1, n1, src, l2, n2, _data.params())
+    res = pair.run(check=False)
+    io = _oracle_loop(oracle, tgt, l1, n1, src, l2, n2)
+    _assert_loop_parity(res, io)
+    m1, m2 = pair.num_patches()
+    assert m1 > 40000 and m2 > 40000
+    idx, d2 = ctx.determineCorrespondences(tgt, src[:4000])
+    t64 = tgt.astype(np.float64)
+    for i in range(0, 4000, 100):
+        d = ((t64 - src[i].astype(np.float64)) ** 2).sum(1)
+        assert abs(d.min() - d2[i]) <= 1e-6 * max(d.min(), 1e-12) + 1e-12
+    pair.close()

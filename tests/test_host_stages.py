@@ -23,6 +23,22 @@ def test_preprocess_matches_oracle(oracle):
         assert len(a) < len(cloud)
 
 
+def test_preprocess_voxel_index_overflow_passes_the_cloud_through(oracle):
+    """pcl::VoxelGrid (PCL 1.8.1): a leaf whose voxel indices would overflow int32 -> warning, output = input; the
+    reference then runs SOR on the full cloud (C.cpp:423-439).  Same here, and SORfilter alone
+    (isDownSamp = false) is the same function."""
+    import pwicp_amd as P
+    tgt, _, _ = _data.pair(20000, reduce=False)
+    cloud = tgt.copy()
+    cloud[:50] += np.float32(3.0)                         # a few outliers and a large extent: 4 m / 1e-4 m per axis
+    a = P.preprocess(cloud, 1.0e-4, 14, 2.7)
+    assert np.array_equal(oracle.voxel_grid(cloud, 1.0e-4)[:, :3], cloud)
+    b = oracle.sor(oracle.f4(cloud), 14, 2.7)
+    assert a.shape == b.shape and np.array_equal(a, b) and len(a) < len(cloud)
+    c = P.sor_filter(cloud, 14, 2.7)
+    assert np.array_equal(a, c)
+
+
 def test_frontend_matches_reference_front_end(oracle):
     """Product segmentation == the reference's own codelibrary front end (oracle/_ref), label for label."""
     if not oracle.ref_frontend_available():
@@ -198,6 +214,12 @@ def test_gpu_preprocess_matches_host(ctx, oracle):
         want = P.preprocess(cloud, leaf, k, mult)
         assert got.shape == want.shape and got.shape[0] > 0
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # SORfilter alone (PCpreprocessing with isDownSamp = false) and the voxel-index-overflow pass-through (PCL semantics)
+    c0 = cases[0][0]
+    want = P.sor_filter(c0, 14, 2.7)
+    assert np.array_equal(ctx.sor_filter(c0, 14, 2.7).view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(ctx.sor_filter(c0, 14, 2.7, 0.005).view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(ctx.preprocess(c0, 1.0e-5, 14, 2.7).view(np.uint32), want.view(np.uint32))
     o = oracle.sor(oracle.voxel_grid(cases[0][0], cases[0][1]), 14, 2.7)
     assert np.array_equal(ctx.preprocess(*cases[0])[:, :3].view(np.uint32), np.ascontiguousarray(o[:, :3]).view(np.uint32))
 
