@@ -102,6 +102,11 @@ struct Grid {
     DevBuf<int> cell_start, ccell_start;
     DevBuf<float4> pts, cpts;
     double kbar27 = 0.0;     // mean #points in the fine 27-cell stencil around an occupied cell, point weighted
+    // optional third level of SMALL cells for the disc-pruned dense search (pw_grid_add_dense), same layout as `fine`
+    GridLevel dense{};
+    bool has_dense = false;
+    DevBuf<int> dcell_start;
+    DevBuf<float4> dpts;
 };
 
 // grid.hip
@@ -110,9 +115,13 @@ int pw_grid_build(pwicp_context* ctx, const float4* d_pts, int n, float cell_edg
 int pw_nn_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_q, int nq, int* d_idx, float* d_d2,
                  unsigned long long* d_examined);
 // dense NN of patch points: query i = patch point qorder[i] (skipped, sentinel written, unless stable[pt_patch[.]])
+// d_qpatch (optional with `dense`): d_pt_patch[d_qorder[i]] precomputed; dense != nullptr selects the disc-pruned kernel
 int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pat, const int* d_qorder,
                            const int* d_pt_patch, const int* d_stable, int nq, float* d_d2,
-                           unsigned long long* d_examined);
+                           unsigned long long* d_examined, const GridLevel* dense = nullptr, const int* d_qpatch = nullptr);
+int pw_grid_add_dense(pwicp_context* ctx, const float4* d_pts, int n, float cell_edge, Grid* g);
+// out[i] = src[order[i]]
+int pw_gather_int_launch(pwicp_context* ctx, const int* d_src, const int* d_order, int n, int* d_out);
 int pw_morton_order(pwicp_context* ctx, const GridDesc& g, const float4* d_pts, int n, DevBuf<int>* order);
 int pw_bbox(pwicp_context* ctx, const float4* d_pts, int n, float mn[3], float mx[3]);
 int pw_check_finite(pwicp_context* ctx, const float4* d_pts, int n);

@@ -11,6 +11,7 @@
 // provably smaller than that of every point outside the block (conservative bound incl. the
 // rounding slack of the cell assignment); otherwise it grows the block shell by shell.
 #include <cfloat>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 
@@ -279,195 +280,8 @@ __global__ void __launch_bounds__(kBlock) k_nn_points_group(GridDesc g, const fl
     }
 }
 
-// ---- dense 1-NN, LDS-staged (EXPERIMENTAL variant, not the default: measured slower than k_nn_dense_direct) ----
-// Queries arrive in Morton order of their (initial) fine cell, so the 256 queries of a block occupy a compact
-// box of cells.  The block stages that box (+-2 cells halo) once — the begin/end table of its cell rows and the
-// target points, each row one coalesced copy — and every lane scans its 27-cell stencil, then if necessary the
-// 5x5x5 shell, out of LDS.  Only queries that are still unresolved (farther than ~2 cell edges from any target
-// point), queries outside the grid, or blocks whose box does not fit the LDS budget take the global-memory
-// two-level path of nn_device.h.  Same arithmetic, same tie rule: results are bit-identical to k_nn_points.
 constexpr int kXcds = 8;           // accelerator complex dies of an MI355X (one L2 each)
-constexpr int kPtCap = 2048;      // staged points   (32 KiB)
-constexpr int kCsCap = 3072;      // staged begin/end words (12 KiB)
-constexpr int kRowCap = 256;      // staged cell rows
-constexpr int kHalo = 2;
 constexpr unsigned kSentinel = 0xffffffffu;   // d2 slot of a query that is not part of this launch
-
-__device__ __forceinline__ void scan_points_lds(const float4* s_pts, int lo, int hi, float qx, float qy, float qz,
-                                                NNBest& b) {
-    int j = lo;
-    for (; j + 1 < hi; j += 2) {
-        const float4 p0 = s_pts[j], p1 = s_pts[j + 1];
-        nn_consider(p0, qx, qy, qz, b);
-        nn_consider(p1, qx, qy, qz, b);
-    }
-    if (j < hi) nn_consider(s_pts[j], qx, qy, qz, b);
-}
-
-__global__ void __launch_bounds__(kBlock) k_nn_dense_lds(GridDesc gd, const float4* __restrict__ pat,
-                                                         const int* __restrict__ qorder,
-                                                         const int* __restrict__ pt_patch,
-                                                         const int* __restrict__ stable, int nq,
-                                                         float* __restrict__ d2out,
-                                                         unsigned long long* __restrict__ examined) {
-    __shared__ float4 s_pts[kPtCap];
-    __shared__ int s_cs[kCsCap];
-    __shared__ int s_rowoff[kRowCap + 1];
-    __shared__ int s_red[kBlock / 64][6];
-    __shared__ int s_box[8];
-    const GridLevel& g = gd.fine;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = blockIdx.x * kBlock + tid;
-    bool active = false;
-    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < nq) {
-        const int p = qorder[i];
-        if (stable[pt_patch[p]]) { active = true; q = pat[p]; }
-    }
-    int cx = 0, cy = 0, cz = 0;
-    bool ingrid = false;
-    if (active) {
-        cx = cell_of(q.x, g.ox, g.inv_h); cy = cell_of(q.y, g.oy, g.inv_hy); cz = cell_of(q.z, g.oz, g.inv_hz);
-        ingrid = cx >= 0 && cx < g.nx && cy >= 0 && cy < g.ny && cz >= 0 && cz < g.nz;
-    }
-    // box of the block's in-grid query cells
-    {
-        int mn0 = ingrid ? cx : 0x7fffffff, mn1 = ingrid ? cy : 0x7fffffff, mn2 = ingrid ? cz : 0x7fffffff;
-        int mx0 = ingrid ? cx : -1, mx1 = ingrid ? cy : -1, mx2 = ingrid ? cz : -1;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            mn0 = min(mn0, __shfl_xor(mn0, o)); mn1 = min(mn1, __shfl_xor(mn1, o)); mn2 = min(mn2, __shfl_xor(mn2, o));
-            mx0 = max(mx0, __shfl_xor(mx0, o)); mx1 = max(mx1, __shfl_xor(mx1, o)); mx2 = max(mx2, __shfl_xor(mx2, o));
-        }
-        if (lane == 0) {
-            s_red[wave][0] = mn0; s_red[wave][1] = mn1; s_red[wave][2] = mn2;
-            s_red[wave][3] = mx0; s_red[wave][4] = mx1; s_red[wave][5] = mx2;
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-1, -1, -1};
-        for (int w = 0; w < kBlock / 64; ++w)
-            for (int d = 0; d < 3; ++d) { mn[d] = min(mn[d], s_red[w][d]); mx[d] = max(mx[d], s_red[w][3 + d]); }
-        int ok = mx[0] >= 0;
-        const int x0 = max(mn[0] - kHalo, 0), x1 = min(mx[0] + kHalo, g.nx - 1);
-        const int y0 = max(mn[1] - kHalo, 0), y1 = min(mx[1] + kHalo, g.ny - 1);
-        const int z0 = max(mn[2] - kHalo, 0), z1 = min(mx[2] + kHalo, g.nz - 1);
-        if (ok) {
-            const long long nrows = (long long)(y1 - y0 + 1) * (z1 - z0 + 1);
-            if (nrows > kRowCap || nrows * (x1 - x0 + 2) > kCsCap) ok = 0;
-        }
-        s_box[0] = x0; s_box[1] = x1; s_box[2] = y0; s_box[3] = y1; s_box[4] = z0; s_box[5] = z1; s_box[6] = ok;
-    }
-    __syncthreads();
-    const int x0 = s_box[0], x1 = s_box[1], y0 = s_box[2], y1 = s_box[3], z0 = s_box[4];
-    int staged = s_box[6];
-    const int bw1 = x1 - x0 + 2;                 // begin/end words per row
-    const int by = y1 - y0 + 1;
-    const int nrows = staged ? by * (s_box[5] - z0 + 1) : 0;
-    if (staged) {
-        for (int idx = tid; idx < nrows * bw1; idx += kBlock) {
-            const int t = idx / bw1, c = idx - t * bw1;
-            const int y = y0 + t % by, z = z0 + t / by;
-            s_cs[idx] = g.cell_start[(z * g.ny + y) * g.nx + x0 + c];
-        }
-    }
-    __syncthreads();
-    if (staged) {
-        // exclusive scan of the row point counts (nrows <= 256 = one element per thread)
-        const int cnt = (tid < nrows) ? (s_cs[tid * bw1 + bw1 - 1] - s_cs[tid * bw1]) : 0;
-        int incl = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o);
-            if (lane >= o) incl += t;
-        }
-        if (lane == 63) s_red[wave][0] = incl;
-        __syncthreads();
-        int base = 0;
-        for (int w = 0; w < wave; ++w) base += s_red[w][0];
-        if (tid < nrows) s_rowoff[tid] = base + incl - cnt;
-        if (tid == kBlock - 1) s_rowoff[kRowCap] = base + incl;      // total
-    }
-    __syncthreads();
-    if (staged && s_rowoff[kRowCap] > kPtCap) staged = 0;           // uniform
-    if (staged) {
-        for (int t = wave; t < nrows; t += kBlock / 64) {
-            const int glo = s_cs[t * bw1], n = s_cs[t * bw1 + bw1 - 1] - glo, dst = s_rowoff[t];
-            for (int k = lane; k < n; k += 64) s_pts[dst + k] = g.pts[glo + k];
-        }
-    }
-    __syncthreads();
-    unsigned cnt = 0;
-    if (active) {
-        NNBest b;
-        b.key = kKeyInit;
-        bool done = false;
-        if (staged && ingrid) {
-            // LDS index range of cells [xa, xb] (clipped to the grid) of row (y, z); empty outside the grid
-            auto lds_range = [&](int y, int z, int xa, int xb, int& lo, int& hi) {
-                lo = 0; hi = 0;
-                if (y < 0 || y >= g.ny || z < 0 || z >= g.nz) return;
-                xa = max(xa, 0); xb = min(xb, g.nx - 1);
-                if (xa > xb) return;
-                const int t = (z - z0) * by + (y - y0);
-                const int rb = t * bw1;
-                const int first = s_cs[rb];
-                lo = s_rowoff[t] + (s_cs[rb + xa - x0] - first);
-                hi = s_rowoff[t] + (s_cs[rb + xb + 1 - x0] - first);
-            };
-            int lo[9], hi[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) lds_range(cy + (k % 3) - 1, cz + (k / 3) - 1, cx - 1, cx + 1, lo[k], hi[k]);
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                scan_points_lds(s_pts, lo[k], hi[k], q.x, q.y, q.z, b);
-                cnt += (unsigned)(hi[k] - lo[k]);
-            }
-            done = nn_resolved(g, 1, b);
-            if (!done) {
-                for (int t = 0; t < 25; ++t) {
-                    const int dz = t / 5 - 2, dy = t % 5 - 2;
-                    int l0, h0, l1 = 0, h1 = 0;
-                    if (dz == -2 || dz == 2 || dy == -2 || dy == 2) {
-                        lds_range(cy + dy, cz + dz, cx - 2, cx + 2, l0, h0);
-                    } else {
-                        lds_range(cy + dy, cz + dz, cx - 2, cx - 2, l0, h0);
-                        lds_range(cy + dy, cz + dz, cx + 2, cx + 2, l1, h1);
-                    }
-                    scan_points_lds(s_pts, l0, h0, q.x, q.y, q.z, b);
-                    scan_points_lds(s_pts, l1, h1, q.x, q.y, q.z, b);
-                    cnt += (unsigned)(h0 - l0) + (unsigned)(h1 - l1);
-                }
-                done = nn_resolved(g, 2, b);
-            }
-        }
-        if (!done) {
-            unsigned ex = 0;
-            if (b.found()) {
-                // seeded continuation on the coarse level (stages 2/3 of nn_query)
-                const GridLevel& c = gd.coarse;
-                const float rho = sqrtf(b.d2()) * 1.00001f + 2.0f * c.slack;
-                const int a0 = max(cell_of(q.x - rho, c.ox, c.inv_h), 0), a1 = min(cell_of(q.x + rho, c.ox, c.inv_h), c.nx - 1);
-                const int b0 = max(cell_of(q.y - rho, c.oy, c.inv_hy), 0), b1 = min(cell_of(q.y + rho, c.oy, c.inv_hy), c.ny - 1);
-                const int c0 = max(cell_of(q.z - rho, c.oz, c.inv_hz), 0), c1 = min(cell_of(q.z + rho, c.oz, c.inv_hz), c.nz - 1);
-                if ((b1 - b0 + 1) * (c1 - c0 + 1) <= 64) {
-                    if (a0 <= a1 && b0 <= b1 && c0 <= c1) ex = scan_box(c, a0, a1, b0, b1, c0, c1, q.x, q.y, q.z, b);
-                } else {
-                    ex = nn_expand(c, q.x, q.y, q.z, b);
-                }
-            } else {
-                b = nn_query(gd, q.x, q.y, q.z, ex);
-            }
-            cnt += ex;
-        }
-        d2out[i] = b.d2();
-    } else if (i < nq) {
-        d2out[i] = __uint_as_float(kSentinel);
-    }
-    add_examined(examined, cnt);
-}
-
 
 // Dense 1-NN straight from global memory (L1/L2) with the two-level search.  Stage 1 (27-cell stencil) runs for
 // every query; the queries it leaves unresolved are then COMPACTED inside the block (ballot + LDS) so that the
@@ -496,36 +310,103 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_direct(GridDesc gd, const f
     add_examined(examined, cnt);
 }
 
-// Dense 1-NN with the group-cooperative query: 8 lanes share one query, take every 8th point of a stencil row (one
-// coalesced 128-byte request per row pass) and split the far path.  The dense search is bound by the length of the
-// per-query chain of dependent memory round trips at full occupancy (SQ_WAIT_ANY ~75 %), not by issue: a row of a
-// column grid holds ~27 points, i.e. ~14 dependent passes for one lane and 1-2 for a group.  Same XCD-aware tile order.
-__global__ void __launch_bounds__(kBlock) k_nn_dense_group(GridDesc gd, const float4* __restrict__ pat,
-                                                           const int* __restrict__ qorder,
-                                                           const int* __restrict__ pt_patch,
-                                                           const int* __restrict__ stable, int nq,
-                                                           float* __restrict__ d2out,
-                                                           unsigned long long* __restrict__ examined, int chunk) {
-    constexpr int kQ = kBlock / kGroup;                   // queries per block
+// ---- dense 1-NN, distance only, disc-pruned (the default dense kernel) --------------------------------------------------
+// One lane per query (queries in Morton order of their target cell, XCD-aware tile order as above).  `dl` is a level of
+// SMALL cells (edge ~1.5 point spacings) over the target cloud: phase A takes a candidate from the query's own row
+// segment (3 cells, ~7 points), phase B scans exactly the cells the candidate's ball touches (scan_disc).  A query whose
+// ball is wider than kMaxRhoCells cells (far from the surface: first iterations, displaced areas) or that found no
+// candidate is compacted inside the block and continues on the larger cells of `far` (fine, then coarse, then the
+// general block / shell expansion).  Same float arithmetic per candidate as every other search: the result is the exact
+// minimum d2 (bit-identical to k_nn_dense_direct and the oracle).
+constexpr float kMaxRhoCells = 2.75f;
+
+__device__ __forceinline__ float dense_far_path(const GridDesc& far, float4 q, float best, unsigned& cnt) {
+    if (best < INFINITY) {
+        const float sq = fast_sqrt_up(best);
+        if (sq + 2.0f * far.fine.slack <= kMaxRhoCells * far.fine.h) {
+            cnt += scan_disc_lean(far.fine, q.x, q.y, q.z, sq + 2.0f * far.fine.slack, INT_MIN, INT_MIN, 0, -1, 0, 0, best);
+            return best;
+        }
+        if (sq + 2.0f * far.coarse.slack <= kMaxRhoCells * far.coarse.h) {
+            cnt += scan_disc_lean(far.coarse, q.x, q.y, q.z, sq + 2.0f * far.coarse.slack, INT_MIN, INT_MIN, 0, -1, 0, 0, best);
+            return best;
+        }
+    }
+    // no candidate yet, or a very wide ball: the general search (stencil, ball box / block + shells on the coarse level)
+    NNBest b;
+    b.key = kKeyInit;
+    unsigned ex = 0;
+    b = nn_query(far, q.x, q.y, q.z, ex);
+    cnt += ex;
+    return fminf(best, b.d2());
+}
+
+__global__ void __launch_bounds__(kBlock) k_nn_dense_disc(GridLevel dl, GridDesc far, const float4* __restrict__ pat,
+                                                          const int* __restrict__ qorder, const int* __restrict__ qpatch,
+                                                          const int* __restrict__ stable, int nq,
+                                                          float* __restrict__ d2out,
+                                                          unsigned long long* __restrict__ examined, int chunk) {
+    __shared__ float4 s_q[kBlock];          // .w carries the candidate d2 of an unresolved query
+    __shared__ int s_slot[kBlock];
+    __shared__ int s_wcnt[kBlock / 64];
     const int tile = chunk > 0 ? (int)(blockIdx.x % kXcds) * chunk + (int)(blockIdx.x / kXcds) : (int)blockIdx.x;
-    const int i = tile * kQ + (int)(threadIdx.x / kGroup), sub = threadIdx.x % kGroup;
-    if (i >= nq) return;
-    const int p = qorder ? qorder[i] : i;
-    if (!stable[pt_patch[p]]) {
-        if (sub == 0) d2out[i] = __uint_as_float(kSentinel);
-        return;
-    }
-    const float4 q = pat[p];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = tile * kBlock + tid;
     unsigned cnt = 0;
-    const NNBest b = nn_query_group_counted(gd, q.x, q.y, q.z, sub, cnt);
-    if (sub == 0) d2out[i] = b.d2();
-    if (examined) {
-        // points examined by this group's lanes, summed over the wave, one atomic per wave on a spread counter
-        unsigned long long c = cnt;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-        if ((threadIdx.x & 63) == 0 && c) atomicAdd(&examined[(blockIdx.x & 255) * 16], c);
+    bool unresolved = false;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    float best = INFINITY;
+    if (i < nq) {
+        const int p = qorder[i], pa = qpatch[i];  // (p < 0: padding slot of a tile-ordered query list)
+        const int st = p >= 0 ? stable[pa] : 0;
+        q = pat[max(p, 0)];                       // (both gathers in flight together)
+        if (st) {
+            const int cx = cell_of(q.x, dl.ox, dl.inv_h), cy = cell_of(q.y, dl.oy, dl.inv_hy), cz = cell_of(q.z, dl.oz, dl.inv_hz);
+            int loA, hiA;
+            row_range(dl, cy, cz, cx - 1, cx + 1, loA, hiA);
+            scan_d2x4(dl.pts, loA, hiA, q.x, q.y, q.z, best);
+            cnt += (unsigned)(hiA - loA);
+            const float rho = fast_sqrt_up(best) + 2.0f * dl.slack;
+            if (best < INFINITY && rho <= kMaxRhoCells * dl.h) {
+                // (a row outside the grid / an empty clipped segment: nothing of the ball has been scanned yet)
+                const bool in = cy >= 0 && cy < dl.ny && cz >= 0 && cz < dl.nz && max(cx - 1, 0) <= min(cx + 1, dl.nx - 1);
+                cnt += scan_disc_lean(dl, q.x, q.y, q.z, rho, in ? cy : INT_MIN, in ? cz : INT_MIN, max(cx - 1, 0), min(cx + 1, dl.nx - 1),
+                                 loA, hiA, best);
+                d2out[i] = best;
+            } else {
+                unresolved = true;
+            }
+        } else {
+            d2out[i] = __uint_as_float(kSentinel);
+        }
     }
+    // far queries: compacted inside the block so that their longer scans run on packed waves
+    const unsigned long long mask = __ballot(unresolved);
+    const int before = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wcnt[wave] = __popcll(mask);
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) {
+        if (w < wave) base += s_wcnt[w];
+        total += s_wcnt[w];
+    }
+    if (unresolved) {
+        s_q[base + before] = make_float4(q.x, q.y, q.z, best);
+        s_slot[base + before] = i;
+    }
+    __syncthreads();
+    if (tid < total) {
+        const float4 u = s_q[tid];
+        d2out[s_slot[tid]] = dense_far_path(far, u, u.w, cnt);
+    }
+    add_examined(examined, cnt);
+}
+
+// patch id of the i-th query of the dense search (static: one coalesced load instead of a dependent gather per launch)
+__global__ void k_gather_int(const int* __restrict__ src, const int* __restrict__ order, int n, int* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[order[i]];
 }
 
 // Morton code (10 bits per axis) of the fine cell of each point, for the one-off query ordering
@@ -975,32 +856,45 @@ int pw_count_below_launch(pwicp_context* ctx, const float* d_d2, int n, float th
     return PWICP_OK;
 }
 
+// third level of small cells over the same points, same layout (cells / columns) as g->d.fine
+int pw_grid_add_dense(pwicp_context* ctx, const float4* d_pts, int n, float cell_edge, Grid* g) {
+    g->has_dense = false;
+    if (n <= 0 || !(cell_edge > 0.f)) return PWICP_OK;
+    float mn[3], mx[3];
+    PWCHK(pw_bbox(ctx, d_pts, n, mn, mx));
+    const int axis = g->d.fine.ny == 1 && g->d.fine.inv_hy == 0.0f ? 1 : (g->d.fine.nz == 1 && g->d.fine.inv_hz == 0.0f ? 2 : 0);
+    PWCHK(build_level(ctx, d_pts, n, cell_edge, mn, mx, &g->dense, &g->dcell_start, &g->dpts, axis));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    g->has_dense = true;
+    return PWICP_OK;
+}
+
+int pw_gather_int_launch(pwicp_context* ctx, const int* d_src, const int* d_order, int n, int* d_out) {
+    if (n > 0) hipLaunchKernelGGL(k_gather_int, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_src, d_order, n, d_out);
+    HIPCHK(ctx, hipGetLastError());
+    return PWICP_OK;
+}
+
 int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pat, const int* d_qorder,
                            const int* d_pt_patch, const int* d_stable, int nq, float* d_d2,
-                           unsigned long long* d_examined) {
+                           unsigned long long* d_examined, const GridLevel* dense, const int* d_qpatch) {
     if (nq <= 0) return PWICP_OK;
-    // default: direct kernel, queries in Morton order.  PWICP_DENSE_KERNEL=0 selects the LDS-staged variant,
-    // =2 the direct kernel in patch order — both kept for A/B measurements only.
-    static int variant = -1;
-    if (variant < 0) { const char* e = getenv("PWICP_DENSE_KERNEL"); variant = e ? atoi(e) : 1; }
-    if (variant == 0)
-        hipLaunchKernelGGL(k_nn_dense_lds, dim3(div_up(nq, kBlock)), dim3(kBlock), 0, ctx->stream, g, d_pat, d_qorder,
-                           d_pt_patch, d_stable, nq, d_d2, d_examined);
-    else
+    if (dense && d_qpatch && d_qorder) {
+        const int tiles = div_up(nq, kBlock);
+        const int chunk = div_up(tiles, kXcds);
+        hipLaunchKernelGGL(k_nn_dense_disc, dim3(chunk * kXcds), dim3(kBlock), 0, ctx->stream, *dense, g, d_pat, d_qorder, d_qpatch,
+                           d_stable, nq, d_d2, d_examined, chunk);
+        HIPCHK(ctx, hipGetLastError());
+        return PWICP_OK;
+    }
+    // no small-cell level (PWICP_DISC_CELL_FACTOR=0): the 27-cell stencil kernel with (d2, index) keys, kept for A/B runs
     {
         static int xcd = -1;                 // PWICP_DENSE_XCD=0: plain block order (A/B measurements only)
         if (xcd < 0) { const char* e = getenv("PWICP_DENSE_XCD"); xcd = e ? atoi(e) : 1; }
-        if (variant == 3) {                  // group-cooperative queries
-            const int tiles = div_up(nq, kBlock / kGroup);
-            const int chunk = xcd ? div_up(tiles, kXcds) : 0;
-            hipLaunchKernelGGL(k_nn_dense_group, dim3(chunk ? chunk * kXcds : tiles), dim3(kBlock), 0, ctx->stream, g, d_pat,
-                               d_qorder, d_pt_patch, d_stable, nq, d_d2, d_examined, chunk);
-        } else {
-            const int tiles = div_up(nq, kBlock);
-            const int chunk = (xcd && variant == 1) ? div_up(tiles, kXcds) : 0;
-            hipLaunchKernelGGL(k_nn_dense_direct, dim3(chunk ? chunk * kXcds : tiles), dim3(kBlock), 0, ctx->stream, g, d_pat,
-                               variant == 1 ? d_qorder : (const int*)nullptr, d_pt_patch, d_stable, nq, d_d2, d_examined, chunk);
-        }
+        const int tiles = div_up(nq, kBlock);
+        const int chunk = xcd ? div_up(tiles, kXcds) : 0;
+        hipLaunchKernelGGL(k_nn_dense_direct, dim3(chunk ? chunk * kXcds : tiles), dim3(kBlock), 0, ctx->stream, g, d_pat, d_qorder,
+                           d_pt_patch, d_stable, nq, d_d2, d_examined, chunk);
     }
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;

@@ -470,6 +470,7 @@ struct pwicp_pair {
     DevBuf<float4> nrm2;
     DevBuf<int> pt_patch2;   // patch id of every source patch point
     DevBuf<int> qorder;      // source patch points in Morton order of their initial target-grid cell
+    DevBuf<int> qpatch;      // pt_patch2[qorder[i]]
     DevBuf<int> all_stable;  // all-ones flags (bench replay over every patch)
     // per-iteration work
     DevBuf<int> mCTBP, stable, blk_cnt;   // matches of the 7*m2 centroid+boundary queries
@@ -523,6 +524,10 @@ int finish_target(pwicp_target* t) {
     if (const char* e = getenv("PWICP_DENSE_CELL_FACTOR")) { float v = (float)atof(e); if (v > 0.f) f_dense = v; }
     if (const char* e = getenv("PWICP_CT_CELL_FACTOR")) { float v = (float)atof(e); if (v > 0.f) f_ct = v; }
     PWCHK(pw_grid_build(ctx, t->cloud1.p, t->n1, f_dense * t->Res1, &t->g_c1));
+    // small cells for the disc-pruned dense search (PWICP_DISC_CELL_FACTOR x point spacing; 0 = off: 27-cell stencil kernel)
+    float f_disc = 2.0f;
+    if (const char* e = getenv("PWICP_DISC_CELL_FACTOR")) f_disc = (float)atof(e);
+    if (f_disc > 0.f) PWCHK(pw_grid_add_dense(ctx, t->cloud1.p, t->n1, f_disc * t->Res1, &t->g_c1));
     PWCHK(pw_grid_build(ctx, t->P1.ct.p, m1, f_ct * t->SVRes1, &t->g_ct1));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return PWICP_OK;
@@ -536,6 +541,8 @@ int finish_create(pwicp_pair* pr) {
     HIPCHK(ctx, pr->pt_patch2.reserve((size_t)std::max(pr->P2.tot, 1)));
     PWCHK(pw_point_patch_ids_launch(ctx, pr->P2.off.p, m2, pr->pt_patch2.p));
     PWCHK(pw_morton_order(ctx, pr->tgt->g_c1.d, pr->P2.pat.p, pr->P2.tot, &pr->qorder));
+    HIPCHK(ctx, pr->qpatch.reserve((size_t)std::max(pr->P2.tot, 1)));
+    PWCHK(pw_gather_int_launch(ctx, pr->pt_patch2.p, pr->qorder.p, pr->P2.tot, pr->qpatch.p));
     // pristine source copies; centroids and boundary points live in ONE buffer so that a single NN launch and a
     // single transform launch serve both (R.cpp:737-747, 946-949)
     HIPCHK(ctx, pr->cloud2_0.reserve((size_t)std::max(pr->n2, 1)));
@@ -973,7 +980,8 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                 HIPCHK(ctx, hipEventRecord(pr->event(n_ev), ctx->stream));
             }
             PWCHK(pw_nn_dense_launch(ctx, pr->tgt->g_c1.d, pr->P2.pat.p, pr->qorder.p, pr->pt_patch2.p, pr->stable.p,
-                                         pr->P2.tot, pr->d2dense.p, pr->examined.p));
+                                         pr->P2.tot, pr->d2dense.p, pr->examined.p,
+                                         pr->tgt->g_c1.has_dense ? &pr->tgt->g_c1.dense : nullptr, pr->qpatch.p));
             if (ev) {
                 HIPCHK(ctx, hipEventRecord(pr->event(n_ev + 1), ctx->stream));
                 n_ev += 2;
@@ -1078,8 +1086,9 @@ int pwicp_pair_bench_dense_nn(pwicp_pair* pr, int n_launches, double* ms_per_lau
     }
     HIPCHK(ctx, hipMemsetAsync(pr->examined.p, 0, 256 * 16 * sizeof(unsigned long long), ctx->stream));
     // warm-up launch (also measures Kbar)
+    const GridLevel* dense = pr->tgt->g_c1.has_dense ? &pr->tgt->g_c1.dense : nullptr;
     PWCHK(pw_nn_dense_launch(ctx, pr->tgt->g_c1.d, pr->pat2_0.p, pr->qorder.p, pr->pt_patch2.p, flags, tot,
-                                 pr->d2dense.p, pr->examined.p));
+                                 pr->d2dense.p, pr->examined.p, dense, pr->qpatch.p));
     unsigned long long ex = 0;
     {
         std::vector<unsigned long long> hx(256 * 16);
@@ -1091,7 +1100,7 @@ int pwicp_pair_bench_dense_nn(pwicp_pair* pr, int n_launches, double* ms_per_lau
     HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
     for (int i = 0; i < n_launches; ++i)
         PWCHK(pw_nn_dense_launch(ctx, pr->tgt->g_c1.d, pr->pat2_0.p, pr->qorder.p, pr->pt_patch2.p, flags, tot,
-                                     pr->d2dense.p, nullptr));
+                                     pr->d2dense.p, nullptr, dense, pr->qpatch.p));
     HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
@@ -1099,7 +1108,7 @@ int pwicp_pair_bench_dense_nn(pwicp_pair* pr, int n_launches, double* ms_per_lau
     if (ms_per_launch) *ms_per_launch = (double)ms / n_launches;
     if (n_queries) *n_queries = npts;
     if (kbar) *kbar = (double)ex / (double)npts;
-    if (cell_edge) *cell_edge = pr->tgt->g_c1.d.fine.h;
+    if (cell_edge) *cell_edge = dense ? dense->h : pr->tgt->g_c1.d.fine.h;
     return PWICP_OK;
 }
 

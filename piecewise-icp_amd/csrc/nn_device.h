@@ -356,60 +356,102 @@ __device__ __forceinline__ NNBest nn_query_group(const GridDesc& gd, float qx, f
     return b;
 }
 
-// The same exact search for LONG stencil rows (dense cloud-to-cloud queries): in stage 1 all lanes of the group walk every
-// row together (nn_query_group gives each lane a row of its own, which suits the 1-3 point rows of the centroid grids).
-// `cnt` receives the points this lane examined.
-__device__ __forceinline__ NNBest nn_query_group_counted(const GridDesc& gd, float qx, float qy, float qz, int sub, unsigned& cnt) {
-    NNBest b;
-    b.key = kKeyInit;
-    const GridLevel& g = gd.fine;
-    if (g.n <= 0) return b;
-    {
-        const int cx = cell_of(qx, g.ox, g.inv_h), cy = cell_of(qy, g.oy, g.inv_hy), cz = cell_of(qz, g.oz, g.inv_hz);
-        cnt += scan_box_group(g, cx - 1, cx + 1, cy - 1, cy + 1, cz - 1, cz + 1, sub, qx, qy, qz, b);
-        group_min(b);
-        if (nn_resolved(g, 1, b)) return b;
+// ---- distance-only search with disc pruning (dense cloud-to-cloud queries) ---------------------------------------------
+// The dense Stage-1 launch (calPercentileDistBetween2PC, C.cpp:266-281) needs min d2 only, not the index: the running
+// best is a float and one v_min_f32 replaces the 64-bit (d2, index) compare.  Instead of a fixed 27-cell stencil the
+// search takes a first candidate from the query's own cell-row segment and then scans exactly the cells a disc of that
+// radius touches, row by row (rows whose distance to the query already exceeds the candidate are never visited, and
+// the x-range of a row shrinks with its distance: cells of the circle, not of its bounding box).
+// Exactness: every target point closer than the candidate lies inside the ball [q - rho, q + rho]; the float cell
+// assignment is monotone in the coordinate, and `rho` carries the rounding slack of the cell boundaries (2 * slack, as
+// in nn_stage23), so every cell that can hold such a point is visited.  The result is the exact minimum of the float
+// expression ((dx*dx)+dy*dy)+dz*dz over ALL targets.
+__device__ __forceinline__ void nn_consider_d2(const float4 p, float qx, float qy, float qz, float& best) {
+    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+    float d2 = dx * dx;
+    d2 = d2 + dy * dy;
+    d2 = d2 + dz * dz;
+    best = fminf(best, d2);          // coordinates are finite (checked at upload): d2 is never NaN
+}
+
+// ---- lean variants for the dense kernel: same exact result, fewer instructions ---------------------------------------------
+// (the dense launch is bound by vector-ALU issue — ~4 cycles per wave instruction — so the search logic around the
+// candidates counts as much as the candidates: no integer divisions, no correctly-rounded sqrt in the PRUNING radius
+// (v_sqrt_f32 with a relative margin instead: a larger radius is always safe), cell indices without the NaN / range
+// guards of cell_of (queries are finite and near the grid), four candidates per pass.)
+__device__ __forceinline__ int icell(float p, float o, float inv_h) { return (int)floorf((p - o) * inv_h); }
+__device__ __forceinline__ float fast_sqrt_up(float x) { return __builtin_amdgcn_sqrtf(x) * 1.0002f; }   // >= sqrt(x) for x >= 0
+
+__device__ __forceinline__ void scan_d2x4(const float4* __restrict__ pts, int lo, int hi, float qx, float qy, float qz, float& best) {
+    int j = lo;
+    for (; j + 4 <= hi; j += 4) {
+        const float4 a = pts[j], b = pts[j + 1], c = pts[j + 2], d = pts[j + 3];
+        nn_consider_d2(a, qx, qy, qz, best);
+        nn_consider_d2(b, qx, qy, qz, best);
+        nn_consider_d2(c, qx, qy, qz, best);
+        nn_consider_d2(d, qx, qy, qz, best);
     }
-    const GridLevel& c = gd.coarse;
-    if (b.found()) {
-        const float rho = sqrtf(b.d2()) * 1.00001f + 2.0f * c.slack;
-        const int x0 = max(cell_of(qx - rho, c.ox, c.inv_h), 0), x1 = min(cell_of(qx + rho, c.ox, c.inv_h), c.nx - 1);
-        const int y0 = max(cell_of(qy - rho, c.oy, c.inv_hy), 0), y1 = min(cell_of(qy + rho, c.oy, c.inv_hy), c.ny - 1);
-        const int z0 = max(cell_of(qz - rho, c.oz, c.inv_hz), 0), z1 = min(cell_of(qz + rho, c.oz, c.inv_hz), c.nz - 1);
-        if ((y1 - y0 + 1) * (z1 - z0 + 1) <= 64) {
-            if (x0 <= x1 && y0 <= y1 && z0 <= z1) cnt += scan_box_group(c, x0, x1, y0, y1, z0, z1, sub, qx, qy, qz, b);
-            group_min(b);
-            return b;
+    if (j + 2 <= hi) {
+        const float4 a = pts[j], b = pts[j + 1];
+        nn_consider_d2(a, qx, qy, qz, best);
+        nn_consider_d2(b, qx, qy, qz, best);
+        j += 2;
+    }
+    if (j < hi) nn_consider_d2(pts[j], qx, qy, qz, best);
+}
+
+// scan_disc without divisions / exact square roots; rows of one z-slab are taken four at a time (all begin/end words of
+// the batch in flight before the first point load).  Same contract as scan_disc.
+__device__ __forceinline__ unsigned scan_disc_lean(const GridLevel& g, float qx, float qy, float qz, float rho, int sy, int sz,
+                                                   int sx0, int sx1, int slo, int shi, float& best) {
+    unsigned cnt = 0;
+    const bool gy = g.inv_hy != 0.0f, gz = g.inv_hz != 0.0f;
+    const int y0 = gy ? max(icell(qy - rho, g.oy, g.inv_hy), 0) : 0, y1 = gy ? min(icell(qy + rho, g.oy, g.inv_hy), g.ny - 1) : 0;
+    const int z0 = gz ? max(icell(qz - rho, g.oz, g.inv_hz), 0) : 0, z1 = gz ? min(icell(qz + rho, g.oz, g.inv_hz), g.nz - 1) : 0;
+    const float rho2 = rho * rho, slack2 = 2.0f * g.slack;
+    for (int z = z0; z <= z1; ++z) {
+        float remz = rho2;
+        if (gz) {
+            const float lo = g.oz + (float)z * g.h;
+            const float ez = fmaxf(fmaxf(lo - qz, qz - (lo + g.h)) - slack2, 0.0f);
+            remz = rho2 - ez * ez;
+            if (!(remz > 0.0f)) continue;
         }
-    }
-    {
-        const int cx = cell_of(qx, c.ox, c.inv_h), cy = cell_of(qy, c.oy, c.inv_hy), cz = cell_of(qz, c.oz, c.inv_hz);
-        const int ex = max(0, max(-cx, cx - (c.nx - 1)));
-        const int ey = max(0, max(-cy, cy - (c.ny - 1)));
-        const int ez = max(0, max(-cz, cz - (c.nz - 1)));
-        int r = max(max(ex, ey), max(ez, 1));
-        const int rcover = max(max(max(cx, c.nx - 1 - cx), max(cy, c.ny - 1 - cy)), max(cz, c.nz - 1 - cz));
-        cnt += scan_box_group(c, cx - r, cx + r, cy - r, cy + r, cz - r, cz + r, sub, qx, qy, qz, b);
-        group_min(b);
-        while (!nn_resolved(c, r, b) && r < rcover) {
-            ++r;
-            const int w = 2 * r + 1;
-            for (int t = sub; t < w * w; t += kGroup) {
-                const int dz = t / w - r, dy = t % w - r;
-                int lo0, hi0, lo1 = 0, hi1 = 0;
-                if (dz == -r || dz == r || dy == -r || dy == r) {
-                    row_range(c, cy + dy, cz + dz, cx - r, cx + r, lo0, hi0);
-                } else {
-                    row_range(c, cy + dy, cz + dz, cx - r, cx - r, lo0, hi0);
-                    row_range(c, cy + dy, cz + dz, cx + r, cx + r, lo1, hi1);
+        for (int yb = y0; yb <= y1; yb += 4) {
+            int lo[4], hi[4], lo2[4], hi2[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                lo[k] = hi[k] = lo2[k] = hi2[k] = 0;
+                const int y = yb + k;
+                if (y > y1) continue;
+                float rem = remz;
+                if (gy) {
+                    const float l = g.oy + (float)y * g.h;
+                    const float ey = fmaxf(fmaxf(l - qy, qy - (l + g.h)) - slack2, 0.0f);
+                    rem = remz - ey * ey;
+                    if (!(rem > 0.0f)) continue;
                 }
-                cnt += scan_points4(c.pts, lo0, hi0, 1, qx, qy, qz, b);
-                cnt += scan_points4(c.pts, lo1, hi1, 1, qx, qy, qz, b);
+                const float rx = fast_sqrt_up(rem) + slack2;
+                const int x0 = max(icell(qx - rx, g.ox, g.inv_h), 0), x1 = min(icell(qx + rx, g.ox, g.inv_h), g.nx - 1);
+                if (x0 > x1) continue;
+                const int row = (z * g.ny + y) * g.nx;
+                if (y == sy && z == sz) {
+                    if (x0 < sx0) { lo[k] = g.cell_start[row + x0]; hi[k] = slo; }
+                    if (x1 > sx1) { lo2[k] = shi; hi2[k] = g.cell_start[row + x1 + 1]; }
+                } else {
+                    lo[k] = g.cell_start[row + x0];
+                    hi[k] = g.cell_start[row + x1 + 1];
+                }
             }
-            group_min(b);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                scan_d2x4(g.pts, lo[k], hi[k], qx, qy, qz, best);
+                scan_d2x4(g.pts, lo2[k], hi2[k], qx, qy, qz, best);
+                cnt += (unsigned)(hi[k] - lo[k]) + (unsigned)(hi2[k] - lo2[k]);
+            }
         }
     }
-    return b;
+    return cnt;
 }
 
 // diagnostic: points examined.  `ctr` is an array of 256 counters, 128 bytes apart (one per cache line), indexed

@@ -100,6 +100,7 @@ int pw_preprocess_dev(pwicp_context* ctx, const float4* d_in, int n, bool downsa
         fprintf(stderr, "[pwicp] Leaf size is too small for the input dataset. Integer indices would overflow: the cloud is passed on "
                         "unfiltered (pcl::VoxelGrid semantics).\n");
         downsample = false;
+        leaf = 0.f;                        // says nothing about the point spacing: the search grid edge is estimated below
     }
     if (!downsample && !(leaf > 0.f)) {
         // grid edge for the SOR search only (any edge is exact): ~2 mean spacings of a surface-like cloud in its bounding box
