@@ -118,7 +118,10 @@ int pw_nn_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_q, int n
 // d_qpatch (optional with `dense`): d_pt_patch[d_qorder[i]] precomputed; dense != nullptr selects the disc-pruned kernel
 int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pat, const int* d_qorder,
                            const int* d_pt_patch, const int* d_stable, int nq, float* d_d2,
-                           unsigned long long* d_examined, const GridLevel* dense = nullptr, const int* d_qpatch = nullptr);
+                           unsigned long long* d_examined, const GridLevel* dense = nullptr, const int* d_qpatch = nullptr,
+                           const struct FusedSelect* fs = nullptr);
+// passes 1 / 2 of the fused percentile selection (select_dev.h) as launches of their own
+int pw_fs_pass_launch(pwicp_context* ctx, int pass, const struct FusedSelect& fs);
 int pw_grid_add_dense(pwicp_context* ctx, const float4* d_pts, int n, float cell_edge, Grid* g);
 // out[i] = src[order[i]]
 int pw_gather_int_launch(pwicp_context* ctx, const int* d_src, const int* d_order, int n, int* d_out);

@@ -19,6 +19,7 @@
 
 #include "common.h"
 #include "nn_device.h"
+#include "select_dev.h"
 
 namespace {
 
@@ -345,7 +346,8 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_disc(GridLevel dl, GridDesc
                                                           const int* __restrict__ qorder, const int* __restrict__ qpatch,
                                                           const int* __restrict__ stable, int nq,
                                                           float* __restrict__ d2out,
-                                                          unsigned long long* __restrict__ examined, int chunk) {
+                                                          unsigned long long* __restrict__ examined, int chunk, FusedSelect fs) {
+    __shared__ unsigned s_hist[kFsBins];    // pass 0 of the percentile selection (select_dev.h), fs.scratch != nullptr only
     __shared__ float4 s_q[kBlock];          // .w carries the candidate d2 of an unresolved query
     __shared__ int s_slot[kBlock];
     __shared__ int s_wcnt[kBlock / 64];
@@ -356,6 +358,10 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_disc(GridLevel dl, GridDesc
     bool unresolved = false;
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     float best = INFINITY;
+    if (fs.scratch) {
+        for (int t = tid; t < kFsBins; t += kBlock) s_hist[t] = 0u;
+        __syncthreads();
+    }
     if (i < nq) {
         const int p = qorder[i], pa = qpatch[i];  // (p < 0: padding slot of a tile-ordered query list)
         const int st = p >= 0 ? stable[pa] : 0;
@@ -373,6 +379,7 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_disc(GridLevel dl, GridDesc
                 cnt += scan_disc_lean(dl, q.x, q.y, q.z, rho, in ? cy : INT_MIN, in ? cz : INT_MIN, max(cx - 1, 0), min(cx + 1, dl.nx - 1),
                                  loA, hiA, best);
                 d2out[i] = best;
+                if (fs.scratch) atomicAdd(&s_hist[__float_as_uint(best) >> 21], 1u);
             } else {
                 unresolved = true;
             }
@@ -398,9 +405,20 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_disc(GridLevel dl, GridDesc
     __syncthreads();
     if (tid < total) {
         const float4 u = s_q[tid];
-        d2out[s_slot[tid]] = dense_far_path(far, u, u.w, cnt);
+        const float d = dense_far_path(far, u, u.w, cnt);
+        d2out[s_slot[tid]] = d;
+        if (fs.scratch) atomicAdd(&s_hist[__float_as_uint(d) >> 21], 1u);
     }
     add_examined(examined, cnt);
+    if (fs.scratch) fs_pass0_epilogue(s_hist, fs);
+}
+
+// passes 1 / 2 of the fused selection as launches of their own (only when no transform / front launch follows the dense
+// search: the iteration that reaches Stage 3 while still in Stage 1)
+template <int PASS>
+__global__ void __launch_bounds__(kBlock) k_fs_pass(FusedSelect fs) {
+    __shared__ unsigned h[kFsBins];
+    fs_pass_embedded<PASS>(h, fs, (int)blockIdx.x);
 }
 
 // patch id of the i-th query of the dense search (static: one coalesced load instead of a dependent gather per launch)
@@ -869,6 +887,13 @@ int pw_grid_add_dense(pwicp_context* ctx, const float4* d_pts, int n, float cell
     return PWICP_OK;
 }
 
+int pw_fs_pass_launch(pwicp_context* ctx, int pass, const FusedSelect& fs) {
+    if (pass == 1) hipLaunchKernelGGL(k_fs_pass<1>, dim3(fs.nblk), dim3(kBlock), 0, ctx->stream, fs);
+    else hipLaunchKernelGGL(k_fs_pass<2>, dim3(fs.nblk), dim3(kBlock), 0, ctx->stream, fs);
+    HIPCHK(ctx, hipGetLastError());
+    return PWICP_OK;
+}
+
 int pw_gather_int_launch(pwicp_context* ctx, const int* d_src, const int* d_order, int n, int* d_out) {
     if (n > 0) hipLaunchKernelGGL(k_gather_int, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_src, d_order, n, d_out);
     HIPCHK(ctx, hipGetLastError());
@@ -877,13 +902,14 @@ int pw_gather_int_launch(pwicp_context* ctx, const int* d_src, const int* d_orde
 
 int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pat, const int* d_qorder,
                            const int* d_pt_patch, const int* d_stable, int nq, float* d_d2,
-                           unsigned long long* d_examined, const GridLevel* dense, const int* d_qpatch) {
+                           unsigned long long* d_examined, const GridLevel* dense, const int* d_qpatch, const FusedSelect* fs) {
     if (nq <= 0) return PWICP_OK;
     if (dense && d_qpatch && d_qorder) {
         const int tiles = div_up(nq, kBlock);
         const int chunk = div_up(tiles, kXcds);
+        FusedSelect none{};
         hipLaunchKernelGGL(k_nn_dense_disc, dim3(chunk * kXcds), dim3(kBlock), 0, ctx->stream, *dense, g, d_pat, d_qorder, d_qpatch,
-                           d_stable, nq, d_d2, d_examined, chunk);
+                           d_stable, nq, d_d2, d_examined, chunk, fs ? *fs : none);
         HIPCHK(ctx, hipGetLastError());
         return PWICP_OK;
     }

@@ -15,6 +15,7 @@
 #include "icp.h"
 #include "nn_device.h"
 #include "patch.h"
+#include "select_dev.h"
 
 using namespace pwdev;
 
@@ -208,15 +209,24 @@ __global__ void __launch_bounds__(kBlock) k_transform_all(float4* __restrict__ c
                                                           float4* __restrict__ ctbp, int n_ctbp,
                                                           float4* __restrict__ pat, int n_pat,
                                                           const IcpState* __restrict__ st, const unsigned* __restrict__ ns_dev,
-                                                          unsigned* __restrict__ bbox_part, unsigned* __restrict__ slot) {
+                                                          unsigned* __restrict__ bbox_part, unsigned* __restrict__ slot,
+                                                          int nb_work, FusedSelect fs) {
     __shared__ float sh[kBlock / 64][6];
+    const int nsel = fs.scratch ? fs.nblk : 0;
+    if ((int)blockIdx.x < nsel) {
+        // leading blocks: pass 1 of the percentile selection of this iteration's dense search (select_dev.h)
+        __shared__ unsigned s_hist[kFsBins];
+        fs_pass_embedded<1>(s_hist, fs, (int)blockIdx.x);
+        return;
+    }
+    const int bid = (int)blockIdx.x - nsel;
     if (!st->done || *ns_dev < 4u) return;
     Mat4 T;
 #pragma unroll
     for (int i = 0; i < 16; ++i) T.m[i] = st->Tfinal[i];
-    if ((int)blockIdx.x >= nb_cloud) {
-        const int nb = gridDim.x - nb_cloud, stride = nb * kBlock, ntot = n_ctbp + n_pat;
-        for (int i = (blockIdx.x - nb_cloud) * kBlock + threadIdx.x; i < ntot; i += 4 * stride) {
+    if (bid >= nb_cloud) {
+        const int nb = nb_work - nb_cloud, stride = nb * kBlock, ntot = n_ctbp + n_pat;
+        for (int i = (bid - nb_cloud) * kBlock + threadIdx.x; i < ntot; i += 4 * stride) {
             float4* q[4];
             float4 v[4];
 #pragma unroll
@@ -234,7 +244,7 @@ __global__ void __launch_bounds__(kBlock) k_transform_all(float4* __restrict__ c
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     {
         const int stride = nb_cloud * kBlock;
-        for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += 4 * stride) {
+        for (int i = bid * kBlock + threadIdx.x; i < n; i += 4 * stride) {
             float4 v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -263,7 +273,7 @@ __global__ void __launch_bounds__(kBlock) k_transform_all(float4* __restrict__ c
         for (int d = 0; d < 3; ++d) { sh[wave][d] = mn[d]; sh[wave][3 + d] = mx[d]; }
     __syncthreads();
     if (threadIdx.x >= 64) return;
-    unsigned* part = bbox_part + (blockIdx.x & (kBoxParts - 1)) * 32;
+    unsigned* part = bbox_part + (bid & (kBoxParts - 1)) * 32;
     if (threadIdx.x < 3) {
         float a = sh[0][threadIdx.x], b = sh[0][3 + threadIdx.x];
         for (int w = 1; w < kBlock / 64; ++w) { a = fminf(a, sh[w][threadIdx.x]); b = fmaxf(b, sh[w][3 + threadIdx.x]); }
@@ -280,7 +290,7 @@ __global__ void __launch_bounds__(kBlock) k_transform_all(float4* __restrict__ c
     // a mere acknowledgement wait is NOT enough (the update may still be on its way to the coherence point).
     unsigned last = 0;
     if (threadIdx.x == 0) {
-        const int pidx = blockIdx.x & (kBoxParts - 1);
+        const int pidx = bid & (kBoxParts - 1);
         const unsigned np = (unsigned)((nb_cloud - pidx + kBoxParts - 1) / kBoxParts);
         if (atomicAdd(&part[8], 1u) == np - 1u) {
             const unsigned nparts = (unsigned)min(nb_cloud, kBoxParts);
@@ -478,6 +488,8 @@ struct pwicp_pair {
     DevBuf<float4> stCT, stN;
     IcpWork icp;
     DevBuf<unsigned> scal, sel_scratch, bbox_part;
+    DevBuf<unsigned> fs_scratch;     // fused percentile selection (select_dev.h), zeroed once
+    bool no_fused_select = false;    // PWICP_FUSED_SELECT=0: three selection launches of their own (A/B measurements)
     DevBuf<float> sel_out;
     DevBuf<unsigned long long> examined;
     // stable flags of the first Stage-1 dense NN launch of the last run (replayed by bench_dense_nn)
@@ -581,6 +593,9 @@ int finish_create(pwicp_pair* pr) {
     HIPCHK(ctx, pr->sel_scratch.reserve(8 + 3 * 2048));
     HIPCHK(ctx, hipMemsetAsync(pr->sel_scratch.p, 0, (8 + 3 * 2048) * sizeof(unsigned), ctx->stream));   // armed: see pw_select_kth_launch
     HIPCHK(ctx, pr->sel_out.reserve(1));
+    HIPCHK(ctx, pr->fs_scratch.reserve(kFsWords));
+    HIPCHK(ctx, hipMemsetAsync(pr->fs_scratch.p, 0, kFsWords * sizeof(unsigned), ctx->stream));
+    if (const char* e = getenv("PWICP_FUSED_SELECT")) pr->no_fused_select = atoi(e) == 0;
     HIPCHK(ctx, pr->examined.reserve(256 * 16 + 2));
     PWCHK(pr->icp.reserve(ctx, m2));
     HIPCHK(ctx, hipHostMalloc((void**)&pr->mail_h, 256 * sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
@@ -866,19 +881,22 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     // "front" of the next iteration (NN of centroids/boundary points + source patch normals) needs no threshold.
     bool front_ready = false;                 // front of iteration k already enqueued by iteration k-1
     float prev_lod = NAN;
-    auto enqueue_front = [&]() -> int {
+    auto enqueue_front = [&](const FusedSelect* fs = nullptr) -> int {
         // (1) R.cpp:737-747 — CT2 and BP2 queries against the static target-centroid grid — and the source patch
         // normals for CTcloud2_withNorm (R.cpp:824), recomputed from the transformed patch points: one launch
+        // (+ pass 2 of the percentile selection on a few extra blocks when a dense search has just run)
         return pw_front_launch(ctx, pr->P2.pat.p, pr->P2.off.p, m2, pr->nrm2.p, pr->tgt->g_ct1.d, pr->ctbp2.p, 7 * m2,
-                               pr->mCTBP.p, pr->dCTBP.p);
+                               pr->mCTBP.p, pr->dCTBP.p, fs);
     };
-    auto enqueue_transform = [&](unsigned* slot) {
+    auto enqueue_transform = [&](unsigned* slot, const FusedSelect* fs = nullptr) {
         // (8) R.cpp:943-954: cloud2 (+ its new bbox into this slot), centroids + boundary points, patch points
+        // (+ pass 1 of the percentile selection on a few extra blocks when a dense search has just run)
         const int nb_cloud = std::min(div_up(pr->n2, kBlock), ctx->n_cu * 8);
         const int nb_rest = std::min(div_up(7 * m2 + pr->P2.tot, kBlock), ctx->n_cu * 8);
-        hipLaunchKernelGGL(k_transform_all, dim3(nb_cloud + nb_rest), dim3(kBlock), 0, ctx->stream, pr->cloud2.p, pr->n2,
-                           nb_cloud, pr->ctbp2.p, 7 * m2, pr->P2.pat.p, pr->P2.tot, (const IcpState*)pr->icp.state.p,
-                           (const unsigned*)(slot + 2), pr->bbox_part.p, slot);
+        FusedSelect none{};
+        hipLaunchKernelGGL(k_transform_all, dim3(nb_cloud + nb_rest + (fs ? fs->nblk : 0)), dim3(kBlock), 0, ctx->stream, pr->cloud2.p,
+                           pr->n2, nb_cloud, pr->ctbp2.p, 7 * m2, pr->P2.pat.p, pr->P2.tot, (const IcpState*)pr->icp.state.p,
+                           (const unsigned*)(slot + 2), pr->bbox_part.p, slot, nb_cloud + nb_rest, fs ? *fs : none);
     };
     const auto t0 = std::chrono::steady_clock::now();
     while (!stage3) {                                                   // R.cpp:680
@@ -979,9 +997,22 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                 ev_kind.push_back({n_ev, 0});
                 HIPCHK(ctx, hipEventRecord(pr->event(n_ev), ctx->stream));
             }
+            // the percentile selection rides on the launches that follow (select_dev.h): pass 0 in the dense kernel, pass 1
+            // beside the transform, pass 2 beside the next front (or on its own when this is the last iteration)
+            const bool fused = pr->tgt->g_c1.has_dense && !pr->no_fused_select;
+            FusedSelect fs{};
+            unsigned sel_seq = 0;
+            if (fused) {
+                int kk = (int)((float)nsp * 0.75f);         // C.cpp:177
+                if (kk >= nsp) kk = nsp - 1;
+                fs.scratch = pr->fs_scratch.p; fs.vals = pr->d2dense.p; fs.n = pr->P2.tot; fs.k = kk; fs.nblk = kFsBlocks;
+                fs.out = pr->sel_out.p;
+                sel_seq = ++pr->mail_seq;
+                fs.mail.dst = pr->mail_d + 16; fs.mail.seq_ptr = pr->mail_d; fs.mail.seq = sel_seq;
+            }
             PWCHK(pw_nn_dense_launch(ctx, pr->tgt->g_c1.d, pr->P2.pat.p, pr->qorder.p, pr->pt_patch2.p, pr->stable.p,
                                          pr->P2.tot, pr->d2dense.p, pr->examined.p,
-                                         pr->tgt->g_c1.has_dense ? &pr->tgt->g_c1.dense : nullptr, pr->qpatch.p));
+                                         pr->tgt->g_c1.has_dense ? &pr->tgt->g_c1.dense : nullptr, pr->qpatch.p, fused ? &fs : nullptr));
             if (ev) {
                 HIPCHK(ctx, hipEventRecord(pr->event(n_ev + 1), ctx->stream));
                 n_ev += 2;
@@ -990,12 +1021,17 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                 HIPCHK(ctx, hipMemcpyAsync(pr->stable0.p, pr->stable.p, (size_t)m2 * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
                 pr->ns0 = ns; pr->nsp0 = nsp;
             }
-            unsigned sel_seq = 0;
-            PWCHK(select_p75_enqueue(pr, pr->P2.tot, nsp, &sel_seq));
+            if (!fused) PWCHK(select_p75_enqueue(pr, pr->P2.tot, nsp, &sel_seq));
             // the percentile only steers the threshold: transform and next front go out while it travels
-            enqueue_transform(slot);
+            // (pass 1 flushes most of its 2048 bins per block with returning atomics, which serialise per cache line: few blocks)
+            static int nb1 = -1;
+            if (nb1 < 0) { const char* e = getenv("PWICP_FS_BLOCKS1"); nb1 = e ? std::max(atoi(e), 1) : 64; }
+            fs.nblk = nb1;
+            enqueue_transform(slot, fused ? &fs : nullptr);
             xf_enqueued = true;
-            if (!stage3) { PWCHK(enqueue_front()); front_ready = true; }
+            fs.nblk = kFsBlocks;
+            if (!stage3) { PWCHK(enqueue_front(fused ? &fs : nullptr)); front_ready = true; }
+            else if (fused) PWCHK(pw_fs_pass_launch(ctx, 2, fs));
             double Dist75 = 0;
             PWCHK(select_p75_finish(pr, sel_seq, &Dist75));
             res->n_corr += nsp; res->n_corr_dense += nsp; res->n_dense_nn_launches++;

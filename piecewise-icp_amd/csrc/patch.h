@@ -17,7 +17,7 @@ struct PatchSet {
 int pw_patch_normals_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, int m, float4* d_nrm);
 // source patch normals + 1-NN of (centroids | boundary points) among the target centroids, one launch
 int pw_front_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, int m, float4* d_nrm, const GridDesc& g,
-                    const float4* d_q, int nq, int* d_idx, float* d_d2);
+                    const float4* d_q, int nq, int* d_idx, float* d_d2, const struct FusedSelect* fs = nullptr);
 int pw_patch_stats_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, int m, float4* ct, float4* bp,
                           float* bpstd, float* ctstd);
 int pw_select_patches_dev(pwicp_context* ctx, const float4* d_cloud, int n, const int* d_labels, int nsv,

@@ -13,6 +13,7 @@
 #include "common.h"
 #include "devmath.h"
 #include "nn_device.h"
+#include "select_dev.h"
 #include "patch.h"
 
 using namespace pwdev;
@@ -240,15 +241,25 @@ __global__ void __launch_bounds__(kFrontBlock) k_patch_normals(const float4* __r
 __global__ void __launch_bounds__(kFrontBlock) k_front(const float4* __restrict__ pat, const int* __restrict__ off, int m,
                                                        float4* __restrict__ nrm_out, int nb_nrm, GridDesc g,
                                                        const float4* __restrict__ q, int nq, int* __restrict__ idx,
-                                                       float* __restrict__ d2) {
+                                                       float* __restrict__ d2, int nb_work, FusedSelect fs) {
     __shared__ float4 tiles[(kFrontBlock / kGroup) * kTileStride];
-    if ((int)blockIdx.x < nb_nrm) {
-        const int t = blockIdx.x * kFrontBlock + threadIdx.x;
+    const int nsel = fs.scratch ? fs.nblk : 0;
+    if ((int)blockIdx.x < nsel) {
+        // leading blocks: pass 2 of the percentile selection of the PREVIOUS iteration's dense search (select_dev.h); the
+        // bins live in the tile buffer
+        static_assert(sizeof(tiles) >= kFsBins * sizeof(unsigned), "tile buffer too small for the selection bins");
+        fs_pass_embedded<2>((unsigned*)tiles, fs, (int)blockIdx.x);
+        return;
+    }
+    const int bid = (int)blockIdx.x - nsel;
+    (void)nb_work;
+    if (bid < nb_nrm) {
+        const int t = bid * kFrontBlock + threadIdx.x;
         const int i = t / kGroup;
         if (i < m) patch_normal_group(pat, off, i, t % kGroup, nrm_out, tiles + (threadIdx.x / kGroup) * kTileStride);
         return;
     }
-    const int t = (blockIdx.x - nb_nrm) * kFrontBlock + threadIdx.x;
+    const int t = (bid - nb_nrm) * kFrontBlock + threadIdx.x;
     const int i = t / kGroup, sub = t % kGroup;
     if (i >= nq) return;                        // a whole group is in or out of range together
     const float4 v = q[i];
@@ -400,18 +411,24 @@ int pw_patch_normals_launch(pwicp_context* ctx, const float4* d_pat, const int* 
 }
 
 int pw_front_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, int m, float4* d_nrm, const GridDesc& g,
-                    const float4* d_q, int nq, int* d_idx, float* d_d2) {
-    if (m <= 0 || nq <= 0) return PWICP_OK;
+                    const float4* d_q, int nq, int* d_idx, float* d_d2, const FusedSelect* fs) {
+    if (m <= 0 || nq <= 0) {
+        if (fs && fs->scratch) return pw_fs_pass_launch(ctx, 2, *fs);
+        return PWICP_OK;
+    }
     static int split = -1;               // PWICP_FRONT_SPLIT=1: two launches (A/B measurements only)
     if (split < 0) { const char* e = getenv("PWICP_FRONT_SPLIT"); split = e ? atoi(e) : 0; }
     if (split) {
+        if (fs && fs->scratch) PWCHK(pw_fs_pass_launch(ctx, 2, *fs));
         PWCHK(pw_patch_normals_launch(ctx, d_pat, d_off, m, d_nrm));
         return pw_nn_launch(ctx, g, d_q, nq, d_idx, d_d2, nullptr);
     }
     const int nb_nrm = div_up((long long)m * kGroup, kFrontBlock);
     const int nb_nn = div_up((long long)nq * kGroup, kFrontBlock);
-    hipLaunchKernelGGL(k_front, dim3(nb_nrm + nb_nn), dim3(kFrontBlock), 0, ctx->stream, d_pat, d_off, m, d_nrm, nb_nrm, g,
-                       d_q, nq, d_idx, d_d2);
+    FusedSelect none{};
+    const bool sel = fs && fs->scratch;
+    hipLaunchKernelGGL(k_front, dim3(nb_nrm + nb_nn + (sel ? fs->nblk : 0)), dim3(kFrontBlock), 0, ctx->stream, d_pat, d_off, m, d_nrm,
+                       nb_nrm, g, d_q, nq, d_idx, d_d2, nb_nrm + nb_nn, sel ? *fs : none);
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }

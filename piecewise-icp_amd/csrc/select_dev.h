@@ -1,0 +1,190 @@
+// k-th smallest of the dense 1-NN distances (the percentile of calPercentileDistBetween2PC, C.cpp:145-179, 266-281) as a
+// 3-pass radix select on the float bit patterns (11 + 11 + 10 bits) whose passes ride on kernels that run anyway:
+//   pass 0  in the epilogue of the dense 1-NN kernel itself (every block histograms the d2 values it has just produced and
+//           adds its bins to global replicas with fire-and-forget atomics),
+//   pass 1  on the FIRST few blocks of the transform launch (k_transform_all) — first, so that they are dispatched at once
+//           and run beside the transform instead of behind it; every block picks the bin of pass 0 for itself,
+//   pass 2  on the first few blocks of the next iteration's front launch (k_front), which also sends the selected value to
+//           the host mailbox.
+// Passes 1 / 2 end with "the block that finishes last picks the bin" (device counter): no launch of its own for any pass
+// (three launches of ~15 us each before).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+constexpr int kFsBins = 2048;
+constexpr int kFsRep = 8;                 // replicas of the pass-0 bins in global memory (same-address atomics serialise)
+constexpr int kFsCtl = 16;                // control words: [0] prefix, [1] rank remaining, [2..4] finished blocks of pass 0..2
+constexpr int kFsWords = kFsCtl + (kFsRep + 2) * kFsBins;
+constexpr int kFsBlocks = 128;            // blocks devoted to an embedded pass
+
+struct FusedSelect {
+    unsigned* scratch = nullptr;          // kFsWords words, zeroed once at allocation (every selection leaves it zeroed); nullptr: off
+    const float* vals = nullptr;          // the dense kernel's output (sentinel 0xffffffff in unused slots)
+    int n = 0;                            // slots
+    int k = 0;                            // rank (0-based) among the non-sentinel values
+    int nblk = 0;                         // blocks running an embedded pass
+    float* out = nullptr;                 // selected value (device)
+    SelectMail mail{};                    // sent by pass 2
+};
+
+// bin -> word of a pass-0 replica: neighbouring bins (the distances crowd a dozen of them) land on different 128-byte lines,
+// because same-line atomics serialise
+__device__ __forceinline__ int fs_word(int bin) { return (bin & 63) * 32 + (bin >> 6); }
+
+// ---- pass 0, called by EVERY block of the dense kernel once its lanes have added their values to the LDS bins `h` ----------
+// Fire-and-forget atomics into one of kFsRep replicas: no completion count, no pick here — a block of the dense kernel
+// retires without waiting for anything; the kernel boundary orders the bins before pass 1, whose blocks pick for themselves.
+__device__ __forceinline__ void fs_pass0_epilogue(unsigned* h, const FusedSelect& fs) {
+    __syncthreads();
+    unsigned* g0 = fs.scratch + kFsCtl + (int)(blockIdx.x & (kFsRep - 1)) * kFsBins;
+    for (int t = threadIdx.x; t < kFsBins; t += blockDim.x) {
+        const unsigned v = h[t];
+        if (v) atomicAdd(&g0[fs_word(t)], v);
+    }
+}
+
+// pick of pass 0 from the replicas (every block of pass 1 does it for itself: 64 loads per thread, blockDim.x == 256):
+// returns the prefix (bin << 21) and the rank remaining inside that bin
+__device__ __forceinline__ void fs_pick0(unsigned* h, const FusedSelect& fs, unsigned* prefix_out, unsigned* krem_out) {
+    __shared__ unsigned s_w[4], s_res[2];
+    const unsigned* g0 = fs.scratch + kFsCtl;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // replicas summed word by word (coalesced), scattered to bin order through the LDS bins `h` (zeroed again below)
+#pragma unroll
+    for (int j = 0; j < kFsBins / 256; ++j) {
+        const int w = t + 256 * j;
+        unsigned s = 0;
+#pragma unroll
+        for (int r = 0; r < kFsRep; ++r) s += g0[r * kFsBins + w];
+        h[(w & 31) * 64 + (w >> 5)] = s;               // inverse of fs_word
+    }
+    __syncthreads();
+    unsigned c[8], local = 0;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        c[b] = h[t * 8 + b];
+        local += c[b];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 8; ++b) h[t * 8 + b] = 0u;
+    unsigned incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = __shfl_up(incl, o);
+        if (lane >= o) incl += u;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    unsigned base = 0;
+    for (int w = 0; w < wave; ++w) base += s_w[w];
+    const unsigned excl = base + incl - local;
+    const unsigned k = (unsigned)fs.k;
+    if (k >= excl && k < excl + local) {
+        unsigned run = excl;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            if (k >= run && k < run + c[b]) { s_res[0] = (unsigned)(t * 8 + b) << 21; s_res[1] = k - run; }
+            run += c[b];
+        }
+    }
+    __syncthreads();
+    *prefix_out = s_res[0];
+    *krem_out = s_res[1];
+}
+
+// ---- passes 1 and 2 on `fs.nblk` blocks of some other launch; `bidx` = index of this block among them --------------------
+template <int PASS>
+__device__ __forceinline__ void fs_pass_embedded(unsigned* h, const FusedSelect& fs, int bidx) {
+    __shared__ unsigned s_last;
+    unsigned prefix, k_in;
+    if (PASS == 1) {
+        fs_pick0(h, fs, &prefix, &k_in);               // from the bins the dense kernel left; leaves h zeroed
+    } else {
+        for (int t = threadIdx.x; t < kFsBins; t += blockDim.x) h[t] = 0u;
+        prefix = fs.scratch[0]; k_in = fs.scratch[1];  // written by pass 1 (previous launch)
+    }
+    __syncthreads();
+    const int stride = fs.nblk * (int)blockDim.x;
+    // (the pass is a chain of memory round trips, not bandwidth: eight loads in flight per lane)
+    for (int i0 = bidx * (int)blockDim.x + (int)threadIdx.x; i0 < fs.n; i0 += 8 * stride) {
+        unsigned u[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) u[j] = (i0 + j * stride < fs.n) ? __float_as_uint(fs.vals[i0 + j * stride]) : 0xffffffffu;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (u[j] == 0xffffffffu) continue;             // slot of a query that was not part of the launch
+            if (PASS == 1) {
+                if ((u[j] >> 21) == (prefix >> 21)) atomicAdd(&h[(u[j] >> 10) & 2047u], 1u);
+            } else {
+                if ((u[j] >> 10) == (prefix >> 10)) atomicAdd(&h[u[j] & 1023u], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    unsigned* gh = fs.scratch + kFsCtl + (kFsRep + PASS - 1) * kFsBins;
+    unsigned seen = 0;
+    for (int t = threadIdx.x; t < kFsBins; t += blockDim.x) {
+        const unsigned v = h[t];
+        if (v) seen |= atomicAdd(&gh[t], v);
+    }
+    asm volatile("" ::"v"(seen));                        // performed before the block is counted (see pass 0)
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(&fs.scratch[2 + PASS], 1u) == (unsigned)fs.nblk - 1u) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last || threadIdx.x >= 64) return;
+    // ---- pick on one wave: lane owns 32 consecutive bins ----
+    const int lane = threadIdx.x;
+    unsigned cnt[32], local = 0;
+#pragma unroll
+    for (int b = 0; b < 32; ++b) {
+        cnt[b] = __hip_atomic_load(&gh[lane * 32 + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        local += cnt[b];
+    }
+    unsigned incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = __shfl_up(incl, o);
+        if (lane >= o) incl += u;
+    }
+    const unsigned excl = incl - local;
+    const unsigned k = k_in;
+    const bool mine = (k >= excl) && (k < incl);
+    unsigned value = 0;
+    if (mine) {
+        unsigned run = excl;
+#pragma unroll
+        for (int b = 0; b < 32; ++b) {
+            const unsigned c = cnt[b];
+            if (k >= run && k < run + c) {
+                const unsigned bin = (unsigned)(lane * 32 + b);
+                const unsigned pf = (PASS == 1) ? (prefix | (bin << 10)) : (prefix | bin);
+                value = pf;
+                fs.scratch[0] = (PASS == 2) ? 0u : pf;
+                fs.scratch[1] = (PASS == 2) ? 0u : k - run;
+                if (PASS == 2 && fs.out) fs.out[0] = __uint_as_float(pf);
+            }
+            run += c;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 32; ++b) gh[lane * 32 + b] = 0u;
+    if (PASS == 1) {                                   // every block of this pass has read the pass-0 replicas: re-arm them
+        unsigned* g0 = fs.scratch + kFsCtl;
+        for (int w = lane; w < kFsRep * kFsBins; w += 64) g0[w] = 0u;
+    }
+    if (lane == 0) fs.scratch[2 + PASS] = 0u;
+    if (PASS == 2 && fs.mail.dst) {
+        const unsigned long long m = __ballot(mine);
+        const int src = m ? (int)__ffsll((long long)m) - 1 : 0;
+        value = (unsigned)__shfl((int)value, src);
+        if (lane == 0) {
+            fs.mail.dst[0] = value;
+            __threadfence_system();
+            __hip_atomic_store(fs.mail.seq_ptr, fs.mail.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}

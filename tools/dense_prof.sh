@@ -19,7 +19,9 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     n = r["Name"]
     if any(k in n for k in ("k_nn_dense", "k_select", "k_icp", "k_front", "k_transform", "k_classify", "k_compact", "k_vcm")):
-        short = n.split("(")[0].split("::")[-1][:40]
+        import re
+        mm = re.search(r"(k_[a-z0-9_]+)(<[^>]*>)?", n)
+        short = (mm.group(1) + (mm.group(2) or "")) if mm else n[:40]
         print("%-42s calls %5s avg %9.1f us  min %8.1f max %8.1f" % (short, r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
 PY
 grep "^DV" gpurun_out/dprof_$TAG.log | cut -c1-200
