@@ -27,6 +27,18 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MI
 R_SPACING = 0.005
 
 
+def kernel_source_hash():
+    """sha256 over the HIP sources of libpwicp.so: ties profiles/traffic_latest.json (PMC passes, collected with
+    tools/collect_profiles.sh) to the kernels that are being timed."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "piecewise-icp_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def make_pair(n_points, epoch, ctx):
     """Synthetic reference tile + source epoch, reduced to the target centroid
     (Registration.cpp:277-294) and labelled."""
@@ -197,31 +209,44 @@ def main():
     if n_launch > 0 and t_dense_ms > 0:
         nq = sum(rr.n_corr_dense for rr in results) / n_launch
         kbar = res.dense_kbar
-        # algorithmic bytes per correspondence: query 16 + d2 out 4 + stencil rows (9 for a
-        # grid of cells, 3 for a grid of columns) x (begin,end) 8 + 16 per target point examined
-        rows = int(res.dense_rows) or 9
-        b_nn = 16.0 + 4.0 + rows * 8.0 + 16.0 * kbar
         dur_s = (t_dense_ms / n_launch) * 1e-3
-        achieved = b_nn * nq / dur_s / 1e9
-        traffic = None
+        # SURVEY 8d's ALGORITHMIC stream (every query re-reads its candidates: query 16 + d2 out 4 + ~5 cell rows x (begin,
+        # end) 8 + 16 per target point examined, Kbar measured by the kernel): mostly L1/L2 hits -> reported as model_gbs only
+        b_nn = 16.0 + 4.0 + 5 * 8.0 + 16.0 * kbar
+        model_gbs = b_nn * nq / dur_s / 1e9
+        # PHYSICAL bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md
+        # prescribes; profiles/traffic_latest.json) — only if they were collected on exactly these kernel sources
+        traffic, pmc, stale = None, {}, None
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("k_nn_dense_bytes_per_launch")
+                tj = json.load(open(tfile))
+                if tj.get("kernel_source_sha256") == kernel_source_hash():
+                    traffic = tj.get("k_nn_dense_bytes_per_launch")
+                    pmc = tj.get("dense_sq_counters", {})
+                else:
+                    stale = "profiles/traffic_latest.json was collected on other kernel sources: traffic not reported"
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_nn_dense_direct", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "bytes_per_correspondence": round(b_nn, 1), "kbar": round(kbar, 2), "stencil_rows": rows,
+        compulsory = (16 + 4) * nq + 16.0 * len(tgt)
+        hbm_bytes = traffic if traffic else compulsory
+        achieved = hbm_bytes / dur_s / 1e9
+        # vector-ALU issue: wave instructions x 4 cycles (measured: SQ_ACTIVE_INST_ANY / instructions) over the chip's
+        # 1024 SIMDs at 2.4 GHz
+        valu = pmc.get("SQ_INSTS_VALU")
+        roofline = {"bound": "hbm", "kernel": "k_nn_dense_disc" if res.dense_rows == 0 else "k_nn_dense_direct",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "traffic_is": ("PMC FETCH_SIZE x correction + WRITE_SIZE per launch" if traffic else
+                                                       "not measured for these sources: achieved uses the compulsory bytes (lower bound)"),
+                    "model_gbs": round(model_gbs, 1), "bytes_per_correspondence_model": round(b_nn, 1), "kbar": round(kbar, 2),
                     "queries_per_launch": int(nq), "avg_launch_us": round(dur_s * 1e6, 2),
-                    "compulsory_bytes_per_correspondence": round(16 + 4 + 16.0 * len(tgt) / max(nq, 1.0), 1),
-                    # the algorithmic stream (every query re-reads its stencil) is mostly served by L1/L2: the bytes
-                    # that actually cross the fabric (PMC, profiles/traffic_latest.json) give the real HBM rate
-                    "hbm_measured_gbs": (round(traffic / dur_s / 1e9, 1) if traffic else None),
-                    "hbm_measured_frac": (round(traffic / dur_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
-                    "note": "achieved = algorithmic bytes (SURVEY 8d model, measured Kbar) / HIP-event time; a value above "
-                            "peak means cache reuse, not HBM speed: the traffic is already compulsory; the kernel is bound by VALU "
-                            "issue (~50 % busy) and load latency at full occupancy (profiles/README.md)"}
+                    "compulsory_bytes_per_launch": int(compulsory),
+                    "valu_issue_frac": (round(valu * 4.0 / (1024 * 2.4e9 * dur_s), 3) if valu else None),
+                    "note": "achieved/frac = PHYSICAL HBM bytes per launch / HIP-event time / 8 TB/s; model_gbs = SURVEY 8d's algorithmic "
+                            "stream (cache hits included) for reference.  The kernel is bound by vector-ALU issue and load latency, not "
+                            "by HBM: its traffic is ~1.2x the compulsory bytes (DESIGN.md 4.1)"}
+        if stale:
+            roofline["stale_profile"] = stale
 
     if rank == 0:
         value = corr_total / tmax

@@ -150,7 +150,7 @@ typedef struct {
     int    n_dense_nn_launches;
     double t_inner_ms;                    /* HIP-event time of the inner-ICP launches        */
     double dense_kbar;                    /* mean target points examined per dense query     */
-    int32_t dense_rows;                   /* stencil rows per dense query: 9 (cells) or 3 (columns) */
+    int32_t dense_rows;                   /* 0: disc-pruned dense search (default); 9 / 3: 27-cell stencil on cells / columns */
     int32_t reserved0;
 } pwicp_result;
 
@@ -187,6 +187,26 @@ PWICP_API int pwicp_pair_reset(pwicp_pair* pair);
 /* The while-loop of Piecewise_ICP (R.cpp:680-694) = repeated PwICP_singleIteration
  * (R.cpp:704-972; decl R.h:181-188), entirely on the device. */
 PWICP_API int pwicp_pair_run(pwicp_pair* pair, pwicp_result* result);
+/* ONE outer iteration: PwICP_singleIteration (R.cpp:704-972; decl R.h:181-188) on the pair's resident data.  The
+ * caller owns what the reference keeps between calls: currDT, BBchange_1/2 (reference parameters of R.h:187) and the two
+ * stage flags (the reference's module globals g_toStage2 / g_toStage3, R.cpp:11-14), and runs the loop of Piecewise_ICP
+ * (R.cpp:680-694) itself:   st = {DTinit, 0, 0, 0, 0};  while (!st.toStage3) { pwicp_pair_step(pair, &st);  T = st.T16 * T; }
+ * Source arrays are transformed in place (R.cpp:943-954).  VCM is written by the call that sets toStage3 (R.cpp:958-961).
+ * Stepping a freshly created / reset pair to Stage 3 gives bit for bit the result of pwicp_pair_run. */
+typedef struct {
+    float currDT;                    /* in/out */
+    float BBchange_1, BBchange_2;    /* in/out */
+    int   toStage2, toStage3;        /* in/out */
+    int   status;                    /* out: pwicp_status of this call */
+    float T16[16];                   /* out: transMatICP of this iteration */
+    double VCM[36];                  /* out: valid once toStage3 is set */
+    int   n_stable, n_stable_pts, n_inner;
+    float LoDmin, maxBB;
+    double d75;                      /* Stage-1 percentile distance, -1 if not computed */
+} pwicp_step;
+PWICP_API int pwicp_pair_step(pwicp_pair* pair, pwicp_step* step);
+/* DTinit when it is not given in the configuration: 3 x the 75th percentile 1-NN distance cloud2 -> cloud1 (R.cpp:626-631) */
+PWICP_API int pwicp_pair_auto_dtinit(pwicp_pair* pair, float* DTinit);
 /* Copies the current (transformed) source cloud back: cloud2 after the loop (R.cpp:943-945). */
 PWICP_API int pwicp_pair_download_source(pwicp_pair* pair, float* cloud2_xyz4);
 

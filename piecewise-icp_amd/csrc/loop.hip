@@ -477,6 +477,7 @@ struct pwicp_pair {
     DevBuf<float4> pat2_0;
     DevBuf<float4> ctbp2, ctbp2_0;   // live / pristine source centroids [0,m2) followed by boundary points [m2,7m2)
     float bmin0[3] = {0, 0, 0}, bmax0[3] = {0, 0, 0};   // tight bbox of the uploaded source cloud
+    float step_bmin[3] = {0, 0, 0}, step_bmax[3] = {0, 0, 0};   // ... of the current source cloud (pwicp_pair_step)
     DevBuf<float4> nrm2;
     DevBuf<int> pt_patch2;   // patch id of every source patch point
     DevBuf<int> qorder;      // source patch points in Morton order of their initial target-grid cell
@@ -589,6 +590,7 @@ int finish_create(pwicp_pair* pr) {
         HIPCHK(ctx, hipMemcpyAsync(hb, pr->scal.p, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         for (int d = 0; d < 3; ++d) { pr->bmin0[d] = ord2f_host(hb[4 + d]); pr->bmax0[d] = ord2f_host(hb[7 + d]); }
+        for (int d = 0; d < 3; ++d) { pr->step_bmin[d] = pr->bmin0[d]; pr->step_bmax[d] = pr->bmax0[d]; }
     }
     HIPCHK(ctx, pr->sel_scratch.reserve(8 + 3 * 2048));
     HIPCHK(ctx, hipMemsetAsync(pr->sel_scratch.p, 0, (8 + 3 * 2048) * sizeof(unsigned), ctx->stream));   // armed: see pw_select_kth_launch
@@ -772,6 +774,7 @@ int pwicp_pair_reset(pwicp_pair* pr) {
         hipLaunchKernelGGL(k_restore3, dim3(nb), dim3(kBlock), 0, ctx->stream, pr->cloud2.p, (const float4*)pr->cloud2_0.p, n1,
                            pr->P2.pat.p, (const float4*)pr->pat2_0.p, n2, pr->ctbp2.p, (const float4*)pr->ctbp2_0.p, n3);
     }
+    for (int d = 0; d < 3; ++d) { pr->step_bmin[d] = pr->bmin0[d]; pr->step_bmax[d] = pr->bmax0[d]; }
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }
@@ -1090,10 +1093,125 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         }
     }
     res->dense_kbar = res->n_corr_dense > 0 ? (double)ex / (double)res->n_corr_dense : 0.0;
-    res->dense_rows = (pr->tgt->g_c1.d.fine.ny == 1 || pr->tgt->g_c1.d.fine.nz == 1) ? 3 : 9;
+    // 0: disc-pruned search (rows vary with the candidate's distance); 3 / 9: the stencil kernel on columns / cells
+    res->dense_rows = pr->tgt->g_c1.has_dense ? 0 : ((pr->tgt->g_c1.d.fine.ny == 1 || pr->tgt->g_c1.d.fine.nz == 1) ? 3 : 9);
     res->status = status;
     HIPCHK(ctx, hipGetLastError());
     return status;
+}
+
+// One outer iteration as a call of its own: PwICP_singleIteration (R.cpp:704-972; decl R.h:181-188).  The caller keeps
+// what the reference keeps between calls — currDT, BBchange_1/2 and the two stage flags (module globals g_toStage2 /
+// g_toStage3 there, R.cpp:11-14) — in a pwicp_step and drives the loop of Piecewise_ICP (R.cpp:680-694) itself.
+// Same kernels as pwicp_pair_run, none of its cross-iteration pipelining: every hand-over is a plain synchronous copy.
+// Stepping a freshly reset pair until toStage3 gives bit for bit the result of pwicp_pair_run.
+int pwicp_pair_step(pwicp_pair* pr, pwicp_step* sp) {
+    if (!pr || !sp) return PWICP_E_INVALID;
+    pwicp_context* ctx = pr->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const pwicp_params& prm = pr->prm;
+    const int m2 = pr->P2.m;
+    float4* const ct2 = pr->ctbp2.p;
+    float4* const bp2 = pr->ctbp2.p + m2;
+    const float DTmin = prm.DTmin;
+    sp->status = PWICP_OK;
+    sp->d75 = -1.0;
+    sp->n_inner = sp->n_stable = sp->n_stable_pts = 0;
+    for (int i = 0; i < 16; ++i) sp->T16[i] = (i % 5 == 0) ? 1.f : 0.f;
+    if (sp->currDT <= DTmin) sp->currDT = DTmin;                                    // R.cpp:724-725
+    if (4 > m2 || 1 > pr->tgt->P1.m) return sp->status = PWICP_E_TOO_FEW_PATCHES;  // R.cpp:728-731
+    const float currDT_in = sp->currDT;
+    // one scalar slot, re-armed for this call
+    unsigned* const slot = pr->scal.p;
+    hipLaunchKernelGGL(k_scal_init, dim3(1), dim3(64), 0, ctx->stream, pr->scal.p, 1, (unsigned long long*)nullptr, 0);
+    // (1) R.cpp:737-747 + source patch normals (R.cpp:824)
+    PWCHK(pw_front_launch(ctx, pr->P2.pat.p, pr->P2.off.p, m2, pr->nrm2.p, pr->tgt->g_ct1.d, pr->ctbp2.p, 7 * m2, pr->mCTBP.p,
+                          pr->dCTBP.p));
+    // (2)-(4) R.cpp:750-871
+    const float DTctct = currDT_in + 1 * (prm.SVRes1 + prm.SVRes2);
+    hipLaunchKernelGGL(k_classify, dim3(div_up(m2, kBlock)), dim3(kBlock), 0, ctx->stream, m2, pr->mCTBP.p, pr->dCTBP.p,
+                       pr->mCTBP.p + m2, pr->dCTBP.p + m2, pr->tgt->P1.ctstd.p, pr->P2.bpstd.p, pr->tgt->nrm1.p, pr->tgt->P1.ct.p, ct2,
+                       bp2, pr->P2.off.p, currDT_in, DTmin, DTctct, pr->stable.p, pr->blk_cnt.p, slot);
+    hipLaunchKernelGGL(k_compact, dim3(div_up(m2, kBlock)), dim3(kBlock), 0, ctx->stream, m2, pr->stable.p, pr->P2.off.p, ct2,
+                       pr->nrm2.p, pr->blk_cnt.p, pr->stCT.p, pr->stN.p, pr->icp.src.p, pr->icp.srcn.p, slot, pr->icp.state.p);
+    unsigned hs[kSlot];
+    HIPCHK(ctx, hipMemcpyAsync(hs, slot, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    float LoDet_min;
+    memcpy(&LoDet_min, &hs[0], 4);
+    const int ns = (int)hs[2], nsp = (int)hs[3];
+    sp->n_stable = ns; sp->n_stable_pts = nsp; sp->LoDmin = LoDet_min;
+    if (4 > ns) return sp->status = PWICP_E_TOO_FEW_STABLE;                         // R.cpp:864-867
+    // (5) R.cpp:875-877
+    IcpState hst;
+    for (;;) {
+        PWCHK(pw_icp_enqueue(ctx, pr->tgt->g_ct1.d, pr->tgt->P1.ct.p, pr->tgt->ct1n.p, &pr->icp, ns, nullptr, 1e-6, 4, nullptr));
+        HIPCHK(ctx, hipMemcpyAsync(&hst, pr->icp.state.p, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (hst.done || hst.iters >= 100) break;
+    }
+    memcpy(sp->T16, hst.Tfinal, sizeof(sp->T16));
+    sp->n_inner = hst.iters;
+    // (6) R.cpp:881-888: octree box of the current source cloud
+    double bb[6];
+    octree_bbox(pr->step_bmin, pr->step_bmax, (double)(prm.Res2 * 2), bb);
+    const float maxBB = bb_corner_change(bb, sp->T16);
+    sp->maxBB = maxBB;
+    // (7) R.cpp:891-935, verbatim control flow
+    bool stage2 = sp->toStage2 != 0, stage3 = sp->toStage3 != 0;
+    float currDT = currDT_in, BB1 = sp->BBchange_1, BB2 = sp->BBchange_2;
+    if (!stage2 && maxBB < DTmin) stage2 = true;
+    else if (currDT == LoDet_min) stage3 = true;
+    if (!stage2) {
+        PWCHK(pw_nn_dense_launch(ctx, pr->tgt->g_c1.d, pr->P2.pat.p, pr->qorder.p, pr->pt_patch2.p, pr->stable.p, pr->P2.tot,
+                                 pr->d2dense.p, nullptr, pr->tgt->g_c1.has_dense ? &pr->tgt->g_c1.dense : nullptr, pr->qpatch.p));
+        double Dist75 = 0;
+        PWCHK(select_p75(pr, pr->P2.tot, nsp, &Dist75));
+        sp->d75 = Dist75;
+        if ((double)currDT > Dist75) currDT = (float)Dist75; else stage2 = true;
+        if (currDT <= LoDet_min) currDT = LoDet_min;
+        BB2 = BB1; BB1 = maxBB;
+    }
+    if (stage2 && !stage3) {
+        const float upperBound = 0.8f, lowerBound = 0.5f;
+        const float alpha = fabsf(BB1 / BB2);
+        if (std::isnan(alpha) || std::isinf(alpha)) currDT = currDT * upperBound;
+        else if (alpha < lowerBound) currDT = currDT * lowerBound;
+        else if (alpha > upperBound) currDT = currDT * upperBound;
+        else currDT = currDT * alpha;
+        if (currDT <= LoDet_min) currDT = LoDet_min;
+        BB2 = BB1; BB1 = maxBB;
+    }
+    // (8) R.cpp:943-954 and the tight box of the moved cloud for the next call
+    {
+        const int nb_cloud = std::min(div_up(pr->n2, kBlock), ctx->n_cu * 8);
+        const int nb_rest = std::min(div_up(7 * m2 + pr->P2.tot, kBlock), ctx->n_cu * 8);
+        FusedSelect none{};
+        hipLaunchKernelGGL(k_transform_all, dim3(nb_cloud + nb_rest), dim3(kBlock), 0, ctx->stream, pr->cloud2.p, pr->n2, nb_cloud,
+                           pr->ctbp2.p, 7 * m2, pr->P2.pat.p, pr->P2.tot, (const IcpState*)pr->icp.state.p, (const unsigned*)(slot + 2),
+                           pr->bbox_part.p, slot, nb_cloud + nb_rest, none);
+        HIPCHK(ctx, hipMemcpyAsync(hs, slot, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int d = 0; d < 3; ++d) { pr->step_bmin[d] = ord2f_host(hs[4 + d]); pr->step_bmax[d] = ord2f_host(hs[7 + d]); }
+    }
+    // (9) R.cpp:958-961
+    if (stage3) PWCHK(pw_vcm_run(ctx, pr->tgt->g_ct1.d, pr->tgt->P1.ct.p, pr->tgt->ct1n.p, &pr->icp, pr->stCT.p, ns, sp->VCM));
+    sp->currDT = currDT; sp->BBchange_1 = BB1; sp->BBchange_2 = BB2;
+    sp->toStage2 = stage2 ? 1 : 0; sp->toStage3 = stage3 ? 1 : 0;
+    HIPCHK(ctx, hipGetLastError());
+    return PWICP_OK;
+}
+
+// DTinit of Piecewise_ICP when it is not given (R.cpp:626-631): 3 x the 75th percentile of the dense 1-NN distances
+int pwicp_pair_auto_dtinit(pwicp_pair* pr, float* DTinit) {
+    if (!pr || !DTinit) return PWICP_E_INVALID;
+    pwicp_context* ctx = pr->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PWCHK(pw_nn_launch(ctx, pr->tgt->g_c1.d, pr->cloud2.p, pr->n2, nullptr, pr->d2dense.p, nullptr));
+    double d75 = 0;
+    PWCHK(select_p75(pr, pr->n2, pr->n2, &d75));
+    *DTinit = (float)(d75 * 3.0);
+    return PWICP_OK;
 }
 
 int pwicp_pair_set_profiling(pwicp_pair* pr, int flags) {

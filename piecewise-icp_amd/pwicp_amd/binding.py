@@ -35,6 +35,14 @@ class Result(C.Structure):
                 ("dense_rows", C.c_int32), ("reserved0", C.c_int32)]
 
 
+class Step(C.Structure):
+    """pwicp_step: the state PwICP_singleIteration keeps between calls (R.h:181-188, R.cpp:11-14) + this call's outputs."""
+    _fields_ = [("currDT", C.c_float), ("BBchange_1", C.c_float), ("BBchange_2", C.c_float),
+                ("toStage2", C.c_int), ("toStage3", C.c_int), ("status", C.c_int), ("T16", C.c_float * 16),
+                ("VCM", C.c_double * 36), ("n_stable", C.c_int), ("n_stable_pts", C.c_int), ("n_inner", C.c_int),
+                ("LoDmin", C.c_float), ("maxBB", C.c_float), ("d75", C.c_double)]
+
+
 def lib_path():
     return os.path.join(os.path.dirname(_HERE), "libpwicp.so")
 
@@ -79,6 +87,8 @@ def load_library():
         ("pwicp_pair_reset", [vp]),
         ("pwicp_pair_run", [vp, C.POINTER(Result)]),
         ("pwicp_pair_download_source", [vp, fp]),
+        ("pwicp_pair_step", [vp, C.POINTER(Step)]),
+        ("pwicp_pair_auto_dtinit", [vp, fp]),
         ("pwicp_pair_bench_dense_nn", [vp, C.c_int, dp, C.POINTER(C.c_longlong), dp, dp]),
         ("pwicp_pair_set_profiling", [vp, C.c_int]),
         ("pwicp_target_create", [vp, fp, C.c_int, ip, C.c_int, C.c_float, C.c_float, C.POINTER(vp)]),
@@ -506,6 +516,17 @@ class Pair:
         if check:
             self._ctx._chk(rc)
         return r
+
+    def step(self, st):
+        """PwICP_singleIteration (R.cpp:704-972) on the resident pair; `st` (Step) carries currDT / BBchange / stage flags."""
+        return self._L.pwicp_pair_step(self._h, C.byref(st))
+
+    def auto_dtinit(self):
+        v = C.c_float()
+        rc = self._L.pwicp_pair_auto_dtinit(self._h, C.byref(v))
+        if rc != 0:
+            raise PwicpError(rc, "pwicp_pair_auto_dtinit")
+        return v.value
 
     def download_source(self):
         out = np.zeros((self.n2, 4), np.float32)

@@ -416,3 +416,44 @@ def test_shared_target_gives_the_same_results(ctx):
         b.close()
     assert outs[0] == outs[2] and outs[0] != outs[1]
     T.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("manual", [True, False])
+def test_single_iteration_steps_equal_the_whole_loop(ctx, oracle, manual):
+    """pwicp_pair_step = PwICP_singleIteration (R.h:181-188): the caller keeps currDT / BBchange_1,2 / the stage flags and
+    runs the loop of Piecewise_ICP (R.cpp:680-694) itself.  Stepping a reset pair to Stage 3 must give, bit for bit, what
+    pwicp_pair_run gives (and therefore the oracle's DT series and counts)."""
+    import pwicp_amd as P
+    tgt, src, _ = _data.pair(60000, epoch=2)
+    l1, n1 = _labels(tgt, "grid")
+    l2, n2 = _labels(src, "grid")
+    pair, res, io = _loop_both(ctx, oracle, tgt, src, l1, n1, l2, n2, manual=manual)
+    _assert_loop_parity(res, io)
+    pair.reset()
+    st = P.Step()
+    st.currDT = res.DTseries[0] if manual else pair.auto_dtinit()
+    assert float(st.currDT) == float(res.DTseries[0])
+    T = np.eye(4, dtype=np.float32)
+    k = 0
+    while not st.toStage3:
+        assert pair.step(st) == 0 and st.status == 0
+        assert list(st.T16) == list(res.Tk[k])
+        assert (st.n_stable, st.n_stable_pts, st.n_inner) == (res.n_stable[k], res.n_stable_pts[k], res.n_inner[k])
+        assert float(st.LoDmin) == float(res.LoDmin[k]) and float(st.maxBB) == float(res.maxBB[k]) and st.d75 == res.d75[k]
+        assert float(st.currDT) == float(res.DTseries[k + 1])
+        Tk = np.array(st.T16, np.float32).reshape(4, 4)
+        new = np.zeros((4, 4), np.float32)
+        for a in range(4):
+            for b in range(4):
+                acc = np.float32(Tk[a, 0] * T[0, b])
+                for kk in range(1, 4):
+                    acc = np.float32(acc + np.float32(Tk[a, kk] * T[kk, b]))
+                new[a, b] = acc
+        T = new
+        k += 1
+        assert k <= res.n_outer
+    assert k == res.n_outer
+    assert np.array_equal(T.reshape(16), np.array(res.T16, np.float32))
+    assert list(st.VCM) == list(res.VCM)
+    pair.close()

@@ -26,7 +26,14 @@ line = [l for l in open(os.path.join(out, "bench_plain.log")) if l.startswith("{
 b = json.loads(line)
 n2 = b["config"]["points_per_cloud"]
 res = {"bench": {k: b[k] for k in ("value", "ms_per_step")}, "roofline_in_run": b["roofline"]}
-dense = "k_nn_dense_direct"
+dense = "k_nn_dense_disc" if ("k_nn_dense_disc", "FETCH_SIZE") in mean else "k_nn_dense_direct"
+res["kernel"] = dense
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as _bench
+res["kernel_source_sha256"] = _bench.kernel_source_hash()
+for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"):
+    if (dense, c) in mean:
+        res.setdefault("dense_sq_counters", {})[c] = mean[(dense, c)]
 if (dense, "FETCH_SIZE") in mean:
     f_dense, w_dense = mean[(dense, "FETCH_SIZE")], mean.get((dense, "WRITE_SIZE"), 0.0)
     f_cal, w_cal = mean.get(("k_transform_all", "FETCH_SIZE")), mean.get(("k_transform_all", "WRITE_SIZE"))
