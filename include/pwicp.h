@@ -104,6 +104,12 @@ PWICP_API int pwicp_select_patches(pwicp_context* ctx, const float* cloud_xyz4, 
                                    float* centroid_xyz4, float* boundary_xyz4,
                                    float* std_bp, float* std_ct);
 
+/* Centroid (compute3DCentroid, float), the six boundary points (Xmax,Xmin,Ymax,Ymin,Zmax,Zmin) and the sigmas of GIVEN
+ * patches: calPatchCTandBP (S.cpp:260-303), calPatchSTD (C.cpp:336-354; decl C.h:150) = std_bp, and calBPandCTSTD
+ * (S.cpp:306-321; decl S.h:451-452: std_ct = std_bp / N) for all patches at once.  Any output may be NULL. */
+PWICP_API int pwicp_patch_stats(pwicp_context* ctx, const float* patch_xyz4, const int32_t* offsets, int n_patches,
+                                float* centroid_xyz4, float* boundary_xyz4, float* std_bp, float* std_ct);
+
 /* Point-to-plane ICP between centroid clouds with normals.  Replaces P2PICPwithPatchNormal
  * (R.cpp:1255-1269; decl R.h:213-214) = pcl::IterativeClosestPointWithNormals<PointNormal,
  * PointNormal>::align with TransformationEpsilon 1e-8, EuclideanFitnessEpsilon euclid_eps,
@@ -168,6 +174,17 @@ PWICP_API int pwicp_pair_create_from_patches(pwicp_context* ctx,
                                 const float* cloud2_xyz4, int n2,
                                 const float* patch2_xyz4, const int32_t* off2, int m2,
                                 const pwicp_params* params, pwicp_pair** pair);
+/* Same, with the per-patch arrays of the CALLER instead of the ones recomputed from the patch points — what the arguments of
+ * PwICP_singleIteration (R.h:181-188) carry: CTcloud (m x 16 B), BPcloud (6 m), the sigmas of calBPandCTSTD.  Any of the
+ * eight arrays may be NULL (= computed).  Needed because the loop transforms the source centroids and boundary points
+ * themselves (R.cpp:946-949): after the first iteration they are no longer the centroids of the (transformed) patch points
+ * to the last bit. */
+PWICP_API int pwicp_pair_create_from_arrays(pwicp_context* ctx,
+                                const float* cloud1_xyz4, int n1, const float* patch1_xyz4, const int32_t* off1, int m1,
+                                const float* centroid1_xyz4, const float* boundary1_xyz4, const float* std_bp1, const float* std_ct1,
+                                const float* cloud2_xyz4, int n2, const float* patch2_xyz4, const int32_t* off2, int m2,
+                                const float* centroid2_xyz4, const float* boundary2_xyz4, const float* std_bp2, const float* std_ct2,
+                                const pwicp_params* params, pwicp_pair** pair);
 /* The static target side of a pair as a handle of its own: cloud, patches, normals, search grids.  Every pair of a
  * Direct2Ref series registers against the same target scan (R.cpp:94-103; the reference rebuilds all of it per pair,
  * R.cpp:653): build it once, create the pairs with it.  params->Res1 / SVRes1 of those pairs must be the target's.
@@ -209,6 +226,12 @@ PWICP_API int pwicp_pair_step(pwicp_pair* pair, pwicp_step* step);
 PWICP_API int pwicp_pair_auto_dtinit(pwicp_pair* pair, float* DTinit);
 /* Copies the current (transformed) source cloud back: cloud2 after the loop (R.cpp:943-945). */
 PWICP_API int pwicp_pair_download_source(pwicp_pair* pair, float* cloud2_xyz4);
+
+/* Everything PwICP_singleIteration transforms in place (R.cpp:943-954) — cloud2 (n2), CTcloud2 (m2), BPcloud2 (6 m2), the
+ * source patch points (pwicp_pair_num_patch_points, concatenated in patch order); any pointer may be NULL. */
+PWICP_API int pwicp_pair_download_state(pwicp_pair* pair, float* cloud2_xyz4, float* centroid2_xyz4, float* boundary2_xyz4,
+                                        float* patch2_xyz4);
+PWICP_API int pwicp_pair_num_patch_points(const pwicp_pair* pair, int* n_patch_points1, int* n_patch_points2);
 
 /* ---- host-side setup stages and the reference's file-in / file-out entry points -------------------------------- */
 /* The stages the reference runs before the loop, exported so that the two entry points below
@@ -253,6 +276,30 @@ PWICP_API int pwicp_pc_resolution_dev(pwicp_context* ctx, const float* cloud_xyz
  * Device: $PWICP_DEVICE or $LOCAL_RANK (default 0).  Never exit(): false on any failure. */
 PWICP_API bool PiecewiseICP_pair_call(const char* confile, const char* outfile);
 PWICP_API bool PiecewiseICP_4D_call(const char* confile, int startEpoch, int epochNum, int pairMode, float overlapThd);
+
+/* ---- the remaining functions of the reference's Registration.h / CommonFunc.h as C entry points ---------------------------
+ * (include/pwicp/Registration.h wraps them in the reference's exact PCL / Eigen signatures) */
+/* Piecewise_ICP_4D (R.cpp:402-548; decl R.h:74-78): PCpreprocessing with SOR multiplier 5.0, reduction by the target
+ * centroid, Piecewise_ICP, T_final = S^-1 T S, parameters (Rx,Ry,Rz [gon], tx,ty,tz [m]); outfileIdx != NULL: writes
+ * "<outfileIdx>TransMatrix.txt" (R.cpp:492-540). */
+PWICP_API int pwicp_piecewise_icp_4d(pwicp_context* ctx, const float* cloud1_xyz4, int n1, const float* cloud2_xyz4, int n2,
+                                     int isSetResSVsize, float Res1, float Res2, float SVsize1, float SVsize2, int isManualDTinit,
+                                     float DTinit, float DTmin, const char* outfileIdx, float* transMat16, float* transPara6,
+                                     double* VCM36);
+/* calAdaptivePairSequence (R.cpp:552-589; decl R.h:93-94): targets[k] = target of source k+1, relative to startEpoch,
+ * n_files - startEpoch - 1 entries; adaptivePairFile (may be NULL) receives the "source target" lines. */
+PWICP_API int pwicp_adaptive_pair_sequence(pwicp_context* ctx, const char* const* fileNameList, int n_files, int startEpoch,
+                                           float DTinit, float ratioThd, int32_t* targets, const char* adaptivePairFile);
+/* calTransToReferenceEpoch (R.cpp:977-1153; decl R.h:127-129).  Optional outputs hold epochNum entries (16 / 36 values each). */
+PWICP_API int pwicp_trans_to_reference_epoch(const char* transMatFile, int pairMode, const char* adaptivePairFile, int epochNum,
+                                             const char* transMat2RefFile, const char* transPara2RefFile, int32_t* timeStamp,
+                                             float* allTransMat2Ref16, double* allVCM2Ref36);
+/* calAbsErrorOfTransPara (R.cpp:1157-1251; decl R.h:198-199) */
+PWICP_API int pwicp_abs_error_of_trans_para(const char* transMatFile, const char* GTtransMatFile, int allEpochNum, int startEpoch,
+                                            const char* transParaErrorFile);
+/* matrix2angle (C.cpp:385-407; decl C.h:172) and calBoundingBoxCornerChange (C.cpp:410-419; decl C.h:183): host arithmetic */
+PWICP_API void  pwicp_matrix2angle(const float* transMat16, float* rotAngle3);
+PWICP_API float pwicp_bbox_corner_change(const double* boundingBox6, const float* transMat16);
 
 /* ---- the 4D series as a handle: independent pairs on any GPU (R.cpp:89-187) -------------------------------
  * PiecewiseICP_4D_call is open + run_pair over all pairs + write_results + close on one GPU.  On a multi-GPU node

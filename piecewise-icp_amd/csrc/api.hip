@@ -238,6 +238,35 @@ int pwicp_patch_normals(pwicp_context* ctx, const float* patch_xyz4, const int32
     return PWICP_OK;
 }
 
+// Per-patch centroid, six boundary points and sigmas of GIVEN patches: calPatchCTandBP (S.cpp:260-303), calPatchSTD
+// (C.cpp:336-354; decl C.h:150) and calBPandCTSTD (S.cpp:306-321; decl S.h:451-452) for all patches at once.  Any output
+// may be NULL.
+int pwicp_patch_stats(pwicp_context* ctx, const float* patch_xyz4, const int32_t* offsets, int n_patches, float* centroid_xyz4,
+                      float* boundary_xyz4, float* std_bp, float* std_ct) {
+    if (!ctx) return PWICP_E_INVALID;
+    if (!patch_xyz4 || !offsets || n_patches < 0) { ctx->set_err("null pointer / negative size"); return PWICP_E_INVALID; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int m = n_patches, tot = m > 0 ? offsets[m] : 0;
+    if (m == 0) return PWICP_OK;
+    DevBuf<float4> pat, ct, bp;
+    DevBuf<int> off;
+    DevBuf<float> sb, sc;
+    PWCHK(upload(ctx, patch_xyz4, tot, &pat));
+    HIPCHK(ctx, off.reserve((size_t)m + 1));
+    HIPCHK(ctx, ct.reserve((size_t)m));
+    HIPCHK(ctx, bp.reserve((size_t)m * 6));
+    HIPCHK(ctx, sb.reserve((size_t)m));
+    HIPCHK(ctx, sc.reserve((size_t)m));
+    HIPCHK(ctx, hipMemcpyAsync(off.p, offsets, ((size_t)m + 1) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    PWCHK(pw_patch_stats_launch(ctx, pat.p, off.p, m, ct.p, bp.p, sb.p, sc.p));
+    if (centroid_xyz4) HIPCHK(ctx, hipMemcpyAsync(centroid_xyz4, ct.p, (size_t)m * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    if (boundary_xyz4) HIPCHK(ctx, hipMemcpyAsync(boundary_xyz4, bp.p, (size_t)m * 6 * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    if (std_bp) HIPCHK(ctx, hipMemcpyAsync(std_bp, sb.p, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (std_ct) HIPCHK(ctx, hipMemcpyAsync(std_ct, sc.p, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PWICP_OK;
+}
+
 int pwicp_select_patches(pwicp_context* ctx, const float* cloud_xyz4, int n, const int32_t* labels, int n_supervoxels,
                          int* n_patches, int* n_patch_points, float* patch_xyz4, int32_t* offsets, int32_t* src_index,
                          float* centroid_xyz4, float* boundary_xyz4, float* std_bp, float* std_ct) {

@@ -718,13 +718,25 @@ int pwicp_pair_create(pwicp_context* ctx, const float* cloud1, int n1, const int
     return PWICP_OK;
 }
 
-int pwicp_pair_create_from_patches(pwicp_context* ctx, const float* cloud1, int n1, const float* patch1,
-                                   const int32_t* off1, int m1, const float* cloud2, int n2, const float* patch2,
-                                   const int32_t* off2, int m2, const pwicp_params* params, pwicp_pair** out) {
+// optional per-patch arrays that replace the ones computed from the patch points (see pwicp_pair_create_from_arrays)
+static int override_patch_arrays(pwicp_context* ctx, PatchSet* P, const float* ct, const float* bp, const float* std_bp, const float* std_ct) {
+    const size_t m = (size_t)P->m;
+    if (m == 0) return PWICP_OK;
+    if (ct) HIPCHK(ctx, hipMemcpyAsync(P->ct.p, ct, m * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    if (bp) HIPCHK(ctx, hipMemcpyAsync(P->bp.p, bp, m * 6 * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    if (std_bp) HIPCHK(ctx, hipMemcpyAsync(P->bpstd.p, std_bp, m * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (std_ct) HIPCHK(ctx, hipMemcpyAsync(P->ctstd.p, std_ct, m * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    return PWICP_OK;
+}
+
+int pwicp_pair_create_from_arrays(pwicp_context* ctx, const float* cloud1, int n1, const float* patch1, const int32_t* off1, int m1,
+                                  const float* ct1, const float* bp1, const float* bpstd1, const float* ctstd1, const float* cloud2,
+                                  int n2, const float* patch2, const int32_t* off2, int m2, const float* ct2, const float* bp2,
+                                  const float* bpstd2, const float* ctstd2, const pwicp_params* params, pwicp_pair** out) {
     if (!ctx) return PWICP_E_INVALID;
     if (!out || !cloud1 || !cloud2 || !patch1 || !patch2 || !off1 || !off2 || n1 <= 0 || n2 <= 0 || m1 < 0 || m2 < 0 ||
         !params_ok(params)) {
-        ctx->set_err("pwicp_pair_create_from_patches: invalid argument");
+        ctx->set_err("pwicp_pair_create_from_patches / _from_arrays: invalid argument");
         return PWICP_E_INVALID;
     }
     *out = nullptr;
@@ -741,12 +753,21 @@ int pwicp_pair_create_from_patches(pwicp_context* ctx, const float* cloud1, int 
         if ((rc = pw_check_finite(ctx, t->cloud1.p, n1)) != PWICP_OK) break;
         if ((rc = upload_patches(ctx, patch1, off1, m1, &t->P1)) != PWICP_OK) break;
         if ((rc = upload_patches(ctx, patch2, off2, m2, &pr->P2)) != PWICP_OK) break;
+        if ((rc = override_patch_arrays(ctx, &t->P1, ct1, bp1, bpstd1, ctstd1)) != PWICP_OK) break;
+        if ((rc = override_patch_arrays(ctx, &pr->P2, ct2, bp2, bpstd2, ctstd2)) != PWICP_OK) break;
         if ((rc = finish_target(t)) != PWICP_OK) break;
         rc = finish_create(pr);
     } while (0);
     if (rc != PWICP_OK) { delete pr; return rc; }
     *out = pr;
     return PWICP_OK;
+}
+
+int pwicp_pair_create_from_patches(pwicp_context* ctx, const float* cloud1, int n1, const float* patch1,
+                                   const int32_t* off1, int m1, const float* cloud2, int n2, const float* patch2,
+                                   const int32_t* off2, int m2, const pwicp_params* params, pwicp_pair** out) {
+    return pwicp_pair_create_from_arrays(ctx, cloud1, n1, patch1, off1, m1, nullptr, nullptr, nullptr, nullptr, cloud2, n2, patch2, off2,
+                                         m2, nullptr, nullptr, nullptr, nullptr, params, out);
 }
 
 void pwicp_pair_destroy(pwicp_pair* pr) {
@@ -785,6 +806,28 @@ int pwicp_pair_download_source(pwicp_pair* pr, float* cloud2_xyz4) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemcpyAsync(cloud2_xyz4, pr->cloud2.p, (size_t)pr->n2 * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PWICP_OK;
+}
+
+// everything PwICP_singleIteration mutates in place (R.cpp:943-954): cloud2, CTcloud2, BPcloud2, the source patch clouds.
+// Any pointer may be NULL.  Sizes: n2 | m2 | 6 m2 | number of source patch points (pwicp_pair_num_patch_points).
+int pwicp_pair_download_state(pwicp_pair* pr, float* cloud2_xyz4, float* centroid2_xyz4, float* boundary2_xyz4, float* patch2_xyz4) {
+    if (!pr) return PWICP_E_INVALID;
+    pwicp_context* ctx = pr->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int m2 = pr->P2.m;
+    if (cloud2_xyz4) HIPCHK(ctx, hipMemcpyAsync(cloud2_xyz4, pr->cloud2.p, (size_t)pr->n2 * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    if (centroid2_xyz4 && m2) HIPCHK(ctx, hipMemcpyAsync(centroid2_xyz4, pr->ctbp2.p, (size_t)m2 * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    if (boundary2_xyz4 && m2) HIPCHK(ctx, hipMemcpyAsync(boundary2_xyz4, pr->ctbp2.p + m2, (size_t)m2 * 6 * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    if (patch2_xyz4 && pr->P2.tot) HIPCHK(ctx, hipMemcpyAsync(patch2_xyz4, pr->P2.pat.p, (size_t)pr->P2.tot * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PWICP_OK;
+}
+
+int pwicp_pair_num_patch_points(const pwicp_pair* pr, int* tot1, int* tot2) {
+    if (!pr) return PWICP_E_INVALID;
+    if (tot1) *tot1 = pr->tgt->P1.tot;
+    if (tot2) *tot2 = pr->P2.tot;
     return PWICP_OK;
 }
 
@@ -1212,6 +1255,13 @@ int pwicp_pair_auto_dtinit(pwicp_pair* pr, float* DTinit) {
     PWCHK(select_p75(pr, pr->n2, pr->n2, &d75));
     *DTinit = (float)(d75 * 3.0);
     return PWICP_OK;
+}
+
+// calBoundingBoxCornerChange (C.cpp:410-419; decl C.h:183): largest displacement of the two extreme corners of the box
+// (min x,y,z | max x,y,z) under transMat (row-major 4x4); pure host arithmetic, the function the loop itself uses
+float pwicp_bbox_corner_change(const double* boundingBox6, const float* transMat16) {
+    if (!boundingBox6 || !transMat16) return 0.f;
+    return bb_corner_change(boundingBox6, transMat16);
 }
 
 int pwicp_pair_set_profiling(pwicp_pair* pr, int flags) {

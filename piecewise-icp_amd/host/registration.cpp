@@ -170,7 +170,8 @@ bool register_pair(pwicp_context* ctx, const std::vector<float>& cloud1, const s
 
 // calTransToReferenceEpoch, R.cpp:977-1153 (re-reads the pairwise file, exactly as the reference does)
 bool trans_to_reference(const std::string& tm_file, int pairMode, const std::map<int, int>& reg_pair, int n,
-                        const std::string& out_tm, const std::string& out_tp) {
+                        const std::string& out_tm, const std::string& out_tp, int32_t* o_stamp = nullptr, float* o_T = nullptr,
+                        double* o_V = nullptr) {
     std::vector<int> stamps;
     std::vector<std::array<float, 16>> Ts;
     std::vector<std::array<double, 36>> Vs;
@@ -235,29 +236,32 @@ bool trans_to_reference(const std::string& tm_file, int pairMode, const std::map
         const float para[6] = {(float)(ang[0] * ARC_TO_GON), (float)(ang[1] * ARC_TO_GON), (float)(ang[2] * ARC_TO_GON),
                                accT[3], accT[7], accT[11]};
         append_transparameters(oTP, stamps[(size_t)i], para, accV.data());
+        if (o_stamp) o_stamp[i] = stamps[(size_t)i];
+        if (o_T) std::memcpy(o_T + 16 * (size_t)i, accT.data(), 16 * sizeof(float));
+        if (o_V) std::memcpy(o_V + 36 * (size_t)i, accV.data(), 36 * sizeof(double));
     }
     return true;
 }
 
 // calAbsErrorOfTransPara, R.cpp:1157-1251; optional here (the reference hard-codes the GT path and exits if missing)
-void abs_error_report(const std::string& toref_file, const std::string& gt_file, int all_epochs, int start, const std::string& out_file) {
+bool abs_error_report(const std::string& toref_file, const std::string& gt_file, int all_epochs, int start, const std::string& out_file) {
     const int n = all_epochs - start - 1;
     std::vector<int> stamps;
     std::vector<std::array<float, 16>> Ts;
     std::vector<std::array<double, 36>> Vs;
-    if (!read_transmatrices(toref_file, n, &stamps, &Ts, &Vs)) return;
+    if (!read_transmatrices(toref_file, n, &stamps, &Ts, &Vs)) return false;
     std::ifstream gt(gt_file);
-    if (!gt) return;
+    if (!gt) return false;
     std::vector<std::array<float, 16>> G;
     for (int i = 0; i < all_epochs; ++i) {
         int stamp;
         std::array<float, 16> T;
-        if (!(gt >> stamp)) return;
-        for (int k = 0; k < 16; ++k) if (!(gt >> T[(size_t)k])) return;
+        if (!(gt >> stamp)) return false;
+        for (int k = 0; k < 16; ++k) if (!(gt >> T[(size_t)k])) return false;
         G.push_back(T);
     }
     std::ofstream o(out_file);
-    if (!o) return;
+    if (!o) return false;
     o << "Err_Rx[mgon]  Err_Ry[mgon]  Err_Rz[mgon]  Err_tx[mm]  Err_ty[mm]  Err_tz[mm]" << std::endl;
     for (int i = 0; i < n; ++i) {
         float a[3], b[3];
@@ -271,6 +275,7 @@ void abs_error_report(const std::string& toref_file, const std::string& gt_file,
                             1000 * std::fabs(G[(size_t)(start + 1 + i)][11] - Ts[(size_t)i][11])};
         o << e[0] << " " << e[1] << " " << e[2] << " " << e[3] << " " << e[4] << " " << e[5] << " " << std::endl;
     }
+    return true;
 }
 
 int env_device() {
@@ -320,6 +325,95 @@ PWICP_API bool PiecewiseICP_pair_call(const char* confile, const char* outfile) 
     std::cout << "--->>> Registered source cloud saved.\n\n";
     return true;
 }
+
+// ---- the remaining functions of include/Registration.h as C entry points (the PCL-typed wrappers with the reference's exact
+// signatures live in include/pwicp/Registration.h) ----------------------------------------------------------------------------
+
+// Piecewise_ICP_4D (R.cpp:402-548; decl R.h:74-78): PCpreprocessing (SOR multiplier 5.0) of both clouds, reduction by the
+// target centroid, Piecewise_ICP, T_final = S^-1 T S, transformation parameters [gon, m], and — when outfileIdx is not
+// NULL — "<outfileIdx>TransMatrix.txt".  isSetResSVsize == 0: patch size 10 x the given point spacing (R.cpp:635-640).
+PWICP_API int pwicp_piecewise_icp_4d(pwicp_context* ctx, const float* cloud1_xyz4, int n1, const float* cloud2_xyz4, int n2,
+                                     int isSetResSVsize, float Res1, float Res2, float SVsize1, float SVsize2, int isManualDTinit,
+                                     float DTinit, float DTmin, const char* outfileIdx, float* transMat16, float* transPara6,
+                                     double* VCM36) {
+    if (!ctx || !cloud1_xyz4 || !cloud2_xyz4 || n1 <= 0 || n2 <= 0 || !transMat16 || !transPara6 || !VCM36) return PWICP_E_INVALID;
+    ConfigPara cfg;
+    cfg.isSetResSVsize = isSetResSVsize != 0; cfg.PCres1 = Res1; cfg.PCres2 = Res2; cfg.SVsize1 = SVsize1; cfg.SVsize2 = SVsize2;
+    cfg.isSetDTinit = isManualDTinit != 0; cfg.DTinit = DTinit; cfg.DTmin = DTmin;
+    std::vector<float> c1(cloud1_xyz4, cloud1_xyz4 + 4 * (size_t)n1), c2(cloud2_xyz4, cloud2_xyz4 + 4 * (size_t)n2);
+    PairOutput out;
+    std::memset(&out, 0, sizeof(out));
+    if (!register_pair(ctx, c1, c2, cfg, Res1, Res2, 5.0, &out)) return out.res.status != 0 ? out.res.status : PWICP_E_INTERNAL;
+    std::memcpy(transMat16, out.T, sizeof(out.T));
+    std::memcpy(transPara6, out.para, sizeof(out.para));
+    std::memcpy(VCM36, out.VCM, sizeof(out.VCM));
+    if (outfileIdx && !write_transmatrix_file(std::string(outfileIdx) + "TransMatrix.txt", out.T, out.VCM)) {
+        std::cerr << "Cannot open TransMatrix.txt for writing!\n\n";
+        return PWICP_E_INTERNAL;
+    }
+    return PWICP_OK;
+}
+
+// calAdaptivePairSequence (R.cpp:552-589; decl R.h:93-94): targets[k] = target of source k+1, both relative to startEpoch
+// (n_files - startEpoch - 1 entries); the pair file (may be NULL) gets the reference's "source target" lines.
+PWICP_API int pwicp_adaptive_pair_sequence(pwicp_context* ctx, const char* const* fileNameList, int n_files, int startEpoch, float DTinit,
+                                           float ratioThd, int32_t* targets, const char* adaptivePairFile) {
+    if (!ctx || !fileNameList || !targets || n_files < 2 || startEpoch < 0 || startEpoch >= n_files - 1) return PWICP_E_INVALID;
+    int idxTarget = startEpoch;
+    std::vector<std::vector<float>> cache((size_t)n_files);
+    auto cloud = [&](int i) -> std::vector<float>& { if (cache[(size_t)i].empty()) load_pcd(fileNameList[i], &cache[(size_t)i]); return cache[(size_t)i]; };
+    for (int j = startEpoch + 1; j < n_files; ++j) {
+        float ratio = 0;
+        for (int i = idxTarget; i < j; ++i) {
+            std::vector<float>&a = cloud(i), &b = cloud(j);
+            if (a.empty() || b.empty()) return PWICP_E_INVALID;
+            const int rc = pwicp_overlap_ratio(ctx, a.data(), (int)(a.size() / 4), b.data(), (int)(b.size() / 4), DTinit, &ratio);
+            if (rc != PWICP_OK) return rc;
+            idxTarget = i;
+            if (ratio > ratioThd) break;
+        }
+        targets[j - startEpoch - 1] = idxTarget - startEpoch;
+        std::cout << "Pair: " << idxTarget - startEpoch << " - " << j - startEpoch << ";  Overlap ratio = " << 100 * ratio << "% \n";
+        if (idxTarget > startEpoch) cache[(size_t)idxTarget - 1].clear();
+    }
+    if (adaptivePairFile) {
+        std::ofstream pf(adaptivePairFile);
+        if (!pf) { std::cerr << "Error: Cannot open adaptivePairFile!\n"; return PWICP_E_INTERNAL; }
+        for (int k = 0; k < n_files - startEpoch - 1; ++k) pf << k + 1 << " " << targets[k] << std::endl;
+    }
+    return PWICP_OK;
+}
+
+// calTransToReferenceEpoch (R.cpp:977-1153; decl R.h:127-129): reads the pairwise file (and, in adaptive mode, the pair file),
+// writes the two "toRef" files and returns the composed matrices.  Optional outputs hold epochNum entries.
+PWICP_API int pwicp_trans_to_reference_epoch(const char* transMatFile, int pairMode, const char* adaptivePairFile, int epochNum,
+                                             const char* transMat2RefFile, const char* transPara2RefFile, int32_t* timeStamp,
+                                             float* allTransMat2Ref16, double* allVCM2Ref36) {
+    if (!transMatFile || !transMat2RefFile || !transPara2RefFile || epochNum <= 0) return PWICP_E_INVALID;
+    std::map<int, int> reg;
+    if (pairMode < 0) {
+        if (!adaptivePairFile) return PWICP_E_INVALID;
+        std::ifstream in(adaptivePairFile);
+        if (!in) { std::cerr << "Error: Cannot open adaptivePairFile!\n"; return PWICP_E_INVALID; }
+        for (int i = 0; i < epochNum; ++i) {                      // R.cpp:1024-1028
+            int a, b;
+            if (!(in >> a >> b)) break;
+            reg.insert(std::make_pair(a, b));
+        }
+    }
+    return trans_to_reference(transMatFile, pairMode, reg, epochNum, transMat2RefFile, transPara2RefFile, timeStamp, allTransMat2Ref16,
+                              allVCM2Ref36) ? PWICP_OK : PWICP_E_INTERNAL;
+}
+
+// calAbsErrorOfTransPara (R.cpp:1157-1251; decl R.h:198-199)
+PWICP_API int pwicp_abs_error_of_trans_para(const char* transMatFile, const char* GTtransMatFile, int allEpochNum, int startEpoch,
+                                            const char* transParaErrorFile) {
+    if (!transMatFile || !GTtransMatFile || !transParaErrorFile) return PWICP_E_INVALID;
+    return abs_error_report(transMatFile, GTtransMatFile, allEpochNum, startEpoch, transParaErrorFile) ? PWICP_OK : PWICP_E_INVALID;
+}
+
+// matrix2angle (C.cpp:385-407; decl C.h:172): rotation angles [rad] about x, y, z of a row-major 4x4
+PWICP_API void pwicp_matrix2angle(const float* T16, float* rotAngle3) { matrix2angle(T16, rotAngle3); }
 
 // ---- 4D series as a handle: the pairs of R.cpp:89-187 are independent, so any subset can run on any GPU ---------
 }  // extern "C"

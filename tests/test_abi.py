@@ -95,3 +95,34 @@ def test_header_is_plain_c99(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "record 384 B" in out.stdout
     assert ("-> -1" in out.stdout) or ("-> 0" in out.stdout)
+
+
+def _build_facade_pcl_check(tmp_path):
+    import subprocess
+    import pwicp_amd
+    exe = str(tmp_path / "facade_pcl_check")
+    libdir = os.path.dirname(pwicp_amd.lib_path())
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "shim"),
+                           os.path.join(ROOT, "tests", "facade_pcl_check.cpp"), "-L" + libdir, "-lpwicp", "-Wl,-rpath," + libdir,
+                           "-o", exe])
+    return exe
+
+
+def test_exact_reference_signatures_compile_against_the_type_shim(tmp_path):
+    """The `#if PWICP_HAVE_PCL` block of include/pwicp/Registration.h — the reference's exact signatures of Registration.h,
+    Segmentation.h and CommonFunc.h (SURVEY 8b "C++ API to keep") — compiled against tests/shim (PointXYZ 16 B, PointNormal
+    48 B, PointCloud<T>::Ptr, Matrix4f, MatrixXd) and linked against libpwicp.so."""
+    import subprocess
+    out = subprocess.run([_build_facade_pcl_check(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "exact signatures compiled: 20" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_exact_reference_signatures_run(tmp_path):
+    """Every exact-signature function called once on the GPU; Piecewise_ICP equals the loop of R.cpp:668-700 written with
+    PwICP_singleIteration, bit for bit."""
+    import subprocess
+    exe = _build_facade_pcl_check(tmp_path)
+    out = subprocess.run([exe, "run", os.path.join(ROOT, "tests", "golden", "reference_results"), str(tmp_path)],
+                         capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert out.returncode == 0 and "FACADE_PCL_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
