@@ -25,6 +25,7 @@
 #define PWICP_H
 
 #include <stdbool.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -331,6 +332,30 @@ PWICP_API int pwicp_series_run_pair(pwicp_series* s, int pair, pwicp_pair_record
  * GPU stages one after the other.  Same records as n calls of pwicp_series_run_pair. */
 PWICP_API int pwicp_series_run_pairs(pwicp_series* s, const int32_t* pairs, int n_pairs, pwicp_pair_record* recs);
 PWICP_API int pwicp_series_write_results(pwicp_series* s, const pwicp_pair_record* recs, int n_recs);
+/* Several GPUs inside ONE process: n >= 1 HIP device ids (duplicates allowed: two workers sharing a GPU, for functional
+ * tests on a 1-GPU box).  pwicp_series_run_pairs then deals the pairs of a call to the devices (pair k -> device k mod n),
+ * one host thread and one context per device, the shared target of a Direct2Ref series prepared once per device.  Same
+ * records as on one device.  PiecewiseICP_4D_call does this with every visible device unless $PWICP_DEVICES ("all" or a
+ * comma-separated list) or $PWICP_DEVICE / $LOCAL_RANK (one rank of a multi-process run) say otherwise. */
+PWICP_API int pwicp_series_set_devices(pwicp_series* s, const int32_t* devices, int n);
+PWICP_API int pwicp_series_num_devices(const pwicp_series* s);
+
+/* ---- several PROCESSES, one GPU each: the series' one exchange over RCCL directly (no Python, no torch) -----------------------
+ * librccl.so is opened with dlopen on first use.  Rendezvous of the ncclUniqueId through `id_file` (single node): rank 0
+ * writes it, the others poll for it.  Buffers are host memory (staged through device memory: RCCL moves it over xGMI). */
+typedef struct pwicp_comm pwicp_comm;
+PWICP_API int  pwicp_comm_init(int rank, int world, int device, const char* id_file, pwicp_comm** comm);
+PWICP_API void pwicp_comm_destroy(pwicp_comm* comm);
+PWICP_API int  pwicp_comm_rank(const pwicp_comm* comm);
+PWICP_API int  pwicp_comm_world(const pwicp_comm* comm);
+PWICP_API int  pwicp_comm_allgather(pwicp_comm* comm, const void* send, size_t bytes, void* recv /* world * bytes */);
+PWICP_API int  pwicp_comm_broadcast(pwicp_comm* comm, void* buf, size_t bytes, int root);
+/* One rank of PiecewiseICP_4D_call sharded over `world` processes: pair p -> rank p mod world, adaptive pair map from rank 0
+ * (broadcast), one all-gather of the 384-byte records, rank 0 writes the files.  Returns the same value on every rank.
+ * PiecewiseICP_4D_call takes this path by itself when $PWICP_RCCL=1 and $WORLD_SIZE > 1 (rank / device from $RANK /
+ * $LOCAL_RANK, id file $PWICP_RCCL_ID_FILE or /tmp/pwicp_rccl_<MASTER_PORT>.id). */
+PWICP_API bool pwicp_series_run_distributed(const char* confile, int startEpoch, int epochNum, int pairMode, float overlapThd,
+                                            int rank, int world, int device, const char* id_file);
 
 /* ---- measurement hooks ------------------------------------------------------------------------------------
  * HIP events on the pair's stream feed pwicp_result.t_dense_nn_ms / t_inner_ms.  An event record costs a ~6 us

@@ -284,6 +284,25 @@ int env_device() {
     return e ? atoi(e) : 0;
 }
 
+// Devices of an entry-point call: $PWICP_DEVICES = "all" or a comma-separated list (duplicates allowed: two workers on one
+// GPU); else $PWICP_DEVICE / $LOCAL_RANK (one rank of a multi-process launch owns one GPU); else every visible device.
+std::vector<int32_t> env_devices() {
+    std::vector<int32_t> d;
+    const char* e = getenv("PWICP_DEVICES");
+    if (e && std::strcmp(e, "all") != 0) {
+        std::stringstream ss(e);
+        std::string tok;
+        while (std::getline(ss, tok, ',')) if (!tok.empty()) d.push_back(atoi(tok.c_str()));
+    } else if (!e && (getenv("PWICP_DEVICE") || getenv("LOCAL_RANK"))) {
+        d.push_back(env_device());
+    } else {
+        const int n = pwicp_device_count();
+        for (int i = 0; i < std::max(n, 1); ++i) d.push_back(i);
+    }
+    if (d.empty()) d.push_back(0);
+    return d;
+}
+
 }  // namespace
 
 extern "C" {
@@ -418,6 +437,27 @@ PWICP_API void pwicp_matrix2angle(const float* T16, float* rotAngle3) { matrix2a
 // ---- 4D series as a handle: the pairs of R.cpp:89-187 are independent, so any subset can run on any GPU ---------
 }  // extern "C"
 
+// One GPU of a series: its context and the target clouds prepared on it.  A series owns one worker per device it was
+// opened on; the pairs handed to pwicp_series_run_pairs are dealt to the workers (pair k of the call -> worker k mod G),
+// each worker runs on a host thread of its own (the pairs are independent, R.cpp:89-187).
+struct SeriesWorker {
+    int device = 0;
+    pwicp_context* ctx = nullptr;         // created by the first call that needs the GPU
+    // prepared target clouds by epoch index (in the Direct2Ref mode every pair has the same target, R.cpp:94-103; in the
+    // adaptive mode runs of pairs share one): prepared once PER DEVICE, kept while the following pairs use them
+    std::map<int, std::shared_ptr<Prepared>> targets;
+    bool need_ctx() {
+        if (ctx) return true;
+        if (pwicp_create(&ctx, device) != PWICP_OK) { std::cerr << "Error: no usable HIP device (pwicp has no CPU fallback).\n"; ctx = nullptr; return false; }
+        return true;
+    }
+    void close() {
+        targets.clear();                  // device-side targets go before their context
+        if (ctx) pwicp_destroy(ctx);
+        ctx = nullptr;
+    }
+};
+
 struct pwicp_series {
     ConfigPara cfg;
     std::string outputFolder;
@@ -425,15 +465,11 @@ struct pwicp_series {
     std::vector<long> times;
     int startEpoch = 0, epochNum = 0, pairMode = 0, device = 0;
     std::map<int, int> regPairs;          // adaptive mode: source -> target, relative to startEpoch (R.cpp:570)
-    pwicp_context* ctx = nullptr;         // created by the first call that needs the GPU
-    // prepared target clouds by epoch index (in the Direct2Ref mode every pair has the same target, R.cpp:94-103; in the
-    // adaptive mode runs of pairs share one): prepared once, kept while the following pairs use them
-    std::map<int, std::shared_ptr<Prepared>> targets;
+    std::vector<std::unique_ptr<SeriesWorker>> workers;      // [0] = `device`; more after pwicp_series_set_devices
 
-    bool need_ctx() {
-        if (ctx) return true;
-        if (pwicp_create(&ctx, device) != PWICP_OK) { std::cerr << "Error: no usable HIP device (pwicp has no CPU fallback).\n"; ctx = nullptr; return false; }
-        return true;
+    SeriesWorker* w0() {
+        if (workers.empty()) { workers.emplace_back(new SeriesWorker); workers[0]->device = device; }
+        return workers[0].get();
     }
     int num_pairs() const { return epochNum - startEpoch - 1; }
     int ref_index(int pair) const {                   // R.cpp:94-103
@@ -448,7 +484,8 @@ namespace {
 
 // calAdaptivePairSequence (R.cpp:552-589) with the overlap ratio on the GPU (R.cpp:593-614)
 bool adaptive_pair_sequence(pwicp_series* s, float overlapThd, const std::string& pairFile) {
-    if (!s->need_ctx()) return false;
+    if (!s->w0()->need_ctx()) return false;
+    pwicp_context* const ctx0 = s->w0()->ctx;
     const int fileCount = (int)s->files.size(), startEpoch = s->startEpoch;
     int idxTarget = startEpoch;
     std::vector<std::vector<float>> cache((size_t)fileCount);
@@ -457,7 +494,7 @@ bool adaptive_pair_sequence(pwicp_series* s, float overlapThd, const std::string
         float ratio = 0;
         for (int i = idxTarget; i < j; ++i) {
             std::vector<float>&a = cloud(i), &b = cloud(j);
-            if (pwicp_overlap_ratio(s->ctx, a.data(), (int)(a.size() / 4), b.data(), (int)(b.size() / 4), s->cfg.DTinit, &ratio) != PWICP_OK) return false;
+            if (pwicp_overlap_ratio(ctx0, a.data(), (int)(a.size() / 4), b.data(), (int)(b.size() / 4), s->cfg.DTinit, &ratio) != PWICP_OK) return false;
             idxTarget = i;
             if (ratio > overlapThd) break;
         }
@@ -493,7 +530,7 @@ PWICP_API int pwicp_series_open(const char* confile, int startEpoch, int epochNu
             for (int k = 0; k < n_adaptive; ++k) s->regPairs[k + 1] = adaptive_targets[k];
         } else {
             std::cout << "--->>> Adaptive pair sequence determination... \n";
-            if (!adaptive_pair_sequence(s.get(), overlapThd, "RegPairFile.txt")) { if (s->ctx) pwicp_destroy(s->ctx); return PWICP_E_INTERNAL; }
+            if (!adaptive_pair_sequence(s.get(), overlapThd, "RegPairFile.txt")) { for (auto& w : s->workers) w->close(); return PWICP_E_INTERNAL; }
         }
     }
     *out = s.release();
@@ -502,8 +539,7 @@ PWICP_API int pwicp_series_open(const char* confile, int startEpoch, int epochNu
 
 PWICP_API void pwicp_series_close(pwicp_series* s) {
     if (!s) return;
-    s->targets.clear();                          // device-side targets go before their context
-    if (s->ctx) pwicp_destroy(s->ctx);
+    for (auto& w : s->workers) w->close();
     delete s;
 }
 
@@ -530,7 +566,7 @@ PWICP_API int pwicp_series_adaptive_targets(const pwicp_series* s, int32_t* targ
 // are read on host threads, the GPU parts of the preparation run one after the other (tens of ms each), the serial
 // host parts (~1.2 s per 1 M points and cloud) run side by side on host threads, then the registrations run on the
 // GPU.  The results do not depend on the window (every stage is a pure function of its cloud).
-PWICP_API int pwicp_series_run_pairs(pwicp_series* s, const int32_t* pairs, int n_pairs, pwicp_pair_record* recs) {
+static int run_pairs_on(pwicp_series* s, SeriesWorker* w, const int32_t* pairs, int n_pairs, pwicp_pair_record* recs) {
     if (!s || !pairs || !recs || n_pairs < 0) return PWICP_E_INVALID;
     for (int k = 0; k < n_pairs; ++k) {
         std::memset(&recs[k], 0, sizeof(recs[k]));
@@ -539,7 +575,7 @@ PWICP_API int pwicp_series_run_pairs(pwicp_series* s, const int32_t* pairs, int 
         if (pairs[k] < 0 || pairs[k] >= s->num_pairs()) return PWICP_E_INVALID;
     }
     if (n_pairs == 0) return PWICP_OK;
-    if (!s->need_ctx()) { for (int k = 0; k < n_pairs; ++k) recs[k].status = PWICP_E_NO_DEVICE; return PWICP_E_NO_DEVICE; }
+    if (!w->need_ctx()) { for (int k = 0; k < n_pairs; ++k) recs[k].status = PWICP_E_NO_DEVICE; return PWICP_E_NO_DEVICE; }
     const ConfigPara& cfg = s->cfg;
     const double sor_mult = 5.0;                                           // R.cpp:415-416
     int window = std::max(1, std::min(host_threads() - 1, 16));
@@ -555,7 +591,7 @@ PWICP_API int pwicp_series_run_pairs(pwicp_series* s, const int32_t* pairs, int 
         for (int k = 0; k < nw; ++k) {
             refIdx[(size_t)k] = s->ref_index(pairs[w0 + k]);
             if (refIdx[(size_t)k] < 0 || refIdx[(size_t)k] >= (int)s->files.size()) return PWICP_E_INVALID;
-            if (!s->targets.count(refIdx[(size_t)k])) raw1[refIdx[(size_t)k]];
+            if (!w->targets.count(refIdx[(size_t)k])) raw1[refIdx[(size_t)k]];
         }
         {
             std::vector<std::thread> th;
@@ -578,11 +614,11 @@ PWICP_API int pwicp_series_run_pairs(pwicp_series* s, const int32_t* pairs, int 
                 auto t = std::make_shared<Prepared>();
                 float Res1 = cfg.PCres1;
                 bool good = !kv.second.empty();
-                if (good && !cfg.isSetResSVsize && pwicp_pc_resolution_dev(s->ctx, kv.second.data(), (int)(kv.second.size() / 4), &Res1) != PWICP_OK) good = false;
+                if (good && !cfg.isSetResSVsize && pwicp_pc_resolution_dev(w->ctx, kv.second.data(), (int)(kv.second.size() / 4), &Res1) != PWICP_OK) good = false;
                 const float SVRes1 = cfg.isSetResSVsize ? cfg.SVsize1 : Res1 * 10;                       // R.cpp:635-640
-                if (good) good = prepare_gpu(s->ctx, kv.second, Res1, SVRes1, sor_mult, nullptr, t.get());
+                if (good) good = prepare_gpu(w->ctx, kv.second, Res1, SVRes1, sor_mult, nullptr, t.get());
                 if (good) {
-                    s->targets[kv.first] = t;
+                    w->targets[kv.first] = t;
                     Prepared* p = t.get();
                     char* flag = &okt[ti];
                     th.emplace_back([p, flag] { *flag = prepare_host(p) ? 1 : 0; });
@@ -592,12 +628,12 @@ PWICP_API int pwicp_series_run_pairs(pwicp_series* s, const int32_t* pairs, int 
             }
         }
         for (int k = 0; k < nw; ++k) {
-            auto it = s->targets.find(refIdx[(size_t)k]);
+            auto it = w->targets.find(refIdx[(size_t)k]);
             float Res2 = cfg.PCres2;
-            bool good = it != s->targets.end() && !raw2[(size_t)k].empty();
-            if (good && !cfg.isSetResSVsize && pwicp_pc_resolution_dev(s->ctx, raw2[(size_t)k].data(), (int)(raw2[(size_t)k].size() / 4), &Res2) != PWICP_OK) good = false;
+            bool good = it != w->targets.end() && !raw2[(size_t)k].empty();
+            if (good && !cfg.isSetResSVsize && pwicp_pc_resolution_dev(w->ctx, raw2[(size_t)k].data(), (int)(raw2[(size_t)k].size() / 4), &Res2) != PWICP_OK) good = false;
             const float SVRes2 = cfg.isSetResSVsize ? cfg.SVsize2 : Res2 * 10;
-            if (good) good = prepare_gpu(s->ctx, raw2[(size_t)k], Res2, SVRes2, sor_mult, it->second->shift, &src[(size_t)k]);
+            if (good) good = prepare_gpu(w->ctx, raw2[(size_t)k], Res2, SVRes2, sor_mult, it->second->shift, &src[(size_t)k]);
             ok[(size_t)k] = good ? 1 : 0;
             if (good) th.emplace_back([&ok, &src, k] { ok[(size_t)k] = prepare_host(&src[(size_t)k]) ? 1 : 0; });
             std::vector<float>().swap(raw2[(size_t)k]);
@@ -606,7 +642,7 @@ PWICP_API int pwicp_series_run_pairs(pwicp_series* s, const int32_t* pairs, int 
         for (auto& t : th) t.join();
         {
             size_t ti = 0;
-            for (auto& kv : raw1) { if (!okt[ti]) s->targets.erase(kv.first); ++ti; }
+            for (auto& kv : raw1) { if (!okt[ti]) w->targets.erase(kv.first); ++ti; }
         }
         tm.lap("normals + supervoxels (host threads, rest)");
         // ---- registrations ---------------------------------------------------------------------------------------------
@@ -617,10 +653,10 @@ PWICP_API int pwicp_series_run_pairs(pwicp_series* s, const int32_t* pairs, int 
             const auto tp = std::chrono::steady_clock::now();
             std::cout << "\n//////////////////////  Process Pair_" << step << ":  Epoch-" << s->times[(size_t)refIdx[(size_t)k]] << " and Epoch-"
                       << s->times[(size_t)i + 1] << "   //////////////////////////////////////////// \n\n";
-            auto it = s->targets.find(refIdx[(size_t)k]);
+            auto it = w->targets.find(refIdx[(size_t)k]);
             PairOutput out;
             std::memset(&out, 0, sizeof(out));
-            if (!ok[(size_t)k] || it == s->targets.end() || !run_prepared(s->ctx, *it->second, src[(size_t)k], cfg, &out)) {
+            if (!ok[(size_t)k] || it == w->targets.end() || !run_prepared(w->ctx, *it->second, src[(size_t)k], cfg, &out)) {
                 std::cerr << "Step " << step << " failed. Skipping to next.\n\n";                          // R.cpp:145-147
                 rec->status = out.res.status != 0 ? out.res.status : PWICP_E_INTERNAL;
                 continue;
@@ -637,14 +673,59 @@ PWICP_API int pwicp_series_run_pairs(pwicp_series* s, const int32_t* pairs, int 
         }
         tm.lap("registrations (GPU)");
         // keep the reference epoch and the targets of this window, drop older ones
-        for (auto it = s->targets.begin(); it != s->targets.end();) {
+        for (auto it = w->targets.begin(); it != w->targets.end();) {
             bool used = it->first == s->startEpoch;
             for (int k = 0; k < nw; ++k) used = used || refIdx[(size_t)k] == it->first;
-            if (used) ++it; else it = s->targets.erase(it);
+            if (used) ++it; else it = w->targets.erase(it);
         }
     }
     return PWICP_OK;
 }
+
+PWICP_API int pwicp_series_run_pairs(pwicp_series* s, const int32_t* pairs, int n_pairs, pwicp_pair_record* recs) {
+    if (!s || !pairs || !recs || n_pairs < 0) return PWICP_E_INVALID;
+    s->w0();
+    const int G = (int)s->workers.size();
+    if (G == 1 || n_pairs <= 1) return run_pairs_on(s, s->workers[0].get(), pairs, n_pairs, recs);
+    // several devices: pair k of this call -> worker k mod G, one host thread per worker; every worker prepares the targets it
+    // needs on its own device.  Same records as on one device (every stage is a pure function of its clouds).
+    std::vector<std::vector<int32_t>> part((size_t)G);
+    std::vector<std::vector<int>> where((size_t)G);
+    for (int k = 0; k < n_pairs; ++k) { part[(size_t)(k % G)].push_back(pairs[k]); where[(size_t)(k % G)].push_back(k); }
+    std::vector<std::vector<pwicp_pair_record>> out((size_t)G);
+    std::vector<int> rc((size_t)G, PWICP_OK);
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; ++g) {
+        out[(size_t)g].resize(part[(size_t)g].size() ? part[(size_t)g].size() : 1);
+        th.emplace_back([&, g] {
+            rc[(size_t)g] = run_pairs_on(s, s->workers[(size_t)g].get(), part[(size_t)g].data(), (int)part[(size_t)g].size(), out[(size_t)g].data());
+        });
+    }
+    for (auto& t : th) t.join();
+    int ret = PWICP_OK;
+    for (int g = 0; g < G; ++g) {
+        for (size_t j = 0; j < part[(size_t)g].size(); ++j) recs[where[(size_t)g][j]] = out[(size_t)g][j];
+        if (rc[(size_t)g] != PWICP_OK && ret == PWICP_OK) ret = rc[(size_t)g];
+    }
+    return ret;
+}
+
+// Devices of a series (before the first pair runs): n >= 1 HIP device ids, duplicates allowed (two workers sharing one
+// GPU: functional tests on a 1-GPU box).  Replaces the single device given to pwicp_series_open.
+PWICP_API int pwicp_series_set_devices(pwicp_series* s, const int32_t* devices, int n) {
+    if (!s || !devices || n < 1) return PWICP_E_INVALID;
+    std::vector<std::unique_ptr<SeriesWorker>> nw;
+    for (int g = 0; g < n; ++g) {
+        if (g == 0 && !s->workers.empty() && s->workers[0]->device == devices[0]) { nw.push_back(std::move(s->workers[0])); continue; }
+        nw.emplace_back(new SeriesWorker);
+        nw.back()->device = devices[g];
+    }
+    for (auto& w : s->workers) if (w) w->close();
+    s->workers.swap(nw);
+    s->device = devices[0];
+    return PWICP_OK;
+}
+PWICP_API int pwicp_series_num_devices(const pwicp_series* s) { return s ? std::max<int>(1, (int)s->workers.size()) : 0; }
 
 // one iteration of the pair loop
 PWICP_API int pwicp_series_run_pair(pwicp_series* s, int pair, pwicp_pair_record* rec) {
@@ -701,8 +782,21 @@ PWICP_API int pwicp_series_write_results(pwicp_series* s, const pwicp_pair_recor
 
 PWICP_API bool PiecewiseICP_4D_call(const char* confile, int startEpoch, int epochNum, int pairMode, float overlapThd) {
     if (!confile) return false;
+    // one rank of a multi-process launch (one process per GPU, RCCL gather of the records): opt-in through the environment
+    if (const char* e = getenv("PWICP_RCCL")) {
+        const char* ws = getenv("WORLD_SIZE");
+        if (atoi(e) != 0 && ws && atoi(ws) > 1) {
+            const char* rk = getenv("RANK");
+            std::string idf = getenv("PWICP_RCCL_ID_FILE") ? getenv("PWICP_RCCL_ID_FILE")
+                                                           : std::string("/tmp/pwicp_rccl_") + (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0") + ".id";
+            return pwicp_series_run_distributed(confile, startEpoch, epochNum, pairMode, overlapThd, rk ? atoi(rk) : 0, atoi(ws), env_device(),
+                                                idf.c_str());
+        }
+    }
     pwicp_series* s = nullptr;
-    if (pwicp_series_open(confile, startEpoch, epochNum, pairMode, overlapThd, env_device(), nullptr, 0, &s) != PWICP_OK) return false;
+    const std::vector<int32_t> devs = env_devices();            // every visible GPU unless the environment says otherwise
+    if (pwicp_series_open(confile, startEpoch, epochNum, pairMode, overlapThd, devs[0], nullptr, 0, &s) != PWICP_OK) return false;
+    if (devs.size() > 1 && pwicp_series_set_devices(s, devs.data(), (int)devs.size()) != PWICP_OK) { pwicp_series_close(s); return false; }
     const int n = pwicp_series_num_pairs(s);
     std::vector<pwicp_pair_record> recs((size_t)std::max(n, 1));
     std::vector<int32_t> all((size_t)std::max(n, 1));

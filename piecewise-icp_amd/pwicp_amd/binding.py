@@ -119,6 +119,9 @@ def load_library():
     L.pwicp_pc_resolution.restype = C.c_float
     L.PiecewiseICP_pair_call.argtypes = [C.c_char_p, C.c_char_p]
     L.PiecewiseICP_pair_call.restype = C.c_bool
+    L.pwicp_series_run_distributed.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    L.pwicp_series_run_distributed.restype = C.c_bool
+    L.pwicp_series_set_devices.argtypes = [vp, ip, C.c_int]
     L.PiecewiseICP_4D_call.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_float]
     L.PiecewiseICP_4D_call.restype = C.c_bool
     _lib = L
@@ -186,6 +189,13 @@ def sor_filter(cloud, sor_k=14, sor_mult=5.0):
     if rc != 0:
         raise PwicpError(rc, "pwicp_sor_filter")
     return out[:m.value].copy()
+
+
+def series_run_distributed(confile, startEpoch, epochNum, pairMode, overlapThd, rank, world, device, id_file):
+    """pwicp_series_run_distributed: one rank of the RCCL-gathered multi-process series (C++, no torch)."""
+    return bool(load_library().pwicp_series_run_distributed(str(confile).encode(), int(startEpoch), int(epochNum), int(pairMode),
+                                                            float(overlapThd), int(rank), int(world), int(device),
+                                                            str(id_file).encode()))
 
 
 def PiecewiseICP_pair_call(confile, outfile):
@@ -282,6 +292,13 @@ class Series:
         if rc != 0:
             raise PwicpError(rc, "pwicp_series_run_pairs")
         return recs
+
+    def set_devices(self, devices):
+        """Several GPUs in this process: pairs of a run_pairs call are dealt to them (pair k -> device k mod n)."""
+        d = np.ascontiguousarray(devices, np.int32)
+        rc = self._L.pwicp_series_set_devices(self._h, _p(d, ip), len(d))
+        if rc != 0:
+            raise PwicpError(rc, "pwicp_series_set_devices")
 
     def write_results(self, records):
         """records: structured array of RECORD rows (all pairs, any order).  Writes the reference's result files."""

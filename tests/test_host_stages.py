@@ -313,6 +313,54 @@ def test_series_driver_two_ranks_matches_single_process(tmp_path, ctx, pair_mode
         assert open(str(tmp_path / "single" / "RegPairFile.txt")).read() == open(str(tmp_path / "sharded" / "RegPairFile.txt")).read()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("pair_mode", [0, -1])
+def test_cpp_multi_device_and_rccl_paths_match_single_device(tmp_path, ctx, pair_mode):
+    """C++-native multi-GPU inside libpwicp.so: (a) PiecewiseICP_4D_call with PWICP_DEVICES=0,0 — two
+    workers (context + host thread each) sharing the one GPU of this box, pairs dealt round-robin, the shared target built
+    per worker; (b) pwicp_series_run_distributed at world 1 — the RCCL all-gather / broadcast path through librccl
+    (ncclCommInitRank with one rank).  Both must write the files of the plain single-device call, byte for byte."""
+    import shutil
+    import subprocess
+    import sys
+    import pwicp_amd as P
+    inp = tmp_path / "in"
+    inp.mkdir()
+    src = os.path.join(G.GOLD, "inputs")
+    for k, e in enumerate((1, 2, 8, 2, 1), start=1):
+        shutil.copy(os.path.join(src, "Epoch_%03d.pcd" % e), inp / ("Epoch_%03d.pcd" % k))
+    outs = {}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for tag in ("single", "two_workers", "rccl_world1"):
+        d = tmp_path / tag
+        d.mkdir()
+        out = str(d) + "/"
+        cfg = d / "cfg.txt"
+        _write_config(cfg, str(inp), out)
+        env = dict(os.environ)
+        env["PYTHONPATH"] = os.path.join(root, "piecewise-icp_amd") + os.pathsep + env.get("PYTHONPATH", "")
+        if tag == "single":
+            env["PWICP_DEVICES"] = "0"
+            code = "import pwicp_amd as P, sys; sys.exit(0 if P.PiecewiseICP_4D_call(%r, 0, 5, %d, 0.75) else 1)" % (str(cfg), pair_mode)
+        elif tag == "two_workers":
+            env["PWICP_DEVICES"] = "0,0"
+            code = "import pwicp_amd as P, sys; sys.exit(0 if P.PiecewiseICP_4D_call(%r, 0, 5, %d, 0.75) else 1)" % (str(cfg), pair_mode)
+        else:
+            code = ("import pwicp_amd as P, sys; sys.exit(0 if P.series_run_distributed(%r, 0, 5, %d, 0.75, 0, 1, 0, %r) else 1)"
+                    % (str(cfg), pair_mode, str(d / "rccl.id")))
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=str(d), env=env)
+        assert res.returncode == 0, tag + ": " + res.stdout[-2000:] + res.stderr[-2000:]
+        outs[tag] = out
+    mode = "Direct2Ref" if pair_mode == 0 else "Adaptive"
+    names = ["TransMatrices.txt", "TransParameters.txt", "TransMatrices_toRef.txt", "TransParameters_toRef.txt"] + \
+            ["%d_%s_TransMatrix.txt" % (e, mode) for e in (2, 3, 4, 5)]
+    for f in names:
+        a = open(outs["single"] + f).read()
+        assert len(a) > 50, f
+        assert a == open(outs["two_workers"] + f).read(), "two workers: " + f
+        assert a == open(outs["rccl_world1"] + f).read(), "rccl: " + f
+
+
 def test_pcd_with_non_finite_points(tmp_path):
     """PCL keeps NaN points of a file and every consumer on this path skips them; the reader drops them."""
     from pwicp_amd.pcd import read_pcd
