@@ -50,49 +50,63 @@ struct alignas(64) Pt {
     double x, y, z, nx, ny, nz;
 };
 
-// pca_estimate_normals.h:42-108 with unit weights, points in the given order
+// Plane normal of a point from its k nearest neighbours: the direction of least variance of the neighbourhood.
+// Specification (must be met to the last bit, the labels depend on it): the reference's front end
+// (codelibrary/geometry/point_cloud/pca_estimate_normals.h:42-108) accumulates, in double and in neighbour order, the mean
+// and then the six second moments about the mean, each divided by the number of neighbours; takes the smallest root of the
+// characteristic polynomial in closed form (trace shift q, scale p = sqrt(|B|^2 / 6), angle acos(det(B/p) / 2) / 3); and
+// returns the normalised cross product of the first two rows of (C - lambda I).  Written here as three steps over small
+// value types; the arithmetic of every step follows that specification operation by operation.
+struct Sym3 {                     // symmetric 3x3: xx xy xz yy yz zz
+    double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+};
+
+inline Sym3 neighbourhood_scatter(const Pt* P, const int32_t* nb, int k) {
+    double mean[3] = {0, 0, 0}, count = 0;
+    for (int e = 0; e < k; ++e) {
+        const Pt& v = P[nb[e]];
+        mean[0] += 1.0 * v.x; mean[1] += 1.0 * v.y; mean[2] += 1.0 * v.z;       // (unit weights, as the reference passes them)
+        count += 1.0;
+    }
+    const double to_mean = 1.0 / count;
+    for (double& m : mean) m *= to_mean;
+    Sym3 S;
+    double weight = 0;
+    for (int e = 0; e < k; ++e) {
+        const Pt& v = P[nb[e]];
+        const double d0 = v.x - mean[0], d1 = v.y - mean[1], d2 = v.z - mean[2];
+        S.xx += 1.0 * d0 * d0; S.xy += 1.0 * d0 * d1; S.xz += 1.0 * d0 * d2;
+        S.yy += 1.0 * d1 * d1; S.yz += 1.0 * d1 * d2; S.zz += 1.0 * d2 * d2;
+        weight += 1.0;
+    }
+    const double scale = 1.0 / weight;
+    S.xx = S.xx * scale; S.xy = S.xy * scale; S.xz = S.xz * scale; S.yy = S.yy * scale; S.yz = S.yz * scale; S.zz = S.zz * scale;
+    return S;
+}
+
+inline double smallest_eigenvalue(const Sym3& C) {
+    const double shift = (C.xx + C.yy + C.zz) / 3.0;
+    const double bx = C.xx - shift, by = C.yy - shift, bz = C.zz - shift;          // diagonal of B = C - shift * I
+    const double p = std::sqrt((bx * bx + by * by + bz * bz + 2.0 * (C.xy * C.xy + C.xz * C.xz + C.yz * C.yz)) / 6.0);
+    const double inv_p3 = std::pow(1.0 / p, 3.0);
+    const double det = inv_p3 * (bx * (by * bz - C.yz * C.yz) - C.xy * (C.xy * bz - C.yz * C.xz) + C.xz * (C.xy * C.yz - by * C.xz));
+    const double half = 0.5 * det;
+    const double angle = half <= -1.0 ? M_PI / 3.0 : (half >= 1.0 ? 0.0 : std::acos(half) / 3.0);
+    return shift + 2.0 * p * std::cos(angle + M_PI * (2.0 / 3.0));
+}
+
 void pca_normal(Pt* P, int self, const int32_t* nb, int k) {
-    double cx = 0, cy = 0, cz = 0, sum = 0;
-    for (int i = 0; i < k; ++i) {
-        const Pt& p = P[nb[i]];
-        const double w = 1.0;
-        cx += w * p.x; cy += w * p.y; cz += w * p.z;
-        sum += w;
-    }
-    const double inv = 1.0 / sum;
-    cx *= inv; cy *= inv; cz *= inv;
-    double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0, s = 0;
-    for (int i = 0; i < k; ++i) {
-        const Pt& p = P[nb[i]];
-        const double x = p.x - cx, y = p.y - cy, z = p.z - cz, w = 1.0;
-        a00 += w * x * x; a01 += w * x * y; a02 += w * x * z;
-        a11 += w * y * y; a12 += w * y * z; a22 += w * z * z;
-        s += w;
-    }
-    const double t = 1.0 / s;
-    a00 = a00 * t; a01 = a01 * t; a02 = a02 * t; a11 = a11 * t; a12 = a12 * t; a22 = a22 * t;
-    // least eigenvalue of the covariance matrix (trigonometric form)
-    const double q = (a00 + a11 + a22) / 3.0;
-    double pq = (a00 - q) * (a00 - q) + (a11 - q) * (a11 - q) + (a22 - q) * (a22 - q) +
-                2.0 * (a01 * a01 + a02 * a02 + a12 * a12);
-    pq = std::sqrt(pq / 6.0);
-    const double mpq = std::pow(1.0 / pq, 3.0);
-    const double det_b = mpq * ((a00 - q) * ((a11 - q) * (a22 - q) - a12 * a12) - a01 * (a01 * (a22 - q) - a12 * a02) +
-                                a02 * (a01 * a12 - (a11 - q) * a02));
-    const double r = 0.5 * det_b;
-    double phi;
-    if (r <= -1.0) phi = M_PI / 3.0;
-    else if (r >= 1.0) phi = 0.0;
-    else phi = std::acos(r) / 3.0;
-    const double eig = q + 2.0 * pq * std::cos(phi + M_PI * (2.0 / 3.0));
-    double nx = a01 * a12 - a02 * (a11 - eig);
-    double ny = a01 * a02 - a12 * (a00 - eig);
-    double nz = (a00 - eig) * (a11 - eig) - a01 * a01;
-    const double norm = std::sqrt(nx * nx + ny * ny + nz * nz);
-    Pt& o = P[self];
-    if (norm == 0.0) { o.nx = 0.0; o.ny = 0.0; o.nz = 1.0; return; }
-    const double f = 1.0 / norm;
-    o.nx = nx * f; o.ny = ny * f; o.nz = nz * f;
+    const Sym3 C = neighbourhood_scatter(P, nb, k);
+    const double lam = smallest_eigenvalue(C);
+    // null direction of (C - lam I): cross product of its first two rows
+    const double n0 = C.xy * C.yz - C.xz * (C.yy - lam);
+    const double n1 = C.xy * C.xz - C.yz * (C.xx - lam);
+    const double n2 = (C.xx - lam) * (C.yy - lam) - C.xy * C.xy;
+    const double len = std::sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+    Pt& out = P[self];
+    if (len == 0.0) { out.nx = 0.0; out.ny = 0.0; out.nz = 1.0; return; }
+    const double unit = 1.0 / len;
+    out.nx = n0 * unit; out.ny = n1 * unit; out.nz = n2 * unit;
 }
 
 struct Metric {      // Segmentation.h:362-375
