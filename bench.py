@@ -97,6 +97,64 @@ def cpu_baseline(tgt, l1, n1, src, l2, n2, passes=10):
     return best, mt, cores
 
 
+def series_workload(args, ctx, P, rank, world):
+    """BASELINE configs[4] shape on one GPU: the source epochs of a Direct2Ref series, one after the other, against ONE
+    device-side target (pwicp_target).  Per epoch: host->device upload of the cloud and its labels, patch selection + statistics,
+    query ordering, work buffers (pwicp_pair_create_with_target), then the registration loop.  Labels (front end) are setup.
+    Prints its own JSON line (metric pairs/s); the loop-only rate of the pair workload is not affected by it."""
+    from pwicp_amd import synth
+    r, n = R_SPACING, args.points
+    tgt, _ = synth.make_tile(n, r)
+    c = tgt.mean(axis=0)
+    tgt = (tgt - c).astype(np.float32)
+    prm = P.Params(r, r, 10 * r, 10 * r, 1, 10 * r, 0.8 * r)
+    l1, n1 = segment(tgt, 10 * r, ctx)
+    t0 = time.perf_counter()
+    T = P.Target(ctx, tgt, l1, n1, prm.Res1, prm.SVRes1)
+    t_target = time.perf_counter() - t0
+    epochs = []
+    for e in range(args.epochs):
+        s, _ = synth.make_source(n, r, epoch=1 + e + rank * args.epochs)
+        s = (s - c).astype(np.float32)
+        l2, n2 = segment(s, 10 * r, ctx)
+        epochs.append((P.f4(s), np.ascontiguousarray(l2, np.int32), n2))
+    import torch
+    torch.cuda.synchronize()
+    t_create = t_loop = 0.0
+    n_corr = up_bytes = 0
+    t0 = time.perf_counter()
+    for s4, l2, n2 in epochs:
+        ta = time.perf_counter()
+        pair = P.Pair(ctx, None, None, 0, s4, l2, n2, prm, target=T)
+        tb = time.perf_counter()
+        res = pair.run()
+        tc = time.perf_counter()
+        pair.close()
+        t_create += tb - ta
+        t_loop += tc - tb
+        n_corr += int(res.n_corr)
+        up_bytes += s4.nbytes + l2.nbytes
+    wall = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({
+            "metric": "pairs/sec (streamed Direct2Ref series, secondary line)", "value": round(args.epochs / wall, 3), "unit": "pairs/s",
+            "n_gpus": world, "steps": args.epochs, "warmup": 0, "ms_per_step": round(1e3 * wall / args.epochs, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Direct2Ref series, %d source epochs x %d points against one shared device-side target, one GPU, "
+                                   "epochs streamed one after the other (BASELINE configs[4] shape)" % (args.epochs, n),
+                       "points_per_cloud": n, "epochs": args.epochs},
+            "ms_per_pair": {"upload_select_grids": round(1e3 * t_create / args.epochs, 3), "loop": round(1e3 * t_loop / args.epochs, 3),
+                            "shared_target_once": round(1e3 * t_target, 3)},
+            "host_to_device": {"bytes_per_pair": up_bytes // args.epochs,
+                               "gbs_lower_bound": round(up_bytes / max(t_create, 1e-9) / 1e9, 2),
+                               "note": "bytes of one epoch / the whole pwicp_pair_create_with_target call (upload + patch selection + "
+                                       "query ordering + buffers): a lower bound of the PCIe rate; the loop itself is %.1f %% of a pair" %
+                                       (100.0 * t_loop / max(t_create + t_loop, 1e-9))},
+            "correspondences_per_s_incl_setup": round(n_corr / wall, 1)}))
+    T.close()
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,6 +164,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--labels", choices=["supervoxel", "grid"], default="supervoxel")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for debugging)")
+    ap.add_argument("--workload", choices=["pair", "series"], default="pair",
+                    help="pair (default): the BASELINE metric line.  series: a SECOND kind of line — a Direct2Ref 4D series streamed "
+                         "through one GPU (shared device-side target, one source epoch after the other: upload, patch selection, grids, "
+                         "loop), per-pair wall time and the host->device rate; never mixed into the pair line's `value`")
+    ap.add_argument("--epochs", type=int, default=4, help="source epochs of --workload series (BASELINE configs[4]: 4 per GPU at 5 M points)")
     ap.add_argument("--single-device", action="store_true",
                     help="debug: every rank uses GPU 0 (functional check of the N>1 path on a 1-GPU box; needs --backend gloo)")
     args = ap.parse_args()
@@ -135,8 +198,10 @@ def main():
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank) if args.backend == "nccl" or world == 1 else torch.device("cpu")
 
-    # ---- setup (untimed): data, labels, upload, patch selection/statistics, grids ------------------------
     ctx = P.Context(local_rank)
+    if args.workload == "series":
+        return series_workload(args, ctx, P, rank, world)
+    # ---- setup (untimed): data, labels, upload, patch selection/statistics, grids ------------------------
     tgt, l1, n1, src, l2, n2, Tgt = make_pair(args.points, epoch=rank + 1, ctx=ctx)
     r = R_SPACING
     prm = P.Params(r, r, 10 * r, 10 * r, 1, 10 * r, 0.8 * r)
