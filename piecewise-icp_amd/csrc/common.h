@@ -107,6 +107,11 @@ struct Grid {
     bool has_dense = false;
     DevBuf<int> dcell_start;
     DevBuf<float4> dpts;
+    // when `fine` is a grid of cells: the same small cells as columns, for pairs whose queries lie on gentle parts
+    GridLevel dense_alt{};
+    bool has_dense_alt = false;
+    DevBuf<int> acell_start;
+    DevBuf<float4> apts;
 };
 
 // grid.hip
@@ -123,6 +128,7 @@ int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pa
 // passes 1 / 2 of the fused percentile selection (select_dev.h) as launches of their own
 int pw_fs_pass_launch(pwicp_context* ctx, int pass, const struct FusedSelect& fs);
 int pw_grid_add_dense(pwicp_context* ctx, const float4* d_pts, int n, float cell_edge, Grid* g);
+int pw_dense_level_for(pwicp_context* ctx, const Grid& g, const float4* d_q, int nq, const GridLevel** out);
 // out[i] = src[order[i]]
 int pw_gather_int_launch(pwicp_context* ctx, const int* d_src, const int* d_order, int n, int* d_out);
 int pw_morton_order(pwicp_context* ctx, const GridDesc& g, const float4* d_pts, int n, DevBuf<int>* order);

@@ -876,14 +876,65 @@ int pw_count_below_launch(pwicp_context* ctx, const float* d_d2, int n, float th
 
 // third level of small cells over the same points, same layout (cells / columns) as g->d.fine
 int pw_grid_add_dense(pwicp_context* ctx, const float4* d_pts, int n, float cell_edge, Grid* g) {
-    g->has_dense = false;
+    g->has_dense = g->has_dense_alt = false;
     if (n <= 0 || !(cell_edge > 0.f)) return PWICP_OK;
     float mn[3], mx[3];
     PWCHK(pw_bbox(ctx, d_pts, n, mn, mx));
     const int axis = g->d.fine.ny == 1 && g->d.fine.inv_hy == 0.0f ? 1 : (g->d.fine.nz == 1 && g->d.fine.inv_hz == 0.0f ? 2 : 0);
     PWCHK(build_level(ctx, d_pts, n, cell_edge, mn, mx, &g->dense, &g->dcell_start, &g->dpts, axis));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     g->has_dense = true;
+    static int want_alt = -1;              // PWICP_DENSE_ALT=0: no level of columns beside a level of cells (A/B measurements)
+    if (want_alt < 0) { const char* e = getenv("PWICP_DENSE_ALT"); want_alt = e ? atoi(e) : 1; }
+    if (axis == 0 && want_alt) {
+        // The target as a whole prefers cells (steep or volumetric parts: pw_grid_build).  The QUERIES of a pair may still
+        // all lie where the cloud is a gentle sheet (patches on steep faces rarely survive the planarity gate), and there
+        // a level of columns costs the disc search a fifth of the rows: keep one, the pair decides (pw_dense_level_for).
+        const int alt = (mx[1] - mn[1]) < (mx[2] - mn[2]) ? 1 : 2;
+        PWCHK(build_level(ctx, d_pts, n, cell_edge, mn, mx, &g->dense_alt, &g->acell_start, &g->apts, alt));
+        g->has_dense_alt = true;
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PWICP_OK;
+}
+
+namespace {
+// points in the 3 x 3 (x 3) cells around every query, summed (the stencil occupancy the queries actually see)
+__global__ void k_query_occupancy(GridLevel g, const float4* __restrict__ q, int nq, unsigned long long* __restrict__ acc) {
+    unsigned long long s = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += gridDim.x * blockDim.x) {
+        const float4 v = q[i];
+        const int cx = cell_of(v.x, g.ox, g.inv_h), cy = cell_of(v.y, g.oy, g.inv_hy), cz = cell_of(v.z, g.oz, g.inv_hz);
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy) {
+                if ((g.inv_hz == 0.0f && dz != 0) || (g.inv_hy == 0.0f && dy != 0)) continue;
+                int lo, hi;
+                row_range(g, cy + dy, cz + dz, cx - 1, cx + 1, lo, hi);
+                s += (unsigned long long)(hi - lo);
+            }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(acc, s);
+}
+}  // namespace
+
+// The small-cell level the dense search of a pair should use: the target's layout, or — when that is cells and a level of
+// columns exists — columns if the queries' stencils hold at most kColsTolerance times as many points there (rows are what
+// the disc search pays for: 36 cell rows against 6 column rows per ball).  Synchronises the stream (one-off, at pair creation).
+int pw_dense_level_for(pwicp_context* ctx, const Grid& g, const float4* d_q, int nq, const GridLevel** out) {
+    *out = g.has_dense ? &g.dense : nullptr;
+    if (!g.has_dense || !g.has_dense_alt || nq <= 0) return PWICP_OK;
+    constexpr double kColsTolerance = 3.0;
+    DevBuf<unsigned long long> acc;
+    HIPCHK(ctx, acc.reserve(2));
+    HIPCHK(ctx, hipMemsetAsync(acc.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    const int nb = std::min(div_up(nq, kBlock), ctx->n_cu * 8);
+    hipLaunchKernelGGL(k_query_occupancy, dim3(nb), dim3(kBlock), 0, ctx->stream, g.dense, d_q, nq, acc.p);
+    hipLaunchKernelGGL(k_query_occupancy, dim3(nb), dim3(kBlock), 0, ctx->stream, g.dense_alt, d_q, nq, acc.p + 1);
+    unsigned long long h[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(h, acc.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if ((double)h[1] <= kColsTolerance * (double)std::max<unsigned long long>(h[0], 1ull)) *out = &g.dense_alt;
     return PWICP_OK;
 }
 

@@ -482,6 +482,7 @@ struct pwicp_pair {
     DevBuf<int> pt_patch2;   // patch id of every source patch point
     DevBuf<int> qorder;      // source patch points in Morton order of their initial target-grid cell
     DevBuf<int> qpatch;      // pt_patch2[qorder[i]]
+    const GridLevel* dense_lv = nullptr;   // small-cell level of the target this pair's dense search uses (pw_dense_level_for)
     DevBuf<int> all_stable;  // all-ones flags (bench replay over every patch)
     // per-iteration work
     DevBuf<int> mCTBP, stable, blk_cnt;   // matches of the 7*m2 centroid+boundary queries
@@ -554,6 +555,7 @@ int finish_create(pwicp_pair* pr) {
     HIPCHK(ctx, pr->pt_patch2.reserve((size_t)std::max(pr->P2.tot, 1)));
     PWCHK(pw_point_patch_ids_launch(ctx, pr->P2.off.p, m2, pr->pt_patch2.p));
     PWCHK(pw_morton_order(ctx, pr->tgt->g_c1.d, pr->P2.pat.p, pr->P2.tot, &pr->qorder));
+    PWCHK(pw_dense_level_for(ctx, pr->tgt->g_c1, pr->P2.pat.p, pr->P2.tot, &pr->dense_lv));
     HIPCHK(ctx, pr->qpatch.reserve((size_t)std::max(pr->P2.tot, 1)));
     PWCHK(pw_gather_int_launch(ctx, pr->pt_patch2.p, pr->qorder.p, pr->P2.tot, pr->qpatch.p));
     // pristine source copies; centroids and boundary points live in ONE buffer so that a single NN launch and a
@@ -1045,7 +1047,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
             }
             // the percentile selection rides on the launches that follow (select_dev.h): pass 0 in the dense kernel, pass 1
             // beside the transform, pass 2 beside the next front (or on its own when this is the last iteration)
-            const bool fused = pr->tgt->g_c1.has_dense && !pr->no_fused_select;
+            const bool fused = pr->dense_lv && !pr->no_fused_select;
             FusedSelect fs{};
             unsigned sel_seq = 0;
             if (fused) {
@@ -1058,7 +1060,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
             }
             PWCHK(pw_nn_dense_launch(ctx, pr->tgt->g_c1.d, pr->P2.pat.p, pr->qorder.p, pr->pt_patch2.p, pr->stable.p,
                                          pr->P2.tot, pr->d2dense.p, pr->examined.p,
-                                         pr->tgt->g_c1.has_dense ? &pr->tgt->g_c1.dense : nullptr, pr->qpatch.p, fused ? &fs : nullptr));
+                                         pr->dense_lv, pr->qpatch.p, fused ? &fs : nullptr));
             if (ev) {
                 HIPCHK(ctx, hipEventRecord(pr->event(n_ev + 1), ctx->stream));
                 n_ev += 2;
@@ -1137,7 +1139,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     }
     res->dense_kbar = res->n_corr_dense > 0 ? (double)ex / (double)res->n_corr_dense : 0.0;
     // 0: disc-pruned search (rows vary with the candidate's distance); 3 / 9: the stencil kernel on columns / cells
-    res->dense_rows = pr->tgt->g_c1.has_dense ? 0 : ((pr->tgt->g_c1.d.fine.ny == 1 || pr->tgt->g_c1.d.fine.nz == 1) ? 3 : 9);
+    res->dense_rows = pr->dense_lv ? 0 : ((pr->tgt->g_c1.d.fine.ny == 1 || pr->tgt->g_c1.d.fine.nz == 1) ? 3 : 9);
     res->status = status;
     HIPCHK(ctx, hipGetLastError());
     return status;
@@ -1207,7 +1209,7 @@ int pwicp_pair_step(pwicp_pair* pr, pwicp_step* sp) {
     else if (currDT == LoDet_min) stage3 = true;
     if (!stage2) {
         PWCHK(pw_nn_dense_launch(ctx, pr->tgt->g_c1.d, pr->P2.pat.p, pr->qorder.p, pr->pt_patch2.p, pr->stable.p, pr->P2.tot,
-                                 pr->d2dense.p, nullptr, pr->tgt->g_c1.has_dense ? &pr->tgt->g_c1.dense : nullptr, pr->qpatch.p));
+                                 pr->d2dense.p, nullptr, pr->dense_lv, pr->qpatch.p));
         double Dist75 = 0;
         PWCHK(select_p75(pr, pr->P2.tot, nsp, &Dist75));
         sp->d75 = Dist75;
@@ -1290,7 +1292,7 @@ int pwicp_pair_bench_dense_nn(pwicp_pair* pr, int n_launches, double* ms_per_lau
     }
     HIPCHK(ctx, hipMemsetAsync(pr->examined.p, 0, 256 * 16 * sizeof(unsigned long long), ctx->stream));
     // warm-up launch (also measures Kbar)
-    const GridLevel* dense = pr->tgt->g_c1.has_dense ? &pr->tgt->g_c1.dense : nullptr;
+    const GridLevel* dense = pr->dense_lv;
     PWCHK(pw_nn_dense_launch(ctx, pr->tgt->g_c1.d, pr->pat2_0.p, pr->qorder.p, pr->pt_patch2.p, flags, tot,
                                  pr->d2dense.p, pr->examined.p, dense, pr->qpatch.p));
     unsigned long long ex = 0;

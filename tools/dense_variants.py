@@ -15,6 +15,10 @@ n = int(os.environ.get("DV_POINTS", "1000000")); r = 0.005
 ctx = P.Context(0)
 t, L = synth.make_tile(n, r); s, _ = synth.make_source(n, r, epoch=1); c = t.mean(0)
 t = (t - c).astype(np.float32); s = (s - c).astype(np.float32)
+if os.environ.get("DV_SHAPE") == "cliff":
+    # cliff-like scene: steep faces (slope up to ~9) so that a column of the grid holds a tall stack of points
+    for a in (t, s):
+        a[:, 2] += (1.5 * np.sin(6.0 * a[:, 0])).astype(np.float32)
 l1, n1 = synth.grid_labels(t, 10 * r); l2, n2 = synth.grid_labels(s, 10 * r)
 prm = P.Params(r, r, 10 * r, 10 * r, 1, 10 * r, 0.8 * r)
 pair = P.Pair(ctx, t, l1, n1, s, l2, n2, prm); pair.set_profiling(1 | 4)
