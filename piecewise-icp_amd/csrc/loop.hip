@@ -502,7 +502,7 @@ struct pwicp_pair {
     // mailbox in pinned coherent host memory: [0] sequence word, [16..] payload
     unsigned* mail_h = nullptr;
     unsigned* mail_d = nullptr;
-    unsigned mail_seq = 0;
+    unsigned mail_seq = 0, sel_mail_seq = 0;
     ~pwicp_pair() {
         for (auto e : ev) (void)hipEventDestroy(e);
         if (mail_h) (void)hipHostFree(mail_h);
@@ -833,16 +833,18 @@ int pwicp_pair_num_patch_points(const pwicp_pair* pr, int* tot1, int* tot2) {
     return PWICP_OK;
 }
 
+constexpr int kSelMailSeq = 4, kSelMailPayload = 8;      // mailbox words of the percentile selection
+
 // waits until the mailbox sequence word reaches `seq` (spin, then fall back to a stream synchronisation)
-static int mail_wait(pwicp_pair* pr, unsigned seq) {
+static int mail_wait(pwicp_pair* pr, unsigned seq, int word = 0) {
     pwicp_context* ctx = pr->ctx;
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
-    while (__atomic_load_n(&pr->mail_h[0], __ATOMIC_ACQUIRE) != seq) {
+    while (__atomic_load_n(&pr->mail_h[word], __ATOMIC_ACQUIRE) != seq) {
         if ((++spins & 0x3ff) == 0 &&
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) {
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            if (__atomic_load_n(&pr->mail_h[0], __ATOMIC_ACQUIRE) != seq) {
+            if (__atomic_load_n(&pr->mail_h[word], __ATOMIC_ACQUIRE) != seq) {
                 ctx->set_err("pwicp: device mailbox never signalled");
                 return PWICP_E_INTERNAL;
             }
@@ -861,9 +863,11 @@ static int select_p75_enqueue(pwicp_pair* pr, int n_slots, int n_valid, unsigned
     pwicp_context* ctx = pr->ctx;
     int k = (int)((float)n_valid * 0.75f);      // C.cpp:177
     if (k >= n_valid) k = n_valid - 1;
-    const unsigned seq = ++pr->mail_seq;
+    // the selection has mailbox words of its own (sequence word 4, payload word 8): its message may be overtaken by later
+    // ICP messages when the search was enqueued speculatively
+    const unsigned seq = ++pr->sel_mail_seq;
     SelectMail mail;
-    mail.dst = pr->mail_d + 16; mail.seq_ptr = pr->mail_d; mail.seq = seq;
+    mail.dst = pr->mail_d + kSelMailPayload; mail.seq_ptr = pr->mail_d + kSelMailSeq; mail.seq = seq;
     PWCHK(pw_select_kth_launch(ctx, pr->d2dense.p, n_slots, k, pr->sel_scratch.p, pr->sel_out.p, /*armed*/ true, &mail));
     *seq_out = seq;
     return PWICP_OK;
@@ -871,9 +875,9 @@ static int select_p75_enqueue(pwicp_pair* pr, int n_slots, int n_valid, unsigned
 
 // ... and pick the value up (work enqueued in between hides the round trip)
 static int select_p75_finish(pwicp_pair* pr, unsigned seq, double* out) {
-    PWCHK(mail_wait(pr, seq));
+    PWCHK(mail_wait(pr, seq, kSelMailSeq));
     float v;
-    memcpy(&v, pr->mail_h + 16, 4);
+    memcpy(&v, pr->mail_h + kSelMailPayload, 4);
     *out = (double)sqrtf(v);                    // C.cpp:277
     return PWICP_OK;
 }
@@ -946,6 +950,49 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                            pr->n2, nb_cloud, pr->ctbp2.p, 7 * m2, pr->P2.pat.p, pr->P2.tot, (const IcpState*)pr->icp.state.p,
                            (const unsigned*)(slot + 2), pr->bbox_part.p, slot, nb_cloud + nb_rest, fs ? *fs : none);
     };
+    // (7) of a Stage-1 iteration: dense NN of the stable patches' points against the full target cloud (C.cpp:266-281) with the
+    // percentile selection riding on the launches that follow (select_dev.h): pass 0 in the dense kernel, pass 1 beside the
+    // transform, pass 2 beside the next front (or on its own when no front follows).  `rank_dev`: the rank of the percentile is
+    // derived on the device from the slot's stable-point count (speculative enqueue, before the host knows the count).
+    unsigned sel_seq = 0;
+    auto enqueue_dense_tail = [&](unsigned* slot, int nsp, bool rank_dev, bool with_front) -> int {
+        const bool ev = (pr->profiling & PWICP_PROF_DENSE) != 0;
+        if (ev) {
+            ev_kind.push_back({n_ev, 0});
+            HIPCHK(ctx, hipEventRecord(pr->event(n_ev), ctx->stream));
+        }
+        const bool fused = pr->dense_lv && !pr->no_fused_select;
+        FusedSelect fs{};
+        if (fused) {
+            int kk = (int)((float)nsp * 0.75f);         // C.cpp:177
+            if (kk >= nsp) kk = nsp - 1;
+            fs.scratch = pr->fs_scratch.p; fs.vals = pr->d2dense.p; fs.n = pr->P2.tot; fs.k = kk; fs.nblk = kFsBlocks;
+            if (rank_dev) fs.n_valid_dev = slot + 3;
+            fs.out = pr->sel_out.p;
+            sel_seq = ++pr->sel_mail_seq;
+            fs.mail.dst = pr->mail_d + kSelMailPayload; fs.mail.seq_ptr = pr->mail_d + kSelMailSeq; fs.mail.seq = sel_seq;
+        }
+        PWCHK(pw_nn_dense_launch(ctx, pr->tgt->g_c1.d, pr->P2.pat.p, pr->qorder.p, pr->pt_patch2.p, pr->stable.p, pr->P2.tot,
+                                 pr->d2dense.p, pr->examined.p, pr->dense_lv, pr->qpatch.p, fused ? &fs : nullptr));
+        if (ev) {
+            HIPCHK(ctx, hipEventRecord(pr->event(n_ev + 1), ctx->stream));
+            n_ev += 2;
+        }
+        if (res->n_dense_nn_launches == 0 && (pr->profiling & PWICP_PROF_REPLAY))      // remember the first launch for stand-alone replays
+            HIPCHK(ctx, hipMemcpyAsync(pr->stable0.p, pr->stable.p, (size_t)m2 * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+        if (!fused) PWCHK(select_p75_enqueue(pr, pr->P2.tot, nsp, &sel_seq));
+        // the percentile only steers the threshold: transform and next front go out while it travels
+        static int nb1 = -1;
+        if (nb1 < 0) { const char* e = getenv("PWICP_FS_BLOCKS1"); nb1 = e ? std::max(atoi(e), 1) : 64; }
+        fs.nblk = nb1;
+        enqueue_transform(slot, fused ? &fs : nullptr);
+        fs.nblk = kFsBlocks;
+        if (with_front) PWCHK(enqueue_front(fused ? &fs : nullptr));
+        else if (fused) PWCHK(pw_fs_pass_launch(ctx, 2, fs));
+        return PWICP_OK;
+    };
+    static int speculate = -1;             // PWICP_SPECULATE_DENSE=0: never enqueue the first dense search ahead of the ICP result
+    if (speculate < 0) { const char* e = getenv("PWICP_SPECULATE_DENSE"); speculate = e ? atoi(e) : 1; }
     const auto t0 = std::chrono::steady_clock::now();
     while (!stage3) {                                                   // R.cpp:680
         const int k = res->n_outer;
@@ -972,6 +1019,14 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         const bool early_xf = stage2;
         const bool early_front = stage2 && !(currDT == prev_lod);
         bool xf_enqueued = false;
+        // First iteration, still Stage 1: the dense search will almost certainly be needed (the clouds have just moved by the
+        // whole initial misalignment), and it reads the PRE-transform positions, which do not change while the ICP iterates.
+        // So it goes out right behind the first ICP batch, with the transform and the next front behind it, instead of after
+        // the host has seen the ICP result (an exposed round trip of ~16 us).  Should the schedule switch to Stage 2 in
+        // this very iteration, its result is simply not used; if the ICP needs more than the first batch, the transform /
+        // front that were enqueued were no-ops / premature and are enqueued again.
+        const bool spec_dense = speculate && k == 0 && !stage2 && pr->dense_lv && !pr->no_fused_select && !(pr->profiling & PWICP_PROF_REPLAY);
+        bool spec_done = false, spec_xf_valid = false;
         unsigned hs[kSlot], hb[6];
         IcpState hst;
         {
@@ -1002,12 +1057,18 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                     enqueue_transform(slot);                 // no-op on the device while the ICP has not converged
                     if (early_front) PWCHK(enqueue_front());
                 }
+                const bool spec_now = spec_dense && !spec_done;
+                if (spec_now) { PWCHK(enqueue_dense_tail(slot, 0, /*rank_dev*/ true, /*with_front*/ true)); spec_done = true; }
                 PWCHK(mail_wait(pr, seq));
                 memcpy(hs, pr->mail_h + 16, sizeof(hs));
                 memcpy(hb, pr->mail_h + 16 + kSlot, sizeof(hb));
                 memcpy(&hst, pr->mail_h + 16 + kSlot + 6, sizeof(IcpState));
                 // (fewer than 4 stable patches: R.cpp:864-867 stops below; the ICP state is then meaningless)
-                if (hst.done || hst.iters >= 100 || (int)hs[2] < 4) { xf_enqueued = early_xf; front_ready = early_xf && early_front; break; }
+                if (hst.done || hst.iters >= 100 || (int)hs[2] < 4) {
+                    xf_enqueued = early_xf; front_ready = early_xf && early_front;
+                    spec_xf_valid = spec_now && hst.done && (int)hs[2] >= 4;     // the transform behind THIS batch saw the converged state
+                    break;
+                }
                 batch = 2;
             }
         }
@@ -1038,48 +1099,19 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         res->d75[k] = -1.0;
         if (!stage2 && maxBB < minLoD) stage2 = true;
         else if (currDT == LoDet_min) stage3 = true;
+        if (spec_done && stage2) {
+            // the schedule switched to Stage 2 in this iteration: the speculative search is not used (its mailbox message is
+            // consumed so that the sequence numbers stay in step)
+            double unused = 0;
+            PWCHK(select_p75_finish(pr, sel_seq, &unused));
+        }
         if (!stage2) {
-            // dense NN of the stable patches' points against the full target cloud (C.cpp:266-281)
-            const bool ev = (pr->profiling & PWICP_PROF_DENSE) != 0;
-            if (ev) {
-                ev_kind.push_back({n_ev, 0});
-                HIPCHK(ctx, hipEventRecord(pr->event(n_ev), ctx->stream));
+            if (!spec_done) {
+                PWCHK(enqueue_dense_tail(slot, nsp, false, !stage3));
+                xf_enqueued = true;
+                front_ready = !stage3;
             }
-            // the percentile selection rides on the launches that follow (select_dev.h): pass 0 in the dense kernel, pass 1
-            // beside the transform, pass 2 beside the next front (or on its own when this is the last iteration)
-            const bool fused = pr->dense_lv && !pr->no_fused_select;
-            FusedSelect fs{};
-            unsigned sel_seq = 0;
-            if (fused) {
-                int kk = (int)((float)nsp * 0.75f);         // C.cpp:177
-                if (kk >= nsp) kk = nsp - 1;
-                fs.scratch = pr->fs_scratch.p; fs.vals = pr->d2dense.p; fs.n = pr->P2.tot; fs.k = kk; fs.nblk = kFsBlocks;
-                fs.out = pr->sel_out.p;
-                sel_seq = ++pr->mail_seq;
-                fs.mail.dst = pr->mail_d + 16; fs.mail.seq_ptr = pr->mail_d; fs.mail.seq = sel_seq;
-            }
-            PWCHK(pw_nn_dense_launch(ctx, pr->tgt->g_c1.d, pr->P2.pat.p, pr->qorder.p, pr->pt_patch2.p, pr->stable.p,
-                                         pr->P2.tot, pr->d2dense.p, pr->examined.p,
-                                         pr->dense_lv, pr->qpatch.p, fused ? &fs : nullptr));
-            if (ev) {
-                HIPCHK(ctx, hipEventRecord(pr->event(n_ev + 1), ctx->stream));
-                n_ev += 2;
-            }
-            if (res->n_dense_nn_launches == 0 && (pr->profiling & PWICP_PROF_REPLAY)) {   // remember the first launch for stand-alone replays
-                HIPCHK(ctx, hipMemcpyAsync(pr->stable0.p, pr->stable.p, (size_t)m2 * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
-                pr->ns0 = ns; pr->nsp0 = nsp;
-            }
-            if (!fused) PWCHK(select_p75_enqueue(pr, pr->P2.tot, nsp, &sel_seq));
-            // the percentile only steers the threshold: transform and next front go out while it travels
-            // (pass 1 flushes most of its 2048 bins per block with returning atomics, which serialise per cache line: few blocks)
-            static int nb1 = -1;
-            if (nb1 < 0) { const char* e = getenv("PWICP_FS_BLOCKS1"); nb1 = e ? std::max(atoi(e), 1) : 64; }
-            fs.nblk = nb1;
-            enqueue_transform(slot, fused ? &fs : nullptr);
-            xf_enqueued = true;
-            fs.nblk = kFsBlocks;
-            if (!stage3) { PWCHK(enqueue_front(fused ? &fs : nullptr)); front_ready = true; }
-            else if (fused) PWCHK(pw_fs_pass_launch(ctx, 2, fs));
+            if (pr->profiling & PWICP_PROF_REPLAY) { pr->ns0 = ns; pr->nsp0 = nsp; }
             double Dist75 = 0;
             PWCHK(select_p75_finish(pr, sel_seq, &Dist75));
             res->n_corr += nsp; res->n_corr_dense += nsp; res->n_dense_nn_launches++;
@@ -1099,6 +1131,11 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
             BB2 = BB1; BB1 = maxBB;
         }
 
+        if (spec_done) {
+            // what went out behind the first ICP batch: valid if that batch already held the converged state
+            xf_enqueued = spec_xf_valid;
+            front_ready = spec_xf_valid && !stage3;
+        }
         if (!xf_enqueued) enqueue_transform(slot);                      // (8)
         // (9) R.cpp:958-961: stable centroids as copied BEFORE the update (R.cpp:868)
         if (stage3) {

@@ -24,7 +24,9 @@ struct FusedSelect {
     unsigned* scratch = nullptr;          // kFsWords words, zeroed once at allocation (every selection leaves it zeroed); nullptr: off
     const float* vals = nullptr;          // the dense kernel's output (sentinel 0xffffffff in unused slots)
     int n = 0;                            // slots
-    int k = 0;                            // rank (0-based) among the non-sentinel values
+    int k = 0;                            // rank (0-based) among the non-sentinel values ...
+    const unsigned* n_valid_dev = nullptr;   // ... or, when set, int(*n_valid_dev * 0.75f) (C.cpp:177) evaluated on the device: the
+                                          // number of values is then not known to the host when the launch is enqueued
     int nblk = 0;                         // blocks running an embedded pass
     float* out = nullptr;                 // selected value (device)
     SelectMail mail{};                    // sent by pass 2
@@ -82,7 +84,13 @@ __device__ __forceinline__ void fs_pick0(unsigned* h, const FusedSelect& fs, uns
     unsigned base = 0;
     for (int w = 0; w < wave; ++w) base += s_w[w];
     const unsigned excl = base + incl - local;
-    const unsigned k = (unsigned)fs.k;
+    unsigned k = (unsigned)fs.k;
+    if (fs.n_valid_dev) {
+        const int nv = (int)*fs.n_valid_dev;
+        int kk = (int)((float)nv * 0.75f);
+        if (kk >= nv) kk = nv - 1;
+        k = (unsigned)max(kk, 0);
+    }
     if (k >= excl && k < excl + local) {
         unsigned run = excl;
 #pragma unroll
