@@ -199,8 +199,9 @@ PWICP_API int pwicp_pair_create_with_target(pwicp_target* target, const float* c
                                             pwicp_pair** out);
 PWICP_API void pwicp_pair_destroy(pwicp_pair* pair);
 PWICP_API int  pwicp_pair_num_patches(const pwicp_pair* pair, int* m1, int* m2);
-/* Restores the source-side arrays to their uploaded state (the loop transforms them in place,
- * R.cpp:943-954) so the same pair can be registered again. Device-to-device copies only. */
+/* Puts the source side back into its uploaded state (the loop transforms it in place, R.cpp:943-954) so that the same pair
+ * can be registered again.  Nothing is copied here: the next pwicp_pair_run reads the pristine device copies until its first
+ * transform has rewritten the working arrays; any other consumer of the working arrays restores them on demand. */
 PWICP_API int pwicp_pair_reset(pwicp_pair* pair);
 /* The while-loop of Piecewise_ICP (R.cpp:680-694) = repeated PwICP_singleIteration
  * (R.cpp:704-972; decl R.h:181-188), entirely on the device. */

@@ -205,9 +205,12 @@ constexpr int kBoxParts = 64;
 // The transformation is read from the ICP state on the device, so that the launch can be enqueued BEFORE the host
 // has seen the ICP result; it does nothing unless that ICP call has converged on >= 4 stable patches (the host then
 // takes the slow path and enqueues it again).
-__global__ void __launch_bounds__(kBlock) k_transform_all(float4* __restrict__ cloud, int n, int nb_cloud,
-                                                          float4* __restrict__ ctbp, int n_ctbp,
-                                                          float4* __restrict__ pat, int n_pat,
+// `*_in` == the output arrays except in the first transform of a run on a reset pair, which reads the PRISTINE copies (the
+// source state is restored by that transform instead of by a 48 MB device-to-device copy per pwicp_pair_reset).
+__global__ void __launch_bounds__(kBlock) k_transform_all(const float4* cloud_in, const float4* ctbp_in, const float4* pat_in,
+                                                          float4* cloud, int n, int nb_cloud,
+                                                          float4* ctbp, int n_ctbp,
+                                                          float4* pat, int n_pat,
                                                           const IcpState* __restrict__ st, const unsigned* __restrict__ ns_dev,
                                                           unsigned* __restrict__ bbox_part, unsigned* __restrict__ slot,
                                                           int nb_work, FusedSelect fs) {
@@ -233,7 +236,7 @@ __global__ void __launch_bounds__(kBlock) k_transform_all(float4* __restrict__ c
             for (int u = 0; u < 4; ++u) {
                 const int j = i + u * stride;
                 q[u] = (j < n_ctbp) ? (ctbp + j) : (pat + (j - n_ctbp));
-                if (j < ntot) v[u] = *q[u];
+                if (j < ntot) v[u] = (j < n_ctbp) ? ctbp_in[j] : pat_in[j - n_ctbp];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -248,7 +251,7 @@ __global__ void __launch_bounds__(kBlock) k_transform_all(float4* __restrict__ c
             float4 v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (i + u * stride < n) v[u] = cloud[i + u * stride];
+                if (i + u * stride < n) v[u] = cloud_in[i + u * stride];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (i + u * stride < n) {
@@ -478,6 +481,14 @@ struct pwicp_pair {
     DevBuf<float4> ctbp2, ctbp2_0;   // live / pristine source centroids [0,m2) followed by boundary points [m2,7m2)
     float bmin0[3] = {0, 0, 0}, bmax0[3] = {0, 0, 0};   // tight bbox of the uploaded source cloud
     float step_bmin[3] = {0, 0, 0}, step_bmax[3] = {0, 0, 0};   // ... of the current source cloud (pwicp_pair_step)
+    // Lazy reset: after pwicp_pair_reset the working arrays (cloud2, P2.pat, ctbp2) are stale and the pristine copies ARE the
+    // source state; pwicp_pair_run reads them until its first transform has written the working arrays.  Everything else that
+    // touches the working arrays calls materialize() first.
+    bool dirty = false;      // the working arrays differ from the pristine copies
+    bool lazy = false;       // ... and a reset is pending
+    const float4* src_cloud() const { return lazy ? cloud2_0.p : cloud2.p; }
+    const float4* src_pat() const { return lazy ? pat2_0.p : P2.pat.p; }
+    const float4* src_ctbp() const { return lazy ? ctbp2_0.p : ctbp2.p; }
     DevBuf<float4> nrm2;
     DevBuf<int> pt_patch2;   // patch id of every source patch point
     DevBuf<int> qorder;      // source patch points in Morton order of their initial target-grid cell
@@ -786,19 +797,31 @@ int pwicp_pair_num_patches(const pwicp_pair* pr, int* m1, int* m2) {
     return PWICP_OK;
 }
 
-int pwicp_pair_reset(pwicp_pair* pr) {
-    if (!pr) return PWICP_E_INVALID;
+// the pristine copies back into the working arrays, in ONE launch (three copy commands cost two more launch gaps than they
+// move bytes); only when something needs the working arrays of a reset pair before a run has rewritten them
+static int materialize(pwicp_pair* pr) {
+    if (!pr->lazy) return PWICP_OK;
     pwicp_context* ctx = pr->ctx;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    // the three pristine copies back in ONE launch (three copy commands cost two more launch gaps than they move bytes)
     const long long n1 = pr->n2, n2 = pr->P2.tot, n3 = (long long)pr->P2.m * 7, tot = n1 + n2 + n3;
     if (tot > 0) {
         const int nb = (int)std::min<long long>((tot + kBlock - 1) / kBlock, (long long)ctx->n_cu * 16);
         hipLaunchKernelGGL(k_restore3, dim3(nb), dim3(kBlock), 0, ctx->stream, pr->cloud2.p, (const float4*)pr->cloud2_0.p, n1,
                            pr->P2.pat.p, (const float4*)pr->pat2_0.p, n2, pr->ctbp2.p, (const float4*)pr->ctbp2_0.p, n3);
     }
-    for (int d = 0; d < 3; ++d) { pr->step_bmin[d] = pr->bmin0[d]; pr->step_bmax[d] = pr->bmax0[d]; }
+    pr->lazy = false;
+    pr->dirty = false;
     HIPCHK(ctx, hipGetLastError());
+    return PWICP_OK;
+}
+
+int pwicp_pair_reset(pwicp_pair* pr) {
+    if (!pr) return PWICP_E_INVALID;
+    pwicp_context* ctx = pr->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // nothing moves here: the next pwicp_pair_run reads the pristine copies until its first transform has rewritten the
+    // working arrays (a reset used to be a 48 MB device-to-device restore per registration at 1 M points)
+    if (pr->dirty) pr->lazy = true;
+    for (int d = 0; d < 3; ++d) { pr->step_bmin[d] = pr->bmin0[d]; pr->step_bmax[d] = pr->bmax0[d]; }
     return PWICP_OK;
 }
 
@@ -806,6 +829,7 @@ int pwicp_pair_download_source(pwicp_pair* pr, float* cloud2_xyz4) {
     if (!pr || !cloud2_xyz4) return PWICP_E_INVALID;
     pwicp_context* ctx = pr->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    PWCHK(materialize(pr));
     HIPCHK(ctx, hipMemcpyAsync(cloud2_xyz4, pr->cloud2.p, (size_t)pr->n2 * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return PWICP_OK;
@@ -818,6 +842,7 @@ int pwicp_pair_download_state(pwicp_pair* pr, float* cloud2_xyz4, float* centroi
     pwicp_context* ctx = pr->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int m2 = pr->P2.m;
+    PWCHK(materialize(pr));
     if (cloud2_xyz4) HIPCHK(ctx, hipMemcpyAsync(cloud2_xyz4, pr->cloud2.p, (size_t)pr->n2 * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
     if (centroid2_xyz4 && m2) HIPCHK(ctx, hipMemcpyAsync(centroid2_xyz4, pr->ctbp2.p, (size_t)m2 * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
     if (boundary2_xyz4 && m2) HIPCHK(ctx, hipMemcpyAsync(boundary2_xyz4, pr->ctbp2.p + m2, (size_t)m2 * 6 * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
@@ -896,15 +921,13 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     for (int i = 0; i < 16; ++i) res->T16[i] = (i % 5 == 0) ? 1.f : 0.f;
     const pwicp_params& prm = pr->prm;
     const int m2 = pr->P2.m, nbp2 = 6 * m2;
-    float4* const ct2 = pr->ctbp2.p;
-    float4* const bp2 = pr->ctbp2.p + m2;
     size_t n_ev = 0;
     std::vector<std::pair<size_t, int>> ev_kind;   // (start event index, kind 0 dense / 1 inner)
 
     // R.cpp:626-631
     float DTinit = prm.DTinit;
     if (!prm.isManualDTinit) {
-        PWCHK(pw_nn_launch(ctx, pr->tgt->g_c1.d, pr->cloud2.p, pr->n2, nullptr, pr->d2dense.p, nullptr));
+        PWCHK(pw_nn_launch(ctx, pr->tgt->g_c1.d, pr->src_cloud(), pr->n2, nullptr, pr->d2dense.p, nullptr));
         double d75 = 0;
         PWCHK(select_p75(pr, pr->n2, pr->n2, &d75));
         DTinit = (float)(d75 * 3.0);
@@ -933,12 +956,14 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     // "front" of the next iteration (NN of centroids/boundary points + source patch normals) needs no threshold.
     bool front_ready = false;                 // front of iteration k already enqueued by iteration k-1
     float prev_lod = NAN;
-    auto enqueue_front = [&](const FusedSelect* fs = nullptr) -> int {
+    // src_now: the front of the CURRENT iteration's state (pristine arrays on a lazily reset pair until the first transform);
+    // false: the front of the NEXT iteration, enqueued behind a transform, reads the working arrays that transform writes
+    auto enqueue_front = [&](const FusedSelect* fs = nullptr, bool src_now = false) -> int {
         // (1) R.cpp:737-747 — CT2 and BP2 queries against the static target-centroid grid — and the source patch
         // normals for CTcloud2_withNorm (R.cpp:824), recomputed from the transformed patch points: one launch
         // (+ pass 2 of the percentile selection on a few extra blocks when a dense search has just run)
-        return pw_front_launch(ctx, pr->P2.pat.p, pr->P2.off.p, m2, pr->nrm2.p, pr->tgt->g_ct1.d, pr->ctbp2.p, 7 * m2,
-                               pr->mCTBP.p, pr->dCTBP.p, fs);
+        return pw_front_launch(ctx, src_now ? pr->src_pat() : pr->P2.pat.p, pr->P2.off.p, m2, pr->nrm2.p, pr->tgt->g_ct1.d,
+                               src_now ? pr->src_ctbp() : pr->ctbp2.p, 7 * m2, pr->mCTBP.p, pr->dCTBP.p, fs);
     };
     auto enqueue_transform = [&](unsigned* slot, const FusedSelect* fs = nullptr) {
         // (8) R.cpp:943-954: cloud2 (+ its new bbox into this slot), centroids + boundary points, patch points
@@ -946,9 +971,10 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         const int nb_cloud = std::min(div_up(pr->n2, kBlock), ctx->n_cu * 8);
         const int nb_rest = std::min(div_up(7 * m2 + pr->P2.tot, kBlock), ctx->n_cu * 8);
         FusedSelect none{};
-        hipLaunchKernelGGL(k_transform_all, dim3(nb_cloud + nb_rest + (fs ? fs->nblk : 0)), dim3(kBlock), 0, ctx->stream, pr->cloud2.p,
-                           pr->n2, nb_cloud, pr->ctbp2.p, 7 * m2, pr->P2.pat.p, pr->P2.tot, (const IcpState*)pr->icp.state.p,
-                           (const unsigned*)(slot + 2), pr->bbox_part.p, slot, nb_cloud + nb_rest, fs ? *fs : none);
+        hipLaunchKernelGGL(k_transform_all, dim3(nb_cloud + nb_rest + (fs ? fs->nblk : 0)), dim3(kBlock), 0, ctx->stream, pr->src_cloud(),
+                           pr->src_ctbp(), pr->src_pat(), pr->cloud2.p, pr->n2, nb_cloud, pr->ctbp2.p, 7 * m2, pr->P2.pat.p, pr->P2.tot,
+                           (const IcpState*)pr->icp.state.p, (const unsigned*)(slot + 2), pr->bbox_part.p, slot, nb_cloud + nb_rest,
+                           fs ? *fs : none);
     };
     // (7) of a Stage-1 iteration: dense NN of the stable patches' points against the full target cloud (C.cpp:266-281) with the
     // percentile selection riding on the launches that follow (select_dev.h): pass 0 in the dense kernel, pass 1 beside the
@@ -972,7 +998,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
             sel_seq = ++pr->sel_mail_seq;
             fs.mail.dst = pr->mail_d + kSelMailPayload; fs.mail.seq_ptr = pr->mail_d + kSelMailSeq; fs.mail.seq = sel_seq;
         }
-        PWCHK(pw_nn_dense_launch(ctx, pr->tgt->g_c1.d, pr->P2.pat.p, pr->qorder.p, pr->pt_patch2.p, pr->stable.p, pr->P2.tot,
+        PWCHK(pw_nn_dense_launch(ctx, pr->tgt->g_c1.d, pr->src_pat(), pr->qorder.p, pr->pt_patch2.p, pr->stable.p, pr->P2.tot,
                                  pr->d2dense.p, pr->examined.p, pr->dense_lv, pr->qpatch.p, fused ? &fs : nullptr));
         if (ev) {
             HIPCHK(ctx, hipEventRecord(pr->event(n_ev + 1), ctx->stream));
@@ -1001,8 +1027,10 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         if (4 > m2 || 1 > pr->tgt->P1.m) { status = PWICP_E_TOO_FEW_PATCHES; break; }   // R.cpp:728-731; an empty target has no match
         unsigned* const slot = pr->scal.p + (size_t)kSlot * k;
 
-        if (!front_ready) PWCHK(enqueue_front());
+        if (!front_ready) PWCHK(enqueue_front(nullptr, true));
         front_ready = false;
+        const float4* const ct2 = pr->src_ctbp();
+        const float4* const bp2 = pr->src_ctbp() + m2;
         res->n_corr += (long long)m2 + nbp2;
         // (2)-(4)
         const float DTctct = currDT + 1 * (prm.SVRes1 + prm.SVRes2);   // R.cpp:817
@@ -1137,6 +1165,8 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
             front_ready = spec_xf_valid && !stage3;
         }
         if (!xf_enqueued) enqueue_transform(slot);                      // (8)
+        pr->lazy = false;                   // a valid transform is on the stream: from here on the working arrays are the source state
+        pr->dirty = true;
         // (9) R.cpp:958-961: stable centroids as copied BEFORE the update (R.cpp:868)
         if (stage3) {
             // last iteration: the VCM's final launch also sends the run's closing message (VCM | diagnostic counter)
@@ -1202,6 +1232,7 @@ int pwicp_pair_step(pwicp_pair* pr, pwicp_step* sp) {
     for (int i = 0; i < 16; ++i) sp->T16[i] = (i % 5 == 0) ? 1.f : 0.f;
     if (sp->currDT <= DTmin) sp->currDT = DTmin;                                    // R.cpp:724-725
     if (4 > m2 || 1 > pr->tgt->P1.m) return sp->status = PWICP_E_TOO_FEW_PATCHES;  // R.cpp:728-731
+    PWCHK(materialize(pr));                  // (a lazily reset pair: the working arrays are restored now)
     const float currDT_in = sp->currDT;
     // one scalar slot, re-armed for this call
     unsigned* const slot = pr->scal.p;
@@ -1269,9 +1300,11 @@ int pwicp_pair_step(pwicp_pair* pr, pwicp_step* sp) {
         const int nb_cloud = std::min(div_up(pr->n2, kBlock), ctx->n_cu * 8);
         const int nb_rest = std::min(div_up(7 * m2 + pr->P2.tot, kBlock), ctx->n_cu * 8);
         FusedSelect none{};
-        hipLaunchKernelGGL(k_transform_all, dim3(nb_cloud + nb_rest), dim3(kBlock), 0, ctx->stream, pr->cloud2.p, pr->n2, nb_cloud,
-                           pr->ctbp2.p, 7 * m2, pr->P2.pat.p, pr->P2.tot, (const IcpState*)pr->icp.state.p, (const unsigned*)(slot + 2),
-                           pr->bbox_part.p, slot, nb_cloud + nb_rest, none);
+        hipLaunchKernelGGL(k_transform_all, dim3(nb_cloud + nb_rest), dim3(kBlock), 0, ctx->stream, (const float4*)pr->cloud2.p,
+                           (const float4*)pr->ctbp2.p, (const float4*)pr->P2.pat.p, pr->cloud2.p, pr->n2, nb_cloud, pr->ctbp2.p, 7 * m2,
+                           pr->P2.pat.p, pr->P2.tot, (const IcpState*)pr->icp.state.p, (const unsigned*)(slot + 2), pr->bbox_part.p, slot,
+                           nb_cloud + nb_rest, none);
+        pr->dirty = true;
         HIPCHK(ctx, hipMemcpyAsync(hs, slot, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         for (int d = 0; d < 3; ++d) { pr->step_bmin[d] = ord2f_host(hs[4 + d]); pr->step_bmax[d] = ord2f_host(hs[7 + d]); }
@@ -1289,7 +1322,7 @@ int pwicp_pair_auto_dtinit(pwicp_pair* pr, float* DTinit) {
     if (!pr || !DTinit) return PWICP_E_INVALID;
     pwicp_context* ctx = pr->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    PWCHK(pw_nn_launch(ctx, pr->tgt->g_c1.d, pr->cloud2.p, pr->n2, nullptr, pr->d2dense.p, nullptr));
+    PWCHK(pw_nn_launch(ctx, pr->tgt->g_c1.d, pr->src_cloud(), pr->n2, nullptr, pr->d2dense.p, nullptr));
     double d75 = 0;
     PWCHK(select_p75(pr, pr->n2, pr->n2, &d75));
     *DTinit = (float)(d75 * 3.0);
