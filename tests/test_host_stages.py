@@ -376,3 +376,42 @@ def test_pcd_with_non_finite_points(tmp_path):
     assert P.PiecewiseICP_pair_call(str(cfg), str(tmp_path) + "/x_") is False
     a = read_pcd(str(g))                                   # the python-side reader of the test utilities keeps the raw rows
     assert a.shape[0] == 4 and np.isnan(a[1]).all()
+
+
+def test_composition_and_error_entry_points_reproduce_reference_files(tmp_path):
+    """The C entry points behind calTransToReferenceEpoch (R.cpp:977-1153) and calAbsErrorOfTransPara (R.cpp:1157-1251), no GPU
+    needed: from the reference's own TransMatrices.txt + the adaptive pair map recovered in SURVEY 4 they must reproduce the
+    reference's TransMatrices_toRef.txt, and from that file + the ground truth its TransPara_AbsError.txt."""
+    import ctypes as C
+    import pwicp_amd as P
+    from test_distributed_cpu import _read_matrices, ADAPTIVE_REL
+    L = P.load_library()
+    gold = os.path.join(G.GOLD, "reference_results")
+    pair_file = tmp_path / "RegPairFile.txt"
+    pair_file.write_text("".join("%d %d\n" % (k, ADAPTIVE_REL[k]) for k in range(1, 20)))
+    n = 19
+    stamps = (C.c_int32 * n)()
+    T = (C.c_float * (16 * n))()
+    V = (C.c_double * (36 * n))()
+    L.pwicp_trans_to_reference_epoch.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p,
+                                                 C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_double)]
+    out_tm, out_tp = str(tmp_path / "toRef.txt"), str(tmp_path / "toRefPara.txt")
+    rc = L.pwicp_trans_to_reference_epoch(os.path.join(gold, "TransMatrices.txt").encode(), -1, str(pair_file).encode(), n,
+                                          out_tm.encode(), out_tp.encode(), stamps, T, V)
+    assert rc == 0 and list(stamps) == list(range(2, 21))
+    Tr, Vr = _read_matrices(os.path.join(gold, "TransMatrices_toRef.txt"), n)
+    Tm, Vm = _read_matrices(out_tm, n)
+    for i in range(n):
+        assert np.abs(Tm[i] - Tr[i]).max() < 5e-6 and np.allclose(Vm[i], Vr[i], rtol=2e-3, atol=3e-12)
+        assert np.array_equal(np.array(T[16 * i:16 * i + 16], np.float32).reshape(4, 4), Tm[i])
+    # a missing pair file is an error code, not an exit()
+    assert L.pwicp_trans_to_reference_epoch(os.path.join(gold, "TransMatrices.txt").encode(), -1, b"/nonexistent/pairs.txt", n,
+                                            out_tm.encode(), out_tp.encode(), stamps, T, V) != 0
+    L.pwicp_abs_error_of_trans_para.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p]
+    err = str(tmp_path / "err.txt")
+    assert L.pwicp_abs_error_of_trans_para(os.path.join(gold, "TransMatrices_toRef.txt").encode(),
+                                           os.path.join(gold, "defined_transformations.txt").encode(), 20, 0, err.encode()) == 0
+    a = np.loadtxt(err, skiprows=1)
+    b = np.loadtxt(os.path.join(gold, "TransPara_AbsError.txt"), skiprows=1)
+    assert a.shape == b.shape == (19, 6)
+    assert np.allclose(a, b, rtol=2e-3, atol=2e-3)          # mgon / mm, printed with 6 significant digits by the reference
