@@ -26,6 +26,7 @@
 #include <unordered_set>
 #include <vector>
 
+#include "frontend.h"
 #include "hostbuf.h"
 #include "kdtree.h"
 #include "parallel.h"
@@ -45,10 +46,7 @@ struct StageTimer {
     }
 };
 
-// one cache line per point: position and PCA normal (double, as in the reference's front end)
-struct alignas(64) Pt {
-    double x, y, z, nx, ny, nz;
-};
+using Pt = pwhost::FePt;      // one cache line per point: position and PCA normal (double, as in the reference's front end)
 
 // Plane normal of a point from its k nearest neighbours: the direction of least variance of the neighbourhood.
 // Specification (must be met to the last bit, the labels depend on it): the reference's front end
@@ -193,8 +191,9 @@ int count_occupied_cells(const Pt* P, int n, double resolution) {
 // writes is appended to one arena (list of node i = arena[off[i] .. off[i]+len[i])) which is compacted in place
 // between rounds.  The serial, order-dependent fusion pass therefore allocates nothing per supervoxel and touches
 // little fresh memory (first-touch page faults dominate this stage on virtualised hosts).
+// roots_out != nullptr: stop after the fusion; labels = root point of every point, *roots_out = the roots in ascending order
 int supervoxel_segmentation(const Metric& metric, const int32_t* nb, int k, int n_points, int n_supervoxels,
-                            std::vector<int>* labels_out) {
+                            std::vector<int>* labels_out, std::vector<int>* roots_out = nullptr) {
     StageTimer tm;
     DisjointSet set(n_points);
     std::vector<int> supervoxels((size_t)n_points);
@@ -311,6 +310,7 @@ int supervoxel_segmentation(const Metric& metric, const int32_t* nb, int k, int 
     labels.resize((size_t)n_points);
     for (int i = 0; i < n_points; ++i) labels[(size_t)i] = set.find(i);
     tm.lap("  fusion");
+    if (roots_out) { *roots_out = supervoxels; return (int)supervoxels.size(); }
 
     // ---- step 2: boundary refinement -------------------------------------------------------------------------
     pwhost::parallel_for(n_points, [&](long long lo, long long hi) {
@@ -452,6 +452,26 @@ int segment_from_neighbors(const float* cloud_xyz4, int n, const int32_t* nb, in
 }  // namespace
 
 namespace pwhost {
+// stages of the front end for the device pipeline (csrc/frontend.hip), see frontend.h
+void fe_points_and_normals(const float* cloud_xyz4, int n, const int32_t* nb, int k, FePt* P) {
+    parallel_for(n, [&](long long lo, long long hi) {
+        for (long long i = lo; i < hi; ++i) {
+            P[(size_t)i].x = (double)cloud_xyz4[4 * (size_t)i];
+            P[(size_t)i].y = (double)cloud_xyz4[4 * (size_t)i + 1];
+            P[(size_t)i].z = (double)cloud_xyz4[4 * (size_t)i + 2];
+        }
+    });
+    parallel_for(n, [&](long long lo, long long hi) {
+        for (long long i = lo; i < hi; ++i) pca_normal(P, (int)i, nb + (size_t)i * (size_t)k, k);
+    });
+}
+int fe_count_occupied_cells(const FePt* P, int n, double resolution) { return count_occupied_cells(P, n, resolution); }
+int fe_fusion_host(const FePt* P, const int32_t* nb, int k, int n, double resolution, int n_supervoxels, std::vector<int>* root_of,
+                   std::vector<int>* roots) {
+    Metric metric{P, resolution};
+    return supervoxel_segmentation(metric, nb, k, n, n_supervoxels, root_of, roots);
+}
+
 // host part of the front end from a given k-NN graph (thread-safe: no shared state), see io.h
 int segment_from_knn(const float* cloud_xyz4, int n, const int32_t* nb, int k, float sv_resolution, int32_t* labels,
                      int* n_supervoxels) {
@@ -491,7 +511,9 @@ PWICP_API int pwicp_frontend_segment_dev(pwicp_context* ctx, const float* cloud_
     if (!nb.reserve((size_t)n * knn)) return PWICP_E_NOMEM;
     const int rc = pwicp_knn(ctx, cloud_xyz4, n, knn, point_spacing > 0.f ? 2.0f * point_spacing : 0.f, nb.data());
     if (rc != PWICP_OK) return rc;
-    return segment_from_neighbors(cloud_xyz4, n, nb.data(), knn, sv_resolution, labels, n_supervoxels);
+    const char* e = std::getenv("PWICP_FRONTEND");
+    if (e && std::strcmp(e, "host") == 0) return segment_from_neighbors(cloud_xyz4, n, nb.data(), knn, sv_resolution, labels, n_supervoxels);
+    return pw_frontend_labels(ctx, cloud_xyz4, n, nb.data(), knn, sv_resolution, labels, n_supervoxels);
 }
 
 }  // extern "C"

@@ -1,0 +1,28 @@
+// Stages of the segmentation front end shared between the host pipeline (frontend.cpp) and the device pipeline
+// (csrc/frontend.hip): S.cpp:18-68 = k-NN graph -> PCA normals -> supervoxel fusion -> boundary refinement -> relabel.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+namespace pwhost {
+
+// one cache line per point: position and PCA normal (double, as in the reference's front end); same layout on the device
+struct alignas(64) FePt {
+    double x, y, z, nx, ny, nz;
+};
+
+// float -> double positions (S.cpp:18-22) and PCA normals (pca_estimate_normals.h:42-108) of all points, host threads
+void fe_points_and_normals(const float* cloud_xyz4, int n, const int32_t* nb, int k, FePt* P);
+// number of occupied cells of edge `resolution` (grid_sample.h:30-75) = the supervoxel count the fusion stops at
+int fe_count_occupied_cells(const FePt* P, int n, double resolution);
+// the serial fusion (supervoxel_segmentation.h:65-170): root point of every point and the roots in ascending order
+int fe_fusion_host(const FePt* P, const int32_t* nb, int k, int n, double resolution, int n_supervoxels, std::vector<int>* root_of,
+                   std::vector<int>* roots);
+
+}  // namespace pwhost
+
+// csrc/frontend.hip: supervoxel labels from the k-NN graph (host array), heavy passes on the device
+struct pwicp_context;
+int pw_frontend_labels(pwicp_context* ctx, const float* cloud_xyz4, int n, const int32_t* nb, int k, float sv_resolution,
+                       int32_t* labels, int* n_supervoxels);

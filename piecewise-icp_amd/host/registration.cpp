@@ -23,6 +23,7 @@
 #include <thread>
 #include <vector>
 
+#include "frontend.h"
 #include "hostbuf.h"
 #include "io.h"
 #include "parallel.h"
@@ -54,12 +55,19 @@ struct Prepared {
     HostBuf<int32_t> nb;           // k-NN graph, m x kNN (released by prepare_host)
     std::vector<int32_t> lab;
     int nsv = 0;
+    bool segmented = false;        // labels already made by the device pipeline
     pwicp_target* dev = nullptr;   // device side of a TARGET (cloud, patches, normals, grids), built at its first pair
     Prepared() = default;
     Prepared(const Prepared&) = delete;
     Prepared& operator=(const Prepared&) = delete;
     ~Prepared() { if (dev) pwicp_target_destroy(dev); }
 };
+
+// $PWICP_FRONTEND=host keeps the serial host passes (same labels); default: the device pipeline
+bool frontend_on_device() {
+    const char* e = std::getenv("PWICP_FRONTEND");
+    return !(e && std::string(e) == "host");
+}
 
 // GPU part.  shift_in == nullptr: the cloud is a target and is reduced by its own centroid (R.cpp:419-436:
 // pcl::compute3DCentroid float sums, float shift); otherwise the target's shift is applied.
@@ -96,11 +104,22 @@ bool prepare_gpu(pwicp_context* ctx, const std::vector<float>& raw, float Res, f
         std::cerr << "Error: supervoxel segmentation failed: " << pwicp_last_error(ctx) << "\n";
         return false;
     }
+    if (frontend_on_device()) {                                    // S.cpp:42-68 on the device (csrc/frontend.hip)
+        c->lab.resize((size_t)m);
+        const int rc = pw_frontend_labels(ctx, c->p.data(), m, c->nb.data(), kNN, c->SVRes, c->lab.data(), &c->nsv);
+        c->nb.release();
+        if (rc != PWICP_OK) {
+            std::cerr << "Error: supervoxel segmentation failed: " << pwicp_last_error(ctx) << "\n";
+            return false;
+        }
+        c->segmented = true;
+    }
     return true;
 }
 
 // host part (thread-safe): supervoxel labels (S.cpp:42-68)
 bool prepare_host(Prepared* c) {
+    if (c->segmented) return true;
     c->lab.resize((size_t)c->m);
     const int rc = segment_from_knn(c->p.data(), c->m, c->nb.data(), kNN, c->SVRes, c->lab.data(), &c->nsv);
     c->nb.release();
