@@ -20,9 +20,11 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cfloat>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "common.h"
@@ -193,6 +195,430 @@ __global__ void k_relabel(int* __restrict__ lab, int n, const int* __restrict__ 
     if (i < n) lab[i] = map[lab[i]];
 }
 
+// ================================================================================================================
+// Supervoxel fusion (supervoxel_segmentation.h:104-170)
+// ================================================================================================================
+// One round (one value of lambda) of the reference visits the current supervoxel roots ("centres") in ascending order;
+// centre i runs a breadth-first search over the roots adjacent to it, absorbs every root j with
+// lambda - size(j) * metric(i, j) > 0 (its neighbours join the search) and keeps the others as its new adjacency list.
+// What centre i sees depends on the centres before it: a root absorbed earlier is seen through its absorber, an earlier
+// centre has its new size and adjacency.  State as of "time i" for a node x, from the standing outcomes of the last sweep:
+//     absorber   ab[x]  (the smallest centre whose outcome absorbs x), followed while the absorbers are < i and increasing
+//     size       x < i ? size after x's own turn : size at the start of the round
+//     adjacency  x < i and x ran ? its new list : its list at the start of the round
+// A sweep re-runs the centres on the work list in parallel (one wavefront per centre: lanes = candidates / list entries,
+// the search order of the reference is kept with ballots, so the lists come out in the reference's order); then the nodes
+// whose state changed wake the centres that may have read them (reverse index of the base lists + the absorber chains).
+// No work left <=> every centre's outcome is consistent with the outcomes before it <=> the serial result.
+
+struct FusState {
+    // static in a round
+    const FePt* P;
+    double res, lambda;
+    const int* root0;          // [n] root of a point at the start of the round
+    const int* s0;             // [n] size of a root
+    const int* len0;           // [n] length of its adjacency list (0: absorbed in an earlier round / isolated)
+    const long long* off0;     // [n] offset of the list in arena0
+    const int* arena0;
+    const int* revoff;         // [n + 1] reverse index: owners of base entries whose root0 is x
+    const int* revown;
+    // standing outcomes
+    int* ab;                   // [n] absorber, kNone
+    int* ab_prev;              // [n] absorber as of the previous sweep
+    int* rec_sz;               // [n] size after the node's own turn (= s0 when it did not run)
+    int* rec_ran;              // [n]
+    int* rec_absn;             // [n] absorbed nodes, in order, at sa[rec_ptr ..], followed by rec_adjn adjacent nodes
+    int* rec_adjn;
+    long long* rec_ptr;
+    int* sa;                   // list arena of the round (bump allocated; nothing is freed inside a round)
+    unsigned long long* sa_top;
+    unsigned long long sa_cap;
+    // work lists and per-slot outcomes of the running sweep
+    const int* W;
+    int* slot_of;              // [n] slot of a centre on W (only valid when W[slot_of[x]] == x)
+    int* o_sz; int* o_ran; int* o_absn; int* o_adjn; long long* o_ptr; int* o_dirty; long long* o_oldptr; int* o_oldabsn;
+    int* wake;                 // [n] 1: already on the next work list
+    int* Wnext; int* nWnext;
+    int* dflag;                // [n] 1: already on a dirty list
+    int* status;               // [0] queue overflow, [1] arena overflow, [2] dirty closure deeper than the levels run
+};
+
+constexpr int kFusQueue = 512, kFusHash = 1024;
+#define WSYNC()                                               \
+    do {                                                      \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                      \
+    } while (0)
+
+struct FusWave {           // per-wavefront scratch (LDS)
+    int* keys; int* vals; int* queue;
+    int qn, gcount;
+    bool overflow;
+};
+
+__device__ __forceinline__ int fus_root_at(const FusState& s, int y, int t) {
+    int x = s.root0[y], g = -1;
+    for (;;) {
+        const int c = s.ab[x];
+        if (c >= t || c <= g) break;
+        g = c; x = c;
+    }
+    return x;
+}
+
+// roots of the entries of a list join the search, in list order, each once
+__device__ __forceinline__ void fus_expand(const FusState& s, FusWave& w, const int* __restrict__ lp, int len, int i, int lane) {
+    for (int base = 0; base < len && !w.overflow; base += 64) {
+        const int e = base + lane;
+        const bool valid = e < len;
+        int slot = 0;
+        int r = 0;
+        const int gidx = w.gcount + lane;
+        if (valid) {
+            r = fus_root_at(s, lp[e], i);
+            slot = (int)(((unsigned)r * 2654435761u) >> 22) & (kFusHash - 1);
+            for (;;) {
+                const int prev = atomicCAS(&w.keys[slot], -1, r);
+                if (prev == -1 || prev == r) break;
+                slot = (slot + 1) & (kFusHash - 1);
+            }
+            atomicMin(&w.vals[slot], gidx);
+        }
+        WSYNC();
+        const bool first = valid && w.vals[slot] == gidx;
+        const unsigned long long m = __ballot(first);
+        const int add = __popcll(m);
+        if (w.qn + add > kFusQueue) { w.overflow = true; break; }
+        if (first) w.queue[w.qn + __popcll(m & ((1ull << lane) - 1ull))] = r;
+        w.qn += add;
+        w.gcount += 64;
+        WSYNC();
+    }
+}
+
+__global__ void __launch_bounds__(256) k_fus_run(FusState s, int nW) {
+    __shared__ int s_keys[4][kFusHash];
+    __shared__ int s_vals[4][kFusHash];
+    __shared__ int s_queue[4][kFusQueue];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    FusWave w;
+    w.keys = s_keys[wave]; w.vals = s_vals[wave]; w.queue = s_queue[wave];
+    for (int slot = blockIdx.x * 4 + wave; slot < nW; slot += gridDim.x * 4) {
+        const int i = s.W[slot];
+        if (lane == 0) { s.slot_of[i] = slot; s.wake[i] = 0; }
+        const int old_ran = s.rec_ran[i], old_sz = s.rec_sz[i], old_absn = s.rec_absn[i], old_adjn = s.rec_adjn[i];
+        const long long old_ptr = s.rec_ptr[i];
+        int ran = 0, size_i = s.s0[i], nabs = 0;
+        w.qn = 1; w.gcount = 0; w.overflow = false;
+        if (s.len0[i] != 0 && !(s.ab[i] < i)) {
+            ran = 1;
+            for (int t = lane; t < kFusHash; t += 64) { w.keys[t] = -1; w.vals[t] = INT_MAX; }
+            WSYNC();
+            if (lane == 0) {
+                const int sl = (int)(((unsigned)i * 2654435761u) >> 22) & (kFusHash - 1);
+                w.keys[sl] = i; w.vals[sl] = -1;
+                w.queue[0] = i;
+            }
+            WSYNC();
+            fus_expand(s, w, s.arena0 + s.off0[i], s.len0[i], i, lane);
+            const FePt me = s.P[i];
+            int front = 1;
+            while (front < w.qn && !w.overflow) {
+                const int stop = w.qn;
+                for (int base = front; base < stop && !w.overflow; base += 64) {
+                    const int idx = base + lane;
+                    const bool valid = idx < stop;
+                    const int j = valid ? w.queue[idx] : 0;
+                    int sj = 0;
+                    bool absorb = false;
+                    if (valid) {
+                        sj = j < i ? s.rec_sz[j] : s.s0[j];
+                        const double loss = (double)sj * sv_metric(me, s.P[j], s.res);
+                        absorb = s.lambda - loss > 0.0;
+                        if (absorb) w.queue[idx] = j | (int)0x80000000;
+                    }
+                    unsigned long long A = __ballot(absorb);
+                    while (A && !w.overflow) {
+                        const int l = __builtin_ctzll(A);
+                        A &= A - 1ull;
+                        const int jj = __builtin_amdgcn_readlane(j, l);
+                        size_i += __builtin_amdgcn_readlane(sj, l);
+                        ++nabs;
+                        if (jj < i && s.rec_ran[jj]) fus_expand(s, w, s.sa + s.rec_ptr[jj] + s.rec_absn[jj], s.rec_adjn[jj], i, lane);
+                        else fus_expand(s, w, s.arena0 + s.off0[jj], s.len0[jj], i, lane);
+                    }
+                }
+                front = stop;
+            }
+        }
+        if (w.overflow) {
+            if (lane == 0) { s.o_dirty[slot] = 2; s.status[0] = 1; }
+            continue;
+        }
+        // outcome: absorbed nodes then adjacent nodes, each in search order; unchanged lists keep their place in the arena
+        const int total = ran ? w.qn - 1 : 0;
+        const int nadj = total - nabs;
+        bool same = ran == old_ran && size_i == old_sz && nabs == old_absn && nadj == old_adjn;
+        for (int pass = 0; pass < 2; ++pass) {
+            long long ptr = old_ptr;
+            if (pass == 0 && !same) continue;
+            if (pass == 1) {
+                if (same) break;
+                unsigned long long at = 0;
+                if (lane == 0) at = atomicAdd(s.sa_top, (unsigned long long)total);
+                at = __shfl(at, 0);
+                if (at + (unsigned long long)total > s.sa_cap) {
+                    if (lane == 0) { s.o_dirty[slot] = 2; s.status[1] = 1; }
+                    same = true;          // (nothing is written; the host aborts)
+                    break;
+                }
+                ptr = (long long)at;
+            }
+            int na = 0, nd = 0;
+            bool diff = false;
+            for (int base = 1; base <= total; base += 64) {
+                const int idx = base + lane;
+                const bool valid = idx <= total;
+                const int q = valid ? w.queue[idx] : 0;
+                const bool isab = valid && q < 0;
+                const unsigned long long ma = __ballot(isab), mv = __ballot(valid);
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                const int node = q & 0x7fffffff;
+                const long long at = isab ? (long long)(na + __popcll(ma & lt)) : (long long)(nabs + nd + __popcll((mv & ~ma) & lt));
+                if (valid) {
+                    if (pass == 0) diff |= s.sa[ptr + at] != node;
+                    else s.sa[ptr + at] = node;
+                }
+                na += __popcll(ma);
+                nd += __popcll(mv & ~ma);
+            }
+            if (pass == 0) {
+                if (same && __ballot(diff)) same = false;
+            } else if (lane == 0) {
+                s.o_ptr[slot] = ptr;
+            }
+        }
+        if (lane == 0) {
+            s.o_sz[slot] = size_i; s.o_ran[slot] = ran; s.o_absn[slot] = nabs; s.o_adjn[slot] = nadj;
+            if (same) s.o_ptr[slot] = old_ptr;
+            s.o_dirty[slot] = same ? 0 : 1;
+            s.o_oldptr[slot] = old_ptr; s.o_oldabsn[slot] = old_absn;
+        }
+    }
+}
+
+// the claims of the outcomes that changed: first all old ones are withdrawn, then the new ones are made (two launches)
+__global__ void k_fus_retract(FusState s, int nW) {
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nW || s.o_dirty[slot] != 1) return;
+    const int c = s.W[slot];
+    const long long p = s.o_oldptr[slot];
+    for (int e = 0, m = s.o_oldabsn[slot]; e < m; ++e) {
+        const int j = s.sa[p + e];
+        if (s.ab[j] == c) s.ab[j] = kNone;
+    }
+}
+__global__ void k_fus_claim(FusState s, int nW) {
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nW || s.o_dirty[slot] != 1) return;
+    const int c = s.W[slot];
+    s.rec_sz[c] = s.o_sz[slot]; s.rec_ran[c] = s.o_ran[slot]; s.rec_absn[c] = s.o_absn[slot]; s.rec_adjn[c] = s.o_adjn[slot];
+    s.rec_ptr[c] = s.o_ptr[slot];
+    const long long p = s.o_ptr[slot];
+    for (int e = 0, m = s.o_absn[slot]; e < m; ++e) atomicMin(&s.ab[s.sa[p + e]], c);
+}
+
+__device__ __forceinline__ void fus_mark_dirty(const FusState& s, int x, int* dq, int* ndq) {
+    if (atomicExch(&s.dflag[x], 1) == 0) dq[atomicAdd(ndq, 1)] = x;
+}
+
+// level 0 of the dirty list: centres whose outcome changed, nodes whose absorber changed
+__global__ void k_fus_dirty0(FusState s, int nW, int* dq, int* ndq) {
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nW || s.o_dirty[slot] != 1) return;
+    const int c = s.W[slot];
+    fus_mark_dirty(s, c, dq, ndq);
+    for (int pass = 0; pass < 2; ++pass) {
+        const long long p = pass ? s.o_ptr[slot] : s.o_oldptr[slot];
+        const int m = pass ? s.o_absn[slot] : s.o_oldabsn[slot];
+        for (int e = 0; e < m; ++e) {
+            const int j = s.sa[p + e];
+            if (s.ab[j] != s.ab_prev[j]) fus_mark_dirty(s, j, dq, ndq);
+        }
+    }
+}
+
+__device__ __forceinline__ void fus_wake_chain(const FusState& s, int owner) {
+    for (int pass = 0; pass < 2; ++pass) {
+        const int* ab = pass ? s.ab_prev : s.ab;
+        int x = owner, g = -1;
+        for (;;) {
+            if (atomicExch(&s.wake[x], 1) == 0) s.Wnext[atomicAdd(s.nWnext, 1)] = x;
+            const int nx = ab[x];
+            if (nx == kNone || nx <= g) break;
+            g = nx; x = nx;
+        }
+    }
+}
+
+// one level of the closure: a changed node wakes the owners of the base entries that lead to it (and whoever absorbed
+// them, transitively); the nodes it has absorbed (old and new outcome) are reached through it, so they are changed too
+__global__ void k_fus_wake_level(FusState s, int* dq, int* ndq, const int* lvl, int last) {
+    for (int t = lvl[0] + blockIdx.x * blockDim.x + threadIdx.x; t < lvl[1]; t += gridDim.x * blockDim.x) {
+        const int x = dq[t];
+        fus_wake_chain(s, x);
+        for (int e = s.revoff[x], m = s.revoff[x + 1]; e < m; ++e) fus_wake_chain(s, s.revown[e]);
+        for (int pass = 0; pass < 2; ++pass) {
+            long long p; int m;
+            if (pass == 0) { p = s.rec_ptr[x]; m = s.rec_absn[x]; }
+            else {
+                const int slot = s.slot_of[x];
+                if (slot < 0 || s.W[slot] != x || s.o_dirty[slot] != 1) break;     // (slot_of is only meaningful for this sweep's W)
+                p = s.o_oldptr[slot]; m = s.o_oldabsn[slot];
+            }
+            for (int e = 0; e < m; ++e) {
+                const int ch = s.sa[p + e];
+                if (atomicExch(&s.dflag[ch], 1) == 0) {
+                    if (last) s.status[2] = 1;
+                    dq[atomicAdd(ndq, 1)] = ch;
+                }
+            }
+        }
+    }
+}
+__global__ void k_fus_snap(const int* ndq, int* lvl_next) { *lvl_next = *ndq; }
+
+__global__ void k_fus_sweep_end(FusState s, const int* dq, const int* ndq) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < *ndq; t += gridDim.x * blockDim.x) {
+        const int x = dq[t];
+        s.dflag[x] = 0;
+        s.ab_prev[x] = s.ab[x];
+    }
+}
+
+// ---- set-up and hand-over between rounds ----------------------------------------------------------------------------
+// smallest metric to a neighbour (:91-102); lambda0 = its median
+__global__ void k_fus_min_metric(const FePt* __restrict__ P, const int* __restrict__ nb, int k, int n, double res, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int* row = nb + (size_t)i * k;
+    const FePt me = P[i];
+    double d = DBL_MAX;
+    for (int e = 0; e < k; ++e) {
+        const int j = row[e];
+        if (j != i) d = fmin(d, sv_metric(me, P[j], res));
+    }
+    out[i] = d;
+}
+__global__ void k_fus_first_round(int n, int k, int* root0, int* s0, int* len0, long long* off0, int* cen) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    root0[i] = i; s0[i] = 1; len0[i] = k; off0[i] = (long long)i * k; cen[i] = i;
+}
+__global__ void k_fus_reset(int n, const int* __restrict__ s0, int* ab, int* ab_prev, int* rec_sz, int* rec_ran, int* rec_absn, int* rec_adjn,
+                            long long* rec_ptr, int* wake, int* dflag, int* slot_of) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ab[i] = kNone; ab_prev[i] = kNone; rec_sz[i] = s0[i]; rec_ran[i] = 0; rec_absn[i] = 0; rec_adjn[i] = 0; rec_ptr[i] = 0;
+    wake[i] = 0; dflag[i] = 0; slot_of[i] = -1;
+}
+// reverse index of the base lists: MODE 0 counts, MODE 1 scatters (cursor = running offsets)
+template <int MODE>
+__global__ void k_fus_reverse(const int* __restrict__ cen, int nc, const int* __restrict__ root0, const int* __restrict__ len0,
+                              const long long* __restrict__ off0, const int* __restrict__ arena0, int* __restrict__ cnt_or_cursor,
+                              int* __restrict__ revown) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nc) return;
+    const int c = cen[t];
+    const int* a = arena0 + off0[c];
+    for (int e = 0, m = len0[c]; e < m; ++e) {
+        const int x0 = root0[a[e]];
+        const int at = atomicAdd(&cnt_or_cursor[x0], 1);
+        if (MODE == 1) revown[at] = c;
+    }
+}
+__global__ void k_fus_total_absorbed(const int* __restrict__ cen, int nc, const int* __restrict__ rec_absn, int* __restrict__ per_centre,
+                                     unsigned long long* __restrict__ total) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nc) return;
+    const int a = rec_absn[cen[t]];
+    per_centre[t] = a;
+    if (a) atomicAdd(total, (unsigned long long)a);
+}
+// end of a round: every point follows the absorbers of the round (valid: see k_fus_final for the round that stops early)
+__global__ void k_fus_new_roots(int n, int* __restrict__ root0, const int* __restrict__ ab) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int x = root0[p], g = -1;
+    for (;;) {
+        const int c = ab[x];
+        if (c == kNone || c <= g) break;
+        g = c; x = c;
+    }
+    root0[p] = x;
+}
+// per centre (by index on cen): still a root? length of its list in the next round
+__global__ void k_fus_next_sizes(const int* __restrict__ cen, int nc, const int* __restrict__ ab, const int* __restrict__ rec_ran,
+                                 const int* __restrict__ rec_adjn, const int* __restrict__ len0, int* __restrict__ alive, int* __restrict__ newlen) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nc) return;
+    const int c = cen[t];
+    const bool root = ab[c] == kNone;
+    alive[t] = root ? 1 : 0;
+    newlen[t] = !root ? 0 : (rec_ran[c] ? rec_adjn[c] : len0[c]);
+}
+// one wavefront per centre: its list moves into the next round's arena; sizes / offsets of the next round
+__global__ void k_fus_next_lists(const int* __restrict__ cen, int nc, const int* __restrict__ alive_scan, const int* __restrict__ len_scan,
+                                 const int* __restrict__ ab, const int* __restrict__ rec_ran, const int* __restrict__ rec_sz,
+                                 const int* __restrict__ rec_absn, const int* __restrict__ rec_adjn, const long long* __restrict__ rec_ptr,
+                                 const int* __restrict__ sa, const int* __restrict__ arena_old, const long long* __restrict__ off_old,
+                                 const int* __restrict__ len_old, int* __restrict__ arena_new, long long* __restrict__ off_new,
+                                 int* __restrict__ len_new, int* __restrict__ s0, int* __restrict__ cen_new) {
+    const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (t >= nc) return;
+    const int c = cen[t];
+    if (ab[c] != kNone) {
+        if (lane == 0) { len_new[c] = 0; off_new[c] = 0; }
+        return;
+    }
+    const int m = len_scan[t + 1] - len_scan[t];
+    const int* src = rec_ran[c] ? sa + rec_ptr[c] + rec_absn[c] : arena_old + off_old[c];
+    int* dst = arena_new + len_scan[t];
+    for (int e = lane; e < m; e += 64) dst[e] = src[e];
+    if (lane == 0) {
+        len_new[c] = m; off_new[c] = len_scan[t];
+        s0[c] = rec_sz[c];
+        cen_new[alive_scan[t]] = c;
+    }
+}
+// the round that reaches the target count stops inside centre `stop_c` after `stop_n` absorptions (:139-141): only the
+// claims made before that moment hold
+__global__ void k_fus_cut_positions(const int* __restrict__ sa, long long ptr, int m, int* __restrict__ cut) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < m) cut[sa[ptr + e]] = e;
+}
+__global__ void k_fus_final(int n, const int* __restrict__ root0, const int* __restrict__ ab, int stop_c, int stop_n,
+                            const int* __restrict__ cut, int* __restrict__ lab) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int x = root0[p], g = -1;
+    for (;;) {
+        const int c = ab[x];
+        if (c == kNone || c <= g) break;
+        if (!(c < stop_c || (c == stop_c && cut[x] < stop_n))) break;
+        g = c; x = c;
+    }
+    lab[p] = x;
+}
+__global__ void k_fus_is_root(const int* __restrict__ cen, int nc, const int* __restrict__ lab, int* __restrict__ flag) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nc) flag[t] = lab[cen[t]] == cen[t] ? 1 : 0;
+}
+__global__ void k_fus_compact(const int* __restrict__ cen, int nc, const int* __restrict__ scan, int* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nc && scan[t + 1] != scan[t]) out[scan[t]] = cen[t];
+}
+
 struct FeTrace {
     pwicp_context* ctx;
     const bool on = getenv("PWICP_TRACE") != nullptr;
@@ -275,6 +701,181 @@ int refine_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     return PWICP_OK;
 }
 
+// Fusion on the device: d_lab[p] = root point of p, *d_roots = the roots in ascending order.  *gave_up: a search queue or
+// the list arena overflowed (the caller falls back to the host pass; nothing else is affected).
+int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, int n, double res, int n_sv_target, int* d_lab,
+                  DevBuf<int>* d_roots, int* n_roots, bool* gave_up) {
+    hipStream_t st = ctx->stream;
+    const bool trace = getenv("PWICP_TRACE") != nullptr;
+    *gave_up = false;
+    // lambda0 (:91-102)
+    double lambda;
+    {
+        DevBuf<double> dmin;
+        HIPCHK(ctx, dmin.reserve((size_t)n));
+        hipLaunchKernelGGL(k_fus_min_metric, grid1(n), dim3(256), 0, st, dP, d_nb, k, n, res, dmin.p);
+        std::vector<double> v((size_t)n);
+        HIPCHK(ctx, hipMemcpyAsync(v.data(), dmin.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
+        lambda = std::max(DBL_EPSILON, v[v.size() / 2]);
+    }
+    DevBuf<int> root0, s0, lenA, lenB, cenA, cenB, revoff, revown, cursor, ab, ab_prev, rec_sz, rec_ran, rec_absn, rec_adjn, slot_of, wake,
+        dflag, Wa, Wb, dq, o_sz, o_ran, o_absn, o_adjn, o_dirty, o_oldabsn, alive, newlen, cut, tmp, arenaA, arenaB, sa, ctr;
+    DevBuf<long long> offA, offB, rec_ptr, o_ptr, o_oldptr;
+    DevBuf<unsigned long long> big;     // [0] sa_top, [1] absorbed in the round
+    const size_t N = (size_t)n;
+    for (DevBuf<int>* b : {&root0, &s0, &lenA, &lenB, &cenA, &cenB, &cursor, &ab, &ab_prev, &rec_sz, &rec_ran, &rec_absn, &rec_adjn, &slot_of,
+                           &wake, &dflag, &Wa, &Wb, &dq, &o_sz, &o_ran, &o_absn, &o_adjn, &o_dirty, &o_oldabsn, &cut})
+        HIPCHK(ctx, b->reserve(N));
+    for (DevBuf<int>* b : {&revoff, &alive, &newlen}) HIPCHK(ctx, b->reserve(N + 1));
+    for (DevBuf<long long>* b : {&offA, &offB, &rec_ptr, &o_ptr, &o_oldptr}) HIPCHK(ctx, b->reserve(N));
+    HIPCHK(ctx, ctr.reserve(16));
+    HIPCHK(ctx, big.reserve(2));
+    const unsigned long long sa_cap = 16ull * (unsigned long long)n * (unsigned long long)k;
+    HIPCHK(ctx, sa.reserve((size_t)sa_cap));
+    hipLaunchKernelGGL(k_fus_first_round, grid1(n), dim3(256), 0, st, n, k, root0.p, s0.p, lenA.p, offA.p, cenA.p);
+    int* len0 = lenA.p; int* len1 = lenB.p;
+    long long* off0 = offA.p; long long* off1 = offB.p;
+    int* cen = cenA.p; int* cen1 = cenB.p;
+    const int* arena0 = d_nb;
+    DevBuf<int>* arena_next = &arenaA;
+    DevBuf<int>* arena_cur = &arenaB;
+    int nc = n, round = 0;
+    long long count = n;
+    FusState s{};
+    s.P = dP; s.res = res;
+    s.root0 = root0.p; s.s0 = s0.p;
+    s.revoff = revoff.p;
+    s.ab = ab.p; s.ab_prev = ab_prev.p; s.rec_sz = rec_sz.p; s.rec_ran = rec_ran.p; s.rec_absn = rec_absn.p; s.rec_adjn = rec_adjn.p;
+    s.rec_ptr = rec_ptr.p; s.sa = sa.p; s.sa_top = big.p; s.sa_cap = sa_cap;
+    s.slot_of = slot_of.p; s.o_sz = o_sz.p; s.o_ran = o_ran.p; s.o_absn = o_absn.p; s.o_adjn = o_adjn.p; s.o_ptr = o_ptr.p;
+    s.o_dirty = o_dirty.p; s.o_oldptr = o_oldptr.p; s.o_oldabsn = o_oldabsn.p;
+    s.wake = wake.p; s.dflag = dflag.p;
+    int* const nWnext = ctr.p; int* const ndq = ctr.p + 1; int* const lvl = ctr.p + 2; int* const status = ctr.p + 8;
+    s.nWnext = nWnext; s.status = status;
+    int h_ctr[16];
+    for (;; lambda *= 2.0, ++round) {
+        if (nc <= 1) {                                  // (:106) nothing left to fuse
+            HIPCHK(ctx, hipMemcpyAsync(d_lab, root0.p, sizeof(int) * N, hipMemcpyDeviceToDevice, st));
+            HIPCHK(ctx, d_roots->reserve((size_t)std::max(nc, 1)));
+            HIPCHK(ctx, hipMemcpyAsync(d_roots->p, cen, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
+            *n_roots = nc;
+            break;
+        }
+        const auto t_round = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(k_fus_reset, grid1(n), dim3(256), 0, st, n, s0.p, ab.p, ab_prev.p, rec_sz.p, rec_ran.p, rec_absn.p, rec_adjn.p,
+                           rec_ptr.p, wake.p, dflag.p, slot_of.p);
+        // reverse index of the base lists
+        HIPCHK(ctx, hipMemsetAsync(revoff.p, 0, sizeof(int) * (N + 1), st));
+        hipLaunchKernelGGL(k_fus_reverse<0>, grid1(nc), dim3(256), 0, st, cen, nc, root0.p, len0, off0, arena0, revoff.p, (int*)nullptr);
+        PWCHK(pw_exclusive_scan(ctx, revoff.p, (long long)n + 1, &tmp));
+        int n_entries = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&n_entries, revoff.p + n, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(cursor.p, revoff.p, sizeof(int) * N, hipMemcpyDeviceToDevice, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        HIPCHK(ctx, revown.reserve((size_t)std::max(n_entries, 1)));
+        hipLaunchKernelGGL(k_fus_reverse<1>, grid1(nc), dim3(256), 0, st, cen, nc, root0.p, len0, off0, arena0, cursor.p, revown.p);
+        HIPCHK(ctx, hipMemsetAsync(big.p, 0, sizeof(unsigned long long) * 2, st));
+        s.lambda = lambda; s.len0 = len0; s.off0 = off0; s.arena0 = arena0; s.revown = revown.p;
+        int* W = Wa.p; int* Wn = Wb.p;
+        HIPCHK(ctx, hipMemcpyAsync(W, cen, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
+        int nW = nc, sweeps = 0;
+        long long runs = 0;
+        while (nW > 0) {
+            if (++sweeps > 100000) { ctx->set_err("front end: the fusion did not converge"); return PWICP_E_INTERNAL; }
+            runs += nW;
+            if (trace && getenv("PWICP_TRACE_SWEEPS")) fprintf(stderr, "      sweep %d: %d\n", sweeps, nW);
+            s.W = W; s.Wnext = Wn;
+            HIPCHK(ctx, hipMemsetAsync(ctr.p, 0, sizeof(int) * 16, st));
+            hipLaunchKernelGGL(k_fus_run, dim3((unsigned)std::min(div_up(nW, 4), 8192)), dim3(256), 0, st, s, nW);
+            hipLaunchKernelGGL(k_fus_retract, grid1(nW), dim3(256), 0, st, s, nW);
+            hipLaunchKernelGGL(k_fus_claim, grid1(nW), dim3(256), 0, st, s, nW);
+            hipLaunchKernelGGL(k_fus_dirty0, grid1(nW), dim3(256), 0, st, s, nW, dq.p, ndq);
+            for (int l = 0; l < 3; ++l) {
+                hipLaunchKernelGGL(k_fus_snap, dim3(1), dim3(1), 0, st, ndq, lvl + l + 1);
+                hipLaunchKernelGGL(k_fus_wake_level, dim3(256), dim3(256), 0, st, s, dq.p, ndq, lvl + l, l == 2 ? 1 : 0);
+            }
+            hipLaunchKernelGGL(k_fus_sweep_end, dim3(256), dim3(256), 0, st, s, dq.p, ndq);
+            HIPCHK(ctx, hipMemcpyAsync(h_ctr, ctr.p, sizeof(int) * 16, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            if (h_ctr[8] || h_ctr[9]) {
+                if (trace) fprintf(stderr, "[pwicp front end/dev]   fusion gives up in round %d (%s overflow)\n", round, h_ctr[8] ? "queue" : "arena");
+                *gave_up = true;
+                return PWICP_OK;
+            }
+            if (h_ctr[10]) {                            // closure deeper than the levels: everybody runs again (always sound)
+                HIPCHK(ctx, hipMemcpyAsync(W, cen, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
+                nW = nc;
+            } else {
+                std::swap(W, Wn);
+                nW = h_ctr[0];
+            }
+        }
+        // absorbed in this round, per centre
+        hipLaunchKernelGGL(k_fus_total_absorbed, grid1(nc), dim3(256), 0, st, cen, nc, rec_absn.p, newlen.p, big.p + 1);
+        unsigned long long total = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&total, big.p + 1, sizeof(total), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        if (trace) {
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_round).count();
+            fprintf(stderr, "[pwicp front end/dev]   round %d: %d centres, %d sweeps, %lld runs (%.1f x), absorbed %llu  %8.2f ms\n", round, nc,
+                    sweeps, runs, (double)runs / nc, total, ms);
+        }
+        const long long need = count - (long long)n_sv_target;
+        if (need >= 1 && (long long)total >= need) {
+            // the round stops inside a centre (:139-141)
+            std::vector<int> per((size_t)nc), hcen((size_t)nc);
+            HIPCHK(ctx, hipMemcpyAsync(per.data(), newlen.p, sizeof(int) * (size_t)nc, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(hcen.data(), cen, sizeof(int) * (size_t)nc, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            long long before = 0;
+            int t_stop = 0;
+            for (; t_stop < nc; ++t_stop) {
+                if (before + per[(size_t)t_stop] >= need) break;
+                before += per[(size_t)t_stop];
+            }
+            const int stop_c = hcen[(size_t)t_stop], stop_n = (int)(need - before);
+            long long ptr = 0;
+            HIPCHK(ctx, hipMemcpyAsync(&ptr, rec_ptr.p + stop_c, sizeof(ptr), hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            hipLaunchKernelGGL(k_fill<int>, grid1(n), dim3(256), 0, st, cut.p, (long long)n, kNone);
+            hipLaunchKernelGGL(k_fus_cut_positions, grid1(per[(size_t)t_stop]), dim3(256), 0, st, sa.p, ptr, per[(size_t)t_stop], cut.p);
+            hipLaunchKernelGGL(k_fus_final, grid1(n), dim3(256), 0, st, n, root0.p, ab.p, stop_c, stop_n, cut.p, d_lab);
+            HIPCHK(ctx, hipMemsetAsync(alive.p, 0, sizeof(int) * ((size_t)nc + 1), st));
+            hipLaunchKernelGGL(k_fus_is_root, grid1(nc), dim3(256), 0, st, cen, nc, d_lab, alive.p);
+            PWCHK(pw_exclusive_scan(ctx, alive.p, (long long)nc + 1, &tmp));
+            int nr = 0;
+            HIPCHK(ctx, hipMemcpyAsync(&nr, alive.p + nc, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            HIPCHK(ctx, d_roots->reserve((size_t)std::max(nr, 1)));
+            hipLaunchKernelGGL(k_fus_compact, grid1(nc), dim3(256), 0, st, cen, nc, alive.p, d_roots->p);
+            *n_roots = nr;
+            break;
+        }
+        count -= (long long)total;
+        // hand-over to the next round
+        hipLaunchKernelGGL(k_fus_new_roots, grid1(n), dim3(256), 0, st, n, root0.p, ab.p);
+        HIPCHK(ctx, hipMemsetAsync(alive.p + nc, 0, sizeof(int), st));
+        HIPCHK(ctx, hipMemsetAsync(newlen.p + nc, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_fus_next_sizes, grid1(nc), dim3(256), 0, st, cen, nc, ab.p, rec_ran.p, rec_adjn.p, len0, alive.p, newlen.p);
+        PWCHK(pw_exclusive_scan(ctx, alive.p, (long long)nc + 1, &tmp));
+        PWCHK(pw_exclusive_scan(ctx, newlen.p, (long long)nc + 1, &tmp));
+        int nc_next = 0, n_list = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&nc_next, alive.p + nc, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(&n_list, newlen.p + nc, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        HIPCHK(ctx, arena_next->reserve((size_t)std::max(n_list, 1)));
+        hipLaunchKernelGGL(k_fus_next_lists, grid1((long long)nc * 64), dim3(256), 0, st, cen, nc, alive.p, newlen.p, ab.p, rec_ran.p, rec_sz.p,
+                           rec_absn.p, rec_adjn.p, rec_ptr.p, sa.p, arena0, off0, len0, arena_next->p, off1, len1, s0.p, cen1);
+        arena0 = arena_next->p;
+        std::swap(arena_next, arena_cur);
+        std::swap(len0, len1); std::swap(off0, off1); std::swap(cen, cen1);
+        nc = nc_next;
+    }
+    return PWICP_OK;
+}
+
 }  // namespace
 
 // Device pipeline from the k-NN graph on the host (n rows of k indices, the point itself first): PCA normals and the fusion
@@ -289,29 +890,40 @@ int pw_frontend_labels(pwicp_context* ctx, const float* cloud_xyz4, int n, const
     tr.lap("pca normals (host)");
     const double res = (double)sv_resolution;
     const int n_sv = pwhost::fe_count_occupied_cells(P.data(), n, res);
-    std::vector<int> root_of, roots;
-    if (pwhost::fe_fusion_host(P.data(), nb, k, n, res, n_sv, &root_of, &roots) < 0) return PWICP_E_NOMEM;
-    tr.lap("cells + fusion (host)");
+    tr.lap("occupied cells (host)");
     DevBuf<FePt> dP;
     DevBuf<int> d_nb, d_lab, d_roots, d_map;
     HIPCHK(ctx, dP.reserve((size_t)n));
     HIPCHK(ctx, d_nb.reserve((size_t)n * k));
     HIPCHK(ctx, d_lab.reserve((size_t)n));
-    HIPCHK(ctx, d_roots.reserve(roots.size()));
     HIPCHK(ctx, d_map.reserve((size_t)n));
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemcpyAsync(dP.p, P.data(), sizeof(FePt) * (size_t)n, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(d_nb.p, nb, sizeof(int) * (size_t)n * k, hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(d_lab.p, root_of.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(d_roots.p, roots.data(), sizeof(int) * roots.size(), hipMemcpyHostToDevice, st));
     tr.lap("upload");
+    int n_roots = 0;
+    bool host_fusion = getenv("PWICP_FUSION") && std::string(getenv("PWICP_FUSION")) == "host";
+    if (!host_fusion) {
+        PWCHK(fusion_device(ctx, dP.p, d_nb.p, k, n, res, n_sv, d_lab.p, &d_roots, &n_roots, &host_fusion));
+        tr.lap("fusion");
+    }
+    if (host_fusion) {                                  // (serial host pass: $PWICP_FUSION=host, or the device pass gave up)
+        std::vector<int> root_of, roots;
+        if (pwhost::fe_fusion_host(P.data(), nb, k, n, res, n_sv, &root_of, &roots) < 0) return PWICP_E_NOMEM;
+        n_roots = (int)roots.size();
+        HIPCHK(ctx, d_roots.reserve(roots.size()));
+        HIPCHK(ctx, hipMemcpyAsync(d_lab.p, root_of.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(d_roots.p, roots.data(), sizeof(int) * roots.size(), hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        tr.lap("fusion (host)");
+    }
     PWCHK(refine_device(ctx, dP.p, d_nb.p, k, n, res, d_lab.p));
     tr.lap("boundary refinement");
-    hipLaunchKernelGGL(k_mark_roots, grid1((long long)roots.size()), dim3(256), 0, st, d_roots.p, (int)roots.size(), d_map.p);
+    hipLaunchKernelGGL(k_mark_roots, grid1(n_roots), dim3(256), 0, st, d_roots.p, n_roots, d_map.p);
     hipLaunchKernelGGL(k_relabel, grid1(n), dim3(256), 0, st, d_lab.p, n, d_map.p);
     HIPCHK(ctx, hipMemcpyAsync(labels, d_lab.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
-    *n_supervoxels = (int)roots.size();
+    *n_supervoxels = n_roots;
     tr.lap("relabel + download");
     return PWICP_OK;
 }
