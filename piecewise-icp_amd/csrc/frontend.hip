@@ -240,10 +240,15 @@ struct FusState {
     int* wake;                 // [n] 1: already on the next work list
     int* Wnext; int* nWnext;
     int* dflag;                // [n] 1: already on a dirty list
-    int* status;               // [0] queue overflow, [1] arena overflow, [2] dirty closure deeper than the levels run
+    int* cflag;                // [n] 1: already handled as a node absorbed by a changed node
+    int* dtmin;                // [n] a changed node concerns the centres after dtmin only (kNone outside a sweep)
+    int* status;               // [0] queue overflow, [1] arena overflow, [2] dirty closure deeper than the levels run,
+                               // [3] too many changed nodes: everybody runs again
+    int wake_all_above;
 };
 
 constexpr int kFusQueue = 512, kFusHash = 1024;
+constexpr int kFusArenas = 256;
 #define WSYNC()                                               \
     do {                                                      \
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
@@ -364,15 +369,18 @@ __global__ void __launch_bounds__(256) k_fus_run(FusState s, int nW) {
             if (pass == 0 && !same) continue;
             if (pass == 1) {
                 if (same) break;
+                // (the arena is split into kFusArenas regions with a bump pointer each: same-address atomics serialise)
+                const unsigned long long region = (unsigned long long)(blockIdx.x & (kFusArenas - 1));
+                const unsigned long long rcap = s.sa_cap / kFusArenas;
                 unsigned long long at = 0;
-                if (lane == 0) at = atomicAdd(s.sa_top, (unsigned long long)total);
+                if (lane == 0) at = atomicAdd(&s.sa_top[region * 16], (unsigned long long)total);
                 at = __shfl(at, 0);
-                if (at + (unsigned long long)total > s.sa_cap) {
+                if (at + (unsigned long long)total > rcap) {
                     if (lane == 0) { s.o_dirty[slot] = 2; s.status[1] = 1; }
                     same = true;          // (nothing is written; the host aborts)
                     break;
                 }
-                ptr = (long long)at;
+                ptr = (long long)(region * rcap + at);
             }
             int na = 0, nd = 0;
             bool diff = false;
@@ -428,72 +436,142 @@ __global__ void k_fus_claim(FusState s, int nW) {
     for (int e = 0, m = s.o_absn[slot]; e < m; ++e) atomicMin(&s.ab[s.sa[p + e]], c);
 }
 
-__device__ __forceinline__ void fus_mark_dirty(const FusState& s, int x, int* dq, int* ndq) {
-    if (atomicExch(&s.dflag[x], 1) == 0) dq[atomicAdd(ndq, 1)] = x;
+// append to a list with ONE atomic per wavefront (the lanes that are active here and want to; same-address atomics serialise)
+__device__ __forceinline__ void wave_append(int* ctr, int* arr, bool want, int v) {
+    const unsigned long long m = __ballot(want);
+    if (!m) return;
+    const int lane = threadIdx.x & 63, leader = __builtin_ctzll(m);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(ctr, __popcll(m));
+    base = __shfl(base, leader);
+    if (want) arr[base + __popcll(m & ((1ull << lane) - 1ull))] = v;
+}
+
+// A changed node x only matters to the centres AFTER t = dtmin[x]: its own outcome is read by later centres only (t = x),
+// a change of its absorber from c to c' is invisible to the centres up to min(c, c') (for them x is a free root either way).
+__device__ __forceinline__ void fus_mark_dirty(const FusState& s, bool on, int x, int tmin, int* dq, int* ndq) {
+    bool fresh = false;
+    if (on) {
+        atomicMin(&s.dtmin[x], tmin);
+        fresh = atomicExch(&s.dflag[x], 1) == 0;
+    }
+    wave_append(ndq, dq, fresh, x);
 }
 
 // level 0 of the dirty list: centres whose outcome changed, nodes whose absorber changed
 __global__ void k_fus_dirty0(FusState s, int nW, int* dq, int* ndq) {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= nW || s.o_dirty[slot] != 1) return;
-    const int c = s.W[slot];
-    fus_mark_dirty(s, c, dq, ndq);
+    const bool on = slot < nW && s.o_dirty[slot] == 1;
+    const int c = on ? s.W[slot] : 0;
+    fus_mark_dirty(s, on, c, c, dq, ndq);
+    if (!on) return;
     for (int pass = 0; pass < 2; ++pass) {
         const long long p = pass ? s.o_ptr[slot] : s.o_oldptr[slot];
         const int m = pass ? s.o_absn[slot] : s.o_oldabsn[slot];
         for (int e = 0; e < m; ++e) {
             const int j = s.sa[p + e];
-            if (s.ab[j] != s.ab_prev[j]) fus_mark_dirty(s, j, dq, ndq);
+            const int a0 = s.ab_prev[j], a1 = s.ab[j];
+            fus_mark_dirty(s, a0 != a1, j, min(a0, a1), dq, ndq);
         }
     }
 }
 
-__device__ __forceinline__ void fus_wake_chain(const FusState& s, int owner) {
-    for (int pass = 0; pass < 2; ++pass) {
-        const int* ab = pass ? s.ab_prev : s.ab;
-        int x = owner, g = -1;
-        for (;;) {
-            if (atomicExch(&s.wake[x], 1) == 0) s.Wnext[atomicAdd(s.nWnext, 1)] = x;
-            const int nx = ab[x];
-            if (nx == kNone || nx <= g) break;
-            g = nx; x = nx;
+// `on` lanes wake their owner and whoever absorbed it, transitively, along the new absorbers; where the old absorber of
+// a node on the way differs, the old chain is followed from there as well (rare)
+__device__ __forceinline__ void fus_wake_chain(const FusState& s, bool on, int owner, int tmin) {
+    int x = owner, g = -1;
+    bool go = on;
+    while (__ballot(go)) {
+        const bool fresh = go && x > tmin && s.wake[x] == 0 && atomicExch(&s.wake[x], 1) == 0;
+        wave_append(s.nWnext, s.Wnext, fresh, x);
+        int y = kNone, gy = -1;
+        if (go) {
+            const int nx = s.ab[x], ox = s.ab_prev[x];
+            if (ox != nx && ox != kNone && ox > g) { y = ox; gy = ox; }
+            if (nx == kNone || nx <= g) go = false;
+            else { g = nx; x = nx; }
         }
-    }
-}
-
-// one level of the closure: a changed node wakes the owners of the base entries that lead to it (and whoever absorbed
-// them, transitively); the nodes it has absorbed (old and new outcome) are reached through it, so they are changed too
-__global__ void k_fus_wake_level(FusState s, int* dq, int* ndq, const int* lvl, int last) {
-    for (int t = lvl[0] + blockIdx.x * blockDim.x + threadIdx.x; t < lvl[1]; t += gridDim.x * blockDim.x) {
-        const int x = dq[t];
-        fus_wake_chain(s, x);
-        for (int e = s.revoff[x], m = s.revoff[x + 1]; e < m; ++e) fus_wake_chain(s, s.revown[e]);
-        for (int pass = 0; pass < 2; ++pass) {
-            long long p; int m;
-            if (pass == 0) { p = s.rec_ptr[x]; m = s.rec_absn[x]; }
-            else {
-                const int slot = s.slot_of[x];
-                if (slot < 0 || s.W[slot] != x || s.o_dirty[slot] != 1) break;     // (slot_of is only meaningful for this sweep's W)
-                p = s.o_oldptr[slot]; m = s.o_oldabsn[slot];
+        while (__ballot(y != kNone)) {                 // old chain from here on
+            const bool on2 = y != kNone;
+            const bool fresh2 = on2 && y > tmin && s.wake[y] == 0 && atomicExch(&s.wake[y], 1) == 0;
+            wave_append(s.nWnext, s.Wnext, fresh2, y);
+            if (on2) {
+                const int ny = s.ab_prev[y];
+                if (ny == kNone || ny <= gy) y = kNone;
+                else { gy = ny; y = ny; }
             }
-            for (int e = 0; e < m; ++e) {
-                const int ch = s.sa[p + e];
-                if (atomicExch(&s.dflag[ch], 1) == 0) {
-                    if (last) s.status[2] = 1;
-                    dq[atomicAdd(ndq, 1)] = ch;
+        }
+    }
+}
+
+// One wavefront per changed node x: it wakes the owners of the base entries that lead to x (and whoever absorbed them,
+// transitively).  The nodes x has absorbed (old and new outcome) are read THROUGH x, so they are handled like x - once per
+// sweep (dflag), for all centres (bound -1: the node may hang below several changed nodes) - from a small stack of the
+// wavefront (wider than the stack: status[2], everybody runs again).  They go on dq2 only to have their flag reset.
+constexpr int kWakeStack = 256;
+__global__ void __launch_bounds__(256) k_fus_wake(FusState s, const int* dq, const int* ndq, int* dq2, int* ndq2) {
+    __shared__ int s_node[4][kWakeStack];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int n_dirty = *ndq;
+    // Many changed nodes: finding who read them costs more than running every centre again (a run is ~2 ns of device
+    // time, a changed node ~10 ns of walks) - the host puts all centres on the next work list (status[3]).
+    if (n_dirty > s.wake_all_above) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) s.status[3] = 1;
+        return;
+    }
+    int* node = s_node[wv];
+    for (int t = wave; t < n_dirty; t += nwaves) {
+        int top = 1;
+        const int root = dq[t];
+        if (lane == 0) node[0] = root;
+        WSYNC();
+        while (top > 0) {
+            --top;
+            const int x = node[top];
+            const int tmin = top == 0 && x == root ? s.dtmin[root] : -1;
+            WSYNC();
+            const int e0 = s.revoff[x] - 1, m0 = s.revoff[x + 1];      // entry e0 stands for x itself
+            for (int base = e0; base < m0; base += 64) {
+                const int e = base + lane;
+                const bool on = e < m0;
+                fus_wake_chain(s, on, on ? (e == e0 ? x : s.revown[e]) : 0, tmin);
+            }
+            for (int pass = 0; pass < 2; ++pass) {
+                long long p; int m;
+                if (pass == 0) { p = s.rec_ptr[x]; m = s.rec_absn[x]; }
+                else {
+                    const int slot = s.slot_of[x];
+                    if (slot < 0 || s.W[slot] != x || s.o_dirty[slot] != 1) break;     // (slot_of is only meaningful for this sweep's W)
+                    p = s.o_oldptr[slot]; m = s.o_oldabsn[slot];
+                }
+                for (int base = 0; base < m; base += 64) {
+                    const bool on = base + lane < m;
+                    const int ch = on ? s.sa[p + base + lane] : 0;
+                    const bool fresh = on && atomicExch(&s.cflag[ch], 1) == 0;
+                    wave_append(ndq2, dq2, fresh, ch);
+                    const unsigned long long mk = __ballot(fresh);
+                    if (top + __popcll(mk) > kWakeStack) {
+                        if (lane == 0) s.status[2] = 1;
+                    } else {
+                        if (fresh) node[top + __popcll(mk & ((1ull << lane) - 1ull))] = ch;
+                        top += __popcll(mk);
+                    }
+                    WSYNC();
                 }
             }
         }
     }
 }
-__global__ void k_fus_snap(const int* ndq, int* lvl_next) { *lvl_next = *ndq; }
 
-__global__ void k_fus_sweep_end(FusState s, const int* dq, const int* ndq) {
+__global__ void k_fus_sweep_end(FusState s, const int* dq, const int* ndq, const int* dq2, const int* ndq2) {
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < *ndq; t += gridDim.x * blockDim.x) {
         const int x = dq[t];
         s.dflag[x] = 0;
+        s.dtmin[x] = kNone;
         s.ab_prev[x] = s.ab[x];
     }
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < *ndq2; t += gridDim.x * blockDim.x) s.cflag[dq2[t]] = 0;
 }
 
 // ---- set-up and hand-over between rounds ----------------------------------------------------------------------------
@@ -516,11 +594,11 @@ __global__ void k_fus_first_round(int n, int k, int* root0, int* s0, int* len0, 
     root0[i] = i; s0[i] = 1; len0[i] = k; off0[i] = (long long)i * k; cen[i] = i;
 }
 __global__ void k_fus_reset(int n, const int* __restrict__ s0, int* ab, int* ab_prev, int* rec_sz, int* rec_ran, int* rec_absn, int* rec_adjn,
-                            long long* rec_ptr, int* wake, int* dflag, int* slot_of) {
+                            long long* rec_ptr, int* wake, int* dflag, int* cflag, int* dtmin, int* slot_of) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     ab[i] = kNone; ab_prev[i] = kNone; rec_sz[i] = s0[i]; rec_ran[i] = 0; rec_absn[i] = 0; rec_adjn[i] = 0; rec_ptr[i] = 0;
-    wake[i] = 0; dflag[i] = 0; slot_of[i] = -1;
+    wake[i] = 0; dflag[i] = 0; cflag[i] = 0; dtmin[i] = kNone; slot_of[i] = -1;
 }
 // reverse index of the base lists: MODE 0 counts, MODE 1 scatters (cursor = running offsets)
 template <int MODE>
@@ -721,17 +799,17 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
         lambda = std::max(DBL_EPSILON, v[v.size() / 2]);
     }
     DevBuf<int> root0, s0, lenA, lenB, cenA, cenB, revoff, revown, cursor, ab, ab_prev, rec_sz, rec_ran, rec_absn, rec_adjn, slot_of, wake,
-        dflag, Wa, Wb, dq, o_sz, o_ran, o_absn, o_adjn, o_dirty, o_oldabsn, alive, newlen, cut, tmp, arenaA, arenaB, sa, ctr;
+        dflag, cflag, dtmin, Wa, Wb, dq, dq2, o_sz, o_ran, o_absn, o_adjn, o_dirty, o_oldabsn, alive, newlen, cut, tmp, arenaA, arenaB, sa, ctr;
     DevBuf<long long> offA, offB, rec_ptr, o_ptr, o_oldptr;
-    DevBuf<unsigned long long> big;     // [0] sa_top, [1] absorbed in the round
+    DevBuf<unsigned long long> big;     // [0] absorbed in the round, [16 * (1 + r)] bump pointer of arena region r
     const size_t N = (size_t)n;
     for (DevBuf<int>* b : {&root0, &s0, &lenA, &lenB, &cenA, &cenB, &cursor, &ab, &ab_prev, &rec_sz, &rec_ran, &rec_absn, &rec_adjn, &slot_of,
-                           &wake, &dflag, &Wa, &Wb, &dq, &o_sz, &o_ran, &o_absn, &o_adjn, &o_dirty, &o_oldabsn, &cut})
+                           &wake, &dflag, &cflag, &dtmin, &Wa, &Wb, &dq, &dq2, &o_sz, &o_ran, &o_absn, &o_adjn, &o_dirty, &o_oldabsn, &cut})
         HIPCHK(ctx, b->reserve(N));
     for (DevBuf<int>* b : {&revoff, &alive, &newlen}) HIPCHK(ctx, b->reserve(N + 1));
     for (DevBuf<long long>* b : {&offA, &offB, &rec_ptr, &o_ptr, &o_oldptr}) HIPCHK(ctx, b->reserve(N));
     HIPCHK(ctx, ctr.reserve(16));
-    HIPCHK(ctx, big.reserve(2));
+    HIPCHK(ctx, big.reserve(16 * (kFusArenas + 1)));
     const unsigned long long sa_cap = 16ull * (unsigned long long)n * (unsigned long long)k;
     HIPCHK(ctx, sa.reserve((size_t)sa_cap));
     hipLaunchKernelGGL(k_fus_first_round, grid1(n), dim3(256), 0, st, n, k, root0.p, s0.p, lenA.p, offA.p, cenA.p);
@@ -748,13 +826,16 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     s.root0 = root0.p; s.s0 = s0.p;
     s.revoff = revoff.p;
     s.ab = ab.p; s.ab_prev = ab_prev.p; s.rec_sz = rec_sz.p; s.rec_ran = rec_ran.p; s.rec_absn = rec_absn.p; s.rec_adjn = rec_adjn.p;
-    s.rec_ptr = rec_ptr.p; s.sa = sa.p; s.sa_top = big.p; s.sa_cap = sa_cap;
+    s.rec_ptr = rec_ptr.p; s.sa = sa.p; s.sa_top = big.p + 16; s.sa_cap = sa_cap;
     s.slot_of = slot_of.p; s.o_sz = o_sz.p; s.o_ran = o_ran.p; s.o_absn = o_absn.p; s.o_adjn = o_adjn.p; s.o_ptr = o_ptr.p;
     s.o_dirty = o_dirty.p; s.o_oldptr = o_oldptr.p; s.o_oldabsn = o_oldabsn.p;
-    s.wake = wake.p; s.dflag = dflag.p;
-    int* const nWnext = ctr.p; int* const ndq = ctr.p + 1; int* const lvl = ctr.p + 2; int* const status = ctr.p + 8;
+    s.wake = wake.p; s.dflag = dflag.p; s.cflag = cflag.p; s.dtmin = dtmin.p;
+    int* const nWnext = ctr.p; int* const ndq = ctr.p + 1; int* const status = ctr.p + 8;
     s.nWnext = nWnext; s.status = status;
-    int h_ctr[16];
+    int* h_ctr = nullptr;                           // pinned: read back after every sweep
+    HIPCHK(ctx, hipHostMalloc((void**)&h_ctr, sizeof(int) * 16, hipHostMallocDefault));
+    struct Unpin { int* p; ~Unpin() { (void)hipHostFree(p); } } unpin{h_ctr};
+    const int wake_all_div = getenv("PWICP_FUSION_WAKE_DIV") ? std::max(atoi(getenv("PWICP_FUSION_WAKE_DIV")), 1) : 32;
     for (;; lambda *= 2.0, ++round) {
         if (nc <= 1) {                                  // (:106) nothing left to fuse
             HIPCHK(ctx, hipMemcpyAsync(d_lab, root0.p, sizeof(int) * N, hipMemcpyDeviceToDevice, st));
@@ -765,7 +846,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
         }
         const auto t_round = std::chrono::steady_clock::now();
         hipLaunchKernelGGL(k_fus_reset, grid1(n), dim3(256), 0, st, n, s0.p, ab.p, ab_prev.p, rec_sz.p, rec_ran.p, rec_absn.p, rec_adjn.p,
-                           rec_ptr.p, wake.p, dflag.p, slot_of.p);
+                           rec_ptr.p, wake.p, dflag.p, cflag.p, dtmin.p, slot_of.p);
         // reverse index of the base lists
         HIPCHK(ctx, hipMemsetAsync(revoff.p, 0, sizeof(int) * (N + 1), st));
         hipLaunchKernelGGL(k_fus_reverse<0>, grid1(nc), dim3(256), 0, st, cen, nc, root0.p, len0, off0, arena0, revoff.p, (int*)nullptr);
@@ -776,7 +857,8 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
         HIPCHK(ctx, hipStreamSynchronize(st));
         HIPCHK(ctx, revown.reserve((size_t)std::max(n_entries, 1)));
         hipLaunchKernelGGL(k_fus_reverse<1>, grid1(nc), dim3(256), 0, st, cen, nc, root0.p, len0, off0, arena0, cursor.p, revown.p);
-        HIPCHK(ctx, hipMemsetAsync(big.p, 0, sizeof(unsigned long long) * 2, st));
+        HIPCHK(ctx, hipMemsetAsync(big.p, 0, sizeof(unsigned long long) * 16 * (kFusArenas + 1), st));
+        s.wake_all_above = std::max(nc / wake_all_div, 64);
         s.lambda = lambda; s.len0 = len0; s.off0 = off0; s.arena0 = arena0; s.revown = revown.p;
         int* W = Wa.p; int* Wn = Wb.p;
         HIPCHK(ctx, hipMemcpyAsync(W, cen, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
@@ -792,11 +874,8 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
             hipLaunchKernelGGL(k_fus_retract, grid1(nW), dim3(256), 0, st, s, nW);
             hipLaunchKernelGGL(k_fus_claim, grid1(nW), dim3(256), 0, st, s, nW);
             hipLaunchKernelGGL(k_fus_dirty0, grid1(nW), dim3(256), 0, st, s, nW, dq.p, ndq);
-            for (int l = 0; l < 3; ++l) {
-                hipLaunchKernelGGL(k_fus_snap, dim3(1), dim3(1), 0, st, ndq, lvl + l + 1);
-                hipLaunchKernelGGL(k_fus_wake_level, dim3(256), dim3(256), 0, st, s, dq.p, ndq, lvl + l, l == 2 ? 1 : 0);
-            }
-            hipLaunchKernelGGL(k_fus_sweep_end, dim3(256), dim3(256), 0, st, s, dq.p, ndq);
+            hipLaunchKernelGGL(k_fus_wake, dim3(1024), dim3(256), 0, st, s, dq.p, ndq, dq2.p, ndq + 1);
+            hipLaunchKernelGGL(k_fus_sweep_end, dim3(256), dim3(256), 0, st, s, dq.p, ndq, dq2.p, ndq + 1);
             HIPCHK(ctx, hipMemcpyAsync(h_ctr, ctr.p, sizeof(int) * 16, hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));
             if (h_ctr[8] || h_ctr[9]) {
@@ -804,7 +883,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
                 *gave_up = true;
                 return PWICP_OK;
             }
-            if (h_ctr[10]) {                            // closure deeper than the levels: everybody runs again (always sound)
+            if (h_ctr[10] || h_ctr[11]) {               // closure deeper than the levels / too many changes: everybody runs again (always sound)
                 HIPCHK(ctx, hipMemcpyAsync(W, cen, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
                 nW = nc;
             } else {
@@ -813,9 +892,9 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
             }
         }
         // absorbed in this round, per centre
-        hipLaunchKernelGGL(k_fus_total_absorbed, grid1(nc), dim3(256), 0, st, cen, nc, rec_absn.p, newlen.p, big.p + 1);
+        hipLaunchKernelGGL(k_fus_total_absorbed, grid1(nc), dim3(256), 0, st, cen, nc, rec_absn.p, newlen.p, big.p);
         unsigned long long total = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&total, big.p + 1, sizeof(total), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(&total, big.p, sizeof(total), hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         if (trace) {
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_round).count();
