@@ -245,6 +245,7 @@ struct FusState {
     int* status;               // [0] queue overflow, [1] arena overflow, [2] dirty closure deeper than the levels run,
                                // [3] too many changed nodes: everybody runs again
     int wake_all_above;
+    int queue_limit;           // <= kFusQueue ($PWICP_FUSION_QUEUE: smaller, to exercise the fallback)
 };
 
 constexpr int kFusQueue = 512, kFusHash = 1024;
@@ -293,7 +294,7 @@ __device__ __forceinline__ void fus_expand(const FusState& s, FusWave& w, const 
         const bool first = valid && w.vals[slot] == gidx;
         const unsigned long long m = __ballot(first);
         const int add = __popcll(m);
-        if (w.qn + add > kFusQueue) { w.overflow = true; break; }
+        if (w.qn + add > s.queue_limit) { w.overflow = true; break; }
         if (first) w.queue[w.qn + __popcll(m & ((1ull << lane) - 1ull))] = r;
         w.qn += add;
         w.gcount += 64;
@@ -829,6 +830,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     s.rec_ptr = rec_ptr.p; s.sa = sa.p; s.sa_top = big.p + 16; s.sa_cap = sa_cap;
     s.slot_of = slot_of.p; s.o_sz = o_sz.p; s.o_ran = o_ran.p; s.o_absn = o_absn.p; s.o_adjn = o_adjn.p; s.o_ptr = o_ptr.p;
     s.o_dirty = o_dirty.p; s.o_oldptr = o_oldptr.p; s.o_oldabsn = o_oldabsn.p;
+    s.queue_limit = getenv("PWICP_FUSION_QUEUE") ? std::min(std::max(atoi(getenv("PWICP_FUSION_QUEUE")), 2), kFusQueue) : kFusQueue;
     s.wake = wake.p; s.dflag = dflag.p; s.cflag = cflag.p; s.dtmin = dtmin.p;
     int* const nWnext = ctr.p; int* const ndq = ctr.p + 1; int* const status = ctr.p + 8;
     s.nWnext = nWnext; s.status = status;

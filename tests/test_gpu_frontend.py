@@ -1,0 +1,87 @@
+"""Segmentation front end on the device (csrc/frontend.hip): supervoxel fusion and boundary refinement as speculative fixed
+points must reproduce the serial passes of the reference (supervoxel_segmentation.h:65-248) label for label.  The host
+pipeline (host/frontend.cpp, $PWICP_FRONTEND=host) is the serial restatement; tests/test_host_stages.py and
+tests/test_oracle_golden.py pin it to the reference's own compiled front end (oracle/_ref)."""
+import os
+
+import numpy as np
+import pytest
+
+import _data
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _both(ctx, cloud, sv, spacing):
+    out = {}
+    for mode in ("host", "device"):
+        os.environ["PWICP_FRONTEND"] = mode
+        try:
+            out[mode] = ctx.frontend_segment(cloud, sv, 45, spacing)
+        finally:
+            os.environ.pop("PWICP_FRONTEND", None)
+    return out["host"], out["device"]
+
+
+def _assert_same(ctx, cloud, sv, spacing):
+    (lh, nh), (ld, nd) = _both(ctx, cloud, sv, spacing)
+    assert nh == nd
+    assert np.array_equal(lh, ld), "%d of %d labels differ" % (int((lh != ld).sum()), len(lh))
+    return nd
+
+
+@pytest.mark.parametrize("n", [2000, 30000, 200000])
+def test_device_labels_equal_serial_labels_synthetic(ctx, n):
+    tgt, src, _ = _data.pair(n)
+    for cloud in (tgt, src):
+        nsv = _assert_same(ctx, cloud, 10 * _data.R, _data.R)
+        assert nsv > 0
+
+
+@pytest.mark.parametrize("sv_factor", [3.0, 6.0, 25.0, 60.0])
+def test_device_labels_equal_serial_labels_other_supervoxel_sizes(ctx, sv_factor):
+    """Small supervoxels: the target count is reached in the first rounds (the round that stops inside a centre is a big one);
+    large supervoxels: many rounds, long adjacency lists (search queues beyond the wavefront's LDS queue fall back to the host
+    pass - same labels either way)."""
+    _, src, _ = _data.pair(60000)
+    _assert_same(ctx, src, sv_factor * _data.R, _data.R)
+
+
+def test_device_labels_equal_serial_labels_rough_surface(ctx):
+    """A noisy cliff: normals vary quickly, lambda0 is large, the fusion takes few rounds with big absorptions."""
+    rng = np.random.default_rng(5)
+    tgt, _, _ = _data.pair(80000)
+    cloud = tgt.copy()
+    cloud[:, 2] += (0.3 * np.sin(9.0 * cloud[:, 0]) + rng.normal(0, 0.004, len(cloud))).astype(np.float32)
+    _assert_same(ctx, cloud, 10 * _data.R, _data.R)
+
+
+@pytest.mark.parametrize("epoch", ["001", "002", "008", "011", "013", "019"])
+def test_device_labels_equal_serial_labels_golden_epochs(ctx, epoch):
+    """The reference's own scans (testdata/Epoch_*.pcd), preprocessed as the entry points do (Res 0.005, SV 0.05)."""
+    from pwicp_amd.pcd import read_pcd
+    raw = read_pcd(os.path.join(HERE, "golden", "inputs", "Epoch_%s.pcd" % epoch))
+    cloud = ctx.preprocess(raw, 0.005, 14, 2.0)
+    cloud = (cloud - cloud.mean(axis=0)).astype(np.float32)
+    nsv = _assert_same(ctx, cloud, 0.05, 0.005)
+    assert nsv > 100
+
+
+def test_one_million_points(ctx):
+    tgt, _, _ = _data.pair(1000000)
+    _assert_same(ctx, tgt, 10 * _data.R, _data.R)
+
+
+def test_search_queue_overflow_falls_back_to_the_serial_pass(ctx, capfd):
+    """A search wider than the wavefront's queue makes the device fusion give up; the serial host pass takes over (refinement
+    stays on the device) - same labels.  $PWICP_FUSION_QUEUE shrinks the queue to force it."""
+    _, src, _ = _data.pair(30000)
+    os.environ["PWICP_FUSION_QUEUE"] = "50"
+    os.environ["PWICP_TRACE"] = "1"
+    try:
+        _assert_same(ctx, src, 10 * _data.R, _data.R)
+    finally:
+        os.environ.pop("PWICP_FUSION_QUEUE", None)
+        os.environ.pop("PWICP_TRACE", None)
+    assert "fusion gives up" in capfd.readouterr().err

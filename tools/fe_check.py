@@ -19,7 +19,7 @@ for n in sizes:
     for mode in ("host", "device"):
         os.environ["PWICP_FRONTEND"] = mode
         t0 = time.time()
-        lab, nsv = ctx.frontend_segment(t, 10 * r, 45, r)
+        lab, nsv = ctx.frontend_segment(t, float(os.environ.get("FE_SV", "10")) * r, 45, r)
         out[mode] = (lab, nsv, time.time() - t0)
     same = out["host"][1] == out["device"][1] and np.array_equal(out["host"][0], out["device"][0])
     print("n=%d nsv=%d/%d host %.3f s device %.3f s identical=%s" % (n, out["host"][1], out["device"][1], out["host"][2], out["device"][2], same),
