@@ -156,6 +156,10 @@ int pwicp_overlap_ratio(pwicp_context* ctx, const float* cloud1_xyz4, int n1, co
 
 extern "C" {
 
+}  // extern "C"
+float pw_estimate_cell_edge(const float* xyz4, int n) { return estimate_cell_edge(xyz4, n); }
+extern "C" {
+
 int pwicp_knn(pwicp_context* ctx, const float* cloud_xyz4, int n, int k, float cell_edge, int32_t* neighbors) {
     if (!ctx) return PWICP_E_INVALID;
     if (!cloud_xyz4 || !neighbors || n <= 0 || k <= 0 || k > n) { ctx->set_err("pwicp_knn: invalid argument"); return PWICP_E_INVALID; }

@@ -698,6 +698,59 @@ __global__ void k_fus_compact(const int* __restrict__ cen, int nc, const int* __
     if (t < nc && scan[t + 1] != scan[t]) out[scan[t]] = cen[t];
 }
 
+// ================================================================================================================
+// PCA normals (pca_estimate_normals.h:42-108): the neighbourhood scatter here, the closed-form eigen step on the host
+// ================================================================================================================
+// Mean and second moments about the mean of the k neighbours of every point, accumulated in double in neighbour order
+// exactly as the reference does (unit weights; sums divided by the neighbour count).  The smallest eigenvector is taken
+// on the host (pwhost::fe_normals_from_scatter): it needs pow / acos / cos, whose last bit differs between libm and the
+// device library, and a different bit there can move a label.
+__global__ void k_fe_scatter(const float4* __restrict__ cloud, const int* __restrict__ nb, int k, int n, double* __restrict__ S6) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int* row = nb + (size_t)i * k;
+    double m0 = 0, m1 = 0, m2 = 0, count = 0;
+    for (int e = 0; e < k; ++e) {
+        const float4 v = cloud[row[e]];
+        m0 += (double)v.x; m1 += (double)v.y; m2 += (double)v.z;
+        count += 1.0;
+    }
+    const double to_mean = 1.0 / count;
+    m0 *= to_mean; m1 *= to_mean; m2 *= to_mean;
+    double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0, weight = 0;
+    for (int e = 0; e < k; ++e) {
+        const float4 v = cloud[row[e]];
+        const double d0 = (double)v.x - m0, d1 = (double)v.y - m1, d2 = (double)v.z - m2;
+        xx += d0 * d0; xy += d0 * d1; xz += d0 * d2;
+        yy += d1 * d1; yz += d1 * d2; zz += d2 * d2;
+        weight += 1.0;
+    }
+    const double scale = 1.0 / weight;
+    double* o = S6 + (size_t)i * 6;
+    o[0] = xx * scale; o[1] = xy * scale; o[2] = xz * scale; o[3] = yy * scale; o[4] = yz * scale; o[5] = zz * scale;
+}
+
+// number of occupied cells of edge `resolution` (grid_sample.h:30-75): distinct cell keys through an open-addressing table
+__global__ void k_fe_count_cells(const FePt* __restrict__ P, int n, double mn0, double mn1, double mn2, double resolution, int s1, int s2,
+                                 int s3, unsigned long long* __restrict__ table, unsigned long long mask, int* __restrict__ count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool fresh = false;
+    if (i < n) {
+        int x = (int)((P[i].x - mn0) / resolution), y = (int)((P[i].y - mn1) / resolution), z = (int)((P[i].z - mn2) / resolution);
+        x = min(max(x, 0), s1 - 1); y = min(max(y, 0), s2 - 1); z = min(max(z, 0), s3 - 1);
+        const unsigned long long key = ((unsigned long long)(unsigned)x << 42) ^ ((unsigned long long)(unsigned)y << 21) ^ (unsigned long long)(unsigned)z;
+        unsigned long long h = (key * 0x9E3779B97F4A7C15ull) >> 20 & mask;
+        for (;;) {
+            const unsigned long long prev = atomicCAS(&table[h], ~0ull, key);
+            if (prev == ~0ull) { fresh = true; break; }
+            if (prev == key) break;
+            h = (h + 1) & mask;
+        }
+    }
+    const unsigned long long m = __ballot(fresh);
+    if (m && (threadIdx.x & 63) == __builtin_ctzll(m)) atomicAdd(count, __popcll(m));
+}
+
 struct FeTrace {
     pwicp_context* ctx;
     const bool on = getenv("PWICP_TRACE") != nullptr;
@@ -957,40 +1010,36 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     return PWICP_OK;
 }
 
-}  // namespace
+__global__ void k_fe_assemble(const float4* __restrict__ cloud, const double* __restrict__ normals3, int n, FePt* __restrict__ P) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 v = cloud[i];
+    FePt p;
+    p.x = (double)v.x; p.y = (double)v.y; p.z = (double)v.z;                 // S.cpp:18-22: float -> double
+    p.nx = normals3[3 * (size_t)i]; p.ny = normals3[3 * (size_t)i + 1]; p.nz = normals3[3 * (size_t)i + 2];
+    P[i] = p;
+}
 
-// Device pipeline from the k-NN graph on the host (n rows of k indices, the point itself first): PCA normals and the fusion
-// on the host (stages of host/frontend.cpp), boundary refinement and relabelling on the device.
-int pw_frontend_labels(pwicp_context* ctx, const float* cloud_xyz4, int n, const int32_t* nb, int k, float sv_resolution,
-                       int32_t* labels, int* n_supervoxels) {
-    if (k > 64) { ctx->set_err("front end: k > 64 neighbours not supported on the device"); return PWICP_E_INVALID; }
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    FeTrace tr{ctx};
-    std::vector<FePt> P((size_t)n);
-    pwhost::fe_points_and_normals(cloud_xyz4, n, nb, k, P.data());
-    tr.lap("pca normals (host)");
-    const double res = (double)sv_resolution;
-    const int n_sv = pwhost::fe_count_occupied_cells(P.data(), n, res);
-    tr.lap("occupied cells (host)");
-    DevBuf<FePt> dP;
-    DevBuf<int> d_nb, d_lab, d_roots, d_map;
-    HIPCHK(ctx, dP.reserve((size_t)n));
-    HIPCHK(ctx, d_nb.reserve((size_t)n * k));
+// fusion (device, or the serial host pass when asked for / when the device pass gives up), refinement, relabel, download
+int segment_from_device_graph(pwicp_context* ctx, FeTrace& tr, const float* cloud_xyz4, const FePt* dP, const int* d_nb, int k, int n,
+                              double res, int n_sv, int32_t* labels, int* n_supervoxels) {
+    hipStream_t st = ctx->stream;
+    DevBuf<int> d_lab, d_roots, d_map;
     HIPCHK(ctx, d_lab.reserve((size_t)n));
     HIPCHK(ctx, d_map.reserve((size_t)n));
-    hipStream_t st = ctx->stream;
-    HIPCHK(ctx, hipMemcpyAsync(dP.p, P.data(), sizeof(FePt) * (size_t)n, hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(d_nb.p, nb, sizeof(int) * (size_t)n * k, hipMemcpyHostToDevice, st));
-    tr.lap("upload");
     int n_roots = 0;
     bool host_fusion = getenv("PWICP_FUSION") && std::string(getenv("PWICP_FUSION")) == "host";
     if (!host_fusion) {
-        PWCHK(fusion_device(ctx, dP.p, d_nb.p, k, n, res, n_sv, d_lab.p, &d_roots, &n_roots, &host_fusion));
+        PWCHK(fusion_device(ctx, dP, d_nb, k, n, res, n_sv, d_lab.p, &d_roots, &n_roots, &host_fusion));
         tr.lap("fusion");
     }
     if (host_fusion) {                                  // (serial host pass: $PWICP_FUSION=host, or the device pass gave up)
-        std::vector<int> root_of, roots;
-        if (pwhost::fe_fusion_host(P.data(), nb, k, n, res, n_sv, &root_of, &roots) < 0) return PWICP_E_NOMEM;
+        std::vector<FePt> P((size_t)n);
+        std::vector<int> nb((size_t)n * k), root_of, roots;
+        HIPCHK(ctx, hipMemcpyAsync(P.data(), dP, sizeof(FePt) * (size_t)n, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(nb.data(), d_nb, sizeof(int) * (size_t)n * k, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        if (pwhost::fe_fusion_host(P.data(), nb.data(), k, n, res, n_sv, &root_of, &roots) < 0) return PWICP_E_NOMEM;
         n_roots = (int)roots.size();
         HIPCHK(ctx, d_roots.reserve(roots.size()));
         HIPCHK(ctx, hipMemcpyAsync(d_lab.p, root_of.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));
@@ -998,7 +1047,7 @@ int pw_frontend_labels(pwicp_context* ctx, const float* cloud_xyz4, int n, const
         HIPCHK(ctx, hipStreamSynchronize(st));
         tr.lap("fusion (host)");
     }
-    PWCHK(refine_device(ctx, dP.p, d_nb.p, k, n, res, d_lab.p));
+    PWCHK(refine_device(ctx, dP, d_nb, k, n, res, d_lab.p));
     tr.lap("boundary refinement");
     hipLaunchKernelGGL(k_mark_roots, grid1(n_roots), dim3(256), 0, st, d_roots.p, n_roots, d_map.p);
     hipLaunchKernelGGL(k_relabel, grid1(n), dim3(256), 0, st, d_lab.p, n, d_map.p);
@@ -1006,5 +1055,71 @@ int pw_frontend_labels(pwicp_context* ctx, const float* cloud_xyz4, int n, const
     HIPCHK(ctx, hipStreamSynchronize(st));
     *n_supervoxels = n_roots;
     tr.lap("relabel + download");
+    (void)cloud_xyz4;
     return PWICP_OK;
+}
+
+}  // namespace
+
+// The whole front end of one cloud (S.cpp:18-68).  Device: k-NN graph, neighbourhood scatter, occupied cells, fusion,
+// refinement, relabel.  Host: the closed-form eigen step of the normals (libm's pow / acos / cos decide label bits) and the
+// median that gives lambda0.
+int pw_frontend_segment_device(pwicp_context* ctx, const float* cloud_xyz4, int n, int k, float cell_edge, float sv_resolution,
+                               int32_t* labels, int* n_supervoxels) {
+    if (k > 64) { ctx->set_err("front end: k > 64 neighbours not supported on the device"); return PWICP_E_INVALID; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    FeTrace tr{ctx};
+    DevBuf<float4> pts;
+    HIPCHK(ctx, pts.reserve((size_t)n));
+    HIPCHK(ctx, hipMemcpyAsync(pts.p, cloud_xyz4, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, st));
+    DevBuf<int> d_nb;
+    HIPCHK(ctx, d_nb.reserve((size_t)n * k));
+    {
+        Grid g;
+        PWCHK(pw_grid_build(ctx, pts.p, n, cell_edge > 0.f ? cell_edge : pw_estimate_cell_edge(cloud_xyz4, n), &g));
+        PWCHK(pw_knn_launch(ctx, g.d, k, d_nb.p));                               // S.cpp:30-41
+        HIPCHK(ctx, hipStreamSynchronize(st));
+    }
+    tr.lap("k-NN graph");
+    // normals: scatter on the device, eigen step on the host
+    DevBuf<double> dS, dN;
+    DevBuf<FePt> dP;
+    HIPCHK(ctx, dS.reserve((size_t)n * 6));
+    HIPCHK(ctx, dN.reserve((size_t)n * 3));
+    HIPCHK(ctx, dP.reserve((size_t)n));
+    hipLaunchKernelGGL(k_fe_scatter, grid1(n), dim3(256), 0, st, pts.p, d_nb.p, k, n, dS.p);
+    std::vector<double> S6((size_t)n * 6), N3((size_t)n * 3);
+    HIPCHK(ctx, hipMemcpyAsync(S6.data(), dS.p, sizeof(double) * 6 * (size_t)n, hipMemcpyDeviceToHost, st));
+    // bounding box for the cell count meanwhile (grid_sample.h:36-44)
+    double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    for (int i = 0; i < n; ++i)
+        for (int d = 0; d < 3; ++d) {
+            const double c = (double)cloud_xyz4[4 * (size_t)i + d];
+            mn[d] = std::min(mn[d], c); mx[d] = std::max(mx[d], c);
+        }
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    pwhost::fe_normals_from_scatter(S6.data(), n, N3.data());
+    HIPCHK(ctx, hipMemcpyAsync(dN.p, N3.data(), sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_fe_assemble, grid1(n), dim3(256), 0, st, pts.p, dN.p, n, dP.p);
+    tr.lap("pca normals");
+    const double res = (double)sv_resolution;
+    int n_sv = 0;
+    {
+        const int s1 = (int)((mx[0] - mn[0]) / res + 1), s2 = (int)((mx[1] - mn[1]) / res + 1), s3 = (int)((mx[2] - mn[2]) / res + 1);
+        size_t cap = 1;
+        while (cap < 2 * (size_t)n) cap <<= 1;
+        DevBuf<unsigned long long> table;
+        DevBuf<int> cnt;
+        HIPCHK(ctx, table.reserve(cap));
+        HIPCHK(ctx, cnt.reserve(1));
+        HIPCHK(ctx, hipMemsetAsync(table.p, 0xff, sizeof(unsigned long long) * cap, st));
+        HIPCHK(ctx, hipMemsetAsync(cnt.p, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_fe_count_cells, grid1(n), dim3(256), 0, st, dP.p, n, mn[0], mn[1], mn[2], res, s1, s2, s3, table.p,
+                           (unsigned long long)(cap - 1), cnt.p);
+        HIPCHK(ctx, hipMemcpyAsync(&n_sv, cnt.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+    }
+    tr.lap("occupied cells");
+    return segment_from_device_graph(ctx, tr, cloud_xyz4, dP.p, d_nb.p, k, n, res, n_sv, labels, n_supervoxels);
 }

@@ -93,18 +93,22 @@ inline double smallest_eigenvalue(const Sym3& C) {
     return shift + 2.0 * p * std::cos(angle + M_PI * (2.0 / 3.0));
 }
 
-void pca_normal(Pt* P, int self, const int32_t* nb, int k) {
-    const Sym3 C = neighbourhood_scatter(P, nb, k);
+// null direction of (C - lambda_min I): cross product of its first two rows, normalised ((0, 0, 1) when it vanishes)
+inline void normal_from_scatter(const Sym3& C, double* n3) {
     const double lam = smallest_eigenvalue(C);
-    // null direction of (C - lam I): cross product of its first two rows
     const double n0 = C.xy * C.yz - C.xz * (C.yy - lam);
     const double n1 = C.xy * C.xz - C.yz * (C.xx - lam);
     const double n2 = (C.xx - lam) * (C.yy - lam) - C.xy * C.xy;
     const double len = std::sqrt(n0 * n0 + n1 * n1 + n2 * n2);
-    Pt& out = P[self];
-    if (len == 0.0) { out.nx = 0.0; out.ny = 0.0; out.nz = 1.0; return; }
+    if (len == 0.0) { n3[0] = 0.0; n3[1] = 0.0; n3[2] = 1.0; return; }
     const double unit = 1.0 / len;
-    out.nx = n0 * unit; out.ny = n1 * unit; out.nz = n2 * unit;
+    n3[0] = n0 * unit; n3[1] = n1 * unit; n3[2] = n2 * unit;
+}
+
+void pca_normal(Pt* P, int self, const int32_t* nb, int k) {
+    double n3[3];
+    normal_from_scatter(neighbourhood_scatter(P, nb, k), n3);
+    P[self].nx = n3[0]; P[self].ny = n3[1]; P[self].nz = n3[2];
 }
 
 struct Metric {      // Segmentation.h:362-375
@@ -466,6 +470,16 @@ void fe_points_and_normals(const float* cloud_xyz4, int n, const int32_t* nb, in
     });
 }
 int fe_count_occupied_cells(const FePt* P, int n, double resolution) { return count_occupied_cells(P, n, resolution); }
+void fe_normals_from_scatter(const double* S6, int n, double* normals3) {
+    parallel_for(n, [&](long long lo, long long hi) {
+        for (long long i = lo; i < hi; ++i) {
+            const double* c = S6 + 6 * (size_t)i;
+            Sym3 C;
+            C.xx = c[0]; C.xy = c[1]; C.xz = c[2]; C.yy = c[3]; C.yz = c[4]; C.zz = c[5];
+            normal_from_scatter(C, normals3 + 3 * (size_t)i);
+        }
+    });
+}
 int fe_fusion_host(const FePt* P, const int32_t* nb, int k, int n, double resolution, int n_supervoxels, std::vector<int>* root_of,
                    std::vector<int>* roots) {
     Metric metric{P, resolution};
@@ -507,13 +521,16 @@ PWICP_API int pwicp_frontend_segment_dev(pwicp_context* ctx, const float* cloud_
                                          float point_spacing, int32_t* labels, int* n_supervoxels) {
     if (!ctx || !cloud_xyz4 || !labels || !n_supervoxels || n <= 0 || knn <= 0 || knn >= n || !(sv_resolution > 0.f))
         return PWICP_E_INVALID;
+    const float cell_edge = point_spacing > 0.f ? 2.0f * point_spacing : 0.f;
+    const char* e = std::getenv("PWICP_FRONTEND");
+    if (!(e && std::strcmp(e, "host") == 0))
+        return pw_frontend_segment_device(ctx, cloud_xyz4, n, knn, cell_edge, sv_resolution, labels, n_supervoxels);
+    // $PWICP_FRONTEND=host: k-NN graph on the device, the serial passes on the host (same labels)
     pwhost::HostBuf<int32_t> nb;
     if (!nb.reserve((size_t)n * knn)) return PWICP_E_NOMEM;
-    const int rc = pwicp_knn(ctx, cloud_xyz4, n, knn, point_spacing > 0.f ? 2.0f * point_spacing : 0.f, nb.data());
+    const int rc = pwicp_knn(ctx, cloud_xyz4, n, knn, cell_edge, nb.data());
     if (rc != PWICP_OK) return rc;
-    const char* e = std::getenv("PWICP_FRONTEND");
-    if (e && std::strcmp(e, "host") == 0) return segment_from_neighbors(cloud_xyz4, n, nb.data(), knn, sv_resolution, labels, n_supervoxels);
-    return pw_frontend_labels(ctx, cloud_xyz4, n, nb.data(), knn, sv_resolution, labels, n_supervoxels);
+    return segment_from_neighbors(cloud_xyz4, n, nb.data(), knn, sv_resolution, labels, n_supervoxels);
 }
 
 }  // extern "C"

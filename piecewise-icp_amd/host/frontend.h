@@ -14,6 +14,8 @@ struct alignas(64) FePt {
 
 // float -> double positions (S.cpp:18-22) and PCA normals (pca_estimate_normals.h:42-108) of all points, host threads
 void fe_points_and_normals(const float* cloud_xyz4, int n, const int32_t* nb, int k, FePt* P);
+// the eigen step of the PCA normals alone: S6 = xx xy xz yy yz zz of every neighbourhood (built on the device) -> unit normals
+void fe_normals_from_scatter(const double* S6, int n, double* normals3);
 // number of occupied cells of edge `resolution` (grid_sample.h:30-75) = the supervoxel count the fusion stops at
 int fe_count_occupied_cells(const FePt* P, int n, double resolution);
 // the serial fusion (supervoxel_segmentation.h:65-170): root point of every point and the roots in ascending order
@@ -22,7 +24,8 @@ int fe_fusion_host(const FePt* P, const int32_t* nb, int k, int n, double resolu
 
 }  // namespace pwhost
 
-// csrc/frontend.hip: supervoxel labels from the k-NN graph (host array), heavy passes on the device
+// csrc/frontend.hip: the whole front end of a cloud on the device - k-NN graph, neighbourhood scatter, occupied cells, fusion,
+// refinement, relabel (cell_edge: of the k-NN search grid, <= 0 estimated)
 struct pwicp_context;
-int pw_frontend_labels(pwicp_context* ctx, const float* cloud_xyz4, int n, const int32_t* nb, int k, float sv_resolution,
-                       int32_t* labels, int* n_supervoxels);
+int pw_frontend_segment_device(pwicp_context* ctx, const float* cloud_xyz4, int n, int k, float cell_edge, float sv_resolution,
+                               int32_t* labels, int* n_supervoxels);

@@ -99,20 +99,19 @@ bool prepare_gpu(pwicp_context* ctx, const std::vector<float>& raw, float Res, f
         q[1] = S[4] * x + S[5] * y + S[6] * z + S[7];
         q[2] = S[8] * x + S[9] * y + S[10] * z + S[11];
     }
-    if (!c->nb.reserve((size_t)m * kNN)) { std::cerr << "Error: out of host memory.\n"; return false; }
-    if (pwicp_knn(ctx, c->p.data(), m, kNN, 2.0f * Res, c->nb.data()) != PWICP_OK) {                          // S.cpp:30-41
-        std::cerr << "Error: supervoxel segmentation failed: " << pwicp_last_error(ctx) << "\n";
-        return false;
-    }
-    if (frontend_on_device()) {                                    // S.cpp:42-68 on the device (csrc/frontend.hip)
+    if (frontend_on_device()) {                                    // S.cpp:30-68 on the device (csrc/frontend.hip)
         c->lab.resize((size_t)m);
-        const int rc = pw_frontend_labels(ctx, c->p.data(), m, c->nb.data(), kNN, c->SVRes, c->lab.data(), &c->nsv);
-        c->nb.release();
-        if (rc != PWICP_OK) {
+        if (pw_frontend_segment_device(ctx, c->p.data(), m, kNN, 2.0f * Res, c->SVRes, c->lab.data(), &c->nsv) != PWICP_OK) {
             std::cerr << "Error: supervoxel segmentation failed: " << pwicp_last_error(ctx) << "\n";
             return false;
         }
         c->segmented = true;
+        return true;
+    }
+    if (!c->nb.reserve((size_t)m * kNN)) { std::cerr << "Error: out of host memory.\n"; return false; }
+    if (pwicp_knn(ctx, c->p.data(), m, kNN, 2.0f * Res, c->nb.data()) != PWICP_OK) {                          // S.cpp:30-41
+        std::cerr << "Error: supervoxel segmentation failed: " << pwicp_last_error(ctx) << "\n";
+        return false;
     }
     return true;
 }
