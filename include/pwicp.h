@@ -53,6 +53,7 @@ typedef struct pwicp_pair pwicp_pair;         /* one target/source pair resident
 /* ---- context ------------------------------------------------------------------------------ */
 PWICP_API int         pwicp_create(pwicp_context** ctx, int device_id);
 PWICP_API void        pwicp_destroy(pwicp_context* ctx);
+PWICP_API int         pwicp_context_device(const pwicp_context* ctx);   /* HIP device ordinal of a context (-1: null) */
 PWICP_API const char* pwicp_last_error(const pwicp_context* ctx);
 PWICP_API const char* pwicp_version(void);
 /* number of visible HIP devices (0 when none / no runtime) */

@@ -40,9 +40,13 @@ int pwicp_create(pwicp_context** out, int device_id) {
 void pwicp_destroy(pwicp_context* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->scratch.reset();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
+
+int pwicp_context_device(const pwicp_context* ctx) { return ctx ? ctx->device : -1; }
 
 const char* pwicp_last_error(const pwicp_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -20,6 +21,7 @@ struct pwicp_context {
     hipStream_t stream = nullptr;
     std::string err;
     int n_cu = 256;
+    std::shared_ptr<void> scratch;        // grow-only work buffers a stage keeps between calls (csrc/frontend.hip), freed with the context
     void set_err(const char* where, hipError_t e) {
         char buf[512];
         snprintf(buf, sizeof(buf), "%s: %s", where, hipGetErrorString(e));

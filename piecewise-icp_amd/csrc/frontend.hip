@@ -751,6 +751,63 @@ __global__ void k_fe_count_cells(const FePt* __restrict__ P, int n, double mn0, 
     if (m && (threadIdx.x & 63) == __builtin_ctzll(m)) atomicAdd(count, __popcll(m));
 }
 
+// Device (and pinned host) buffers of the front end, kept by the context between calls and only ever grown: a front end is
+// ~50 buffers; allocating and freeing them per cloud costs milliseconds, and hipFree waits for the whole device - which
+// stalls the front ends of other clouds running on other streams (host/registration.cpp: AuxContexts).
+struct FeWorkspace {
+    // pipeline
+    DevBuf<float4> pts;
+    Grid grid;
+    DevBuf<int> d_nb, d_lab, d_roots, d_map, cell_cnt;
+    DevBuf<double> dS, dN;
+    DevBuf<FePt> dP;
+    DevBuf<unsigned long long> table;
+    double* hS = nullptr;               // pinned: scatter down, normals up
+    double* hN = nullptr;
+    size_t h_n = 0;
+    int* h_ctr = nullptr;               // pinned: counters read back after every sweep
+    // refinement
+    DevBuf<double> dis, nd;
+    DevBuf<unsigned long long> key;
+    DevBuf<int> pos, cnt, La, Lb, nla, nlb, flag, tmp;
+    // fusion
+    DevBuf<double> dmin;
+    DevBuf<int> root0, s0, lenA, lenB, cenA, cenB, revoff, revown, cursor, ab, ab_prev, rec_sz, rec_ran, rec_absn, rec_adjn, slot_of, wake,
+        dflag, cflag, dtmin, Wa, Wb, dq, dq2, o_sz, o_ran, o_absn, o_adjn, o_dirty, o_oldabsn, alive, newlen, cut, arenaA, arenaB, sa, ctr;
+    DevBuf<long long> offA, offB, rec_ptr, o_ptr, o_oldptr;
+    DevBuf<unsigned long long> big;     // [0] absorbed in the round, [16 * (1 + r)] bump pointer of arena region r
+    FeWorkspace() = default;
+    FeWorkspace(const FeWorkspace&) = delete;
+    FeWorkspace& operator=(const FeWorkspace&) = delete;
+    ~FeWorkspace() {
+        if (hS) (void)hipHostFree(hS);
+        if (hN) (void)hipHostFree(hN);
+        if (h_ctr) (void)hipHostFree(h_ctr);
+    }
+    hipError_t host_reserve(size_t n) {
+        if (!h_ctr) {
+            const hipError_t e = hipHostMalloc((void**)&h_ctr, sizeof(int) * 16, hipHostMallocDefault);
+            if (e != hipSuccess) return e;
+        }
+        if (n <= h_n) return hipSuccess;
+        if (hS) (void)hipHostFree(hS);
+        if (hN) (void)hipHostFree(hN);
+        hS = hN = nullptr;
+        h_n = 0;
+        hipError_t e = hipHostMalloc((void**)&hS, sizeof(double) * 6 * n, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        e = hipHostMalloc((void**)&hN, sizeof(double) * 3 * n, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        h_n = n;
+        return hipSuccess;
+    }
+};
+
+FeWorkspace* workspace_of(pwicp_context* ctx) {
+    if (!ctx->scratch) ctx->scratch = std::shared_ptr<void>(new FeWorkspace, [](void* p) { delete static_cast<FeWorkspace*>(p); });
+    return static_cast<FeWorkspace*>(ctx->scratch.get());
+}
+
 struct FeTrace {
     pwicp_context* ctx;
     const bool on = getenv("PWICP_TRACE") != nullptr;
@@ -769,9 +826,10 @@ inline dim3 grid1(long long n, int block = 256) { return dim3((unsigned)std::max
 // labels (root point per point) -> refined labels, in place
 int refine_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, int n, double res, int* d_lab) {
     hipStream_t st = ctx->stream;
-    DevBuf<double> dis, nd;
-    DevBuf<unsigned long long> key;
-    DevBuf<int> pos, cnt, La, Lb, nla, nlb, flag, tmp;
+    FeWorkspace& ws = *workspace_of(ctx);
+    DevBuf<double>&dis = ws.dis, &nd = ws.nd;
+    DevBuf<unsigned long long>& key = ws.key;
+    DevBuf<int>&pos = ws.pos, &cnt = ws.cnt, &La = ws.La, &Lb = ws.Lb, &nla = ws.nla, &nlb = ws.nlb, &flag = ws.flag, &tmp = ws.tmp;
     HIPCHK(ctx, dis.reserve((size_t)n));
     HIPCHK(ctx, nd.reserve((size_t)n));
     HIPCHK(ctx, key.reserve((size_t)n));
@@ -840,10 +898,11 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     hipStream_t st = ctx->stream;
     const bool trace = getenv("PWICP_TRACE") != nullptr;
     *gave_up = false;
+    FeWorkspace& ws = *workspace_of(ctx);
     // lambda0 (:91-102)
     double lambda;
     {
-        DevBuf<double> dmin;
+        DevBuf<double>& dmin = ws.dmin;
         HIPCHK(ctx, dmin.reserve((size_t)n));
         hipLaunchKernelGGL(k_fus_min_metric, grid1(n), dim3(256), 0, st, dP, d_nb, k, n, res, dmin.p);
         std::vector<double> v((size_t)n);
@@ -852,10 +911,15 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
         std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
         lambda = std::max(DBL_EPSILON, v[v.size() / 2]);
     }
-    DevBuf<int> root0, s0, lenA, lenB, cenA, cenB, revoff, revown, cursor, ab, ab_prev, rec_sz, rec_ran, rec_absn, rec_adjn, slot_of, wake,
-        dflag, cflag, dtmin, Wa, Wb, dq, dq2, o_sz, o_ran, o_absn, o_adjn, o_dirty, o_oldabsn, alive, newlen, cut, tmp, arenaA, arenaB, sa, ctr;
-    DevBuf<long long> offA, offB, rec_ptr, o_ptr, o_oldptr;
-    DevBuf<unsigned long long> big;     // [0] absorbed in the round, [16 * (1 + r)] bump pointer of arena region r
+    DevBuf<int>&root0 = ws.root0, &s0 = ws.s0, &lenA = ws.lenA, &lenB = ws.lenB, &cenA = ws.cenA, &cenB = ws.cenB,
+        &revoff = ws.revoff, &revown = ws.revown, &cursor = ws.cursor, &ab = ws.ab, &ab_prev = ws.ab_prev,
+        &rec_sz = ws.rec_sz, &rec_ran = ws.rec_ran, &rec_absn = ws.rec_absn, &rec_adjn = ws.rec_adjn,
+        &slot_of = ws.slot_of, &wake = ws.wake, &dflag = ws.dflag, &cflag = ws.cflag, &dtmin = ws.dtmin, &Wa = ws.Wa,
+        &Wb = ws.Wb, &dq = ws.dq, &dq2 = ws.dq2, &o_sz = ws.o_sz, &o_ran = ws.o_ran, &o_absn = ws.o_absn,
+        &o_adjn = ws.o_adjn, &o_dirty = ws.o_dirty, &o_oldabsn = ws.o_oldabsn, &alive = ws.alive, &newlen = ws.newlen,
+        &cut = ws.cut, &tmp = ws.tmp, &arenaA = ws.arenaA, &arenaB = ws.arenaB, &sa = ws.sa, &ctr = ws.ctr;
+    DevBuf<long long>&offA = ws.offA, &offB = ws.offB, &rec_ptr = ws.rec_ptr, &o_ptr = ws.o_ptr, &o_oldptr = ws.o_oldptr;
+    DevBuf<unsigned long long>& big = ws.big;
     const size_t N = (size_t)n;
     for (DevBuf<int>* b : {&root0, &s0, &lenA, &lenB, &cenA, &cenB, &cursor, &ab, &ab_prev, &rec_sz, &rec_ran, &rec_absn, &rec_adjn, &slot_of,
                            &wake, &dflag, &cflag, &dtmin, &Wa, &Wb, &dq, &dq2, &o_sz, &o_ran, &o_absn, &o_adjn, &o_dirty, &o_oldabsn, &cut})
@@ -887,9 +951,8 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     s.wake = wake.p; s.dflag = dflag.p; s.cflag = cflag.p; s.dtmin = dtmin.p;
     int* const nWnext = ctr.p; int* const ndq = ctr.p + 1; int* const status = ctr.p + 8;
     s.nWnext = nWnext; s.status = status;
-    int* h_ctr = nullptr;                           // pinned: read back after every sweep
-    HIPCHK(ctx, hipHostMalloc((void**)&h_ctr, sizeof(int) * 16, hipHostMallocDefault));
-    struct Unpin { int* p; ~Unpin() { (void)hipHostFree(p); } } unpin{h_ctr};
+    HIPCHK(ctx, ws.host_reserve(0));
+    int* const h_ctr = ws.h_ctr;                    // pinned: read back after every sweep
     const int wake_all_div = getenv("PWICP_FUSION_WAKE_DIV") ? std::max(atoi(getenv("PWICP_FUSION_WAKE_DIV")), 1) : 32;
     for (;; lambda *= 2.0, ++round) {
         if (nc <= 1) {                                  // (:106) nothing left to fuse
@@ -1024,7 +1087,8 @@ __global__ void k_fe_assemble(const float4* __restrict__ cloud, const double* __
 int segment_from_device_graph(pwicp_context* ctx, FeTrace& tr, const float* cloud_xyz4, const FePt* dP, const int* d_nb, int k, int n,
                               double res, int n_sv, int32_t* labels, int* n_supervoxels) {
     hipStream_t st = ctx->stream;
-    DevBuf<int> d_lab, d_roots, d_map;
+    FeWorkspace& ws = *workspace_of(ctx);
+    DevBuf<int>&d_lab = ws.d_lab, &d_roots = ws.d_roots, &d_map = ws.d_map;
     HIPCHK(ctx, d_lab.reserve((size_t)n));
     HIPCHK(ctx, d_map.reserve((size_t)n));
     int n_roots = 0;
@@ -1070,27 +1134,30 @@ int pw_frontend_segment_device(pwicp_context* ctx, const float* cloud_xyz4, int 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     FeTrace tr{ctx};
-    DevBuf<float4> pts;
+    FeWorkspace& ws = *workspace_of(ctx);
+    DevBuf<float4>& pts = ws.pts;
     HIPCHK(ctx, pts.reserve((size_t)n));
     HIPCHK(ctx, hipMemcpyAsync(pts.p, cloud_xyz4, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, st));
-    DevBuf<int> d_nb;
+    DevBuf<int>& d_nb = ws.d_nb;
     HIPCHK(ctx, d_nb.reserve((size_t)n * k));
     {
-        Grid g;
+        Grid& g = ws.grid;
         PWCHK(pw_grid_build(ctx, pts.p, n, cell_edge > 0.f ? cell_edge : pw_estimate_cell_edge(cloud_xyz4, n), &g));
         PWCHK(pw_knn_launch(ctx, g.d, k, d_nb.p));                               // S.cpp:30-41
         HIPCHK(ctx, hipStreamSynchronize(st));
     }
     tr.lap("k-NN graph");
     // normals: scatter on the device, eigen step on the host
-    DevBuf<double> dS, dN;
-    DevBuf<FePt> dP;
+    DevBuf<double>&dS = ws.dS, &dN = ws.dN;
+    DevBuf<FePt>& dP = ws.dP;
+    HIPCHK(ctx, ws.host_reserve((size_t)n));
     HIPCHK(ctx, dS.reserve((size_t)n * 6));
     HIPCHK(ctx, dN.reserve((size_t)n * 3));
     HIPCHK(ctx, dP.reserve((size_t)n));
     hipLaunchKernelGGL(k_fe_scatter, grid1(n), dim3(256), 0, st, pts.p, d_nb.p, k, n, dS.p);
-    std::vector<double> S6((size_t)n * 6), N3((size_t)n * 3);
-    HIPCHK(ctx, hipMemcpyAsync(S6.data(), dS.p, sizeof(double) * 6 * (size_t)n, hipMemcpyDeviceToHost, st));
+    double* const S6 = ws.hS;
+    double* const N3 = ws.hN;
+    HIPCHK(ctx, hipMemcpyAsync(S6, dS.p, sizeof(double) * 6 * (size_t)n, hipMemcpyDeviceToHost, st));
     // bounding box for the cell count meanwhile (grid_sample.h:36-44)
     double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
     for (int i = 0; i < n; ++i)
@@ -1099,8 +1166,8 @@ int pw_frontend_segment_device(pwicp_context* ctx, const float* cloud_xyz4, int 
             mn[d] = std::min(mn[d], c); mx[d] = std::max(mx[d], c);
         }
     HIPCHK(ctx, hipStreamSynchronize(st));
-    pwhost::fe_normals_from_scatter(S6.data(), n, N3.data());
-    HIPCHK(ctx, hipMemcpyAsync(dN.p, N3.data(), sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
+    pwhost::fe_normals_from_scatter(S6, n, N3);
+    HIPCHK(ctx, hipMemcpyAsync(dN.p, N3, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_fe_assemble, grid1(n), dim3(256), 0, st, pts.p, dN.p, n, dP.p);
     tr.lap("pca normals");
     const double res = (double)sv_resolution;
@@ -1109,8 +1176,8 @@ int pw_frontend_segment_device(pwicp_context* ctx, const float* cloud_xyz4, int 
         const int s1 = (int)((mx[0] - mn[0]) / res + 1), s2 = (int)((mx[1] - mn[1]) / res + 1), s3 = (int)((mx[2] - mn[2]) / res + 1);
         size_t cap = 1;
         while (cap < 2 * (size_t)n) cap <<= 1;
-        DevBuf<unsigned long long> table;
-        DevBuf<int> cnt;
+        DevBuf<unsigned long long>& table = ws.table;
+        DevBuf<int>& cnt = ws.cell_cnt;
         HIPCHK(ctx, table.reserve(cap));
         HIPCHK(ctx, cnt.reserve(1));
         HIPCHK(ctx, hipMemsetAsync(table.p, 0xff, sizeof(unsigned long long) * cap, st));

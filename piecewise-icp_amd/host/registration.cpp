@@ -16,8 +16,10 @@
 #include <fstream>
 #include <iomanip>
 #include <iostream>
+#include <condition_variable>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -52,7 +54,7 @@ struct Prepared {
     float shift[3] = {0, 0, 0};    // the translation that was applied (minus the centroid of the pair's target)
     float Res = 0.f, SVRes = 0.f;
     double sor_mult = 0.0;
-    HostBuf<int32_t> nb;           // k-NN graph, m x kNN (released by prepare_host)
+    HostBuf<int32_t> nb;           // k-NN graph, m x kNN (host front end only; released by prepare_labels)
     std::vector<int32_t> lab;
     int nsv = 0;
     bool segmented = false;        // labels already made by the device pipeline
@@ -99,15 +101,7 @@ bool prepare_gpu(pwicp_context* ctx, const std::vector<float>& raw, float Res, f
         q[1] = S[4] * x + S[5] * y + S[6] * z + S[7];
         q[2] = S[8] * x + S[9] * y + S[10] * z + S[11];
     }
-    if (frontend_on_device()) {                                    // S.cpp:30-68 on the device (csrc/frontend.hip)
-        c->lab.resize((size_t)m);
-        if (pw_frontend_segment_device(ctx, c->p.data(), m, kNN, 2.0f * Res, c->SVRes, c->lab.data(), &c->nsv) != PWICP_OK) {
-            std::cerr << "Error: supervoxel segmentation failed: " << pwicp_last_error(ctx) << "\n";
-            return false;
-        }
-        c->segmented = true;
-        return true;
-    }
+    if (frontend_on_device()) return true;                         // S.cpp:30-68 follow in prepare_labels, on a stream of their own
     if (!c->nb.reserve((size_t)m * kNN)) { std::cerr << "Error: out of host memory.\n"; return false; }
     if (pwicp_knn(ctx, c->p.data(), m, kNN, 2.0f * Res, c->nb.data()) != PWICP_OK) {                          // S.cpp:30-41
         std::cerr << "Error: supervoxel segmentation failed: " << pwicp_last_error(ctx) << "\n";
@@ -116,9 +110,51 @@ bool prepare_gpu(pwicp_context* ctx, const std::vector<float>& raw, float Res, f
     return true;
 }
 
-// host part (thread-safe): supervoxel labels (S.cpp:42-68)
-bool prepare_host(Prepared* c) {
+// Auxiliary contexts (= streams) of one device: the front ends of several clouds run side by side, each on its own stream
+// and host thread (a front end is hundreds of small dependent launches: one alone leaves most of the GPU idle).
+struct AuxContexts {
+    int device = 0, limit = 3, made = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<pwicp_context*> idle;
+    explicit AuxContexts(int dev) : device(dev) {
+        if (const char* e = std::getenv("PWICP_FRONTEND_STREAMS")) limit = std::max(1, std::min(atoi(e), 16));
+    }
+    AuxContexts(const AuxContexts&) = delete;
+    AuxContexts& operator=(const AuxContexts&) = delete;
+    ~AuxContexts() { for (pwicp_context* c : idle) pwicp_destroy(c); }
+    pwicp_context* acquire() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            if (!idle.empty()) { pwicp_context* c = idle.back(); idle.pop_back(); return c; }
+            if (made < limit) {
+                pwicp_context* c = nullptr;
+                if (pwicp_create(&c, device) == PWICP_OK) { ++made; return c; }
+                if (made == 0) return nullptr;
+            }
+            cv.wait(lk);
+        }
+    }
+    void release(pwicp_context* c) {
+        { std::lock_guard<std::mutex> lk(m); idle.push_back(c); }
+        cv.notify_one();
+    }
+};
+
+// supervoxel labels of a prepared cloud (S.cpp:30-68; thread-safe): the device pipeline on a stream of its own, or
+// ($PWICP_FRONTEND=host) the serial host passes from the k-NN graph prepare_gpu left
+bool prepare_labels(Prepared* c, AuxContexts* aux) {
     if (c->segmented) return true;
+    if (frontend_on_device()) {
+        pwicp_context* ctx = aux->acquire();
+        if (!ctx) { std::cerr << "Error: no usable HIP device (pwicp has no CPU fallback).\n"; return false; }
+        c->lab.resize((size_t)c->m);
+        const int rc = pw_frontend_segment_device(ctx, c->p.data(), c->m, kNN, 2.0f * c->Res, c->SVRes, c->lab.data(), &c->nsv);
+        if (rc != PWICP_OK) std::cerr << "Error: supervoxel segmentation failed: " << pwicp_last_error(ctx) << "\n";
+        aux->release(ctx);
+        c->segmented = rc == PWICP_OK;
+        return c->segmented;
+    }
     c->lab.resize((size_t)c->m);
     const int rc = segment_from_knn(c->p.data(), c->m, c->nb.data(), kNN, c->SVRes, c->lab.data(), &c->nsv);
     c->nb.release();
@@ -176,10 +212,11 @@ bool register_pair(pwicp_context* ctx, const std::vector<float>& cloud1, const s
     std::cout << "PC-1 avg. point spacing: " << Res1 << "\t PC-2 avg. point spacing: " << Res2 << std::endl << std::endl;
     const float SVRes1 = cfg.isSetResSVsize ? cfg.SVsize1 : Res1 * 10, SVRes2 = cfg.isSetResSVsize ? cfg.SVsize2 : Res2 * 10;   // R.cpp:635-640
     Prepared t, s;
+    AuxContexts aux(pwicp_context_device(ctx));
     if (!prepare_gpu(ctx, cloud1, Res1, SVRes1, sor_mult, nullptr, &t)) return false;
     bool ok1 = true;
-    std::thread th([&] { ok1 = prepare_host(&t); });            // the target's host passes run beside the source's GPU part
-    const bool ok2 = prepare_gpu(ctx, cloud2, Res2, SVRes2, sor_mult, t.shift, &s) && prepare_host(&s);
+    std::thread th([&] { ok1 = prepare_labels(&t, &aux); });    // the target's front end runs beside the source's preparation and front end
+    const bool ok2 = prepare_gpu(ctx, cloud2, Res2, SVRes2, sor_mult, t.shift, &s) && prepare_labels(&s, &aux);
     th.join();
     tm.lap("preparation (GPU: voxel grid, SOR, k-NN; host: supervoxels)");
     if (!ok1 || !ok2) { std::cerr << "Error: supervoxel segmentation failed.\n"; return false; }
@@ -464,12 +501,15 @@ struct SeriesWorker {
     // prepared target clouds by epoch index (in the Direct2Ref mode every pair has the same target, R.cpp:94-103; in the
     // adaptive mode runs of pairs share one): prepared once PER DEVICE, kept while the following pairs use them
     std::map<int, std::shared_ptr<Prepared>> targets;
+    std::unique_ptr<AuxContexts> aux;     // streams for the front ends of the clouds of a window
     bool need_ctx() {
+        if (!aux) aux.reset(new AuxContexts(device));
         if (ctx) return true;
         if (pwicp_create(&ctx, device) != PWICP_OK) { std::cerr << "Error: no usable HIP device (pwicp has no CPU fallback).\n"; ctx = nullptr; return false; }
         return true;
     }
     void close() {
+        aux.reset();
         targets.clear();                  // device-side targets go before their context
         if (ctx) pwicp_destroy(ctx);
         ctx = nullptr;
@@ -639,7 +679,8 @@ static int run_pairs_on(pwicp_series* s, SeriesWorker* w, const int32_t* pairs, 
                     w->targets[kv.first] = t;
                     Prepared* p = t.get();
                     char* flag = &okt[ti];
-                    th.emplace_back([p, flag] { *flag = prepare_host(p) ? 1 : 0; });
+                    AuxContexts* aux = w->aux.get();
+                    th.emplace_back([p, flag, aux] { *flag = prepare_labels(p, aux) ? 1 : 0; });
                 }
                 std::vector<float>().swap(kv.second);
                 ++ti;
@@ -653,7 +694,7 @@ static int run_pairs_on(pwicp_series* s, SeriesWorker* w, const int32_t* pairs, 
             const float SVRes2 = cfg.isSetResSVsize ? cfg.SVsize2 : Res2 * 10;
             if (good) good = prepare_gpu(w->ctx, raw2[(size_t)k], Res2, SVRes2, sor_mult, it->second->shift, &src[(size_t)k]);
             ok[(size_t)k] = good ? 1 : 0;
-            if (good) th.emplace_back([&ok, &src, k] { ok[(size_t)k] = prepare_host(&src[(size_t)k]) ? 1 : 0; });
+            if (good) th.emplace_back([&ok, &src, k, w] { ok[(size_t)k] = prepare_labels(&src[(size_t)k], w->aux.get()) ? 1 : 0; });
             std::vector<float>().swap(raw2[(size_t)k]);
         }
         tm.lap("voxel grid + SOR, k-NN graphs (GPU)");
