@@ -256,16 +256,53 @@ constexpr int kFusArenas = 256;
         __builtin_amdgcn_wave_barrier();                      \
     } while (0)
 
+// A wavefront takes a CHUNK of consecutive work-list slots and runs them one after the other: a centre then sees what the
+// centres of its own chunk have just decided (their outcomes and claims are kept in LDS) instead of their outcomes of the
+// previous sweep - Gauss-Seidel inside the chunk, Jacobi between chunks.  Neighbouring centres are neighbours in the visiting
+// order, which is where most dependencies are: the worst round needs ~3x fewer sweeps.  Any mixture of old and new guesses
+// converges to the same fixed point; a sweep without changes still certifies it.
+constexpr int kFusChunk = 16, kFusFresh = 256;
+
 struct FusWave {           // per-wavefront scratch (LDS)
     int* keys; int* vals; int* queue;
     int qn, gcount;
     bool overflow;
+    // centres this wavefront has already run in this sweep (chunk), and the nodes they absorbed
+    int* cid; int* csz; int* cran; int* cabsn; int* cadjn; long long* cptr;
+    int* fkey; int* fval;
+    int ndone, nfresh;
 };
 
-__device__ __forceinline__ int fus_root_at(const FusState& s, int y, int t) {
+__device__ __forceinline__ int fus_chunk_index(const FusWave& w, int c) {
+    int q = -1;
+    for (int t = 0; t < w.ndone; ++t)
+        if (w.cid[t] == c) q = t;
+    return q;
+}
+
+// absorber of x as the running sweep knows it: the standing one, unless it belongs to a centre of the chunk that has run
+// again (then only the claims that centre has just made count)
+__device__ __forceinline__ int fus_absorber(const FusState& s, const FusWave& w, int x) {
+    int c = s.ab[x];
+    if (w.ndone) {
+        if (c != kNone && fus_chunk_index(w, c) >= 0) c = kNone;
+        if (w.nfresh) {
+            int sl = (int)(((unsigned)x * 2654435761u) >> 24) & (kFusFresh - 1);
+            for (;;) {
+                const int key = w.fkey[sl];
+                if (key == -1) break;
+                if (key == x) { c = min(c, w.fval[sl]); break; }
+                sl = (sl + 1) & (kFusFresh - 1);
+            }
+        }
+    }
+    return c;
+}
+
+__device__ __forceinline__ int fus_root_at(const FusState& s, const FusWave& w, int y, int t) {
     int x = s.root0[y], g = -1;
     for (;;) {
-        const int c = s.ab[x];
+        const int c = fus_absorber(s, w, x);
         if (c >= t || c <= g) break;
         g = c; x = c;
     }
@@ -281,7 +318,7 @@ __device__ __forceinline__ void fus_expand(const FusState& s, FusWave& w, const 
         int r = 0;
         const int gidx = w.gcount + lane;
         if (valid) {
-            r = fus_root_at(s, lp[e], i);
+            r = fus_root_at(s, w, lp[e], i);
             slot = (int)(((unsigned)r * 2654435761u) >> 22) & (kFusHash - 1);
             for (;;) {
                 const int prev = atomicCAS(&w.keys[slot], -1, r);
@@ -302,21 +339,36 @@ __device__ __forceinline__ void fus_expand(const FusState& s, FusWave& w, const 
     }
 }
 
-__global__ void __launch_bounds__(256) k_fus_run(FusState s, int nW) {
+__global__ void __launch_bounds__(256) k_fus_run(FusState s, int nW, int chunk) {
     __shared__ int s_keys[4][kFusHash];
     __shared__ int s_vals[4][kFusHash];
     __shared__ int s_queue[4][kFusQueue];
+    __shared__ int s_chunk[4][5][kFusChunk];
+    __shared__ long long s_cptr[4][kFusChunk];
+    __shared__ int s_fresh[4][2][kFusFresh];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     FusWave w;
     w.keys = s_keys[wave]; w.vals = s_vals[wave]; w.queue = s_queue[wave];
-    for (int slot = blockIdx.x * 4 + wave; slot < nW; slot += gridDim.x * 4) {
+    w.cid = s_chunk[wave][0]; w.csz = s_chunk[wave][1]; w.cran = s_chunk[wave][2]; w.cabsn = s_chunk[wave][3]; w.cadjn = s_chunk[wave][4];
+    w.cptr = s_cptr[wave];
+    w.fkey = s_fresh[wave][0]; w.fval = s_fresh[wave][1];
+    const int n_chunks = (nW + chunk - 1) / chunk;
+    for (int ci = blockIdx.x * 4 + wave; ci < n_chunks; ci += gridDim.x * 4) {
+      w.ndone = 0; w.nfresh = 0;
+      bool chunk_live = chunk > 1;
+      if (chunk > 1) {
+          for (int t = lane; t < kFusFresh; t += 64) w.fkey[t] = -1;
+          WSYNC();
+      }
+      const int slot_end = min(nW, (ci + 1) * chunk);
+      for (int slot = ci * chunk; slot < slot_end; ++slot) {
         const int i = s.W[slot];
         if (lane == 0) { s.slot_of[i] = slot; s.wake[i] = 0; }
         const int old_ran = s.rec_ran[i], old_sz = s.rec_sz[i], old_absn = s.rec_absn[i], old_adjn = s.rec_adjn[i];
         const long long old_ptr = s.rec_ptr[i];
         int ran = 0, size_i = s.s0[i], nabs = 0;
         w.qn = 1; w.gcount = 0; w.overflow = false;
-        if (s.len0[i] != 0 && !(s.ab[i] < i)) {
+        if (s.len0[i] != 0 && !(fus_absorber(s, w, i) < i)) {
             ran = 1;
             for (int t = lane; t < kFusHash; t += 64) { w.keys[t] = -1; w.vals[t] = INT_MAX; }
             WSYNC();
@@ -338,7 +390,12 @@ __global__ void __launch_bounds__(256) k_fus_run(FusState s, int nW) {
                     int sj = 0;
                     bool absorb = false;
                     if (valid) {
-                        sj = j < i ? s.rec_sz[j] : s.s0[j];
+                        if (j < i) {
+                            const int q = fus_chunk_index(w, j);
+                            sj = q >= 0 ? w.csz[q] : s.rec_sz[j];
+                        } else {
+                            sj = s.s0[j];
+                        }
                         const double loss = (double)sj * sv_metric(me, s.P[j], s.res);
                         absorb = s.lambda - loss > 0.0;
                         if (absorb) w.queue[idx] = j | (int)0x80000000;
@@ -350,8 +407,15 @@ __global__ void __launch_bounds__(256) k_fus_run(FusState s, int nW) {
                         const int jj = __builtin_amdgcn_readlane(j, l);
                         size_i += __builtin_amdgcn_readlane(sj, l);
                         ++nabs;
-                        if (jj < i && s.rec_ran[jj]) fus_expand(s, w, s.sa + s.rec_ptr[jj] + s.rec_absn[jj], s.rec_adjn[jj], i, lane);
-                        else fus_expand(s, w, s.arena0 + s.off0[jj], s.len0[jj], i, lane);
+                        const int q = jj < i ? fus_chunk_index(w, jj) : -1;
+                        if (q >= 0) {
+                            if (w.cran[q]) fus_expand(s, w, s.sa + w.cptr[q] + w.cabsn[q], w.cadjn[q], i, lane);
+                            else fus_expand(s, w, s.arena0 + s.off0[jj], s.len0[jj], i, lane);
+                        } else if (jj < i && s.rec_ran[jj]) {
+                            fus_expand(s, w, s.sa + s.rec_ptr[jj] + s.rec_absn[jj], s.rec_adjn[jj], i, lane);
+                        } else {
+                            fus_expand(s, w, s.arena0 + s.off0[jj], s.len0[jj], i, lane);
+                        }
                     }
                 }
                 front = stop;
@@ -365,6 +429,7 @@ __global__ void __launch_bounds__(256) k_fus_run(FusState s, int nW) {
         const int total = ran ? w.qn - 1 : 0;
         const int nadj = total - nabs;
         bool same = ran == old_ran && size_i == old_sz && nabs == old_absn && nadj == old_adjn;
+        long long new_ptr = old_ptr;
         for (int pass = 0; pass < 2; ++pass) {
             long long ptr = old_ptr;
             if (pass == 0 && !same) continue;
@@ -382,6 +447,7 @@ __global__ void __launch_bounds__(256) k_fus_run(FusState s, int nW) {
                     break;
                 }
                 ptr = (long long)(region * rcap + at);
+                new_ptr = ptr;
             }
             int na = 0, nd = 0;
             bool diff = false;
@@ -413,6 +479,41 @@ __global__ void __launch_bounds__(256) k_fus_run(FusState s, int nW) {
             s.o_dirty[slot] = same ? 0 : 1;
             s.o_oldptr[slot] = old_ptr; s.o_oldabsn[slot] = old_absn;
         }
+        // what the later centres of the chunk see of this one
+        if (chunk_live && slot + 1 < slot_end && w.ndone < kFusChunk) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // its lists are in memory before they are read back
+            if (lane == 0) {
+                const int q = w.ndone;
+                w.cid[q] = i; w.csz[q] = size_i; w.cran[q] = ran; w.cabsn[q] = nabs; w.cadjn[q] = nadj; w.cptr[q] = new_ptr;
+            }
+            if (nabs > 0 && w.nfresh + nabs > kFusFresh / 2) {
+                // no room for its claims: the rest of the chunk reads the standing state only (a view that is neither the old
+                // nor the new state would not be flagged as a change)
+                chunk_live = false;
+                w.ndone = 0; w.nfresh = 0;
+                WSYNC();
+                continue;
+            }
+            if (nabs > 0) {
+                for (int base = 1; base <= total; base += 64) {
+                    const int idx = base + lane;
+                    if (idx <= total && w.queue[idx] < 0) {
+                        const int node = w.queue[idx] & 0x7fffffff;
+                        int sl = (int)(((unsigned)node * 2654435761u) >> 24) & (kFusFresh - 1);
+                        for (;;) {
+                            const int prev = atomicCAS(&w.fkey[sl], -1, node);
+                            if (prev == -1) { w.fval[sl] = i; break; }
+                            if (prev == node) { atomicMin(&w.fval[sl], i); break; }
+                            sl = (sl + 1) & (kFusFresh - 1);
+                        }
+                    }
+                }
+                w.nfresh += nabs;
+            }
+            ++w.ndone;
+            WSYNC();
+        }
+      }
     }
 }
 
@@ -429,12 +530,30 @@ __global__ void k_fus_retract(FusState s, int nW) {
 }
 __global__ void k_fus_claim(FusState s, int nW) {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= nW || s.o_dirty[slot] != 1) return;
+    if (slot >= nW || s.o_dirty[slot] == 2) return;
     const int c = s.W[slot];
-    s.rec_sz[c] = s.o_sz[slot]; s.rec_ran[c] = s.o_ran[slot]; s.rec_absn[c] = s.o_absn[slot]; s.rec_adjn[c] = s.o_adjn[slot];
-    s.rec_ptr[c] = s.o_ptr[slot];
+    if (s.o_dirty[slot] == 1) {
+        s.rec_sz[c] = s.o_sz[slot]; s.rec_ran[c] = s.o_ran[slot]; s.rec_absn[c] = s.o_absn[slot]; s.rec_adjn[c] = s.o_adjn[slot];
+        s.rec_ptr[c] = s.o_ptr[slot];
+    }
+    // the claims of EVERY centre that ran are made again: a standing claim that was hidden behind a smaller one (ab keeps only
+    // the smallest) would otherwise be lost when the smaller one is withdrawn while its owner, seeing the node free, stays as it is
     const long long p = s.o_ptr[slot];
     for (int e = 0, m = s.o_absn[slot]; e < m; ++e) atomicMin(&s.ab[s.sa[p + e]], c);
+}
+// all standing claims (the certificate of a round rebuilds the absorbers from scratch)
+__global__ void k_fus_claim_all(FusState s, const int* __restrict__ cen, int nc) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nc) return;
+    const int c = cen[t];
+    if (!s.rec_ran[c]) return;
+    const long long p = s.rec_ptr[c];
+    for (int e = 0, m = s.rec_absn[c]; e < m; ++e) atomicMin(&s.ab[s.sa[p + e]], c);
+}
+__global__ void k_fus_ab_changed(const int* __restrict__ ab, int* __restrict__ ab_prev, int n, int* __restrict__ changed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (ab[i] != ab_prev[i]) { ab_prev[i] = ab[i]; *changed = 1; }
 }
 
 // append to a list with ONE atomic per wavefront (the lanes that are active here and want to; same-address atomics serialise)
@@ -462,11 +581,12 @@ __device__ __forceinline__ void fus_mark_dirty(const FusState& s, bool on, int x
 // level 0 of the dirty list: centres whose outcome changed, nodes whose absorber changed
 __global__ void k_fus_dirty0(FusState s, int nW, int* dq, int* ndq) {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool on = slot < nW && s.o_dirty[slot] == 1;
-    const int c = on ? s.W[slot] : 0;
+    const bool live = slot < nW && s.o_dirty[slot] != 2;
+    const bool on = live && s.o_dirty[slot] == 1;
+    const int c = live ? s.W[slot] : 0;
     fus_mark_dirty(s, on, c, c, dq, ndq);
-    if (!on) return;
-    for (int pass = 0; pass < 2; ++pass) {
+    if (!live) return;
+    for (int pass = on ? 0 : 1; pass < 2; ++pass) {
         const long long p = pass ? s.o_ptr[slot] : s.o_oldptr[slot];
         const int m = pass ? s.o_absn[slot] : s.o_oldabsn[slot];
         for (int e = 0; e < m; ++e) {
@@ -953,6 +1073,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     s.nWnext = nWnext; s.status = status;
     HIPCHK(ctx, ws.host_reserve(0));
     int* const h_ctr = ws.h_ctr;                    // pinned: read back after every sweep
+    const int gs_chunk = getenv("PWICP_FUSION_CHUNK") ? std::max(atoi(getenv("PWICP_FUSION_CHUNK")), 1) : kFusChunk;
     const int wake_all_div = getenv("PWICP_FUSION_WAKE_DIV") ? std::max(atoi(getenv("PWICP_FUSION_WAKE_DIV")), 1) : 32;
     for (;; lambda *= 2.0, ++round) {
         if (nc <= 1) {                                  // (:106) nothing left to fuse
@@ -982,13 +1103,32 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
         HIPCHK(ctx, hipMemcpyAsync(W, cen, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
         int nW = nc, sweeps = 0;
         long long runs = 0;
-        while (nW > 0) {
+        // The round ends with a CERTIFICATE: one sweep over all centres, every one reading the standing state only, that
+        // changes nothing - i.e. every centre's outcome follows from the outcomes before it, which is the definition of the
+        // serial result.  Whatever the work lists missed before only costs more sweeps, never a label.
+        bool certified = false, certify = false;
+        while (!certified) {
+            if (nW == 0) {
+                HIPCHK(ctx, hipMemcpyAsync(W, cen, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
+                nW = nc;
+                certify = true;
+                // absorbers from scratch: the smallest centre whose standing outcome absorbs the node
+                hipLaunchKernelGGL(k_fill<int>, grid1(n), dim3(256), 0, st, ab.p, (long long)n, kNone);
+                hipLaunchKernelGGL(k_fus_claim_all, grid1(nc), dim3(256), 0, st, s, cen, nc);
+                HIPCHK(ctx, hipMemsetAsync(ctr.p + 15, 0, sizeof(int), st));
+                hipLaunchKernelGGL(k_fus_ab_changed, grid1(n), dim3(256), 0, st, ab.p, ab_prev.p, n, ctr.p + 15);
+                int differs = 0;
+                HIPCHK(ctx, hipMemcpyAsync(&differs, ctr.p + 15, sizeof(int), hipMemcpyDeviceToHost, st));
+                HIPCHK(ctx, hipStreamSynchronize(st));
+                if (trace && differs) fprintf(stderr, "[pwicp front end/dev]   (round %d: absorbers rebuilt for the certificate differ)\n", round);
+            }
             if (++sweeps > 100000) { ctx->set_err("front end: the fusion did not converge"); return PWICP_E_INTERNAL; }
             runs += nW;
             if (trace && getenv("PWICP_TRACE_SWEEPS")) fprintf(stderr, "      sweep %d: %d\n", sweeps, nW);
             s.W = W; s.Wnext = Wn;
             HIPCHK(ctx, hipMemsetAsync(ctr.p, 0, sizeof(int) * 16, st));
-            hipLaunchKernelGGL(k_fus_run, dim3((unsigned)std::min(div_up(nW, 4), 8192)), dim3(256), 0, st, s, nW);
+            const int chunk = certify ? 1 : std::max(1, std::min(std::min(nW / 8192, kFusChunk), gs_chunk));
+            hipLaunchKernelGGL(k_fus_run, dim3((unsigned)std::min(div_up(div_up(nW, chunk), 4), 8192)), dim3(256), 0, st, s, nW, chunk);
             hipLaunchKernelGGL(k_fus_retract, grid1(nW), dim3(256), 0, st, s, nW);
             hipLaunchKernelGGL(k_fus_claim, grid1(nW), dim3(256), 0, st, s, nW);
             hipLaunchKernelGGL(k_fus_dirty0, grid1(nW), dim3(256), 0, st, s, nW, dq.p, ndq);
@@ -1001,6 +1141,8 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
                 *gave_up = true;
                 return PWICP_OK;
             }
+            if (certify && h_ctr[1] == 0) { certified = true; break; }       // nothing changed against the rebuilt absorbers
+            certify = false;
             if (h_ctr[10] || h_ctr[11]) {               // closure deeper than the levels / too many changes: everybody runs again (always sound)
                 HIPCHK(ctx, hipMemcpyAsync(W, cen, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
                 nW = nc;

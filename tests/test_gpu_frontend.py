@@ -85,3 +85,18 @@ def test_search_queue_overflow_falls_back_to_the_serial_pass(ctx, capfd):
         os.environ.pop("PWICP_FUSION_QUEUE", None)
         os.environ.pop("PWICP_TRACE", None)
     assert "fusion gives up" in capfd.readouterr().err
+
+
+@pytest.mark.parametrize("knobs", [{"PWICP_FUSION_CHUNK": "1"}, {"PWICP_FUSION_CHUNK": "2"}, {"PWICP_FUSION_CHUNK": "4"},
+                                   {"PWICP_FUSION_CHUNK": "16", "PWICP_FUSION_WAKE_DIV": "1"},
+                                   {"PWICP_FUSION_CHUNK": "3", "PWICP_FUSION_WAKE_DIV": "100000"}])
+def test_labels_do_not_depend_on_the_sweep_schedule(ctx, knobs):
+    """The fixed point is the serial result whatever the schedule: chunks of 1 (Jacobi) ... 16 centres per wavefront
+    (Gauss-Seidel inside a chunk), work lists from the first sweep on (WAKE_DIV 1) or hardly ever (100000)."""
+    tgt, _, _ = _data.pair(400000)
+    os.environ.update(knobs)
+    try:
+        _assert_same(ctx, tgt, 10 * _data.R, _data.R)
+    finally:
+        for k in knobs:
+            os.environ.pop(k, None)
