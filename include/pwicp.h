@@ -240,8 +240,9 @@ PWICP_API int pwicp_pair_num_patch_points(const pwicp_pair* pair, int* n_patch_p
 /* The stages the reference runs before the loop, exported so that the two entry points below
  * are a complete drop-in.  The *_dev functions (and pwicp_knn) run on the GPU and are what the entry points use; the
  * functions without a context are host implementations of the SAME stage with identical output, kept as separate,
- * explicitly named entry points (the tests cross-check the two; nothing ever selects them as a fallback).  The serial
- * passes of the supervoxel front end (fusion, boundary refinement) are host code in both variants. */
+ * explicitly named entry points (the tests cross-check the two; nothing ever selects them as a fallback - with one
+ * documented exception: a supervoxel fusion whose search queue outgrows the wavefront's LDS queue hands that one pass to
+ * the serial host code, same labels). */
 
 /* Supervoxel label of every point.  Replaces the first half of PatchGenerationAndRefinement (S.cpp:18-68):
  * k-NN (knn = 45 in the reference, C.h:41, query point included), PCA normals, boundary-preserving supervoxel
@@ -252,7 +253,10 @@ PWICP_API int pwicp_frontend_segment(const float* cloud_xyz4, int n, float sv_re
  * order of the double squared distance, ties by index, the point itself first.  Replaces the
  * cl::KDTree::FindKNearestNeighbors loop of S.cpp:30-41.  cell_edge <= 0: estimated from the cloud. */
 PWICP_API int pwicp_knn(pwicp_context* ctx, const float* cloud_xyz4, int n, int k, float cell_edge, int32_t* neighbors);
-/* pwicp_frontend_segment with the k-NN graph built on the GPU (identical labels). point_spacing <= 0: estimated. */
+/* pwicp_frontend_segment on the GPU (csrc/frontend.hip): k-NN graph, neighbourhood scatter, supervoxel fusion and boundary
+ * refinement as speculative fixed points over the reference's serial visiting order - identical labels.  Host: the
+ * closed-form eigen step of the normals, one median.  Work buffers stay with the context (grow-only) until pwicp_destroy.
+ * point_spacing <= 0: estimated.  $PWICP_FRONTEND=host: the serial host passes behind the GPU k-NN graph. */
 PWICP_API int pwicp_frontend_segment_dev(pwicp_context* ctx, const float* cloud_xyz4, int n, float sv_resolution,
                                          int knn, float point_spacing, int32_t* labels, int* n_supervoxels);
 /* PCpreprocessing(cloud, out, true, voxel_size, sor_k, sor_mult) (C.cpp:423-452). out_xyz4 holds n points.
