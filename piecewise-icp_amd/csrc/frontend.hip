@@ -1048,7 +1048,9 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     for (DevBuf<long long>* b : {&offA, &offB, &rec_ptr, &o_ptr, &o_oldptr}) HIPCHK(ctx, b->reserve(N));
     HIPCHK(ctx, ctr.reserve(16));
     HIPCHK(ctx, big.reserve(16 * (kFusArenas + 1)));
-    const unsigned long long sa_cap = 16ull * (unsigned long long)n * (unsigned long long)k;
+    // lists of changed outcomes are appended, nothing is freed inside a round: 14 % of 16 n k entries at most on the clouds
+    // measured (the round after the first one); 6 n k = 1.1 GB per 1 M points, overflow = the device pass gives up
+    const unsigned long long sa_cap = 6ull * (unsigned long long)n * (unsigned long long)k;
     HIPCHK(ctx, sa.reserve((size_t)sa_cap));
     hipLaunchKernelGGL(k_fus_first_round, grid1(n), dim3(256), 0, st, n, k, root0.p, s0.p, lenA.p, offA.p, cenA.p);
     int* len0 = lenA.p; int* len1 = lenB.p;
@@ -1157,6 +1159,12 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
         HIPCHK(ctx, hipMemcpyAsync(&total, big.p, sizeof(total), hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         if (trace) {
+            std::vector<unsigned long long> tops(16 * (kFusArenas + 1));
+            (void)hipMemcpy(tops.data(), big.p, sizeof(unsigned long long) * tops.size(), hipMemcpyDeviceToHost);
+            unsigned long long used = 0, most = 0;
+            for (int r = 0; r < kFusArenas; ++r) { used += tops[16 * (1 + r)]; most = std::max(most, tops[16 * (1 + r)]); }
+            fprintf(stderr, "[pwicp front end/dev]   list arena: %.1f %% used, fullest region %.1f %%\n", 100.0 * (double)used / (double)sa_cap,
+                    100.0 * (double)most / (double)(sa_cap / kFusArenas));
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_round).count();
             fprintf(stderr, "[pwicp front end/dev]   round %d: %d centres, %d sweeps, %lld runs (%.1f x), absorbed %llu  %8.2f ms\n", round, nc,
                     sweeps, runs, (double)runs / nc, total, ms);
