@@ -14,7 +14,11 @@ for G in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum
   N=$(echo $G | cut -d' ' -f1)
   rocprofv3 --pmc $G --output-format csv -d $OUT/pmc -o $N -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc_$N.log 2>&1
 done
+# the segmentation front end (row f1): kernel statistics of one warm-up + 3 timed clouds of 1 M points
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_frontend -o fe -- python $R/bench.py --workload frontend --steps 3 > $OUT/bench_frontend_trace.log 2>&1
 cd $R
 python bench.py --no-cpu-baseline > $OUT/bench_plain.log 2>&1
+python bench.py --workload frontend --steps 5 > $OUT/bench_frontend.log 2>&1
+python bench.py --workload series --epochs 4 --points 5000000 > $OUT/bench_series.log 2>&1
 python tools/summarize_pmc.py $OUT > $OUT/summary.log 2>&1
 tail -5 $OUT/summary.log
