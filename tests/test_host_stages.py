@@ -66,6 +66,25 @@ def test_frontend_on_reference_epoch(oracle):
     assert np.array_equal(lab, lab_ref)
 
 
+@pytest.mark.parametrize("epoch", list(range(2, 21)))
+def test_frontend_on_every_reference_epoch(oracle, epoch):
+    """The serial passes of the product (the ones the device pipeline is tested against, tests/test_gpu_frontend.py) reproduce
+    the reference's own compiled front end on every scan of its 4D series (here: wherever /root/reference is present; the six
+    epochs kept as fixtures run everywhere)."""
+    if not oracle.ref_frontend_available():
+        pytest.skip("oracle/_ref not built")
+    path = G.epoch_path(epoch)
+    if path is None:
+        pytest.skip("scan not available here")
+    import pwicp_amd as P
+    from pwicp_amd.pcd import read_pcd
+    p = P.preprocess(read_pcd(path), 0.005, 14, 5.0)
+    r, _, _ = G.reduce_pair(p, p)
+    lab, nsv = P.frontend_segment(r, 0.05)
+    lab_ref, nsv_ref = oracle.ref_frontend(r, 0.05)
+    assert nsv == nsv_ref and np.array_equal(lab, lab_ref)
+
+
 def test_pcd_roundtrip(tmp_path):
     from pwicp_amd.pcd import read_pcd, write_pcd_binary
     pts = np.random.default_rng(1).normal(size=(1000, 3)).astype(np.float32)
