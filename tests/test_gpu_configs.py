@@ -45,14 +45,17 @@ def test_loop_parity_1m_supervoxel_labels(ctx, oracle):
 
 
 # tolerance vs the reference's result file, as tests/test_oracle_golden.py (rad, m)
-GOLD_TOL = {8: (5e-5, 5e-5), 11: (5e-6, 5e-6), 13: (5e-6, 5e-6), 19: (2e-3, 3e-3)}
+GOLD_TOL = {e: (5e-6, 5e-6) for e in range(2, 21)}
+GOLD_TOL[8] = (5e-5, 5e-5)
+GOLD_TOL[19] = (2e-3, 3e-3)
 
 
-@pytest.mark.parametrize("epoch", [8, 11, 13, 19])
-def test_flip_sensitive_golden_pairs_through_gpu(ctx, oracle, epoch):
-    """The pairs of the reference's synthetic series that end with <= 65-300 stable patches: one patch
-    classified differently moves the result.  GPU == oracle on every discrete quantity, and the GPU result is as close
-    to the reference's own file as the oracle's."""
+@pytest.mark.parametrize("epoch", list(range(2, 21)))
+def test_golden_pairs_through_gpu(ctx, oracle, epoch):
+    """Every pair of the reference's synthetic 4D series (Direct2Ref: epoch 1 against epoch e), among them the pairs that end
+    with <= 65-300 stable patches (e8, e11, e13, e19) where one patch classified differently moves the result.
+    GPU == oracle on every discrete quantity, and the GPU result is as close to the reference's own result file as the
+    oracle's."""
     if not oracle.ref_frontend_available():
         pytest.skip("oracle/_ref not built")
     import pwicp_amd as P

@@ -57,9 +57,10 @@ def test_device_labels_equal_serial_labels_rough_surface(ctx):
     _assert_same(ctx, cloud, 10 * _data.R, _data.R)
 
 
-@pytest.mark.parametrize("epoch", ["001", "002", "008", "011", "013", "019"])
+@pytest.mark.parametrize("epoch", ["%03d" % e for e in range(1, 21)])
 def test_device_labels_equal_serial_labels_golden_epochs(ctx, epoch):
-    """The reference's own scans (testdata/Epoch_*.pcd), preprocessed as the entry points do (Res 0.005, SV 0.05)."""
+    """The reference's own 4D series (data/data_synthetic/syntheticPC_with_transformations/Epoch_001..020.pcd, kept as
+    fixtures), preprocessed as the entry points do (Res 0.005, SV 0.05)."""
     from pwicp_amd.pcd import read_pcd
     raw = read_pcd(os.path.join(HERE, "golden", "inputs", "Epoch_%s.pcd" % epoch))
     cloud = ctx.preprocess(raw, 0.005, 14, 2.0)
