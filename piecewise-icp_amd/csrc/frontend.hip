@@ -1022,56 +1022,47 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     // lambda0 (:91-102)
     double lambda;
     {
-        DevBuf<double>& dmin = ws.dmin;
-        HIPCHK(ctx, dmin.reserve((size_t)n));
-        hipLaunchKernelGGL(k_fus_min_metric, grid1(n), dim3(256), 0, st, dP, d_nb, k, n, res, dmin.p);
+        HIPCHK(ctx, ws.dmin.reserve((size_t)n));
+        hipLaunchKernelGGL(k_fus_min_metric, grid1(n), dim3(256), 0, st, dP, d_nb, k, n, res, ws.dmin.p);
         std::vector<double> v((size_t)n);
-        HIPCHK(ctx, hipMemcpyAsync(v.data(), dmin.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(v.data(), ws.dmin.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
         lambda = std::max(DBL_EPSILON, v[v.size() / 2]);
     }
-    DevBuf<int>&root0 = ws.root0, &s0 = ws.s0, &lenA = ws.lenA, &lenB = ws.lenB, &cenA = ws.cenA, &cenB = ws.cenB,
-        &revoff = ws.revoff, &revown = ws.revown, &cursor = ws.cursor, &ab = ws.ab, &ab_prev = ws.ab_prev,
-        &rec_sz = ws.rec_sz, &rec_ran = ws.rec_ran, &rec_absn = ws.rec_absn, &rec_adjn = ws.rec_adjn,
-        &slot_of = ws.slot_of, &wake = ws.wake, &dflag = ws.dflag, &cflag = ws.cflag, &dtmin = ws.dtmin, &Wa = ws.Wa,
-        &Wb = ws.Wb, &dq = ws.dq, &dq2 = ws.dq2, &o_sz = ws.o_sz, &o_ran = ws.o_ran, &o_absn = ws.o_absn,
-        &o_adjn = ws.o_adjn, &o_dirty = ws.o_dirty, &o_oldabsn = ws.o_oldabsn, &alive = ws.alive, &newlen = ws.newlen,
-        &cut = ws.cut, &tmp = ws.tmp, &arenaA = ws.arenaA, &arenaB = ws.arenaB, &sa = ws.sa, &ctr = ws.ctr;
-    DevBuf<long long>&offA = ws.offA, &offB = ws.offB, &rec_ptr = ws.rec_ptr, &o_ptr = ws.o_ptr, &o_oldptr = ws.o_oldptr;
-    DevBuf<unsigned long long>& big = ws.big;
     const size_t N = (size_t)n;
-    for (DevBuf<int>* b : {&root0, &s0, &lenA, &lenB, &cenA, &cenB, &cursor, &ab, &ab_prev, &rec_sz, &rec_ran, &rec_absn, &rec_adjn, &slot_of,
-                           &wake, &dflag, &cflag, &dtmin, &Wa, &Wb, &dq, &dq2, &o_sz, &o_ran, &o_absn, &o_adjn, &o_dirty, &o_oldabsn, &cut})
+    for (DevBuf<int>* b : {&ws.root0, &ws.s0, &ws.lenA, &ws.lenB, &ws.cenA, &ws.cenB, &ws.cursor, &ws.ab, &ws.ab_prev, &ws.rec_sz,
+                           &ws.rec_ran, &ws.rec_absn, &ws.rec_adjn, &ws.slot_of, &ws.wake, &ws.dflag, &ws.cflag, &ws.dtmin, &ws.Wa,
+                           &ws.Wb, &ws.dq, &ws.dq2, &ws.o_sz, &ws.o_ran, &ws.o_absn, &ws.o_adjn, &ws.o_dirty, &ws.o_oldabsn, &ws.cut})
         HIPCHK(ctx, b->reserve(N));
-    for (DevBuf<int>* b : {&revoff, &alive, &newlen}) HIPCHK(ctx, b->reserve(N + 1));
-    for (DevBuf<long long>* b : {&offA, &offB, &rec_ptr, &o_ptr, &o_oldptr}) HIPCHK(ctx, b->reserve(N));
-    HIPCHK(ctx, ctr.reserve(16));
-    HIPCHK(ctx, big.reserve(16 * (kFusArenas + 1)));
+    for (DevBuf<int>* b : {&ws.revoff, &ws.alive, &ws.newlen}) HIPCHK(ctx, b->reserve(N + 1));
+    for (DevBuf<long long>* b : {&ws.offA, &ws.offB, &ws.rec_ptr, &ws.o_ptr, &ws.o_oldptr}) HIPCHK(ctx, b->reserve(N));
+    HIPCHK(ctx, ws.ctr.reserve(16));
+    HIPCHK(ctx, ws.big.reserve(16 * (kFusArenas + 1)));
     // lists of changed outcomes are appended, nothing is freed inside a round: 14 % of 16 n k entries at most on the clouds
     // measured (the round after the first one); 6 n k = 1.1 GB per 1 M points, overflow = the device pass gives up
     const unsigned long long sa_cap = 6ull * (unsigned long long)n * (unsigned long long)k;
-    HIPCHK(ctx, sa.reserve((size_t)sa_cap));
-    hipLaunchKernelGGL(k_fus_first_round, grid1(n), dim3(256), 0, st, n, k, root0.p, s0.p, lenA.p, offA.p, cenA.p);
-    int* len0 = lenA.p; int* len1 = lenB.p;
-    long long* off0 = offA.p; long long* off1 = offB.p;
-    int* cen = cenA.p; int* cen1 = cenB.p;
+    HIPCHK(ctx, ws.sa.reserve((size_t)sa_cap));
+    hipLaunchKernelGGL(k_fus_first_round, grid1(n), dim3(256), 0, st, n, k, ws.root0.p, ws.s0.p, ws.lenA.p, ws.offA.p, ws.cenA.p);
+    int* len0 = ws.lenA.p; int* len1 = ws.lenB.p;
+    long long* off0 = ws.offA.p; long long* off1 = ws.offB.p;
+    int* cen = ws.cenA.p; int* cen1 = ws.cenB.p;
     const int* arena0 = d_nb;
-    DevBuf<int>* arena_next = &arenaA;
-    DevBuf<int>* arena_cur = &arenaB;
+    DevBuf<int>* arena_next = &ws.arenaA;
+    DevBuf<int>* arena_cur = &ws.arenaB;       // (the one arena0 points into from the second round on)
     int nc = n, round = 0;
     long long count = n;
     FusState s{};
     s.P = dP; s.res = res;
-    s.root0 = root0.p; s.s0 = s0.p;
-    s.revoff = revoff.p;
-    s.ab = ab.p; s.ab_prev = ab_prev.p; s.rec_sz = rec_sz.p; s.rec_ran = rec_ran.p; s.rec_absn = rec_absn.p; s.rec_adjn = rec_adjn.p;
-    s.rec_ptr = rec_ptr.p; s.sa = sa.p; s.sa_top = big.p + 16; s.sa_cap = sa_cap;
-    s.slot_of = slot_of.p; s.o_sz = o_sz.p; s.o_ran = o_ran.p; s.o_absn = o_absn.p; s.o_adjn = o_adjn.p; s.o_ptr = o_ptr.p;
-    s.o_dirty = o_dirty.p; s.o_oldptr = o_oldptr.p; s.o_oldabsn = o_oldabsn.p;
+    s.root0 = ws.root0.p; s.s0 = ws.s0.p;
+    s.revoff = ws.revoff.p;
+    s.ab = ws.ab.p; s.ab_prev = ws.ab_prev.p; s.rec_sz = ws.rec_sz.p; s.rec_ran = ws.rec_ran.p; s.rec_absn = ws.rec_absn.p; s.rec_adjn = ws.rec_adjn.p;
+    s.rec_ptr = ws.rec_ptr.p; s.sa = ws.sa.p; s.sa_top = ws.big.p + 16; s.sa_cap = sa_cap;
+    s.slot_of = ws.slot_of.p; s.o_sz = ws.o_sz.p; s.o_ran = ws.o_ran.p; s.o_absn = ws.o_absn.p; s.o_adjn = ws.o_adjn.p; s.o_ptr = ws.o_ptr.p;
+    s.o_dirty = ws.o_dirty.p; s.o_oldptr = ws.o_oldptr.p; s.o_oldabsn = ws.o_oldabsn.p;
     s.queue_limit = getenv("PWICP_FUSION_QUEUE") ? std::min(std::max(atoi(getenv("PWICP_FUSION_QUEUE")), 2), kFusQueue) : kFusQueue;
-    s.wake = wake.p; s.dflag = dflag.p; s.cflag = cflag.p; s.dtmin = dtmin.p;
-    int* const nWnext = ctr.p; int* const ndq = ctr.p + 1; int* const status = ctr.p + 8;
+    s.wake = ws.wake.p; s.dflag = ws.dflag.p; s.cflag = ws.cflag.p; s.dtmin = ws.dtmin.p;
+    int* const nWnext = ws.ctr.p; int* const ndq = ws.ctr.p + 1; int* const status = ws.ctr.p + 8;
     s.nWnext = nWnext; s.status = status;
     HIPCHK(ctx, ws.host_reserve(0));
     int* const h_ctr = ws.h_ctr;                    // pinned: read back after every sweep
@@ -1079,29 +1070,29 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     const int wake_all_div = getenv("PWICP_FUSION_WAKE_DIV") ? std::max(atoi(getenv("PWICP_FUSION_WAKE_DIV")), 1) : 32;
     for (;; lambda *= 2.0, ++round) {
         if (nc <= 1) {                                  // (:106) nothing left to fuse
-            HIPCHK(ctx, hipMemcpyAsync(d_lab, root0.p, sizeof(int) * N, hipMemcpyDeviceToDevice, st));
+            HIPCHK(ctx, hipMemcpyAsync(d_lab, ws.root0.p, sizeof(int) * N, hipMemcpyDeviceToDevice, st));
             HIPCHK(ctx, d_roots->reserve((size_t)std::max(nc, 1)));
             HIPCHK(ctx, hipMemcpyAsync(d_roots->p, cen, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
             *n_roots = nc;
             break;
         }
         const auto t_round = std::chrono::steady_clock::now();
-        hipLaunchKernelGGL(k_fus_reset, grid1(n), dim3(256), 0, st, n, s0.p, ab.p, ab_prev.p, rec_sz.p, rec_ran.p, rec_absn.p, rec_adjn.p,
-                           rec_ptr.p, wake.p, dflag.p, cflag.p, dtmin.p, slot_of.p);
+        hipLaunchKernelGGL(k_fus_reset, grid1(n), dim3(256), 0, st, n, ws.s0.p, ws.ab.p, ws.ab_prev.p, ws.rec_sz.p, ws.rec_ran.p, ws.rec_absn.p, ws.rec_adjn.p,
+                           ws.rec_ptr.p, ws.wake.p, ws.dflag.p, ws.cflag.p, ws.dtmin.p, ws.slot_of.p);
         // reverse index of the base lists
-        HIPCHK(ctx, hipMemsetAsync(revoff.p, 0, sizeof(int) * (N + 1), st));
-        hipLaunchKernelGGL(k_fus_reverse<0>, grid1(nc), dim3(256), 0, st, cen, nc, root0.p, len0, off0, arena0, revoff.p, (int*)nullptr);
-        PWCHK(pw_exclusive_scan(ctx, revoff.p, (long long)n + 1, &tmp));
+        HIPCHK(ctx, hipMemsetAsync(ws.revoff.p, 0, sizeof(int) * (N + 1), st));
+        hipLaunchKernelGGL(k_fus_reverse<0>, grid1(nc), dim3(256), 0, st, cen, nc, ws.root0.p, len0, off0, arena0, ws.revoff.p, (int*)nullptr);
+        PWCHK(pw_exclusive_scan(ctx, ws.revoff.p, (long long)n + 1, &ws.tmp));
         int n_entries = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&n_entries, revoff.p + n, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipMemcpyAsync(cursor.p, revoff.p, sizeof(int) * N, hipMemcpyDeviceToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(&n_entries, ws.revoff.p + n, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(ws.cursor.p, ws.revoff.p, sizeof(int) * N, hipMemcpyDeviceToDevice, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
-        HIPCHK(ctx, revown.reserve((size_t)std::max(n_entries, 1)));
-        hipLaunchKernelGGL(k_fus_reverse<1>, grid1(nc), dim3(256), 0, st, cen, nc, root0.p, len0, off0, arena0, cursor.p, revown.p);
-        HIPCHK(ctx, hipMemsetAsync(big.p, 0, sizeof(unsigned long long) * 16 * (kFusArenas + 1), st));
+        HIPCHK(ctx, ws.revown.reserve((size_t)std::max(n_entries, 1)));
+        hipLaunchKernelGGL(k_fus_reverse<1>, grid1(nc), dim3(256), 0, st, cen, nc, ws.root0.p, len0, off0, arena0, ws.cursor.p, ws.revown.p);
+        HIPCHK(ctx, hipMemsetAsync(ws.big.p, 0, sizeof(unsigned long long) * 16 * (kFusArenas + 1), st));
         s.wake_all_above = std::max(nc / wake_all_div, 64);
-        s.lambda = lambda; s.len0 = len0; s.off0 = off0; s.arena0 = arena0; s.revown = revown.p;
-        int* W = Wa.p; int* Wn = Wb.p;
+        s.lambda = lambda; s.len0 = len0; s.off0 = off0; s.arena0 = arena0; s.revown = ws.revown.p;
+        int* W = ws.Wa.p; int* Wn = ws.Wb.p;
         HIPCHK(ctx, hipMemcpyAsync(W, cen, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
         int nW = nc, sweeps = 0;
         long long runs = 0;
@@ -1115,12 +1106,12 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
                 nW = nc;
                 certify = true;
                 // absorbers from scratch: the smallest centre whose standing outcome absorbs the node
-                hipLaunchKernelGGL(k_fill<int>, grid1(n), dim3(256), 0, st, ab.p, (long long)n, kNone);
+                hipLaunchKernelGGL(k_fill<int>, grid1(n), dim3(256), 0, st, ws.ab.p, (long long)n, kNone);
                 hipLaunchKernelGGL(k_fus_claim_all, grid1(nc), dim3(256), 0, st, s, cen, nc);
-                HIPCHK(ctx, hipMemsetAsync(ctr.p + 15, 0, sizeof(int), st));
-                hipLaunchKernelGGL(k_fus_ab_changed, grid1(n), dim3(256), 0, st, ab.p, ab_prev.p, n, ctr.p + 15);
+                HIPCHK(ctx, hipMemsetAsync(ws.ctr.p + 15, 0, sizeof(int), st));
+                hipLaunchKernelGGL(k_fus_ab_changed, grid1(n), dim3(256), 0, st, ws.ab.p, ws.ab_prev.p, n, ws.ctr.p + 15);
                 int differs = 0;
-                HIPCHK(ctx, hipMemcpyAsync(&differs, ctr.p + 15, sizeof(int), hipMemcpyDeviceToHost, st));
+                HIPCHK(ctx, hipMemcpyAsync(&differs, ws.ctr.p + 15, sizeof(int), hipMemcpyDeviceToHost, st));
                 HIPCHK(ctx, hipStreamSynchronize(st));
                 if (trace && differs) fprintf(stderr, "[pwicp front end/dev]   (round %d: absorbers rebuilt for the certificate differ)\n", round);
             }
@@ -1128,15 +1119,15 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
             runs += nW;
             if (trace && getenv("PWICP_TRACE_SWEEPS")) fprintf(stderr, "      sweep %d: %d\n", sweeps, nW);
             s.W = W; s.Wnext = Wn;
-            HIPCHK(ctx, hipMemsetAsync(ctr.p, 0, sizeof(int) * 16, st));
+            HIPCHK(ctx, hipMemsetAsync(ws.ctr.p, 0, sizeof(int) * 16, st));
             const int chunk = certify ? 1 : std::max(1, std::min(std::min(nW / 8192, kFusChunk), gs_chunk));
             hipLaunchKernelGGL(k_fus_run, dim3((unsigned)std::min(div_up(div_up(nW, chunk), 4), 8192)), dim3(256), 0, st, s, nW, chunk);
             hipLaunchKernelGGL(k_fus_retract, grid1(nW), dim3(256), 0, st, s, nW);
             hipLaunchKernelGGL(k_fus_claim, grid1(nW), dim3(256), 0, st, s, nW);
-            hipLaunchKernelGGL(k_fus_dirty0, grid1(nW), dim3(256), 0, st, s, nW, dq.p, ndq);
-            hipLaunchKernelGGL(k_fus_wake, dim3(1024), dim3(256), 0, st, s, dq.p, ndq, dq2.p, ndq + 1);
-            hipLaunchKernelGGL(k_fus_sweep_end, dim3(256), dim3(256), 0, st, s, dq.p, ndq, dq2.p, ndq + 1);
-            HIPCHK(ctx, hipMemcpyAsync(h_ctr, ctr.p, sizeof(int) * 16, hipMemcpyDeviceToHost, st));
+            hipLaunchKernelGGL(k_fus_dirty0, grid1(nW), dim3(256), 0, st, s, nW, ws.dq.p, ndq);
+            hipLaunchKernelGGL(k_fus_wake, dim3(1024), dim3(256), 0, st, s, ws.dq.p, ndq, ws.dq2.p, ndq + 1);
+            hipLaunchKernelGGL(k_fus_sweep_end, dim3(256), dim3(256), 0, st, s, ws.dq.p, ndq, ws.dq2.p, ndq + 1);
+            HIPCHK(ctx, hipMemcpyAsync(h_ctr, ws.ctr.p, sizeof(int) * 16, hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));
             if (h_ctr[8] || h_ctr[9]) {
                 if (trace) fprintf(stderr, "[pwicp front end/dev]   fusion gives up in round %d (%s overflow)\n", round, h_ctr[8] ? "queue" : "arena");
@@ -1154,13 +1145,13 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
             }
         }
         // absorbed in this round, per centre
-        hipLaunchKernelGGL(k_fus_total_absorbed, grid1(nc), dim3(256), 0, st, cen, nc, rec_absn.p, newlen.p, big.p);
+        hipLaunchKernelGGL(k_fus_total_absorbed, grid1(nc), dim3(256), 0, st, cen, nc, ws.rec_absn.p, ws.newlen.p, ws.big.p);
         unsigned long long total = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&total, big.p, sizeof(total), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(&total, ws.big.p, sizeof(total), hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         if (trace) {
             std::vector<unsigned long long> tops(16 * (kFusArenas + 1));
-            (void)hipMemcpy(tops.data(), big.p, sizeof(unsigned long long) * tops.size(), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(tops.data(), ws.big.p, sizeof(unsigned long long) * tops.size(), hipMemcpyDeviceToHost);
             unsigned long long used = 0, most = 0;
             for (int r = 0; r < kFusArenas; ++r) { used += tops[16 * (1 + r)]; most = std::max(most, tops[16 * (1 + r)]); }
             fprintf(stderr, "[pwicp front end/dev]   list arena: %.1f %% used, fullest region %.1f %%\n", 100.0 * (double)used / (double)sa_cap,
@@ -1173,7 +1164,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
         if (need >= 1 && (long long)total >= need) {
             // the round stops inside a centre (:139-141)
             std::vector<int> per((size_t)nc), hcen((size_t)nc);
-            HIPCHK(ctx, hipMemcpyAsync(per.data(), newlen.p, sizeof(int) * (size_t)nc, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(per.data(), ws.newlen.p, sizeof(int) * (size_t)nc, hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipMemcpyAsync(hcen.data(), cen, sizeof(int) * (size_t)nc, hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));
             long long before = 0;
@@ -1184,37 +1175,37 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
             }
             const int stop_c = hcen[(size_t)t_stop], stop_n = (int)(need - before);
             long long ptr = 0;
-            HIPCHK(ctx, hipMemcpyAsync(&ptr, rec_ptr.p + stop_c, sizeof(ptr), hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(&ptr, ws.rec_ptr.p + stop_c, sizeof(ptr), hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));
-            hipLaunchKernelGGL(k_fill<int>, grid1(n), dim3(256), 0, st, cut.p, (long long)n, kNone);
-            hipLaunchKernelGGL(k_fus_cut_positions, grid1(per[(size_t)t_stop]), dim3(256), 0, st, sa.p, ptr, per[(size_t)t_stop], cut.p);
-            hipLaunchKernelGGL(k_fus_final, grid1(n), dim3(256), 0, st, n, root0.p, ab.p, stop_c, stop_n, cut.p, d_lab);
-            HIPCHK(ctx, hipMemsetAsync(alive.p, 0, sizeof(int) * ((size_t)nc + 1), st));
-            hipLaunchKernelGGL(k_fus_is_root, grid1(nc), dim3(256), 0, st, cen, nc, d_lab, alive.p);
-            PWCHK(pw_exclusive_scan(ctx, alive.p, (long long)nc + 1, &tmp));
+            hipLaunchKernelGGL(k_fill<int>, grid1(n), dim3(256), 0, st, ws.cut.p, (long long)n, kNone);
+            hipLaunchKernelGGL(k_fus_cut_positions, grid1(per[(size_t)t_stop]), dim3(256), 0, st, ws.sa.p, ptr, per[(size_t)t_stop], ws.cut.p);
+            hipLaunchKernelGGL(k_fus_final, grid1(n), dim3(256), 0, st, n, ws.root0.p, ws.ab.p, stop_c, stop_n, ws.cut.p, d_lab);
+            HIPCHK(ctx, hipMemsetAsync(ws.alive.p, 0, sizeof(int) * ((size_t)nc + 1), st));
+            hipLaunchKernelGGL(k_fus_is_root, grid1(nc), dim3(256), 0, st, cen, nc, d_lab, ws.alive.p);
+            PWCHK(pw_exclusive_scan(ctx, ws.alive.p, (long long)nc + 1, &ws.tmp));
             int nr = 0;
-            HIPCHK(ctx, hipMemcpyAsync(&nr, alive.p + nc, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(&nr, ws.alive.p + nc, sizeof(int), hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));
             HIPCHK(ctx, d_roots->reserve((size_t)std::max(nr, 1)));
-            hipLaunchKernelGGL(k_fus_compact, grid1(nc), dim3(256), 0, st, cen, nc, alive.p, d_roots->p);
+            hipLaunchKernelGGL(k_fus_compact, grid1(nc), dim3(256), 0, st, cen, nc, ws.alive.p, d_roots->p);
             *n_roots = nr;
             break;
         }
         count -= (long long)total;
         // hand-over to the next round
-        hipLaunchKernelGGL(k_fus_new_roots, grid1(n), dim3(256), 0, st, n, root0.p, ab.p);
-        HIPCHK(ctx, hipMemsetAsync(alive.p + nc, 0, sizeof(int), st));
-        HIPCHK(ctx, hipMemsetAsync(newlen.p + nc, 0, sizeof(int), st));
-        hipLaunchKernelGGL(k_fus_next_sizes, grid1(nc), dim3(256), 0, st, cen, nc, ab.p, rec_ran.p, rec_adjn.p, len0, alive.p, newlen.p);
-        PWCHK(pw_exclusive_scan(ctx, alive.p, (long long)nc + 1, &tmp));
-        PWCHK(pw_exclusive_scan(ctx, newlen.p, (long long)nc + 1, &tmp));
+        hipLaunchKernelGGL(k_fus_new_roots, grid1(n), dim3(256), 0, st, n, ws.root0.p, ws.ab.p);
+        HIPCHK(ctx, hipMemsetAsync(ws.alive.p + nc, 0, sizeof(int), st));
+        HIPCHK(ctx, hipMemsetAsync(ws.newlen.p + nc, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_fus_next_sizes, grid1(nc), dim3(256), 0, st, cen, nc, ws.ab.p, ws.rec_ran.p, ws.rec_adjn.p, len0, ws.alive.p, ws.newlen.p);
+        PWCHK(pw_exclusive_scan(ctx, ws.alive.p, (long long)nc + 1, &ws.tmp));
+        PWCHK(pw_exclusive_scan(ctx, ws.newlen.p, (long long)nc + 1, &ws.tmp));
         int nc_next = 0, n_list = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&nc_next, alive.p + nc, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipMemcpyAsync(&n_list, newlen.p + nc, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(&nc_next, ws.alive.p + nc, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(&n_list, ws.newlen.p + nc, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         HIPCHK(ctx, arena_next->reserve((size_t)std::max(n_list, 1)));
-        hipLaunchKernelGGL(k_fus_next_lists, grid1((long long)nc * 64), dim3(256), 0, st, cen, nc, alive.p, newlen.p, ab.p, rec_ran.p, rec_sz.p,
-                           rec_absn.p, rec_adjn.p, rec_ptr.p, sa.p, arena0, off0, len0, arena_next->p, off1, len1, s0.p, cen1);
+        hipLaunchKernelGGL(k_fus_next_lists, grid1((long long)nc * 64), dim3(256), 0, st, cen, nc, ws.alive.p, ws.newlen.p, ws.ab.p, ws.rec_ran.p, ws.rec_sz.p,
+                           ws.rec_absn.p, ws.rec_adjn.p, ws.rec_ptr.p, ws.sa.p, arena0, off0, len0, arena_next->p, off1, len1, ws.s0.p, cen1);
         arena0 = arena_next->p;
         std::swap(arena_next, arena_cur);
         std::swap(len0, len1); std::swap(off0, off1); std::swap(cen, cen1);
