@@ -101,3 +101,18 @@ def test_labels_do_not_depend_on_the_sweep_schedule(ctx, knobs):
     finally:
         for k in knobs:
             os.environ.pop(k, None)
+
+
+def test_degenerate_inputs(ctx):
+    """Exact ties and degenerate neighbourhoods: a perfectly regular planar lattice (every distance tied, normals exactly +-z,
+    metric exactly 0 between neighbours), a cloud with 10 % duplicated points (zero distances, rank-deficient scatter), a
+    cloud barely larger than k."""
+    g = np.arange(120, dtype=np.float32) * np.float32(0.005)
+    lattice = np.stack(np.meshgrid(g, g, indexing="ij"), -1).reshape(-1, 2)
+    lattice = np.concatenate([lattice, np.zeros((len(lattice), 1), np.float32)], 1).astype(np.float32)
+    _assert_same(ctx, lattice, 10 * _data.R, _data.R)
+    tgt, _, _ = _data.pair(20000)
+    rng = np.random.default_rng(11)
+    dup = np.concatenate([tgt, tgt[rng.integers(0, len(tgt), len(tgt) // 10)]]).astype(np.float32)
+    _assert_same(ctx, dup, 10 * _data.R, _data.R)
+    _assert_same(ctx, tgt[:60], 10 * _data.R, _data.R)
