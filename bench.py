@@ -180,6 +180,23 @@ def frontend_workload(args, ctx, P, rank, world):
     finally:
         os.environ.pop("PWICP_FRONTEND", None)
     t = float(np.median(times))
+    # the reference's OWN front end (codelibrary k-d tree, PCA normals, supervoxel segmentation compiled into oracle/_ref) on a
+    # bounded sample of the same cloud: its first 300 k points (a contiguous strip of the tile), single-threaded as the reference runs it
+    ref = None
+    if rank == 0 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _oracle as O
+        if O.ref_frontend_available():
+            m = min(n, 300000)
+            sample = np.ascontiguousarray(cloud[:m])
+            t0 = time.perf_counter()
+            lab_r, nsv_r = O.ref_frontend(sample, 10 * r)
+            t_ref = time.perf_counter() - t0
+            lab_s, nsv_s = ctx.frontend_segment(sample, 10 * r, 45, r)
+            ref = {"value": round(m / t_ref, 1), "unit": "points/s", "cores": 1, "kind": "reference",
+                   "sample": "the first %d points of the same cloud through the reference's own codelibrary front end (oracle/_ref, k-d tree "
+                             "k-NN included), %.2f s" % (m, t_ref),
+                   "device_labels_identical_on_sample": bool(nsv_r == nsv_s and np.array_equal(lab_r, lab_s))}
     if rank == 0:
         print(json.dumps({
             "metric": "points/sec segmented (front end of one cloud, secondary line)", "value": round(n / t, 1), "unit": "points/s",
@@ -190,7 +207,8 @@ def frontend_workload(args, ctx, P, rank, world):
             "labels_identical_to_serial_passes": bool(nsv_d == nsv_h and np.array_equal(lab_d, lab_h)),
             "cpu_baseline": {"value": round(n / t_host, 1), "unit": "points/s", "kind": "port",
                              "sample": "the same cloud through the serial host passes (host/frontend.cpp; k-NN graph still on the "
-                                       "device), host threads only for normals / lambda0 / seeds", "ms": round(1e3 * t_host, 3)}}))
+                                       "device), host threads only for normals / lambda0 / seeds", "ms": round(1e3 * t_host, 3)},
+            "cpu_reference": ref}))
     ctx.close()
 
 
