@@ -248,7 +248,10 @@ struct FusState {
     int queue_limit;           // <= kFusQueue ($PWICP_FUSION_QUEUE: smaller, to exercise the fallback)
 };
 
-constexpr int kFusQueue = 512, kFusHash = 1024;
+// search queue / visited hash of a wavefront: the common case in LDS small enough for 5 blocks of 4 wavefronts per CU (the kernel
+// is bound by the latency of dependent gathers: occupancy is throughput); a centre whose search outgrows it runs again in
+// the same sweep on a wavefront with the large configuration
+constexpr int kFusQueueS = 256, kFusHashS = 512, kFusQueue = 2048, kFusHash = 4096;
 constexpr int kFusArenas = 256;
 #define WSYNC()                                               \
     do {                                                      \
@@ -265,7 +268,7 @@ constexpr int kFusChunk = 16, kFusFresh = 256;
 
 struct FusWave {           // per-wavefront scratch (LDS)
     int* keys; int* vals; int* queue;
-    int qn, gcount;
+    int qn, gcount, qcap;
     bool overflow;
     // centres this wavefront has already run in this sweep (chunk), and the nodes they absorbed
     int* cid; int* csz; int* cran; int* cabsn; int* cadjn; long long* cptr;
@@ -310,6 +313,7 @@ __device__ __forceinline__ int fus_root_at(const FusState& s, const FusWave& w, 
 }
 
 // roots of the entries of a list join the search, in list order, each once
+template <int HCAP>
 __device__ __forceinline__ void fus_expand(const FusState& s, FusWave& w, const int* __restrict__ lp, int len, int i, int lane) {
     for (int base = 0; base < len && !w.overflow; base += 64) {
         const int e = base + lane;
@@ -319,11 +323,11 @@ __device__ __forceinline__ void fus_expand(const FusState& s, FusWave& w, const 
         const int gidx = w.gcount + lane;
         if (valid) {
             r = fus_root_at(s, w, lp[e], i);
-            slot = (int)(((unsigned)r * 2654435761u) >> 22) & (kFusHash - 1);
+            slot = (int)(((unsigned)r * 2654435761u) >> (32 - __builtin_ctz(HCAP)));
             for (;;) {
                 const int prev = atomicCAS(&w.keys[slot], -1, r);
                 if (prev == -1 || prev == r) break;
-                slot = (slot + 1) & (kFusHash - 1);
+                slot = (slot + 1) & (HCAP - 1);
             }
             atomicMin(&w.vals[slot], gidx);
         }
@@ -331,7 +335,7 @@ __device__ __forceinline__ void fus_expand(const FusState& s, FusWave& w, const 
         const bool first = valid && w.vals[slot] == gidx;
         const unsigned long long m = __ballot(first);
         const int add = __popcll(m);
-        if (w.qn + add > s.queue_limit) { w.overflow = true; break; }
+        if (w.qn + add > w.qcap) { w.overflow = true; break; }
         if (first) w.queue[w.qn + __popcll(m & ((1ull << lane) - 1ull))] = r;
         w.qn += add;
         w.gcount += 64;
@@ -339,21 +343,27 @@ __device__ __forceinline__ void fus_expand(const FusState& s, FusWave& w, const 
     }
 }
 
-__global__ void __launch_bounds__(256) k_fus_run(FusState s, int nW, int chunk) {
-    __shared__ int s_keys[4][kFusHash];
-    __shared__ int s_vals[4][kFusHash];
-    __shared__ int s_queue[4][kFusQueue];
-    __shared__ int s_chunk[4][5][kFusChunk];
-    __shared__ long long s_cptr[4][kFusChunk];
-    __shared__ int s_fresh[4][2][kFusFresh];
+// QCAP / HCAP: capacity of the search queue / visited hash; WAVES wavefronts per block.  list == nullptr: the work list W in
+// chunks; else the slots on `list` (the centres whose search outgrew the small configuration), one at a time.
+template <int QCAP, int HCAP, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) k_fus_run(FusState s, int nW, int chunk, const int* __restrict__ list,
+                                                         const int* __restrict__ n_list, int* __restrict__ ovf, int* __restrict__ n_ovf) {
+    __shared__ int s_keys[WAVES][HCAP];
+    __shared__ int s_vals[WAVES][HCAP];
+    __shared__ int s_queue[WAVES][QCAP];
+    __shared__ int s_chunk[WAVES][5][kFusChunk];
+    __shared__ long long s_cptr[WAVES][kFusChunk];
+    __shared__ int s_fresh[WAVES][2][kFusFresh];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     FusWave w;
     w.keys = s_keys[wave]; w.vals = s_vals[wave]; w.queue = s_queue[wave];
     w.cid = s_chunk[wave][0]; w.csz = s_chunk[wave][1]; w.cran = s_chunk[wave][2]; w.cabsn = s_chunk[wave][3]; w.cadjn = s_chunk[wave][4];
     w.cptr = s_cptr[wave];
     w.fkey = s_fresh[wave][0]; w.fval = s_fresh[wave][1];
+    w.qcap = min(QCAP, s.queue_limit);
+    if (list) { nW = *n_list; chunk = 1; }
     const int n_chunks = (nW + chunk - 1) / chunk;
-    for (int ci = blockIdx.x * 4 + wave; ci < n_chunks; ci += gridDim.x * 4) {
+    for (int ci = blockIdx.x * WAVES + wave; ci < n_chunks; ci += gridDim.x * WAVES) {
       w.ndone = 0; w.nfresh = 0;
       bool chunk_live = chunk > 1;
       if (chunk > 1) {
@@ -361,7 +371,8 @@ __global__ void __launch_bounds__(256) k_fus_run(FusState s, int nW, int chunk) 
           WSYNC();
       }
       const int slot_end = min(nW, (ci + 1) * chunk);
-      for (int slot = ci * chunk; slot < slot_end; ++slot) {
+      for (int sl_i = ci * chunk; sl_i < slot_end; ++sl_i) {
+        const int slot = list ? list[sl_i] : sl_i;
         const int i = s.W[slot];
         if (lane == 0) { s.slot_of[i] = slot; s.wake[i] = 0; }
         const int old_ran = s.rec_ran[i], old_sz = s.rec_sz[i], old_absn = s.rec_absn[i], old_adjn = s.rec_adjn[i];
@@ -370,15 +381,15 @@ __global__ void __launch_bounds__(256) k_fus_run(FusState s, int nW, int chunk) 
         w.qn = 1; w.gcount = 0; w.overflow = false;
         if (s.len0[i] != 0 && !(fus_absorber(s, w, i) < i)) {
             ran = 1;
-            for (int t = lane; t < kFusHash; t += 64) { w.keys[t] = -1; w.vals[t] = INT_MAX; }
+            for (int t = lane; t < HCAP; t += 64) { w.keys[t] = -1; w.vals[t] = INT_MAX; }
             WSYNC();
             if (lane == 0) {
-                const int sl = (int)(((unsigned)i * 2654435761u) >> 22) & (kFusHash - 1);
+                const int sl = (int)(((unsigned)i * 2654435761u) >> (32 - __builtin_ctz(HCAP)));
                 w.keys[sl] = i; w.vals[sl] = -1;
                 w.queue[0] = i;
             }
             WSYNC();
-            fus_expand(s, w, s.arena0 + s.off0[i], s.len0[i], i, lane);
+            fus_expand<HCAP>(s, w, s.arena0 + s.off0[i], s.len0[i], i, lane);
             const FePt me = s.P[i];
             int front = 1;
             while (front < w.qn && !w.overflow) {
@@ -409,12 +420,12 @@ __global__ void __launch_bounds__(256) k_fus_run(FusState s, int nW, int chunk) 
                         ++nabs;
                         const int q = jj < i ? fus_chunk_index(w, jj) : -1;
                         if (q >= 0) {
-                            if (w.cran[q]) fus_expand(s, w, s.sa + w.cptr[q] + w.cabsn[q], w.cadjn[q], i, lane);
-                            else fus_expand(s, w, s.arena0 + s.off0[jj], s.len0[jj], i, lane);
+                            if (w.cran[q]) fus_expand<HCAP>(s, w, s.sa + w.cptr[q] + w.cabsn[q], w.cadjn[q], i, lane);
+                            else fus_expand<HCAP>(s, w, s.arena0 + s.off0[jj], s.len0[jj], i, lane);
                         } else if (jj < i && s.rec_ran[jj]) {
-                            fus_expand(s, w, s.sa + s.rec_ptr[jj] + s.rec_absn[jj], s.rec_adjn[jj], i, lane);
+                            fus_expand<HCAP>(s, w, s.sa + s.rec_ptr[jj] + s.rec_absn[jj], s.rec_adjn[jj], i, lane);
                         } else {
-                            fus_expand(s, w, s.arena0 + s.off0[jj], s.len0[jj], i, lane);
+                            fus_expand<HCAP>(s, w, s.arena0 + s.off0[jj], s.len0[jj], i, lane);
                         }
                     }
                 }
@@ -422,7 +433,10 @@ __global__ void __launch_bounds__(256) k_fus_run(FusState s, int nW, int chunk) 
             }
         }
         if (w.overflow) {
-            if (lane == 0) { s.o_dirty[slot] = 2; s.status[0] = 1; }
+            if (lane == 0) {
+                if (ovf && w.qcap == QCAP) { s.o_dirty[slot] = 2; ovf[atomicAdd(n_ovf, 1)] = slot; }     // again, with the large configuration
+                else { s.o_dirty[slot] = 2; s.status[0] = 1; }
+            }
             continue;
         }
         // outcome: absorbed nodes then adjacent nodes, each in search order; unchanged lists keep their place in the arena
@@ -480,7 +494,7 @@ __global__ void __launch_bounds__(256) k_fus_run(FusState s, int nW, int chunk) 
             s.o_oldptr[slot] = old_ptr; s.o_oldabsn[slot] = old_absn;
         }
         // what the later centres of the chunk see of this one
-        if (chunk_live && slot + 1 < slot_end && w.ndone < kFusChunk) {
+        if (chunk_live && sl_i + 1 < slot_end && w.ndone < kFusChunk) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // its lists are in memory before they are read back
             if (lane == 0) {
                 const int q = w.ndone;
@@ -893,7 +907,7 @@ struct FeWorkspace {
     // fusion
     DevBuf<double> dmin;
     DevBuf<int> root0, s0, lenA, lenB, cenA, cenB, revoff, revown, cursor, ab, ab_prev, rec_sz, rec_ran, rec_absn, rec_adjn, slot_of, wake,
-        dflag, cflag, dtmin, Wa, Wb, dq, dq2, o_sz, o_ran, o_absn, o_adjn, o_dirty, o_oldabsn, alive, newlen, cut, arenaA, arenaB, sa, ctr;
+        dflag, cflag, dtmin, Wa, Wb, dq, dq2, ovf, o_sz, o_ran, o_absn, o_adjn, o_dirty, o_oldabsn, alive, newlen, cut, arenaA, arenaB, sa, ctr;
     DevBuf<long long> offA, offB, rec_ptr, o_ptr, o_oldptr;
     DevBuf<unsigned long long> big;     // [0] absorbed in the round, [16 * (1 + r)] bump pointer of arena region r
     FeWorkspace() = default;
@@ -1033,7 +1047,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     const size_t N = (size_t)n;
     for (DevBuf<int>* b : {&ws.root0, &ws.s0, &ws.lenA, &ws.lenB, &ws.cenA, &ws.cenB, &ws.cursor, &ws.ab, &ws.ab_prev, &ws.rec_sz,
                            &ws.rec_ran, &ws.rec_absn, &ws.rec_adjn, &ws.slot_of, &ws.wake, &ws.dflag, &ws.cflag, &ws.dtmin, &ws.Wa,
-                           &ws.Wb, &ws.dq, &ws.dq2, &ws.o_sz, &ws.o_ran, &ws.o_absn, &ws.o_adjn, &ws.o_dirty, &ws.o_oldabsn, &ws.cut})
+                           &ws.Wb, &ws.dq, &ws.dq2, &ws.ovf, &ws.o_sz, &ws.o_ran, &ws.o_absn, &ws.o_adjn, &ws.o_dirty, &ws.o_oldabsn, &ws.cut})
         HIPCHK(ctx, b->reserve(N));
     for (DevBuf<int>* b : {&ws.revoff, &ws.alive, &ws.newlen}) HIPCHK(ctx, b->reserve(N + 1));
     for (DevBuf<long long>* b : {&ws.offA, &ws.offB, &ws.rec_ptr, &ws.o_ptr, &ws.o_oldptr}) HIPCHK(ctx, b->reserve(N));
@@ -1121,7 +1135,10 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
             s.W = W; s.Wnext = Wn;
             HIPCHK(ctx, hipMemsetAsync(ws.ctr.p, 0, sizeof(int) * 16, st));
             const int chunk = certify ? 1 : std::max(1, std::min(std::min(nW / 8192, kFusChunk), gs_chunk));
-            hipLaunchKernelGGL(k_fus_run, dim3((unsigned)std::min(div_up(div_up(nW, chunk), 4), 8192)), dim3(256), 0, st, s, nW, chunk);
+            hipLaunchKernelGGL((k_fus_run<kFusQueueS, kFusHashS, 4>), dim3((unsigned)std::min(div_up(div_up(nW, chunk), 4), 8192)), dim3(256), 0, st,
+                               s, nW, chunk, (const int*)nullptr, (const int*)nullptr, ws.ovf.p, ws.ctr.p + 3);
+            hipLaunchKernelGGL((k_fus_run<kFusQueue, kFusHash, 1>), dim3(256), dim3(64), 0, st, s, 0, 1, (const int*)ws.ovf.p,
+                               (const int*)(ws.ctr.p + 3), (int*)nullptr, (int*)nullptr);
             hipLaunchKernelGGL(k_fus_retract, grid1(nW), dim3(256), 0, st, s, nW);
             hipLaunchKernelGGL(k_fus_claim, grid1(nW), dim3(256), 0, st, s, nW);
             hipLaunchKernelGGL(k_fus_dirty0, grid1(nW), dim3(256), 0, st, s, nW, ws.dq.p, ndq);
