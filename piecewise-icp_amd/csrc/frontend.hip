@@ -264,7 +264,7 @@ constexpr int kFusArenas = 256;
 // previous sweep - Gauss-Seidel inside the chunk, Jacobi between chunks.  Neighbouring centres are neighbours in the visiting
 // order, which is where most dependencies are: the worst round needs ~3x fewer sweeps.  Any mixture of old and new guesses
 // converges to the same fixed point; a sweep without changes still certifies it.
-constexpr int kFusChunk = 16, kFusFresh = 256;
+constexpr int kFusChunk = 16, kFusFresh = 128;
 
 struct FusWave {           // per-wavefront scratch (LDS)
     int* keys; int* vals; int* queue;
