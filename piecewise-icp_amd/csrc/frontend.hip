@@ -892,7 +892,7 @@ struct FeWorkspace {
     // pipeline
     DevBuf<float4> pts;
     Grid grid;
-    DevBuf<int> d_nb, d_lab, d_roots, d_map, cell_cnt;
+    DevBuf<int> d_nb, d_lab, lab0, d_roots, d_map, cell_cnt;
     DevBuf<double> dS, dN;
     DevBuf<FePt> dP;
     DevBuf<unsigned long long> table;
@@ -958,7 +958,11 @@ struct FeTrace {
 inline dim3 grid1(long long n, int block = 256) { return dim3((unsigned)std::max<long long>(1, (n + block - 1) / block)); }
 
 // labels (root point per point) -> refined labels, in place
-int refine_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, int n, double res, int* d_lab) {
+// *gave_up: a generation did not settle within the sweep cap ($PWICP_REFINE_SWEEPS, default 4096; 2-5 sweeps are normal) - the
+// caller restarts the pass on the host from the labels it kept
+int refine_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, int n, double res, int* d_lab, bool* gave_up) {
+    *gave_up = false;
+    const int sweep_cap = getenv("PWICP_REFINE_SWEEPS") ? std::max(atoi(getenv("PWICP_REFINE_SWEEPS")), 1) : 4096;
     hipStream_t st = ctx->stream;
     FeWorkspace& ws = *workspace_of(ctx);
     DevBuf<double>&dis = ws.dis, &nd = ws.nd;
@@ -996,7 +1000,12 @@ int refine_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
         hipLaunchKernelGGL(k_ref_begin_generation, grid1(m), dim3(256), 0, st, L, m, d_lab, pos.p, nla.p, key.p);
         int* nl_prev = nla.p;
         int* nl_new = nlb.p;
-        for (;;) {
+        for (int in_generation = 0;; ++in_generation) {
+            if (in_generation >= sweep_cap) {
+                if (trace) fprintf(stderr, "[pwicp front end/dev]   refinement gives up (generation %d not settled after %d sweeps)\n", generations, in_generation);
+                *gave_up = true;
+                return PWICP_OK;
+            }
             ++sweeps;
             HIPCHK(ctx, hipMemsetAsync(flag.p, 0, sizeof(int), st));
             hipLaunchKernelGGL(k_ref_sweep, grid1(m), dim3(256), 0, st, L, m, d_nb, k, pos.p, d_lab, dis.p, dP, res, nl_prev, nl_new,
@@ -1273,8 +1282,23 @@ int segment_from_device_graph(pwicp_context* ctx, FeTrace& tr, const float* clou
         HIPCHK(ctx, hipStreamSynchronize(st));
         tr.lap("fusion (host)");
     }
-    PWCHK(refine_device(ctx, dP, d_nb, k, n, res, d_lab.p));
-    tr.lap("boundary refinement");
+    // (the fused labels are kept: a refinement that gives up is redone on the host from them)
+    HIPCHK(ctx, ws.lab0.reserve((size_t)n));
+    HIPCHK(ctx, hipMemcpyAsync(ws.lab0.p, d_lab.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    bool host_refine = false;
+    PWCHK(refine_device(ctx, dP, d_nb, k, n, res, d_lab.p, &host_refine));
+    if (host_refine) {
+        std::vector<FePt> P((size_t)n);
+        std::vector<int> nb((size_t)n * k), root_of((size_t)n);
+        HIPCHK(ctx, hipMemcpyAsync(P.data(), dP, sizeof(FePt) * (size_t)n, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(nb.data(), d_nb, sizeof(int) * (size_t)n * k, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(root_of.data(), ws.lab0.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        pwhost::fe_refine_host(P.data(), nb.data(), k, n, res, &root_of);
+        HIPCHK(ctx, hipMemcpyAsync(d_lab.p, root_of.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+    }
+    tr.lap(host_refine ? "boundary refinement (host)" : "boundary refinement");
     hipLaunchKernelGGL(k_mark_roots, grid1(n_roots), dim3(256), 0, st, d_roots.p, n_roots, d_map.p);
     hipLaunchKernelGGL(k_relabel, grid1(n), dim3(256), 0, st, d_lab.p, n, d_map.p);
     HIPCHK(ctx, hipMemcpyAsync(labels, d_lab.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));

@@ -190,6 +190,113 @@ int count_occupied_cells(const Pt* P, int n, double resolution) {
     return (int)(std::unique(cells.begin(), cells.end()) - cells.begin());
 }
 
+// supervoxel_segmentation.h:172-236: boundary refinement of the labels (root point of every point) in place
+void boundary_refinement(const Metric& metric, const int32_t* nb, int k, int n_points, std::vector<int>& labels) {
+    StageTimer tm;
+    std::vector<double> dis((size_t)n_points);
+    pwhost::parallel_for(n_points, [&](long long lo, long long hi) {
+        for (long long i = lo; i < hi; ++i) dis[(size_t)i] = metric((int)i, labels[(size_t)i]);
+    });
+    std::vector<int> q((size_t)n_points);              // ring buffer: every point is queued at most once at a time
+    size_t qh = 0, qt = 0, qn = 0;
+    const size_t qcap = (size_t)n_points;
+    auto push = [&](int v) { q[qt] = v; qt = (qt + 1 == qcap) ? 0 : qt + 1; ++qn; };
+    std::vector<char> in_q((size_t)n_points, 0);
+    // seed: every point with a differently labelled neighbour, and that neighbour, in scan order.  The label
+    // comparisons (n*k random reads) run on all threads into one bit mask per point; the order-dependent pushes
+    // then only visit the boundary points.
+    if (k <= 64) {
+        std::vector<uint64_t> diff((size_t)n_points);
+        pwhost::parallel_for(n_points, [&](long long lo, long long hi) {
+            for (long long i = lo; i < hi; ++i) {
+                const int32_t* row = nb + (size_t)i * (size_t)k;
+                const int li = labels[(size_t)i];
+                uint64_t m = 0;
+                for (int e = 0; e < k; ++e) m |= (uint64_t)(labels[(size_t)row[e]] != li) << e;
+                diff[(size_t)i] = m;
+            }
+        });
+        for (int i = 0; i < n_points; ++i) {
+            uint64_t m = diff[(size_t)i];
+            if (!m) continue;
+            const int32_t* row = nb + (size_t)i * (size_t)k;
+            if (!in_q[(size_t)i]) { push(i); in_q[(size_t)i] = 1; }
+            while (m) {
+                const int j = row[__builtin_ctzll(m)];
+                m &= m - 1;
+                if (!in_q[(size_t)j]) { push(j); in_q[(size_t)j] = 1; }
+            }
+        }
+    } else {
+        for (int i = 0; i < n_points; ++i) {
+            const int32_t* row = nb + (size_t)i * (size_t)k;
+            for (int e = 0; e < k; ++e) {
+                const int j = row[e];
+                if (labels[(size_t)i] != labels[(size_t)j]) {
+                    if (!in_q[(size_t)i]) { push(i); in_q[(size_t)i] = 1; }
+                    if (!in_q[(size_t)j]) { push(j); in_q[(size_t)j] = 1; }
+                }
+            }
+        }
+    }
+    if (tm.on) { char b[64]; std::snprintf(b, sizeof b, "    seeds: %zu", qn); tm.lap(b); }
+    size_t pops = 0;
+    const DifferingFn differing = pick_differing();
+    while (qn) {
+        const int i = q[qh];
+        qh = (qh + 1 == qcap) ? 0 : qh + 1;
+        --qn;
+        ++pops;
+        in_q[(size_t)i] = 0;
+        bool change = false;
+        const int32_t* row = nb + (size_t)i * (size_t)k;
+        // Only neighbours whose label differs from the point's label at the START of the visit can matter (a label the
+        // point switches to during the visit is skipped from then on, its old label can never win again), and a label
+        // already tried cannot win later either (dis[i] only decreases): each distinct neighbouring label is evaluated
+        // once, in the order of its first occurrence; the outcome is the reference's.
+        if (k <= 64) {
+            uint64_t m = differing(labels.data(), row, k, labels[(size_t)i]);
+            int tried[8], n_tried = 0;
+            while (m) {
+                const int e = __builtin_ctzll(m);
+                m &= m - 1;
+                const int a = labels[(size_t)i], b = labels[(size_t)row[e]];
+                if (a == b) continue;
+                bool seen = false;
+                for (int t = 0; t < n_tried; ++t) seen |= (tried[t] == b);
+                if (seen) continue;
+                if (n_tried < 8) tried[n_tried++] = b;
+                const double d = metric(i, b);
+                if (d < dis[(size_t)i]) { labels[(size_t)i] = b; dis[(size_t)i] = d; change = true; }
+            }
+        } else {
+            for (int e = 0; e < k; ++e) {
+                const int a = labels[(size_t)i], b = labels[(size_t)row[e]];
+                if (a == b) continue;
+                const double d = metric(i, b);
+                if (d < dis[(size_t)i]) { labels[(size_t)i] = b; dis[(size_t)i] = d; change = true; }
+            }
+        }
+        if (change) {
+            if (k <= 64) {
+                uint64_t m = differing(labels.data(), row, k, labels[(size_t)i]);
+                while (m) {
+                    const int j = row[__builtin_ctzll(m)];
+                    m &= m - 1;
+                    if (!in_q[(size_t)j]) { push(j); in_q[(size_t)j] = 1; }
+                }
+            } else {
+                for (int e = 0; e < k; ++e) {
+                    const int j = row[e];
+                    if (labels[(size_t)i] != labels[(size_t)j] && !in_q[(size_t)j]) { push(j); in_q[(size_t)j] = 1; }
+                }
+            }
+        }
+    }
+    if (tm.on) { char b[64]; std::snprintf(b, sizeof b, "  boundary refinement (%zu pops)", pops); tm.lap(b); }
+
+}
+
 // supervoxel_segmentation.h:65-248.  nb: the k-NN graph, n_points rows of k indices.
 // Adjacency lists: a node that was never a fusion centre still reads its row of the k-NN graph; every list a round
 // writes is appended to one arena (list of node i = arena[off[i] .. off[i]+len[i])) which is compacted in place
@@ -317,106 +424,7 @@ int supervoxel_segmentation(const Metric& metric, const int32_t* nb, int k, int 
     if (roots_out) { *roots_out = supervoxels; return (int)supervoxels.size(); }
 
     // ---- step 2: boundary refinement -------------------------------------------------------------------------
-    pwhost::parallel_for(n_points, [&](long long lo, long long hi) {
-        for (long long i = lo; i < hi; ++i) dis[(size_t)i] = metric((int)i, labels[(size_t)i]);
-    });
-    std::vector<int> q((size_t)n_points);              // ring buffer: every point is queued at most once at a time
-    size_t qh = 0, qt = 0, qn = 0;
-    const size_t qcap = (size_t)n_points;
-    auto push = [&](int v) { q[qt] = v; qt = (qt + 1 == qcap) ? 0 : qt + 1; ++qn; };
-    std::vector<char> in_q((size_t)n_points, 0);
-    // seed: every point with a differently labelled neighbour, and that neighbour, in scan order.  The label
-    // comparisons (n*k random reads) run on all threads into one bit mask per point; the order-dependent pushes
-    // then only visit the boundary points.
-    if (k <= 64) {
-        std::vector<uint64_t> diff((size_t)n_points);
-        pwhost::parallel_for(n_points, [&](long long lo, long long hi) {
-            for (long long i = lo; i < hi; ++i) {
-                const int32_t* row = nb + (size_t)i * (size_t)k;
-                const int li = labels[(size_t)i];
-                uint64_t m = 0;
-                for (int e = 0; e < k; ++e) m |= (uint64_t)(labels[(size_t)row[e]] != li) << e;
-                diff[(size_t)i] = m;
-            }
-        });
-        for (int i = 0; i < n_points; ++i) {
-            uint64_t m = diff[(size_t)i];
-            if (!m) continue;
-            const int32_t* row = nb + (size_t)i * (size_t)k;
-            if (!in_q[(size_t)i]) { push(i); in_q[(size_t)i] = 1; }
-            while (m) {
-                const int j = row[__builtin_ctzll(m)];
-                m &= m - 1;
-                if (!in_q[(size_t)j]) { push(j); in_q[(size_t)j] = 1; }
-            }
-        }
-    } else {
-        for (int i = 0; i < n_points; ++i) {
-            const int32_t* row = nb + (size_t)i * (size_t)k;
-            for (int e = 0; e < k; ++e) {
-                const int j = row[e];
-                if (labels[(size_t)i] != labels[(size_t)j]) {
-                    if (!in_q[(size_t)i]) { push(i); in_q[(size_t)i] = 1; }
-                    if (!in_q[(size_t)j]) { push(j); in_q[(size_t)j] = 1; }
-                }
-            }
-        }
-    }
-    if (tm.on) { char b[64]; std::snprintf(b, sizeof b, "    seeds: %zu", qn); tm.lap(b); }
-    size_t pops = 0;
-    const DifferingFn differing = pick_differing();
-    while (qn) {
-        const int i = q[qh];
-        qh = (qh + 1 == qcap) ? 0 : qh + 1;
-        --qn;
-        ++pops;
-        in_q[(size_t)i] = 0;
-        bool change = false;
-        const int32_t* row = nb + (size_t)i * (size_t)k;
-        // Only neighbours whose label differs from the point's label at the START of the visit can matter (a label the
-        // point switches to during the visit is skipped from then on, its old label can never win again), and a label
-        // already tried cannot win later either (dis[i] only decreases): each distinct neighbouring label is evaluated
-        // once, in the order of its first occurrence; the outcome is the reference's.
-        if (k <= 64) {
-            uint64_t m = differing(labels.data(), row, k, labels[(size_t)i]);
-            int tried[8], n_tried = 0;
-            while (m) {
-                const int e = __builtin_ctzll(m);
-                m &= m - 1;
-                const int a = labels[(size_t)i], b = labels[(size_t)row[e]];
-                if (a == b) continue;
-                bool seen = false;
-                for (int t = 0; t < n_tried; ++t) seen |= (tried[t] == b);
-                if (seen) continue;
-                if (n_tried < 8) tried[n_tried++] = b;
-                const double d = metric(i, b);
-                if (d < dis[(size_t)i]) { labels[(size_t)i] = b; dis[(size_t)i] = d; change = true; }
-            }
-        } else {
-            for (int e = 0; e < k; ++e) {
-                const int a = labels[(size_t)i], b = labels[(size_t)row[e]];
-                if (a == b) continue;
-                const double d = metric(i, b);
-                if (d < dis[(size_t)i]) { labels[(size_t)i] = b; dis[(size_t)i] = d; change = true; }
-            }
-        }
-        if (change) {
-            if (k <= 64) {
-                uint64_t m = differing(labels.data(), row, k, labels[(size_t)i]);
-                while (m) {
-                    const int j = row[__builtin_ctzll(m)];
-                    m &= m - 1;
-                    if (!in_q[(size_t)j]) { push(j); in_q[(size_t)j] = 1; }
-                }
-            } else {
-                for (int e = 0; e < k; ++e) {
-                    const int j = row[e];
-                    if (labels[(size_t)i] != labels[(size_t)j] && !in_q[(size_t)j]) { push(j); in_q[(size_t)j] = 1; }
-                }
-            }
-        }
-    }
-    if (tm.on) { char b[64]; std::snprintf(b, sizeof b, "  boundary refinement (%zu pops)", pops); tm.lap(b); }
+    boundary_refinement(metric, nb, k, n_points, labels);
 
     // ---- step 3: relabel -----------------------------------------------------------------------------------------
     std::vector<int> map((size_t)n_points, 0);
@@ -479,6 +487,10 @@ void fe_normals_from_scatter(const double* S6, int n, double* normals3) {
             normal_from_scatter(C, normals3 + 3 * (size_t)i);
         }
     });
+}
+void fe_refine_host(const FePt* P, const int32_t* nb, int k, int n, double resolution, std::vector<int>* root_of) {
+    Metric metric{P, resolution};
+    boundary_refinement(metric, nb, k, n, *root_of);
 }
 int fe_fusion_host(const FePt* P, const int32_t* nb, int k, int n, double resolution, int n_supervoxels, std::vector<int>* root_of,
                    std::vector<int>* roots) {

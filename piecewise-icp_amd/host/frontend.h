@@ -22,6 +22,9 @@ int fe_count_occupied_cells(const FePt* P, int n, double resolution);
 int fe_fusion_host(const FePt* P, const int32_t* nb, int k, int n, double resolution, int n_supervoxels, std::vector<int>* root_of,
                    std::vector<int>* roots);
 
+// the serial boundary refinement (supervoxel_segmentation.h:172-236) of root labels, in place
+void fe_refine_host(const FePt* P, const int32_t* nb, int k, int n, double resolution, std::vector<int>* root_of);
+
 }  // namespace pwhost
 
 // csrc/frontend.hip: the whole front end of a cloud on the device - k-NN graph, neighbourhood scatter, occupied cells, fusion,

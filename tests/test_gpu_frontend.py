@@ -116,3 +116,17 @@ def test_degenerate_inputs(ctx):
     dup = np.concatenate([tgt, tgt[rng.integers(0, len(tgt), len(tgt) // 10)]]).astype(np.float32)
     _assert_same(ctx, dup, 10 * _data.R, _data.R)
     _assert_same(ctx, tgt[:60], 10 * _data.R, _data.R)
+
+
+def test_refinement_sweep_cap_falls_back_to_the_serial_pass(ctx, capfd):
+    """A queue generation that has not settled after $PWICP_REFINE_SWEEPS sweeps (default 4096; 2-5 are normal) is redone by the
+    serial host pass from the fused labels - same labels."""
+    _, src, _ = _data.pair(30000)
+    os.environ["PWICP_REFINE_SWEEPS"] = "1"
+    os.environ["PWICP_TRACE"] = "1"
+    try:
+        _assert_same(ctx, src, 10 * _data.R, _data.R)
+    finally:
+        os.environ.pop("PWICP_REFINE_SWEEPS", None)
+        os.environ.pop("PWICP_TRACE", None)
+    assert "refinement gives up" in capfd.readouterr().err
