@@ -130,3 +130,11 @@ def test_refinement_sweep_cap_falls_back_to_the_serial_pass(ctx, capfd):
         os.environ.pop("PWICP_REFINE_SWEEPS", None)
         os.environ.pop("PWICP_TRACE", None)
     assert "refinement gives up" in capfd.readouterr().err
+
+
+def test_rockfall_scale(ctx):
+    """BASELINE configs[2] stand-in (SURVEY 8d cfg 3): point spacing 0.3 m, supervoxels of 3 m, coordinates of a few hundred
+    metres after the centroid reduction."""
+    tgt, _, _ = _data.pair(150000)
+    big = (tgt * np.float32(60.0)).astype(np.float32)
+    _assert_same(ctx, big, 3.0, 0.3)
