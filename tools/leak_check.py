@@ -15,3 +15,12 @@ for i in range(120):
         a=ctx.preprocess(tgt,_data.R,14,5.0); nb=ctx.knn(src[:20000],45)
     if i==10: f0=free()
 print("free MiB after 10: %.1f, after 120: %.1f"%(f0, free()))
+# the front end keeps its work buffers with the context (grow-only): repeated calls must not drift, closing the context frees them
+f1 = None
+for i in range(24):
+    n = 60000 + 20000 * (i % 4)
+    ctx.frontend_segment(tgt[:n], 10 * _data.R, 45, _data.R)
+    if i == 7: f1 = free()
+print("front end: free MiB after 8 calls: %.1f, after 24: %.1f" % (f1, free()))
+ctx.close()
+print("after closing the context: %.1f MiB free" % free())
