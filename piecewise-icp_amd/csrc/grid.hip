@@ -1003,9 +1003,84 @@ int pw_morton_order(pwicp_context* ctx, const GridDesc& g, const float4* d_pts, 
 }
 
 // k nearest neighbours of every point of the cloud within the cloud (row i of d_nb = neighbours of point i)
+// The same search with the lane's sorted candidate list in LDS (entry e of lane l at [e * 64 + l]: conflict free), for
+// k <= KMAX.  The list is where the time goes (a candidate shifts ~10 entries on average, ~100 candidates per point): in
+// global memory that is ~24 KB of traffic per point, in LDS it is a handful of ds_read / ds_write per shift.  One
+// wavefront per block; 36.9 KB (double) / 24.6 KB (float) of LDS per block.
+template <typename Real, int KMAX>
+__global__ void __launch_bounds__(64) k_knn_lds(GridLevel g, int k, int* __restrict__ out_nb, float* __restrict__ out_mean) {
+    __shared__ Real s_d[KMAX * 64];
+    __shared__ int s_i[KMAX * 64];
+    const int lane = threadIdx.x;
+    const int t = blockIdx.x * 64 + lane;
+    const int n = g.n;
+    if (t >= n) return;
+    Real* const nd = s_d + lane;
+    int* const ni = s_i + lane;
+    const float4 q = g.pts[t];
+    const int self = __float_as_int(q.w);
+    const Real qx = (Real)q.x, qy = (Real)q.y, qz = (Real)q.z;
+    const int cx = cell_of(q.x, g.ox, g.inv_h), cy = cell_of(q.y, g.oy, g.inv_hy), cz = cell_of(q.z, g.oz, g.inv_hz);
+    const int rcover = max(max(max(cx, g.nx - 1 - cx), max(cy, g.ny - 1 - cy)), max(cz, g.nz - 1 - cz));
+    int cnt = 0;
+    for (int r = 2;; ++r) {
+        cnt = 0;
+        Real worst = (Real)0;
+        int worst_i = 0;
+        for (int dz = -r; dz <= r; ++dz)
+            for (int dy = -r; dy <= r; ++dy) {
+                int lo, hi;
+                row_range(g, cy + dy, cz + dz, cx - r, cx + r, lo, hi);
+                for (int j = lo; j < hi; ++j) {
+                    const float4 p = g.pts[j];
+                    const Real dx = qx - (Real)p.x, dy2 = qy - (Real)p.y, dz2 = qz - (Real)p.z;
+                    Real d2 = dx * dx;
+                    d2 = d2 + dy2 * dy2;
+                    d2 = d2 + dz2 * dz2;
+                    const int id = __float_as_int(p.w);
+                    // sorted insertion by (d2, id); the current k-th entry is kept in registers
+                    if (cnt == k && !(d2 < worst || (d2 == worst && id < worst_i))) continue;
+                    int pos = cnt < k ? cnt : k - 1;
+                    while (pos > 0) {
+                        const Real pd = nd[(pos - 1) * 64];
+                        const int pi = ni[(pos - 1) * 64];
+                        if (!(d2 < pd || (d2 == pd && id < pi))) break;
+                        nd[pos * 64] = pd;
+                        ni[pos * 64] = pi;
+                        --pos;
+                    }
+                    nd[pos * 64] = d2;
+                    ni[pos * 64] = id;
+                    if (cnt < k) ++cnt;
+                    if (cnt == k) { worst = nd[(k - 1) * 64]; worst_i = ni[(k - 1) * 64]; }
+                }
+            }
+        if (r >= rcover) break;
+        if (cnt == k) {
+            const double bound = (double)r * (double)g.h - 2.0 * (double)g.slack;
+            if (bound > 0.0 && (double)worst < bound * bound * 0.99999) break;
+        }
+    }
+    if (out_nb)
+        for (int e = 0; e < k; ++e) out_nb[(size_t)self * k + e] = (e < cnt) ? ni[e * 64] : -1;
+    if (out_mean) {
+        double s = 0.0;
+        for (int e = 1; e < cnt; ++e) s += (double)sqrtf((float)nd[e * 64]);
+        out_mean[self] = (float)(s / (double)(k - 1));
+    }
+}
+constexpr int kKnnLdsMax = 48;
+
 int pw_knn_launch(pwicp_context* ctx, const GridDesc& g, int k, int* d_nb) {
     const int n = g.fine.n;
     if (n <= 0) return PWICP_OK;
+    static const bool lds_off = getenv("PWICP_KNN_LDS") && atoi(getenv("PWICP_KNN_LDS")) == 0;      // A/B knob
+    if (k <= kKnnLdsMax && !lds_off) {
+        hipLaunchKernelGGL((k_knn_lds<double, kKnnLdsMax>), dim3(div_up(n, 64)), dim3(64), 0, ctx->stream, g.fine, k, d_nb, (float*)nullptr);
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipGetLastError());
+        return PWICP_OK;
+    }
     DevBuf<double> nd;
     DevBuf<int> ni;
     HIPCHK(ctx, nd.reserve((size_t)n * k));
@@ -1022,6 +1097,13 @@ int pw_knn_mean_dist_launch(pwicp_context* ctx, const GridDesc& g, int mean_k, f
     const int n = g.fine.n;
     if (n <= 0) return PWICP_OK;
     const int k = mean_k + 1;
+    static const bool lds_off = getenv("PWICP_KNN_LDS") && atoi(getenv("PWICP_KNN_LDS")) == 0;
+    if (k <= kKnnLdsMax && !lds_off) {
+        hipLaunchKernelGGL((k_knn_lds<float, kKnnLdsMax>), dim3(div_up(n, 64)), dim3(64), 0, ctx->stream, g.fine, k, (int*)nullptr, d_mean);
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipGetLastError());
+        return PWICP_OK;
+    }
     DevBuf<float> nd;
     DevBuf<int> ni;
     HIPCHK(ctx, nd.reserve((size_t)n * k));
