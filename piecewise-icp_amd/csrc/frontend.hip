@@ -906,6 +906,8 @@ struct FeWorkspace {
     DevBuf<int> pos, cnt, La, Lb, nla, nlb, flag, tmp;
     // fusion
     DevBuf<double> dmin;
+    DevBuf<unsigned long long> sel_state;
+    DevBuf<unsigned> sel_hist;
     DevBuf<int> root0, s0, lenA, lenB, cenA, cenB, revoff, revown, cursor, ab, ab_prev, rec_sz, rec_ran, rec_absn, rec_adjn, slot_of, wake,
         dflag, cflag, dtmin, Wa, Wb, dq, dq2, ovf, o_sz, o_ran, o_absn, o_adjn, o_dirty, o_oldabsn, alive, newlen, cut, arenaA, arenaB, sa, ctr;
     DevBuf<long long> offA, offB, rec_ptr, o_ptr, o_oldptr;
@@ -940,6 +942,52 @@ struct FeWorkspace {
 FeWorkspace* workspace_of(pwicp_context* ctx) {
     if (!ctx->scratch) ctx->scratch = std::shared_ptr<void>(new FeWorkspace, [](void* p) { delete static_cast<FeWorkspace*>(p); });
     return static_cast<FeWorkspace*>(ctx->scratch.get());
+}
+
+// ---- k-th smallest of n doubles (exact; lambda0 = the median of the smallest neighbour metric, :98-102) ---------------------
+// MSB-first radix select on the order-preserving 64-bit image of a double, 8 passes of 8 bits: a histogram pass over the
+// values that match the digits found so far, then a one-block pick.  (std::nth_element over 1 M doubles costs 6 ms on the
+// host plus the 8 MB download; this is ~0.2 ms.)
+__device__ __forceinline__ unsigned long long sel_key(double d) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(d);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+// state: [0] prefix, [1] mask of the digits already fixed, [2] rank remaining
+__global__ void k_sel_hist(const double* __restrict__ v, int n, int shift, const unsigned long long* __restrict__ state,
+                           unsigned* __restrict__ hist) {
+    __shared__ unsigned s_h[256];
+    s_h[threadIdx.x] = 0u;
+    __syncthreads();
+    const unsigned long long prefix = state[0], mask = state[1];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned long long key = sel_key(v[i]);
+        if ((key & mask) == prefix) atomicAdd(&s_h[(unsigned)(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    const unsigned c = s_h[threadIdx.x];
+    if (c) atomicAdd(&hist[threadIdx.x], c);
+}
+__global__ void k_sel_pick(unsigned* __restrict__ hist, unsigned long long* __restrict__ state, int shift) {
+    __shared__ unsigned s_h[256];
+    s_h[threadIdx.x] = hist[threadIdx.x];
+    hist[threadIdx.x] = 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long k = state[2], run = 0;
+        int digit = 255;
+        for (int b = 0; b < 256; ++b) {
+            if (k < run + s_h[b]) { digit = b; break; }
+            run += s_h[b];
+        }
+        state[0] |= (unsigned long long)digit << shift;
+        state[1] |= 255ull << shift;
+        state[2] = k - run;
+    }
+}
+__global__ void k_sel_result(const unsigned long long* __restrict__ state, double* __restrict__ out) {
+    const unsigned long long key = state[0];
+    const unsigned long long u = (key >> 63) ? (key & 0x7fffffffffffffffull) : ~key;
+    *out = __longlong_as_double((long long)u);
 }
 
 struct FeTrace {
@@ -1047,11 +1095,23 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     {
         HIPCHK(ctx, ws.dmin.reserve((size_t)n));
         hipLaunchKernelGGL(k_fus_min_metric, grid1(n), dim3(256), 0, st, dP, d_nb, k, n, res, ws.dmin.p);
-        std::vector<double> v((size_t)n);
-        HIPCHK(ctx, hipMemcpyAsync(v.data(), ws.dmin.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+        // median = the value of rank n / 2 (what std::nth_element(v.begin() + v.size() / 2) leaves there)
+        HIPCHK(ctx, ws.sel_state.reserve(4));
+        HIPCHK(ctx, ws.sel_hist.reserve(256));
+        const unsigned long long init[4] = {0ull, 0ull, (unsigned long long)(n / 2), 0ull};
+        HIPCHK(ctx, hipMemcpyAsync(ws.sel_state.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemsetAsync(ws.sel_hist.p, 0, sizeof(unsigned) * 256, st));
+        for (int shift = 56; shift >= 0; shift -= 8) {
+            hipLaunchKernelGGL(k_sel_hist, dim3((unsigned)std::min(div_up(n, 256), 1024)), dim3(256), 0, st, ws.dmin.p, n, shift, ws.sel_state.p,
+                               ws.sel_hist.p);
+            hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(256), 0, st, ws.sel_hist.p, ws.sel_state.p, shift);
+        }
+        hipLaunchKernelGGL(k_sel_result, dim3(1), dim3(1), 0, st, ws.sel_state.p, (double*)(ws.sel_state.p + 3));
+        double median = 0.0;
+        HIPCHK(ctx, hipMemcpyAsync(&median, ws.sel_state.p + 3, sizeof(double), hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
-        std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
-        lambda = std::max(DBL_EPSILON, v[v.size() / 2]);
+        lambda = std::max(DBL_EPSILON, median);
+        if (trace) fprintf(stderr, "[pwicp front end/dev]   lambda0 = %.17g\n", lambda);
     }
     const size_t N = (size_t)n;
     for (DevBuf<int>* b : {&ws.root0, &ws.s0, &ws.lenA, &ws.lenB, &ws.cenA, &ws.cenB, &ws.cursor, &ws.ab, &ws.ab_prev, &ws.rec_sz,
