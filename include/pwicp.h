@@ -255,7 +255,7 @@ PWICP_API int pwicp_frontend_segment(const float* cloud_xyz4, int n, float sv_re
 PWICP_API int pwicp_knn(pwicp_context* ctx, const float* cloud_xyz4, int n, int k, float cell_edge, int32_t* neighbors);
 /* pwicp_frontend_segment on the GPU (csrc/frontend.hip): k-NN graph, neighbourhood scatter, supervoxel fusion and boundary
  * refinement as speculative fixed points over the reference's serial visiting order - identical labels.  Host: the
- * closed-form eigen step of the normals, one median.  Work buffers stay with the context (grow-only) until pwicp_destroy.
+ * closed-form eigen step of the normals.  Work buffers stay with the context (grow-only) until pwicp_destroy.
  * point_spacing <= 0: estimated.  $PWICP_FRONTEND=host: the serial host passes behind the GPU k-NN graph. */
 PWICP_API int pwicp_frontend_segment_dev(pwicp_context* ctx, const float* cloud_xyz4, int n, float sv_resolution,
                                          int knn, float point_spacing, int32_t* labels, int* n_supervoxels);

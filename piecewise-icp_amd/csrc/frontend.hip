@@ -1372,8 +1372,7 @@ int segment_from_device_graph(pwicp_context* ctx, FeTrace& tr, const float* clou
 }  // namespace
 
 // The whole front end of one cloud (S.cpp:18-68).  Device: k-NN graph, neighbourhood scatter, occupied cells, fusion,
-// refinement, relabel.  Host: the closed-form eigen step of the normals (libm's pow / acos / cos decide label bits) and the
-// median that gives lambda0.
+// refinement, relabel.  Host: only the closed-form eigen step of the normals (libm's pow / acos / cos decide label bits).
 int pw_frontend_segment_device(pwicp_context* ctx, const float* cloud_xyz4, int n, int k, float cell_edge, float sv_resolution,
                                int32_t* labels, int* n_supervoxels) {
     if (k > 64) { ctx->set_err("front end: k > 64 neighbours not supported on the device"); return PWICP_E_INVALID; }
