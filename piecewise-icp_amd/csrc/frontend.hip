@@ -23,7 +23,9 @@
 #include <cfloat>
 #include <climits>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -990,6 +992,33 @@ __global__ void k_sel_result(const unsigned long long* __restrict__ state, doubl
     *out = __longlong_as_double((long long)u);
 }
 
+// EXPERIMENT ($PWICP_NORMALS=device): the eigen step with the device library's pow / acos / cos / sqrt.  Kept to document why
+// the default takes it on the host: the result differs from libm's in the last bit of a fraction of the normals, and such a
+// bit can move a label.
+__global__ void k_fe_eigen_device(const double* __restrict__ S6, int n, double* __restrict__ normals3) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* c = S6 + (size_t)i * 6;
+    const double xx = c[0], xy = c[1], xz = c[2], yy = c[3], yz = c[4], zz = c[5];
+    const double shift = (xx + yy + zz) / 3.0;
+    const double bx = xx - shift, by = yy - shift, bz = zz - shift;
+    const double p = sqrt((bx * bx + by * by + bz * bz + 2.0 * (xy * xy + xz * xz + yz * yz)) / 6.0);
+    const double inv_p3 = pow(1.0 / p, 3.0);
+    const double det = inv_p3 * (bx * (by * bz - yz * yz) - xy * (xy * bz - yz * xz) + xz * (xy * yz - by * xz));
+    const double half = 0.5 * det;
+    const double kPi = 3.14159265358979323846;
+    const double angle = half <= -1.0 ? kPi / 3.0 : (half >= 1.0 ? 0.0 : acos(half) / 3.0);
+    const double lam = shift + 2.0 * p * cos(angle + kPi * (2.0 / 3.0));
+    const double n0 = xy * yz - xz * (yy - lam);
+    const double n1 = xy * xz - yz * (xx - lam);
+    const double n2 = (xx - lam) * (yy - lam) - xy * xy;
+    const double len = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+    double* o = normals3 + (size_t)i * 3;
+    if (len == 0.0) { o[0] = 0.0; o[1] = 0.0; o[2] = 1.0; return; }
+    const double unit = 1.0 / len;
+    o[0] = n0 * unit; o[1] = n1 * unit; o[2] = n2 * unit;
+}
+
 struct FeTrace {
     pwicp_context* ctx;
     const bool on = getenv("PWICP_TRACE") != nullptr;
@@ -1412,6 +1441,25 @@ int pw_frontend_segment_device(pwicp_context* ctx, const float* cloud_xyz4, int 
         }
     HIPCHK(ctx, hipStreamSynchronize(st));
     pwhost::fe_normals_from_scatter(S6, n, N3);
+    if (getenv("PWICP_NORMALS") && std::string(getenv("PWICP_NORMALS")) == "device") {
+        // experiment: eigen step on the device; report how many normals differ from the host's in any bit
+        hipLaunchKernelGGL(k_fe_eigen_device, grid1(n), dim3(256), 0, st, dS.p, n, dN.p);
+        std::vector<double> dev3((size_t)n * 3);
+        HIPCHK(ctx, hipMemcpyAsync(dev3.data(), dN.p, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        size_t differ = 0;
+        double worst = 0.0;
+        for (int i = 0; i < n; ++i) {
+            bool d = false;
+            for (int c = 0; c < 3; ++c) {
+                const double a = dev3[3 * (size_t)i + c], b = N3[3 * (size_t)i + c];
+                if (memcmp(&a, &b, sizeof(double)) != 0) { d = true; worst = std::max(worst, fabs(a - b)); }
+            }
+            differ += d;
+        }
+        fprintf(stderr, "[pwicp front end/dev]   eigen step on the device: %zu of %d normals differ from libm's (largest component difference %.3g)\n",
+                differ, n, worst);
+    } else
     HIPCHK(ctx, hipMemcpyAsync(dN.p, N3, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_fe_assemble, grid1(n), dim3(256), 0, st, pts.p, dN.p, n, dP.p);
     tr.lap("pca normals");
