@@ -138,3 +138,13 @@ def test_rockfall_scale(ctx):
     tgt, _, _ = _data.pair(150000)
     big = (tgt * np.float32(60.0)).astype(np.float32)
     _assert_same(ctx, big, 3.0, 0.3)
+
+
+def test_randomised_clouds_and_schedules():
+    """tools/fe_fuzz.py: 24 random combinations of size, roughness, point order, supervoxel size, chunk size, wake threshold
+    and queue limit, device labels against the serial passes."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "tools", "fe_fuzz.py"), "24", "2026"], capture_output=True,
+                         text=True, timeout=600)
+    assert "different: 0 of 24" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
