@@ -1405,6 +1405,10 @@ int segment_from_device_graph(pwicp_context* ctx, FeTrace& tr, const float* clou
 int pw_frontend_segment_device(pwicp_context* ctx, const float* cloud_xyz4, int n, int k, float cell_edge, float sv_resolution,
                                int32_t* labels, int* n_supervoxels) {
     if (k > 64) { ctx->set_err("front end: k > 64 neighbours not supported on the device"); return PWICP_E_INVALID; }
+    if ((long long)n * k > (long long)INT_MAX - 64) {          // list offsets / entry counts are 32-bit (47 M points at k = 45)
+        ctx->set_err("front end: cloud too large for the device pipeline (n * k must stay below 2^31)");
+        return PWICP_E_INVALID;
+    }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     FeTrace tr{ctx};
