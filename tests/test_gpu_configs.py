@@ -172,3 +172,50 @@ def test_pair_5m_points(ctx, oracle):
         d = ((t64 - src[i].astype(np.float64)) ** 2).sum(1)
         assert abs(d.min() - d2[i]) <= 1e-6 * max(d.min(), 1e-12) + 1e-12
     pair.close()
+
+
+AMAP = {2: 1, 3: 1, 4: 1, 5: 1, 6: 1, 7: 3, 8: 4, 9: 4, 10: 5, 11: 6, 12: 6, 13: 7, 14: 9, 15: 12, 16: 13, 17: 14, 18: 14,
+        19: 14, 20: 14}
+
+
+@pytest.mark.parametrize("pair_mode", [0, -1])
+def test_the_references_own_run_through_the_exported_entry_point(tmp_path, ctx, pair_mode):
+    """src/main.cpp:27-28 of the reference: PiecewiseICP_4D_call(configuration_4d.txt, 0, 20, pairMode, 0.75) on its 20 scans
+    (kept as fixtures), here through libpwicp.so's function of the same name - preprocessing, front end, loop, composition and
+    result files all by the product.  pairMode 0: every <e>_Direct2Ref_TransMatrix.txt within the tolerance the oracle meets
+    against the reference's checked-in file; pairMode -1 (what main.cpp passes): RegPairFile.txt equal to the pair map recovered
+    from the reference's Adaptive results, and every <e>_Adaptive_TransMatrix.txt at registration-noise level of the
+    reference's."""
+    import pwicp_amd as P
+    out = str(tmp_path) + "/"
+    cfg = tmp_path / "cfg.txt"
+    with open(cfg, "w") as f:      # configuration_files/configuration_4d.txt
+        f.write("string FolderFilePath1: %s\nstring FolderFilePath2: %s\nbool isSetResSVsize (yes-1, no-0): 1\n"
+                "float PCres1 (m): 0.005\nfloat PCres2 (m): 0.005\nfloat SVsize1 (m): 0.05\nfloat SVsize2 (m): 0.05\n"
+                "bool isSetDTinit (yes-1, no-0): 1\nfloat DTinit (m): 0.05\nfloat DTmin (m): 0.004\nbool isVisual (yes-1, no-0): 0"
+                % (os.path.join(G.GOLD, "inputs"), out))
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        assert P.PiecewiseICP_4D_call(str(cfg), 0, 20, pair_mode, 0.75) is True
+    finally:
+        os.chdir(cwd)
+    mode = "Direct2Ref" if pair_mode == 0 else "Adaptive"
+    if pair_mode < 0:
+        pairs = [tuple(int(v) for v in line.split()[:2]) for line in open(str(tmp_path / "RegPairFile.txt")) if line.strip() and line.split()[0].isdigit()]
+        got = {}
+        for a, b in pairs:
+            got[max(a, b) + 1] = min(a, b) + 1          # the file is 0-based (R.cpp:578-586)
+        assert got == AMAP, got
+    worst = {}
+    for e in range(2, 21):
+        T, _, _ = G.parse_transmatrix_file(out + "%d_%s_TransMatrix.txt" % (e, mode))
+        Tg, _, _ = G.parse_transmatrix_file(os.path.join(G.GOLD, "reference_results", "%d_%s_TransMatrix.txt" % (e, mode)))
+        worst[e] = (float(np.abs(G.euler(T) - G.euler(Tg)).max()), float(np.abs(T[:3, 3] - Tg[:3, 3]).max()))
+    if pair_mode == 0:
+        for e, (da, dt) in worst.items():
+            assert da < GOLD_TOL[e][0] and dt < GOLD_TOL[e][1], (e, da, dt)
+    else:
+        assert all(v[0] < 2e-3 and v[1] < 3e-3 for v in worst.values()), worst
+        assert sum(1 for v in worst.values() if v[0] < 5e-6 and v[1] < 5e-6) >= 12, worst
+    assert os.path.exists(out + "TransMatrices_toRef.txt") and os.path.exists(out + "TransParameters_toRef.txt")
