@@ -219,3 +219,34 @@ def test_the_references_own_run_through_the_exported_entry_point(tmp_path, ctx, 
         assert all(v[0] < 2e-3 and v[1] < 3e-3 for v in worst.values()), worst
         assert sum(1 for v in worst.values() if v[0] < 5e-6 and v[1] < 5e-6) >= 12, worst
     assert os.path.exists(out + "TransMatrices_toRef.txt") and os.path.exists(out + "TransParameters_toRef.txt")
+
+
+@pytest.mark.parametrize("shape", ["steep_z", "face_yz", "diagonal"])
+def test_loop_parity_on_cliff_like_scenes(ctx, oracle, shape):
+    """Steep / volumetric scenes (the rockfall use case): a column of the search grid holds a tall stack of points, the
+    per-pair choice between the levels of columns and of cells goes to cells, the far path of the dense search is exercised.
+    steep_z: slopes up to ~9 on the tile; face_yz: the tile turned into the y-z plane (a cliff looked at along x: no column
+    layout fits); diagonal: the tile tilted 45 degrees about y.  GPU == oracle bit for bit on every discrete quantity."""
+    import pwicp_amd as P
+    tgt, src, _ = _data.pair(120000)
+    out = []
+    for a in (tgt, src):
+        a = a.copy()
+        if shape == "steep_z":
+            a[:, 2] += (1.5 * np.sin(6.0 * a[:, 0])).astype(np.float32)
+        elif shape == "face_yz":
+            a = np.ascontiguousarray(a[:, [2, 0, 1]])
+        else:
+            c, s_ = np.float32(np.cos(np.pi / 4)), np.float32(np.sin(np.pi / 4))
+            x, z = a[:, 0].copy(), a[:, 2].copy()
+            a[:, 0] = c * x + s_ * z
+            a[:, 2] = -s_ * x + c * z
+        out.append(a.astype(np.float32))
+    tgt, src = out
+    l1, n1 = ctx.frontend_segment(tgt, 10 * R, 45, R)
+    l2, n2 = ctx.frontend_segment(src, 10 * R, 45, R)
+    pair = P.Pair(ctx, tgt, l1, n1, src, l2, n2, _data.params())
+    res = pair.run(check=False)
+    io = _oracle_loop(oracle, tgt, l1, n1, src, l2, n2)
+    _assert_loop_parity(res, io)
+    pair.close()
