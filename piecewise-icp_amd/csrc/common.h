@@ -89,6 +89,10 @@ struct GridLevel {
     float slack;             // bound on |computed cell boundary - true boundary| (rounding)
     int nx, ny, nz;
     int n;                   // number of points
+    int perm;                // axis roles of this level: 0 = (x, y, z); 1 = the level is built on (y, z, x), 2 = on (z, x, y) —
+                             // pts hold the coordinates in THAT order, origin / counts refer to it, queries are permuted on
+                             // entry and squared distances are still summed in the original x, y, z order (nn_device.h).
+                             // Only the small-cell levels of the dense search use 1 / 2 (pw_grid_add_dense).
     const int* cell_start;   // nx*ny*nz + 1 entries
     const float4* pts;       // sorted by cell; w = __int_as_float(original index)
 };
@@ -114,6 +118,13 @@ struct Grid {
     bool has_dense_alt = false;
     DevBuf<int> acell_start;
     DevBuf<float4> apts;
+    // ... and with other axis roles (rows along y or z, columns along x): a face that no layout on (x, y, z) fits
+    struct Extra {
+        GridLevel lv{};
+        bool has = false;
+        DevBuf<int> cell_start;
+        DevBuf<float4> pts;
+    } extra[3];
 };
 
 // grid.hip

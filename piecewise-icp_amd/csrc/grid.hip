@@ -342,6 +342,9 @@ __device__ __forceinline__ float dense_far_path(const GridDesc& far, float4 q, f
     return fminf(best, b.d2());
 }
 
+// PERM = dl.perm: the level's axis roles (the query is put into the level's order for everything that concerns `dl`;
+// the far path works on the levels of `far`, which are always in (x, y, z))
+template <int PERM>
 __global__ void __launch_bounds__(kBlock) k_nn_dense_disc(GridLevel dl, GridDesc far, const float4* __restrict__ pat,
                                                           const int* __restrict__ qorder, const int* __restrict__ qpatch,
                                                           const int* __restrict__ stable, int nq,
@@ -367,16 +370,19 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_disc(GridLevel dl, GridDesc
         const int st = p >= 0 ? stable[pa] : 0;
         q = pat[max(p, 0)];                       // (both gathers in flight together)
         if (st) {
-            const int cx = cell_of(q.x, dl.ox, dl.inv_h), cy = cell_of(q.y, dl.oy, dl.inv_hy), cz = cell_of(q.z, dl.oz, dl.inv_hz);
+            const float ux = PERM == 0 ? q.x : (PERM == 1 ? q.y : q.z);       // the query in the level's axis order
+            const float uy = PERM == 0 ? q.y : (PERM == 1 ? q.z : q.x);
+            const float uz = PERM == 0 ? q.z : (PERM == 1 ? q.x : q.y);
+            const int cx = cell_of(ux, dl.ox, dl.inv_h), cy = cell_of(uy, dl.oy, dl.inv_hy), cz = cell_of(uz, dl.oz, dl.inv_hz);
             int loA, hiA;
             row_range(dl, cy, cz, cx - 1, cx + 1, loA, hiA);
-            scan_d2x4(dl.pts, loA, hiA, q.x, q.y, q.z, best);
+            scan_d2x4<PERM>(dl.pts, loA, hiA, ux, uy, uz, best);
             cnt += (unsigned)(hiA - loA);
             const float rho = fast_sqrt_up(best) + 2.0f * dl.slack;
             if (best < INFINITY && rho <= kMaxRhoCells * dl.h) {
                 // (a row outside the grid / an empty clipped segment: nothing of the ball has been scanned yet)
                 const bool in = cy >= 0 && cy < dl.ny && cz >= 0 && cz < dl.nz && max(cx - 1, 0) <= min(cx + 1, dl.nx - 1);
-                cnt += scan_disc_lean(dl, q.x, q.y, q.z, rho, in ? cy : INT_MIN, in ? cz : INT_MIN, max(cx - 1, 0), min(cx + 1, dl.nx - 1),
+                cnt += scan_disc_lean<PERM>(dl, ux, uy, uz, rho, in ? cy : INT_MIN, in ? cz : INT_MIN, max(cx - 1, 0), min(cx + 1, dl.nx - 1),
                                  loA, hiA, best);
                 d2out[i] = best;
                 if (fs.scratch) atomicAdd(&s_hist[__float_as_uint(best) >> 21], 1u);
@@ -690,6 +696,7 @@ int build_level(pwicp_context* ctx, const float4* d_pts, int n, float h, const f
         h *= 1.26f;
     }
     d->n = n;
+    d->perm = 0;
     d->h = h;
     d->inv_h = 1.0f / h;
     d->ox = mn[0]; d->oy = mn[1]; d->oz = mn[2];
@@ -875,8 +882,19 @@ int pw_count_below_launch(pwicp_context* ctx, const float* d_d2, int n, float th
 }
 
 // third level of small cells over the same points, same layout (cells / columns) as g->d.fine
+namespace {
+// (x, y, z) -> the axis order of a permuted level; w (the original index) is kept
+__global__ void k_permute_axes(const float4* __restrict__ in, int n, int perm, float4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = in[i];
+    out[i] = perm == 1 ? make_float4(p.y, p.z, p.x, p.w) : make_float4(p.z, p.x, p.y, p.w);
+}
+}  // namespace
+
 int pw_grid_add_dense(pwicp_context* ctx, const float4* d_pts, int n, float cell_edge, Grid* g) {
     g->has_dense = g->has_dense_alt = false;
+    for (auto& x : g->extra) x.has = false;
     if (n <= 0 || !(cell_edge > 0.f)) return PWICP_OK;
     float mn[3], mx[3];
     PWCHK(pw_bbox(ctx, d_pts, n, mn, mx));
@@ -892,10 +910,69 @@ int pw_grid_add_dense(pwicp_context* ctx, const float4* d_pts, int n, float cell
         const int alt = (mx[1] - mn[1]) < (mx[2] - mn[2]) ? 1 : 2;
         PWCHK(build_level(ctx, d_pts, n, cell_edge, mn, mx, &g->dense_alt, &g->acell_start, &g->apts, alt));
         g->has_dense_alt = true;
+        // ... and levels with other axis roles: columns along x (no layout on (x, y, z) has them: a face in the y-z plane), cells
+        // with their rows along y / along z (a sheet tilted about that axis is contiguous along it).  Built on a copy of the
+        // points in the permuted order; which one a pair uses is decided by a cost probe on its queries (pw_dense_level_for).
+        static int want_perm = -1;         // PWICP_DENSE_PERM=0: none (A/B measurements)
+        if (want_perm < 0) { const char* e = getenv("PWICP_DENSE_PERM"); want_perm = e ? atoi(e) : 1; }
+        if (want_perm) {
+            DevBuf<float4> tmp;
+            HIPCHK(ctx, tmp.reserve((size_t)n));
+            const int perm_of[3] = {1, 1, 2}, flat_of[3] = {2, 0, 0};       // columns along x | cells, rows along y | cells, rows along z
+            for (int e = 0; e < 3; ++e) {
+                const int perm = perm_of[e];
+                hipLaunchKernelGGL(k_permute_axes, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_pts, n, perm, tmp.p);
+                const float pmn[3] = {perm == 1 ? mn[1] : mn[2], perm == 1 ? mn[2] : mn[0], perm == 1 ? mn[0] : mn[1]};
+                const float pmx[3] = {perm == 1 ? mx[1] : mx[2], perm == 1 ? mx[2] : mx[0], perm == 1 ? mx[0] : mx[1]};
+                PWCHK(build_level(ctx, tmp.p, n, cell_edge, pmn, pmx, &g->extra[e].lv, &g->extra[e].cell_start, &g->extra[e].pts, flat_of[e]));
+                g->extra[e].lv.perm = perm;
+                g->extra[e].has = true;
+            }
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // (tmp goes out of scope)
+        }
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return PWICP_OK;
 }
+
+namespace {
+// Cost of the disc search on a level for the queries of a pair, on every `stride`-th query: candidates examined and rows
+// whose begin / end words are read (the two things the search pays for), exactly as k_nn_dense_disc would do it.
+template <int PERM>
+__global__ void k_dense_probe(GridLevel dl, const float4* __restrict__ q4, int nq, int stride, unsigned long long* __restrict__ acc) {
+    unsigned long long cand = 0, rows = 0, far = 0;
+    for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * stride; i < nq; i += gridDim.x * blockDim.x * stride) {
+        const float4 q = q4[i];
+        const float ux = PERM == 0 ? q.x : (PERM == 1 ? q.y : q.z);
+        const float uy = PERM == 0 ? q.y : (PERM == 1 ? q.z : q.x);
+        const float uz = PERM == 0 ? q.z : (PERM == 1 ? q.x : q.y);
+        const int cx = cell_of(ux, dl.ox, dl.inv_h), cy = cell_of(uy, dl.oy, dl.inv_hy), cz = cell_of(uz, dl.oz, dl.inv_hz);
+        int loA, hiA;
+        row_range(dl, cy, cz, cx - 1, cx + 1, loA, hiA);
+        float best = INFINITY;
+        scan_d2x4<PERM>(dl.pts, loA, hiA, ux, uy, uz, best);
+        cand += (unsigned long long)(hiA - loA);
+        rows += 1;
+        const float rho = fast_sqrt_up(best) + 2.0f * dl.slack;
+        if (best < INFINITY && rho <= kMaxRhoCells * dl.h) {
+            const bool in = cy >= 0 && cy < dl.ny && cz >= 0 && cz < dl.nz && max(cx - 1, 0) <= min(cx + 1, dl.nx - 1);
+            const unsigned c = scan_disc_lean<PERM, true>(dl, ux, uy, uz, rho, in ? cy : INT_MIN, in ? cz : INT_MIN, max(cx - 1, 0),
+                                                          min(cx + 1, dl.nx - 1), loA, hiA, best);
+            cand += c & 0xfffffu;
+            rows += c >> 20;
+        } else {
+            far += 1;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cand += __shfl_xor(cand, o); rows += __shfl_xor(rows, o); far += __shfl_xor(far, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (cand) atomicAdd(acc, cand);
+        if (rows) atomicAdd(acc + 1, rows);
+        if (far) atomicAdd(acc + 2, far);
+    }
+}
+}  // namespace
 
 namespace {
 // points in the 3 x 3 (x 3) cells around every query, summed (the stencil occupancy the queries actually see)
@@ -924,17 +1001,36 @@ __global__ void k_query_occupancy(GridLevel g, const float4* __restrict__ q, int
 int pw_dense_level_for(pwicp_context* ctx, const Grid& g, const float4* d_q, int nq, const GridLevel** out) {
     *out = g.has_dense ? &g.dense : nullptr;
     if (!g.has_dense || !g.has_dense_alt || nq <= 0) return PWICP_OK;
-    constexpr double kColsTolerance = 3.0;
+    // candidates: the target's own layout (cells), the columns beside it, the levels with other axis roles.  Cost of a level =
+    // candidates + kRowCost * rows + kFarCost * queries that leave the disc search, probed on ~16 k of the pair's queries.
+    constexpr double kRowCost = 8.0, kFarCost = 40.0;   // (measured on the steep scene of tools/scene_shapes.py: a far query ~ 40-50 candidates)
+    const GridLevel* cand[5] = {&g.dense, &g.dense_alt, nullptr, nullptr, nullptr};
+    int nc = 2;
+    for (const auto& x : g.extra)
+        if (x.has) cand[nc++] = &x.lv;
     DevBuf<unsigned long long> acc;
-    HIPCHK(ctx, acc.reserve(2));
-    HIPCHK(ctx, hipMemsetAsync(acc.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
-    const int nb = std::min(div_up(nq, kBlock), ctx->n_cu * 8);
-    hipLaunchKernelGGL(k_query_occupancy, dim3(nb), dim3(kBlock), 0, ctx->stream, g.dense, d_q, nq, acc.p);
-    hipLaunchKernelGGL(k_query_occupancy, dim3(nb), dim3(kBlock), 0, ctx->stream, g.dense_alt, d_q, nq, acc.p + 1);
-    unsigned long long h[2] = {0, 0};
+    HIPCHK(ctx, acc.reserve(15));
+    HIPCHK(ctx, hipMemsetAsync(acc.p, 0, 15 * sizeof(unsigned long long), ctx->stream));
+    const int stride = std::max(1, nq / 16384);
+    const int nb = std::max(1, std::min(div_up(div_up(nq, stride), kBlock), ctx->n_cu * 4));
+    for (int c = 0; c < nc; ++c) {
+        const GridLevel& lv = *cand[c];
+        if (lv.perm == 0) hipLaunchKernelGGL(k_dense_probe<0>, dim3(nb), dim3(kBlock), 0, ctx->stream, lv, d_q, nq, stride, acc.p + 3 * c);
+        else if (lv.perm == 1) hipLaunchKernelGGL(k_dense_probe<1>, dim3(nb), dim3(kBlock), 0, ctx->stream, lv, d_q, nq, stride, acc.p + 3 * c);
+        else hipLaunchKernelGGL(k_dense_probe<2>, dim3(nb), dim3(kBlock), 0, ctx->stream, lv, d_q, nq, stride, acc.p + 3 * c);
+    }
+    unsigned long long h[15];
     HIPCHK(ctx, hipMemcpyAsync(h, acc.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if ((double)h[1] <= kColsTolerance * (double)std::max<unsigned long long>(h[0], 1ull)) *out = &g.dense_alt;
+    double best_cost = 0.0;
+    const bool trace = getenv("PWICP_TRACE") != nullptr;
+    for (int c = 0; c < nc; ++c) {
+        const double cost = (double)h[3 * c] + kRowCost * (double)h[3 * c + 1] + kFarCost * (double)h[3 * c + 2];
+        if (trace)
+            fprintf(stderr, "[pwicp dense level] candidate %d (perm %d, %s): %llu candidates, %llu rows, %llu far -> cost %.3g\n", c, cand[c]->perm,
+                    (cand[c]->inv_hy == 0.0f || cand[c]->inv_hz == 0.0f) ? "columns" : "cells", h[3 * c], h[3 * c + 1], h[3 * c + 2], cost);
+        if (c == 0 || cost < best_cost) { best_cost = cost; *out = cand[c]; }
+    }
     return PWICP_OK;
 }
 
@@ -959,8 +1055,15 @@ int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pa
         const int tiles = div_up(nq, kBlock);
         const int chunk = div_up(tiles, kXcds);
         FusedSelect none{};
-        hipLaunchKernelGGL(k_nn_dense_disc, dim3(chunk * kXcds), dim3(kBlock), 0, ctx->stream, *dense, g, d_pat, d_qorder, d_qpatch,
-                           d_stable, nq, d_d2, d_examined, chunk, fs ? *fs : none);
+        if (dense->perm == 0)
+            hipLaunchKernelGGL(k_nn_dense_disc<0>, dim3(chunk * kXcds), dim3(kBlock), 0, ctx->stream, *dense, g, d_pat, d_qorder, d_qpatch,
+                               d_stable, nq, d_d2, d_examined, chunk, fs ? *fs : none);
+        else if (dense->perm == 1)
+            hipLaunchKernelGGL(k_nn_dense_disc<1>, dim3(chunk * kXcds), dim3(kBlock), 0, ctx->stream, *dense, g, d_pat, d_qorder, d_qpatch,
+                               d_stable, nq, d_d2, d_examined, chunk, fs ? *fs : none);
+        else
+            hipLaunchKernelGGL(k_nn_dense_disc<2>, dim3(chunk * kXcds), dim3(kBlock), 0, ctx->stream, *dense, g, d_pat, d_qorder, d_qpatch,
+                               d_stable, nq, d_d2, d_examined, chunk, fs ? *fs : none);
         HIPCHK(ctx, hipGetLastError());
         return PWICP_OK;
     }

@@ -366,8 +366,15 @@ __device__ __forceinline__ NNBest nn_query_group(const GridDesc& gd, float qx, f
 // assignment is monotone in the coordinate, and `rho` carries the rounding slack of the cell boundaries (2 * slack, as
 // in nn_stage23), so every cell that can hold such a point is visited.  The result is the exact minimum of the float
 // expression ((dx*dx)+dy*dy)+dz*dz over ALL targets.
+// PERM: axis roles of the level (GridLevel::perm).  The point and the query come in the level's order; the squared
+// distance is ALWAYS ((dx*dx)+dy*dy)+dz*dz over the original axes: level order (y, z, x) -> original x is the third
+// component, level order (z, x, y) -> original x is the second.
+template <int PERM = 0>
 __device__ __forceinline__ void nn_consider_d2(const float4 p, float qx, float qy, float qz, float& best) {
-    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+    const float d0 = qx - p.x, d1 = qy - p.y, d2_ = qz - p.z;
+    const float dx = PERM == 0 ? d0 : (PERM == 1 ? d2_ : d1);
+    const float dy = PERM == 0 ? d1 : (PERM == 1 ? d0 : d2_);
+    const float dz = PERM == 0 ? d2_ : (PERM == 1 ? d1 : d0);
     float d2 = dx * dx;
     d2 = d2 + dy * dy;
     d2 = d2 + dz * dz;
@@ -382,26 +389,30 @@ __device__ __forceinline__ void nn_consider_d2(const float4 p, float qx, float q
 __device__ __forceinline__ int icell(float p, float o, float inv_h) { return (int)floorf((p - o) * inv_h); }
 __device__ __forceinline__ float fast_sqrt_up(float x) { return __builtin_amdgcn_sqrtf(x) * 1.0002f; }   // >= sqrt(x) for x >= 0
 
+template <int PERM = 0>
 __device__ __forceinline__ void scan_d2x4(const float4* __restrict__ pts, int lo, int hi, float qx, float qy, float qz, float& best) {
     int j = lo;
     for (; j + 4 <= hi; j += 4) {
         const float4 a = pts[j], b = pts[j + 1], c = pts[j + 2], d = pts[j + 3];
-        nn_consider_d2(a, qx, qy, qz, best);
-        nn_consider_d2(b, qx, qy, qz, best);
-        nn_consider_d2(c, qx, qy, qz, best);
-        nn_consider_d2(d, qx, qy, qz, best);
+        nn_consider_d2<PERM>(a, qx, qy, qz, best);
+        nn_consider_d2<PERM>(b, qx, qy, qz, best);
+        nn_consider_d2<PERM>(c, qx, qy, qz, best);
+        nn_consider_d2<PERM>(d, qx, qy, qz, best);
     }
     if (j + 2 <= hi) {
         const float4 a = pts[j], b = pts[j + 1];
-        nn_consider_d2(a, qx, qy, qz, best);
-        nn_consider_d2(b, qx, qy, qz, best);
+        nn_consider_d2<PERM>(a, qx, qy, qz, best);
+        nn_consider_d2<PERM>(b, qx, qy, qz, best);
         j += 2;
     }
-    if (j < hi) nn_consider_d2(pts[j], qx, qy, qz, best);
+    if (j < hi) nn_consider_d2<PERM>(pts[j], qx, qy, qz, best);
 }
 
 // scan_disc without divisions / exact square roots; rows of one z-slab are taken four at a time (all begin/end words of
 // the batch in flight before the first point load).  Same contract as scan_disc.
+// ROWS: also count the rows whose begin / end words are read, in bits 20.. of the result (the cost probe of
+// pw_dense_level_for; the search itself uses ROWS = false).
+template <int PERM = 0, bool ROWS = false>
 __device__ __forceinline__ unsigned scan_disc_lean(const GridLevel& g, float qx, float qy, float qz, float rho, int sy, int sz,
                                                    int sx0, int sx1, int slo, int shi, float& best) {
     unsigned cnt = 0;
@@ -435,6 +446,7 @@ __device__ __forceinline__ unsigned scan_disc_lean(const GridLevel& g, float qx,
                 const int x0 = max(icell(qx - rx, g.ox, g.inv_h), 0), x1 = min(icell(qx + rx, g.ox, g.inv_h), g.nx - 1);
                 if (x0 > x1) continue;
                 const int row = (z * g.ny + y) * g.nx;
+                if (ROWS) cnt += 1u << 20;
                 if (y == sy && z == sz) {
                     if (x0 < sx0) { lo[k] = g.cell_start[row + x0]; hi[k] = slo; }
                     if (x1 > sx1) { lo2[k] = shi; hi2[k] = g.cell_start[row + x1 + 1]; }
@@ -445,8 +457,8 @@ __device__ __forceinline__ unsigned scan_disc_lean(const GridLevel& g, float qx,
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                scan_d2x4(g.pts, lo[k], hi[k], qx, qy, qz, best);
-                scan_d2x4(g.pts, lo2[k], hi2[k], qx, qy, qz, best);
+                scan_d2x4<PERM>(g.pts, lo[k], hi[k], qx, qy, qz, best);
+                scan_d2x4<PERM>(g.pts, lo2[k], hi2[k], qx, qy, qz, best);
                 cnt += (unsigned)(hi[k] - lo[k]) + (unsigned)(hi2[k] - lo2[k]);
             }
         }

@@ -19,6 +19,14 @@ if os.environ.get("DV_SHAPE") == "cliff":
     # cliff-like scene: steep faces (slope up to ~9) so that a column of the grid holds a tall stack of points
     for a in (t, s):
         a[:, 2] += (1.5 * np.sin(6.0 * a[:, 0])).astype(np.float32)
+elif os.environ.get("DV_SHAPE") == "face_yz":
+    # the tile turned into the y-z plane: a cliff looked at along x (no column layout fits)
+    t = np.ascontiguousarray(t[:, [2, 0, 1]]); s = np.ascontiguousarray(s[:, [2, 0, 1]])
+elif os.environ.get("DV_SHAPE") == "diagonal":
+    c_, s_ = np.float32(np.cos(np.pi / 4)), np.float32(np.sin(np.pi / 4))
+    for a in (t, s):
+        x, z = a[:, 0].copy(), a[:, 2].copy()
+        a[:, 0] = c_ * x + s_ * z; a[:, 2] = -s_ * x + c_ * z
 l1, n1 = synth.grid_labels(t, 10 * r); l2, n2 = synth.grid_labels(s, 10 * r)
 prm = P.Params(r, r, 10 * r, 10 * r, 1, 10 * r, 0.8 * r)
 pair = P.Pair(ctx, t, l1, n1, s, l2, n2, prm); pair.set_profiling(1 | 4)
