@@ -247,6 +247,10 @@ struct FusState {
     int* status;               // [0] queue overflow, [1] arena overflow, [2] dirty closure deeper than the levels run,
                                // [3] too many changed nodes: everybody runs again
     int wake_all_above;
+    // short work lists: several sweeps are enqueued before the host reads anything back; the number of slots then lives on the
+    // device (nW_dev; nullptr: the launch argument counts) and `stop` != 0 makes the remaining launches of the batch return
+    const int* nW_dev;
+    int* stop;
     int queue_limit;           // <= kFusQueue ($PWICP_FUSION_QUEUE: smaller, to exercise the fallback)
 };
 
@@ -255,6 +259,15 @@ struct FusState {
 // the same sweep on a wavefront with the large configuration
 constexpr int kFusQueueS = 256, kFusHashS = 512, kFusQueue = 2048, kFusHash = 4096;
 constexpr int kFusArenas = 256;
+
+// batched sweeps (FusState::nW_dev): the number of slots lives on the device, a raised stop flag ends the batch
+#define FUS_BATCHED_NW(s, nW)            \
+    do {                                 \
+        if ((s).nW_dev) {                \
+            if (*(s).stop) return;       \
+            nW = *(s).nW_dev;            \
+        }                                \
+    } while (0)
 #define WSYNC()                                               \
     do {                                                      \
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
@@ -363,6 +376,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_fus_run(FusState s, int nW, int 
     w.cptr = s_cptr[wave];
     w.fkey = s_fresh[wave][0]; w.fval = s_fresh[wave][1];
     w.qcap = min(QCAP, s.queue_limit);
+    FUS_BATCHED_NW(s, nW);
     if (list) { nW = *n_list; chunk = 1; }
     const int n_chunks = (nW + chunk - 1) / chunk;
     for (int ci = blockIdx.x * WAVES + wave; ci < n_chunks; ci += gridDim.x * WAVES) {
@@ -535,6 +549,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_fus_run(FusState s, int nW, int 
 
 // the claims of the outcomes that changed: first all old ones are withdrawn, then the new ones are made (two launches)
 __global__ void k_fus_retract(FusState s, int nW) {
+    FUS_BATCHED_NW(s, nW);
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= nW || s.o_dirty[slot] != 1) return;
     const int c = s.W[slot];
@@ -545,6 +560,7 @@ __global__ void k_fus_retract(FusState s, int nW) {
     }
 }
 __global__ void k_fus_claim(FusState s, int nW) {
+    FUS_BATCHED_NW(s, nW);
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= nW || s.o_dirty[slot] == 2) return;
     const int c = s.W[slot];
@@ -596,6 +612,7 @@ __device__ __forceinline__ void fus_mark_dirty(const FusState& s, bool on, int x
 
 // level 0 of the dirty list: centres whose outcome changed, nodes whose absorber changed
 __global__ void k_fus_dirty0(FusState s, int nW, int* dq, int* ndq) {
+    FUS_BATCHED_NW(s, nW);
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = slot < nW && s.o_dirty[slot] != 2;
     const bool on = live && s.o_dirty[slot] == 1;
@@ -650,6 +667,7 @@ __global__ void __launch_bounds__(256) k_fus_wake(FusState s, const int* dq, con
     __shared__ int s_node[4][kWakeStack];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    if (s.nW_dev && *s.stop) return;
     const int n_dirty = *ndq;
     // Many changed nodes: finding who read them costs more than running every centre again (a run is ~2 ns of device
     // time, a changed node ~10 ns of walks) - the host puts all centres on the next work list (status[3]).
@@ -702,6 +720,7 @@ __global__ void __launch_bounds__(256) k_fus_wake(FusState s, const int* dq, con
 }
 
 __global__ void k_fus_sweep_end(FusState s, const int* dq, const int* ndq, const int* dq2, const int* ndq2) {
+    if (s.nW_dev && *s.stop) return;
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < *ndq; t += gridDim.x * blockDim.x) {
         const int x = dq[t];
         s.dflag[x] = 0;
@@ -709,6 +728,74 @@ __global__ void k_fus_sweep_end(FusState s, const int* dq, const int* ndq, const
         s.ab_prev[x] = s.ab[x];
     }
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < *ndq2; t += gridDim.x * blockDim.x) s.cflag[dq2[t]] = 0;
+}
+
+// Batched sweeps (<= 1024 slots): what k_fus_retract, k_fus_claim and k_fus_dirty0 do, as the phases of ONE block - between
+// dependent launches the device idles ~5 us, which is what a sweep over a few hundred centres is made of.
+__global__ void __launch_bounds__(1024) k_fus_post(FusState s, int* dq, int* ndq) {
+    if (*s.stop) return;
+    const int nW = *s.nW_dev;
+    const int slot = threadIdx.x;
+    const bool live = slot < nW && s.o_dirty[slot] != 2;
+    const bool on = live && s.o_dirty[slot] == 1;
+    const int c = live ? s.W[slot] : 0;
+    if (on) {                                          // withdraw
+        const long long p = s.o_oldptr[slot];
+        for (int e = 0, m = s.o_oldabsn[slot]; e < m; ++e) atomicCAS(&s.ab[s.sa[p + e]], c, kNone);
+    }
+    __syncthreads();
+    if (on) {
+        s.rec_sz[c] = s.o_sz[slot]; s.rec_ran[c] = s.o_ran[slot]; s.rec_absn[c] = s.o_absn[slot]; s.rec_adjn[c] = s.o_adjn[slot];
+        s.rec_ptr[c] = s.o_ptr[slot];
+    }
+    if (live) {                                        // claim (every centre that ran)
+        const long long p = s.o_ptr[slot];
+        for (int e = 0, m = s.o_absn[slot]; e < m; ++e) atomicMin(&s.ab[s.sa[p + e]], c);
+    }
+    __syncthreads();
+    fus_mark_dirty(s, on, c, c, dq, ndq);              // changed nodes
+    if (!live) return;
+    for (int pass = on ? 0 : 1; pass < 2; ++pass) {
+        const long long p = pass ? s.o_ptr[slot] : s.o_oldptr[slot];
+        const int m = pass ? s.o_absn[slot] : s.o_oldabsn[slot];
+        for (int e = 0; e < m; ++e) {
+            const int j = s.sa[p + e];
+            const int a0 = s.ab_prev[j], a1 = __hip_atomic_load(&s.ab[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fus_mark_dirty(s, a0 != a1, j, min(a0, a1), dq, ndq);
+        }
+    }
+}
+
+// Batched sweeps only: the hand-over to the next sweep that the host does otherwise.  ctr: [0] nWnext, [1] ndq, [2] ndq2,
+// [3] overflow slots, [4] nW, [5] stop, [6] sweeps executed, [7] runs; [8..11] status.
+__global__ void __launch_bounds__(1024) k_fus_advance(FusState s, int* __restrict__ W, const int* __restrict__ Wnext, int* __restrict__ ctr, int cap,
+                                                      const int* __restrict__ dq, const int* __restrict__ dq2) {
+    __shared__ int s_next;
+    if (ctr[5]) return;
+    // (k_fus_sweep_end: flags of the changed nodes, absorbers of this sweep become the previous ones)
+    for (int t = threadIdx.x, m = ctr[1]; t < m; t += blockDim.x) {
+        const int x = dq[t];
+        s.dflag[x] = 0;
+        s.dtmin[x] = kNone;
+        s.ab_prev[x] = __hip_atomic_load(&s.ab[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int t = threadIdx.x, m = ctr[2]; t < m; t += blockDim.x) s.cflag[dq2[t]] = 0;
+    if (threadIdx.x == 0) s_next = ctr[0];
+    __syncthreads();
+    const int next = s_next, now = ctr[4];
+    if (now == 0) return;                                                       // nothing was left: idle launch of the batch
+    const bool halt = ctr[3] || ctr[8] || ctr[9] || ctr[10] || ctr[11] || next > cap;      // the host decides how to go on
+                                                                                             // ([3]: a search outgrew the small queue)
+    if (!halt)
+        for (int t = threadIdx.x; t < next; t += blockDim.x) W[t] = Wnext[t];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ctr[6] += 1;
+        ctr[7] += now;
+        if (halt) { ctr[5] = 1; return; }
+        ctr[4] = next;
+        ctr[0] = 0; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0;
+    }
 }
 
 // ---- set-up and hand-over between rounds ----------------------------------------------------------------------------
@@ -1179,6 +1266,9 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     HIPCHK(ctx, ws.host_reserve(0));
     int* const h_ctr = ws.h_ctr;                    // pinned: read back after every sweep
     const int gs_chunk = getenv("PWICP_FUSION_CHUNK") ? std::max(atoi(getenv("PWICP_FUSION_CHUNK")), 1) : kFusChunk;
+    const int batch_sweeps = getenv("PWICP_FUSION_BATCH") ? std::max(atoi(getenv("PWICP_FUSION_BATCH")), 1) : 4;
+    const int batch_cap = 1024;
+    s.nW_dev = nullptr; s.stop = nullptr;
     const int wake_all_div = getenv("PWICP_FUSION_WAKE_DIV") ? std::max(atoi(getenv("PWICP_FUSION_WAKE_DIV")), 1) : 32;
     for (;; lambda *= 2.0, ++round) {
         if (nc <= 1) {                                  // (:106) nothing left to fuse
@@ -1232,9 +1322,43 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
                 *gave_up = true;
                 return PWICP_OK;
             }
+            s.W = W; s.Wnext = Wn;
+            if (!certify && nW <= batch_cap && batch_sweeps > 1) {
+                // short work list: batch_sweeps sweeps per read-back (a sweep of a few hundred centres is ~50 us of kernels; the
+                // read-back, the wake-up of the host thread and the next enqueue cost as much again)
+                const int init[16] = {0, 0, 0, 0, nW, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                HIPCHK(ctx, hipMemcpyAsync(ws.ctr.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+                s.nW_dev = ws.ctr.p + 4; s.stop = ws.ctr.p + 5;
+                for (int b = 0; b < batch_sweeps; ++b) {
+                    hipLaunchKernelGGL((k_fus_run<kFusQueueS, kFusHashS, 4>), dim3((unsigned)div_up(batch_cap, 4)), dim3(256), 0, st, s, 0, 1,
+                                       (const int*)nullptr, (const int*)nullptr, ws.ovf.p, ws.ctr.p + 3);
+                    hipLaunchKernelGGL(k_fus_post, dim3(1), dim3(1024), 0, st, s, ws.dq.p, ndq);
+                    hipLaunchKernelGGL(k_fus_wake, dim3(64), dim3(256), 0, st, s, ws.dq.p, ndq, ws.dq2.p, ndq + 1);
+                    hipLaunchKernelGGL(k_fus_advance, dim3(1), dim3(1024), 0, st, s, W, Wn, ws.ctr.p, batch_cap, (const int*)ws.dq.p,
+                                       (const int*)ws.dq2.p);
+                }
+                s.nW_dev = nullptr; s.stop = nullptr;
+                HIPCHK(ctx, hipMemcpyAsync(h_ctr, ws.ctr.p, sizeof(int) * 16, hipMemcpyDeviceToHost, st));
+                HIPCHK(ctx, hipStreamSynchronize(st));
+                sweeps += h_ctr[6] - 1;
+                runs += h_ctr[7];
+                if (h_ctr[8] || h_ctr[9]) {
+                    if (trace) fprintf(stderr, "[pwicp front end/dev]   fusion gives up in round %d (%s overflow)\n", round, h_ctr[8] ? "queue" : "arena");
+                    *gave_up = true;
+                    return PWICP_OK;
+                }
+                if (!h_ctr[5]) { nW = h_ctr[4]; continue; }              // the batch ran through (W holds the next list, possibly empty)
+                if (h_ctr[3] || h_ctr[10] || h_ctr[11]) {                // everybody runs again ([3]: a search outgrew the small queue)
+                    HIPCHK(ctx, hipMemcpyAsync(W, cen, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
+                    nW = nc;
+                } else {                                                 // the next list outgrew the batch: back to single sweeps
+                    std::swap(W, Wn);
+                    nW = h_ctr[0];
+                }
+                continue;
+            }
             runs += nW;
             if (trace && getenv("PWICP_TRACE_SWEEPS")) fprintf(stderr, "      sweep %d: %d\n", sweeps, nW);
-            s.W = W; s.Wnext = Wn;
             HIPCHK(ctx, hipMemsetAsync(ws.ctr.p, 0, sizeof(int) * 16, st));
             const int chunk = certify ? 1 : std::max(1, std::min(std::min(nW / 8192, kFusChunk), gs_chunk));
             hipLaunchKernelGGL((k_fus_run<kFusQueueS, kFusHashS, 4>), dim3((unsigned)std::min(div_up(div_up(nW, chunk), 4), 8192)), dim3(256), 0, st,
@@ -1244,8 +1368,10 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
             hipLaunchKernelGGL(k_fus_retract, grid1(nW), dim3(256), 0, st, s, nW);
             hipLaunchKernelGGL(k_fus_claim, grid1(nW), dim3(256), 0, st, s, nW);
             hipLaunchKernelGGL(k_fus_dirty0, grid1(nW), dim3(256), 0, st, s, nW, ws.dq.p, ndq);
-            hipLaunchKernelGGL(k_fus_wake, dim3(1024), dim3(256), 0, st, s, ws.dq.p, ndq, ws.dq2.p, ndq + 1);
-            hipLaunchKernelGGL(k_fus_sweep_end, dim3(256), dim3(256), 0, st, s, ws.dq.p, ndq, ws.dq2.p, ndq + 1);
+            // (grids for the changed nodes: at most a few per slot)
+            hipLaunchKernelGGL(k_fus_wake, dim3((unsigned)std::min(1024, std::max(32, nW / 64))), dim3(256), 0, st, s, ws.dq.p, ndq, ws.dq2.p, ndq + 1);
+            hipLaunchKernelGGL(k_fus_sweep_end, dim3((unsigned)std::min(256, std::max(8, nW / 256))), dim3(256), 0, st, s, ws.dq.p, ndq, ws.dq2.p,
+                               ndq + 1);
             HIPCHK(ctx, hipMemcpyAsync(h_ctr, ws.ctr.p, sizeof(int) * 16, hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));
             if (h_ctr[8] || h_ctr[9]) {

@@ -33,6 +33,8 @@ for c in range(cases):
         knobs["PWICP_FUSION_WAKE_DIV"] = str(int(rng.choice([1, 4, 1000])))
     if rng.random() < 0.2:
         knobs["PWICP_FUSION_QUEUE"] = str(int(rng.choice([40, 100, 300])))
+    if rng.random() < 0.4:
+        knobs["PWICP_FUSION_BATCH"] = str(int(rng.choice([1, 2, 16])))
     out = {}
     for mode in ("host", "device"):
         os.environ["PWICP_FRONTEND"] = mode
