@@ -1125,41 +1125,53 @@ __global__ void __launch_bounds__(64) k_knn_lds(GridLevel g, int k, int* __restr
     const Real qx = (Real)q.x, qy = (Real)q.y, qz = (Real)q.z;
     const int cx = cell_of(q.x, g.ox, g.inv_h), cy = cell_of(q.y, g.oy, g.inv_hy), cz = cell_of(q.z, g.oz, g.inv_hz);
     const int rcover = max(max(max(cx, g.nx - 1 - cx), max(cy, g.ny - 1 - cy)), max(cz, g.nz - 1 - cz));
+    const int ry_max = g.inv_hy != 0.0f ? INT_MAX : 0, rz_max = g.inv_hz != 0.0f ? INT_MAX : 0;     // collapsed axes have one row
     int cnt = 0;
-    for (int r = 2;; ++r) {
-        cnt = 0;
-        Real worst = (Real)0;
-        int worst_i = 0;
-        for (int dz = -r; dz <= r; ++dz)
-            for (int dy = -r; dy <= r; ++dy) {
+    Real worst = (Real)0;
+    int worst_i = 0;
+    // one candidate into the sorted list (by (d2, id); the current k-th entry is kept in registers)
+    auto consider = [&](int j) {
+        const float4 p = g.pts[j];
+        const Real dx = qx - (Real)p.x, dy2 = qy - (Real)p.y, dz2 = qz - (Real)p.z;
+        Real d2 = dx * dx;
+        d2 = d2 + dy2 * dy2;
+        d2 = d2 + dz2 * dz2;
+        const int id = __float_as_int(p.w);
+        if (cnt == k && !(d2 < worst || (d2 == worst && id < worst_i))) return;
+        int pos = cnt < k ? cnt : k - 1;
+        while (pos > 0) {
+            const Real pd = nd[(pos - 1) * 64];
+            const int pi = ni[(pos - 1) * 64];
+            if (!(d2 < pd || (d2 == pd && id < pi))) break;
+            nd[pos * 64] = pd;
+            ni[pos * 64] = pi;
+            --pos;
+        }
+        nd[pos * 64] = d2;
+        ni[pos * 64] = id;
+        if (cnt < k) ++cnt;
+        if (cnt == k) { worst = nd[(k - 1) * 64]; worst_i = ni[(k - 1) * 64]; }
+    };
+    // The block of cells grows shell by shell and the list is kept: every cell is scanned once (the search with its list in
+    // global memory restarts at every radius: the slowest lane of a wavefront - a corner of the cloud, a hole: radius 6 to 12
+    // cells - made its whole wavefront rescan (2r+1)^2 or ^3 cells for every r on the way, a floor of ~4 ms per launch).
+    for (int r = 0;; ++r) {
+        const int rz = min(r, rz_max), ry = min(r, ry_max);
+        for (int dz = -rz; dz <= rz; ++dz)
+            for (int dy = -ry; dy <= ry; ++dy) {
                 int lo, hi;
-                row_range(g, cy + dy, cz + dz, cx - r, cx + r, lo, hi);
-                for (int j = lo; j < hi; ++j) {
-                    const float4 p = g.pts[j];
-                    const Real dx = qx - (Real)p.x, dy2 = qy - (Real)p.y, dz2 = qz - (Real)p.z;
-                    Real d2 = dx * dx;
-                    d2 = d2 + dy2 * dy2;
-                    d2 = d2 + dz2 * dz2;
-                    const int id = __float_as_int(p.w);
-                    // sorted insertion by (d2, id); the current k-th entry is kept in registers
-                    if (cnt == k && !(d2 < worst || (d2 == worst && id < worst_i))) continue;
-                    int pos = cnt < k ? cnt : k - 1;
-                    while (pos > 0) {
-                        const Real pd = nd[(pos - 1) * 64];
-                        const int pi = ni[(pos - 1) * 64];
-                        if (!(d2 < pd || (d2 == pd && id < pi))) break;
-                        nd[pos * 64] = pd;
-                        ni[pos * 64] = pi;
-                        --pos;
-                    }
-                    nd[pos * 64] = d2;
-                    ni[pos * 64] = id;
-                    if (cnt < k) ++cnt;
-                    if (cnt == k) { worst = nd[(k - 1) * 64]; worst_i = ni[(k - 1) * 64]; }
+                if (max(abs(dy), abs(dz)) == r) {             // a row that no smaller block had: its whole x-range
+                    row_range(g, cy + dy, cz + dz, cx - r, cx + r, lo, hi);
+                    for (int j = lo; j < hi; ++j) consider(j);
+                } else {                                        // a row of the previous block: its two new end cells
+                    row_range(g, cy + dy, cz + dz, cx - r, cx - r, lo, hi);
+                    for (int j = lo; j < hi; ++j) consider(j);
+                    row_range(g, cy + dy, cz + dz, cx + r, cx + r, lo, hi);
+                    for (int j = lo; j < hi; ++j) consider(j);
                 }
             }
         if (r >= rcover) break;
-        if (cnt == k) {
+        if (cnt == k && r >= 1) {
             const double bound = (double)r * (double)g.h - 2.0 * (double)g.slack;
             if (bound > 0.0 && (double)worst < bound * bound * 0.99999) break;
         }
