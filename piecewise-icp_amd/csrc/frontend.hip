@@ -12,7 +12,15 @@
 //     unit is read from the previous sweep's outcome of that unit, everything else from the state at the start);
 //   * sweeps repeat until no outcome changes.  The outcome of the first unit never depends on a guess, so by induction over
 //     the serial order the fixed point IS the serial result; order-dependent side products (which point enters the next
-//     queue generation first) are rebuilt afterwards from (position, neighbour) keys with an atomic min.
+//     queue generation first) are rebuilt afterwards from (position, neighbour) keys with an atomic min;
+//   * which units a sweep re-runs, and whether a unit may already see what its neighbours in the order decided in the SAME
+//     sweep (chunks of consecutive fusion centres inside a wavefront), only changes the number of sweeps: any mixture of
+//     guesses is admissible because a fusion round is only closed by a sweep over all units, from the standing state alone,
+//     that changes nothing (the certificate in fusion_device).
+//
+// File map: boundary refinement (k_ref_*, refine_device) | fusion (FusState, k_fus_run and the bookkeeping kernels of a
+// sweep, hand-over between rounds) | normals scatter, occupied cells, lambda0 select | FeWorkspace | fusion_device |
+// pw_frontend_segment_device.
 //
 // All decisions use the reference's double arithmetic (no contraction: the library is built with -ffp-contract=off;
 // sqrt and the division are IEEE on gfx950), so labels are identical to the host pipeline's, which the tests assert.
