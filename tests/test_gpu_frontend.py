@@ -148,3 +148,18 @@ def test_randomised_clouds_and_schedules():
     out = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "tools", "fe_fuzz.py"), "24", "2026"], capture_output=True,
                          text=True, timeout=600)
     assert "different: 0 of 24" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("k", [10, 48, 49, 64])
+def test_other_neighbourhood_sizes(ctx, k):
+    """k = 45 in the reference (CommonFunc.h:41); the device pipeline takes any k <= 64 (k > 48: the k-NN kernel with its lists
+    in global memory)."""
+    _, src, _ = _data.pair(40000)
+    out = {}
+    for mode in ("host", "device"):
+        os.environ["PWICP_FRONTEND"] = mode
+        try:
+            out[mode] = ctx.frontend_segment(src, 10 * _data.R, k, _data.R)
+        finally:
+            os.environ.pop("PWICP_FRONTEND", None)
+    assert out["host"][1] == out["device"][1] and np.array_equal(out["host"][0], out["device"][0])
