@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stddef.h>
 #include <time.h>
 
 static double now_s(void)
@@ -26,6 +27,81 @@ static double now_s(void)
 }
 
 void orc_free(void* p) { free(p); }
+
+/* =====================================================================================
+ * diagnosis hooks (tools/rootcause_golden.py only; off by default, results unchanged):
+ * record the classification decisions of R.cpp:828-853 that sit within a relative margin
+ * of their threshold, force single decisions the other way, and switch arithmetic variants
+ * that a different compiler / libm could plausibly have used.
+ * ===================================================================================== */
+static double g_dbg_rel = -1.0;                  /* < 0: recording off */
+static int g_dbg_nflip = 0, g_dbg_flip[64][2];   /* (outer iteration, source patch) */
+static orc_dbg_rec* g_dbg_rec = NULL;
+static int g_dbg_nrec = 0, g_dbg_cap = 0;
+static unsigned g_dbg_variant = 0;
+static int g_dbg_inner_outer = -1, g_dbg_inner_count = 0, g_dbg_cur_outer = -2;   /* force the inner iteration count of one outer iteration */
+
+void orc_debug_config(double rel_margin, const int* flips, int nflip, unsigned variant)
+{
+    g_dbg_rel = rel_margin;
+    g_dbg_nflip = nflip > 64 ? 64 : (nflip < 0 ? 0 : nflip);
+    for (int i = 0; i < g_dbg_nflip; ++i) { g_dbg_flip[i][0] = flips[2 * i]; g_dbg_flip[i][1] = flips[2 * i + 1]; }
+    g_dbg_variant = variant;
+    g_dbg_nrec = 0;
+}
+void orc_debug_force_inner(int outer, int count) { g_dbg_inner_outer = outer; g_dbg_inner_count = count; }
+int orc_debug_records(orc_dbg_rec* out, int cap)
+{
+    int n = g_dbg_nrec < cap ? g_dbg_nrec : cap;
+    if (n > 0) memcpy(out, g_dbg_rec, sizeof(orc_dbg_rec) * (size_t)n);
+    return g_dbg_nrec;
+}
+/* patch-selection side (S.cpp:109-127, 220-225): kind 0 = refinement of point k of supervoxel s (|d| < 2 sigma), 1 = variation
+ * gate, 2 = planarity gate, 3 = whole supervoxel s excluded; recorded through the same record type (outer = kind, patch = s,
+ * which = k) */
+static double g_sel_rel = -1.0;
+static int g_sel_nflip = 0, g_sel_flip[64][3];
+static int g_sel_cur_sv = -1;
+void orc_debug_select_config(double rel_margin, const int* flips, int nflip)
+{
+    g_sel_rel = rel_margin;
+    g_sel_nflip = nflip > 64 ? 64 : (nflip < 0 ? 0 : nflip);
+    for (int i = 0; i < g_sel_nflip; ++i) for (int d = 0; d < 3; ++d) g_sel_flip[i][d] = flips[3 * i + d];
+    g_dbg_nrec = 0;
+}
+static int sel_flipped(int kind, int sv, int k)
+{
+    for (int i = 0; i < g_sel_nflip; ++i)
+        if (g_sel_flip[i][0] == kind && g_sel_flip[i][1] == sv && (kind != 0 || g_sel_flip[i][2] == k)) return 1;
+    return 0;
+}
+static void sel_record(int kind, int sv, int k, double val, double thr, int decision)
+{
+    double rel = fabs(val - thr) / fabs(thr);
+    if (rel > g_sel_rel) return;
+    if (g_dbg_nrec == g_dbg_cap) {
+        g_dbg_cap = g_dbg_cap ? 2 * g_dbg_cap : 1024;
+        g_dbg_rec = (orc_dbg_rec*)realloc(g_dbg_rec, sizeof(orc_dbg_rec) * (size_t)g_dbg_cap);
+    }
+    orc_dbg_rec r; r.outer = kind; r.patch = sv; r.which = k; r.dist = (float)val; r.thr = (float)thr; r.rel = (float)rel; r.stable = decision;
+    g_dbg_rec[g_dbg_nrec++] = r;
+}
+static void dbg_record(int outer, int patch, int which, float dist, float thr, int stable)
+{
+    double rel = fabs((double)dist - (double)thr) / (double)thr;
+    if (rel > g_dbg_rel) return;
+    if (g_dbg_nrec == g_dbg_cap) {
+        g_dbg_cap = g_dbg_cap ? 2 * g_dbg_cap : 1024;
+        g_dbg_rec = (orc_dbg_rec*)realloc(g_dbg_rec, sizeof(orc_dbg_rec) * (size_t)g_dbg_cap);
+    }
+    orc_dbg_rec r; r.outer = outer; r.patch = patch; r.which = which; r.dist = dist; r.thr = thr; r.rel = (float)rel; r.stable = stable;
+    g_dbg_rec[g_dbg_nrec++] = r;
+}
+static int dbg_flipped(int outer, int patch)
+{
+    for (int i = 0; i < g_dbg_nflip; ++i) if (g_dbg_flip[i][0] == outer && g_dbg_flip[i][1] == patch) return 1;
+    return 0;
+}
 
 /* =====================================================================================
  * KD-tree — FLANN KDTreeSingleIndex semantics (PCL: kdtree/impl/kdtree_flann.hpp builds
@@ -155,6 +231,7 @@ typedef struct { int k, cnt; int* idx; float* d2; } kd_result;
 
 static inline int kd_better(float d2, int idx, float bd2, int bidx)
 {
+    if (g_dbg_variant & 2u) return d2 < bd2 || (d2 == bd2 && idx > bidx);
     return d2 < bd2 || (d2 == bd2 && idx < bidx);
 }
 
@@ -376,9 +453,9 @@ static void pcl_compute_roots2(float b, float c, float* roots)
 
 /* float trig: evaluated in double and rounded once (== correctly rounded float result
  * except for ~2^-29 double-rounding cases); keeps CPU oracle and GPU bit-compatible */
-static inline float f_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
-static inline float f_cos(float x) { return (float)cos((double)x); }
-static inline float f_sin(float x) { return (float)sin((double)x); }
+static inline float f_atan2(float y, float x) { return (g_dbg_variant & 1u) ? atan2f(y, x) : (float)atan2((double)y, (double)x); }
+static inline float f_cos(float x) { return (g_dbg_variant & 1u) ? cosf(x) : (float)cos((double)x); }
+static inline float f_sin(float x) { return (g_dbg_variant & 1u) ? sinf(x) : (float)sin((double)x); }
 
 static void pcl_compute_roots(const float m[9], float* roots)
 {
@@ -485,15 +562,15 @@ int orc_cal_patch_normal(const float* p4, int n, float* nx, float* ny, float* nz
         float mean[3] = {0, 0, 0};
         for (int i = 0; i < n; ++i) for (int d = 0; d < 3; ++d) mean[d] += p4[4 * (size_t)i + d];
         for (int d = 0; d < 3; ++d) mean[d] /= (float)n;
-        double S[9] = {0};
+        float S[9] = {0};                       /* float GEMM, as above */
         for (int i = 0; i < n; ++i) {
             float dx = p4[4 * (size_t)i] - mean[0], dy = p4[4 * (size_t)i + 1] - mean[1],
                   dz = p4[4 * (size_t)i + 2] - mean[2];
-            S[0] += (double)dx * dx; S[1] += (double)dx * dy; S[2] += (double)dx * dz;
-            S[4] += (double)dy * dy; S[5] += (double)dy * dz; S[8] += (double)dz * dz;
+            S[0] += dx * dx; S[1] += dx * dy; S[2] += dx * dz;
+            S[4] += dy * dy; S[5] += dy * dz; S[8] += dz * dz;
         }
         double C[9];
-        for (int i = 0; i < 9; ++i) C[i] = (double)((float)S[i] / (float)n);
+        for (int i = 0; i < 9; ++i) C[i] = (double)(S[i] / (float)n);
         C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
         double w[3], V[9];
         jacobi3(C, w, V);
@@ -505,28 +582,124 @@ int orc_cal_patch_normal(const float* p4, int n, float* nx, float* ny, float* nz
     return 0;
 }
 
+/* Eigen 3.3 SelfAdjointEigenSolver<Matrix3f>::compute() (the iterative one PCL's pca.hpp calls), restated in float:
+ * scale by the largest |coefficient| of the lower triangle, closed-form 3x3 tridiagonalisation, implicit symmetric QR steps
+ * with Wilkinson shift (deflation test |e_i| <= 2 eps (|d_i| + |d_i+1|)), eigenvalues sorted ascending.  Returns the
+ * eigenvector of the SMALLEST eigenvalue in v[3]. */
+static inline float eig_hypotf(float x, float y)
+{
+    float ax = fabsf(x), ay = fabsf(y);
+    float p = ax > ay ? ax : ay;
+    if (p == 0.0f) return 0.0f;
+    float qp = (ax > ay ? ay : ax) / p;
+    return p * sqrtf(1.0f + qp * qp);
+}
+static void eigen_saes3f_smallest(const float Ain[9], float* v)
+{
+    float m10 = Ain[3], m20 = Ain[6], m21 = Ain[7], m00 = Ain[0], m11 = Ain[4], m22 = Ain[8];
+    float scale = 0.0f;
+    { float t[6] = {m00, m10, m20, m11, m21, m22}; for (int i = 0; i < 6; ++i) if (fabsf(t[i]) > scale) scale = fabsf(t[i]); }
+    if (scale == 0.0f) scale = 1.0f;
+    m00 /= scale; m10 /= scale; m20 /= scale; m11 /= scale; m21 /= scale; m22 /= scale;
+    float diag[3], sub[2], Q[3][3];
+    diag[0] = m00;
+    float v1norm2 = m20 * m20;
+    if (v1norm2 <= FLT_MIN) {
+        diag[1] = m11; diag[2] = m22; sub[0] = m10; sub[1] = m21;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Q[i][j] = (i == j) ? 1.0f : 0.0f;
+    } else {
+        float beta = sqrtf(m10 * m10 + v1norm2);
+        float invBeta = 1.0f / beta;
+        float m01 = m10 * invBeta, m02 = m20 * invBeta;
+        float q = 2.0f * m01 * m21 + m02 * (m22 - m11);
+        diag[1] = m11 + m02 * q;
+        diag[2] = m22 - m02 * q;
+        sub[0] = beta;
+        sub[1] = m21 - m01 * q;
+        Q[0][0] = 1; Q[0][1] = 0; Q[0][2] = 0;
+        Q[1][0] = 0; Q[1][1] = m01; Q[1][2] = m02;
+        Q[2][0] = 0; Q[2][1] = m02; Q[2][2] = -m01;
+    }
+    const float precision = (g_dbg_variant & 128u) ? 1e-5f : 2.0f * FLT_EPSILON;    /* 128: Eigen 3.2's dummy_precision test */
+    int end = 2, start = 0, iter = 0;
+    while (end > 0) {
+        for (int i = start; i < end; ++i)
+            if (fabsf(sub[i]) <= (fabsf(diag[i]) + fabsf(diag[i + 1])) * precision || fabsf(sub[i]) <= FLT_MIN) sub[i] = 0.0f;
+        while (end > 0 && sub[end - 1] == 0.0f) end--;
+        if (end <= 0) break;
+        if (++iter > 30 * 3) break;
+        start = end - 1;
+        while (start > 0 && sub[start - 1] != 0.0f) start--;
+        /* tridiagonal_qr_step */
+        float td = (diag[end - 1] - diag[end]) * 0.5f;
+        float e = sub[end - 1];
+        float mu = diag[end];
+        if (td == 0.0f) mu -= fabsf(e);
+        else {
+            float e2 = e * e;
+            float h = eig_hypotf(td, e);
+            if (e2 == 0.0f) mu -= (e / (td + (td > 0.0f ? 1.0f : -1.0f))) * (e / h);
+            else mu -= e2 / (td + (td > 0.0f ? h : -h));
+        }
+        float x = diag[start] - mu, z = sub[start];
+        for (int k = start; k < end; ++k) {
+            float c, sn;                      /* JacobiRotation::makeGivens(x, z) */
+            if (z == 0.0f) { c = x < 0.0f ? -1.0f : 1.0f; sn = 0.0f; }
+            else if (x == 0.0f) { c = 0.0f; sn = z < 0.0f ? 1.0f : -1.0f; }
+            else if (fabsf(x) > fabsf(z)) { float t = z / x; float u = sqrtf(1.0f + t * t); if (x < 0.0f) u = -u; c = 1.0f / u; sn = -t * c; }
+            else { float t = x / z; float u = sqrtf(1.0f + t * t); if (z < 0.0f) u = -u; sn = -1.0f / u; c = -t * sn; }
+            float sdk = sn * diag[k] + c * sub[k];
+            float dkp1 = sn * sub[k] + c * diag[k + 1];
+            diag[k] = c * (c * diag[k] - sn * sub[k]) - sn * (c * sub[k] - sn * diag[k + 1]);
+            diag[k + 1] = sn * sdk + c * dkp1;
+            sub[k] = c * sdk - sn * dkp1;
+            if (k > start) sub[k - 1] = c * sub[k - 1] - sn * z;
+            x = sub[k];
+            if (k < end - 1) { z = -sn * sub[k + 1]; sub[k + 1] = c * sub[k + 1]; }
+            for (int i = 0; i < 3; ++i) {     /* Q = Q * G */
+                float xi = Q[i][k], yi = Q[i][k + 1];
+                Q[i][k] = c * xi - sn * yi;
+                Q[i][k + 1] = sn * xi + c * yi;
+            }
+        }
+    }
+    int best = 0;
+    if (diag[1] < diag[best]) best = 1;
+    if (diag[2] < diag[best]) best = 2;
+    v[0] = Q[0][best]; v[1] = Q[1][best]; v[2] = Q[2][best];
+}
+
 /* PCL: common/impl/pca.hpp initCompute(): float centroid (compute3DCentroid), demean,
  * alpha = D D^T (Matrix3f), SelfAdjointEigenSolver, eigenvectors descending -> col(2) is
- * the plane normal.  The 3x3 product order inside Eigen's GEMM is not observable; the
- * scatter is accumulated in double from the float demeaned coordinates and rounded to
- * float once.  Returns plane (a,b,c,d) as used by C.cpp:341-346 / S.cpp:204-209. */
+ * the plane normal.  Returns plane (a,b,c,d) as used by C.cpp:341-346 / S.cpp:204-209. */
 static void pca_plane(const float* p4, int n, float* abcd)
 {
     float c[3] = {0, 0, 0};
     for (int i = 0; i < n; ++i) { c[0] += p4[4 * (size_t)i]; c[1] += p4[4 * (size_t)i + 1]; c[2] += p4[4 * (size_t)i + 2]; }
     c[0] /= (float)n; c[1] /= (float)n; c[2] /= (float)n;
+    /* alpha = D D^T is a float GEMM in the reference (Eigen, inner dimension = the points): every element is a float sum over
+     * the points in order.  (Accumulating in double and rounding once - diagnosis variant 16 - moves 3 of the reference's 57
+     * result files from <= 2e-8 rad to 3e-7 .. 9e-7 rad: refinement decisions |d| < 2 sigma at 1e-6 relative margins flip.) */
+    float F[9] = {0};
     double S[9] = {0};
     for (int i = 0; i < n; ++i) {
         float dx = p4[4 * (size_t)i] - c[0], dy = p4[4 * (size_t)i + 1] - c[1], dz = p4[4 * (size_t)i + 2] - c[2];
+        F[0] += dx * dx; F[1] += dx * dy; F[2] += dx * dz; F[4] += dy * dy; F[5] += dy * dz; F[8] += dz * dz;
         S[0] += (double)dx * dx; S[1] += (double)dx * dy; S[2] += (double)dx * dz;
         S[4] += (double)dy * dy; S[5] += (double)dy * dz; S[8] += (double)dz * dz;
     }
     double A[9];
-    for (int i = 0; i < 9; ++i) A[i] = (double)(float)S[i];
+    for (int i = 0; i < 9; ++i) A[i] = (g_dbg_variant & 16u) ? (double)(float)S[i] : (double)F[i];
     A[3] = A[1]; A[6] = A[2]; A[7] = A[5];
     double w[3], V[9];
     jacobi3(A, w, V);
     float a = (float)V[0], b = (float)V[3], cc = (float)V[6];
+    if (g_dbg_variant & 32u) {          /* diagnosis: Eigen's float solver on the float product */
+        float Af[9], ev[3];
+        for (int i = 0; i < 9; ++i) Af[i] = (float)A[i];
+        eigen_saes3f_smallest(Af, ev);
+        a = ev[0]; b = ev[1]; cc = ev[2];
+    }
     abcd[0] = a; abcd[1] = b; abcd[2] = cc;
     abcd[3] = -((a * c[0] + b * c[1]) + cc * c[2]);
 }
@@ -559,7 +732,12 @@ int orc_patch_refinement(const float* p4, int n, double sigma_mul, unsigned char
     for (int i = 0; i < n; ++i) { dist[i] = pt2plane(p4 + 4 * (size_t)i, abcd); s += dist[i] * dist[i]; }
     s = sqrt(s / (double)n);
     int cnt = 0;
-    for (int i = 0; i < n; ++i) { keep[i] = fabs(dist[i]) < fabs(sigma_mul * s); cnt += keep[i]; }
+    for (int i = 0; i < n; ++i) {
+        keep[i] = fabs(dist[i]) < fabs(sigma_mul * s);
+        if (g_sel_rel >= 0.0) sel_record(0, g_sel_cur_sv, i, fabs(dist[i]), fabs(sigma_mul * s), keep[i]);
+        if (g_sel_nflip && sel_flipped(0, g_sel_cur_sv, i)) keep[i] = !keep[i];
+        cnt += keep[i];
+    }
     free(dist);
     return cnt;
 }
@@ -570,14 +748,17 @@ void orc_cal_patch_feature(const float* p4, int n, float* variation, float* plan
     float m[3] = {0, 0, 0};
     for (int i = 0; i < n; ++i) { m[0] += p4[4 * (size_t)i]; m[1] += p4[4 * (size_t)i + 1]; m[2] += p4[4 * (size_t)i + 2]; }
     m[0] /= (float)n; m[1] /= (float)n; m[2] /= (float)n;
+    /* covMat = (cloud_mat^T cloud_mat) / pointNum: a float GEMM, every element a float sum over the points in order */
+    float F[9] = {0};
     double S[9] = {0};
     for (int i = 0; i < n; ++i) {
         float dx = p4[4 * (size_t)i] - m[0], dy = p4[4 * (size_t)i + 1] - m[1], dz = p4[4 * (size_t)i + 2] - m[2];
+        F[0] += dx * dx; F[1] += dx * dy; F[2] += dx * dz; F[4] += dy * dy; F[5] += dy * dz; F[8] += dz * dz;
         S[0] += (double)dx * dx; S[1] += (double)dx * dy; S[2] += (double)dx * dz;
         S[4] += (double)dy * dy; S[5] += (double)dy * dz; S[8] += (double)dz * dz;
     }
     double C[9];
-    for (int i = 0; i < 9; ++i) C[i] = (double)((float)S[i] / (float)n);
+    for (int i = 0; i < 9; ++i) C[i] = (double)(((g_dbg_variant & 64u) ? (float)S[i] : F[i]) / (float)n);
     C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
     double w[3], V[9];
     jacobi3(C, w, V);
@@ -645,7 +826,10 @@ int orc_select_patches(const float* cloud4, int n, const int* labels, int nsv,
         int sz = cnt[s + 1] - cnt[s];
         if (sz < minPtNum) continue;                                   /* S.cpp:109 */
         for (int k = 0; k < sz; ++k) memcpy(tmp + 4 * (size_t)k, cloud4 + 4 * (size_t)order[cnt[s] + k], 16);
+        if (g_sel_nflip && sel_flipped(3, s, 0)) continue;            /* diagnosis only */
+        g_sel_cur_sv = s;
         int kept = orc_patch_refinement(tmp, sz, 2.0, keep);          /* S.cpp:116 */
+        g_sel_cur_sv = -1;
         if (kept < minPtNum) continue;                                 /* S.cpp:119 */
         int w0 = w;
         for (int k = 0; k < sz; ++k)
@@ -657,7 +841,10 @@ int orc_select_patches(const float* cloud4, int n, const int* labels, int nsv,
             }
         float variation, planarity, linearity;
         orc_cal_patch_feature(pat4 + 4 * (size_t)w0, kept, &variation, &planarity, &linearity);
-        if (variation > 0.02f || planarity < 0.25f) { w = w0; continue; }   /* S.cpp:127 */
+        int reject = (variation > 0.02f || planarity < 0.25f);          /* S.cpp:127 */
+        if (g_sel_rel >= 0.0) { sel_record(1, s, 0, variation, 0.02, !reject); sel_record(2, s, 0, planarity, 0.25, !reject); }
+        if (g_sel_nflip && (sel_flipped(1, s, 0) || sel_flipped(2, s, 0))) reject = !reject;
+        if (reject) { w = w0; continue; }
         orc_cal_patch_ct_bp(pat4 + 4 * (size_t)w0, kept, ct4 + 4 * (size_t)np, bp4 + 24 * (size_t)np);
         float sd = orc_cal_patch_std(pat4 + 4 * (size_t)w0, kept);    /* S.cpp:315 */
         bpstd[np] = sd;
@@ -775,6 +962,7 @@ int orc_p2p_icp(const float* tgt4, const float* tgt_n4, int nt, const float* src
         orc_mat4_mul(T, final, final);
         ++iters;
         /* hasConverged() */
+        if (g_dbg_inner_outer == g_dbg_cur_outer) { if (iters >= g_dbg_inner_count) break; else continue; }   /* diagnosis only */
         if (iters >= max_iterations) break;
         double cos_angle = 0.5 * (double)(T[0] + T[5] + T[10] - 1.0f);
         double translation_sqr = (double)(T[3] * T[3] + T[7] * T[7] + T[11] * T[11]);
@@ -968,9 +1156,101 @@ static int vg_cmp(const void* a, const void* b)
 {
     const vg_entry* x = (const vg_entry*)a; const vg_entry* y = (const vg_entry*)b;
     if (x->idx != y->idx) return x->idx < y->idx ? -1 : 1;
-    return x->pt < y->pt ? -1 : (x->pt > y->pt);     /* std::sort is unstable in the reference;
-                                                        point order inside a voxel is made
-                                                        deterministic (input order) here */
+    return x->pt < y->pt ? -1 : (x->pt > y->pt);     /* input order inside a voxel (diagnosis variant 8 and the
+                                                        heap-sort fall-back only; see msvc_sort below) */
+}
+
+/* std::sort as shipped with MSVC 14.1x (<algorithm>: _Sort_unchecked1 / _Partition_by_median_guess_unchecked /
+ * _Guess_median_unchecked / _Med3_unchecked / _Insertion_sort_unchecked, _ISORT_MAX = 32), restated: the reference's
+ * checked-in results come from that build, PCL's VoxelGrid sorts (voxel index, point) entries with an UNSTABLE
+ * std::sort whose comparator looks at the voxel index only, and the order of the points inside a voxel is the order of the
+ * float centroid sum.  The order std::sort leaves equal keys in is a property of the implementation. */
+#define VG_LT(a, b) ((a).idx < (b).idx)
+static inline void vg_swap(vg_entry* a, vg_entry* b) { vg_entry t = *a; *a = *b; *b = t; }
+static void msvc_med3(vg_entry* f, vg_entry* m, vg_entry* l)
+{
+    if (VG_LT(*m, *f)) vg_swap(m, f);
+    if (VG_LT(*l, *m)) {
+        vg_swap(l, m);
+        if (VG_LT(*m, *f)) vg_swap(m, f);
+    }
+}
+static void msvc_guess_median(vg_entry* f, vg_entry* m, vg_entry* l)
+{
+    if (40 < l - f) {
+        size_t step = (size_t)(l - f + 1) / 8;
+        msvc_med3(f, f + step, f + 2 * step);
+        msvc_med3(m - step, m, m + step);
+        msvc_med3(l - 2 * step, l - step, l);
+        msvc_med3(f + step, m, l - step);
+    } else msvc_med3(f, m, l);
+}
+static void msvc_partition(vg_entry* first, vg_entry* last, vg_entry** pf_o, vg_entry** pl_o)
+{
+    vg_entry* mid = first + (last - first) / 2;
+    msvc_guess_median(first, mid, last - 1);
+    vg_entry* pfirst = mid;
+    vg_entry* plast = pfirst + 1;
+    while (first < pfirst && !VG_LT(*(pfirst - 1), *pfirst) && !VG_LT(*pfirst, *(pfirst - 1))) --pfirst;
+    while (plast < last && !VG_LT(*plast, *pfirst) && !VG_LT(*pfirst, *plast)) ++plast;
+    vg_entry* gfirst = plast;
+    vg_entry* glast = pfirst;
+    for (;;) {
+        for (; gfirst < last; ++gfirst) {
+            if (VG_LT(*pfirst, *gfirst)) ;
+            else if (VG_LT(*gfirst, *pfirst)) break;
+            else if (plast++ != gfirst) vg_swap(plast - 1, gfirst);
+        }
+        for (; first < glast; --glast) {
+            if (VG_LT(*(glast - 1), *pfirst)) ;
+            else if (VG_LT(*pfirst, *(glast - 1))) break;
+            else if (--pfirst != glast - 1) vg_swap(pfirst, glast - 1);
+        }
+        if (glast == first && gfirst == last) { *pf_o = pfirst; *pl_o = plast; return; }
+        if (glast == first) {                   /* no room at bottom, rotate pivot upward */
+            if (plast != gfirst) vg_swap(pfirst, plast);
+            ++plast;
+            vg_swap(pfirst++, gfirst++);
+        } else if (gfirst == last) {            /* no room at top, rotate pivot downward */
+            if (--glast != --pfirst) vg_swap(glast, pfirst);
+            vg_swap(pfirst, --plast);
+        } else vg_swap(gfirst++, --glast);
+    }
+}
+static void msvc_insertion_sort(vg_entry* first, vg_entry* last)
+{
+    if (first == last) return;
+    for (vg_entry* next = first; ++next != last;) {
+        vg_entry* next1 = next;
+        vg_entry val = *next;
+        if (VG_LT(val, *first)) {
+            memmove(first + 1, first, (size_t)(next - first) * sizeof(vg_entry));
+            *first = val;
+        } else {
+            for (vg_entry* first1 = next1; VG_LT(val, *--first1); next1 = first1) *next1 = *first1;
+            *next1 = val;
+        }
+    }
+}
+static void msvc_heap_sort(vg_entry* first, vg_entry* last);   /* depth-limit fall-back, never reached on the data here */
+static void msvc_sort(vg_entry* first, vg_entry* last, ptrdiff_t ideal)
+{
+    ptrdiff_t count;
+    while (32 < (count = last - first) && 0 < ideal) {
+        vg_entry *pf, *pl;
+        msvc_partition(first, last, &pf, &pl);
+        ideal /= 2; ideal += ideal / 2;
+        if (pf - first < last - pl) { msvc_sort(first, pf, ideal); first = pl; }
+        else { msvc_sort(pl, last, ideal); last = pf; }
+    }
+    if (32 < count) msvc_heap_sort(first, last);
+    else if (2 <= count) msvc_insertion_sort(first, last);
+}
+static int g_msvc_heap_used = 0;
+static void msvc_heap_sort(vg_entry* first, vg_entry* last)
+{
+    g_msvc_heap_used = 1;                                        /* order of equal keys after a heap sort not restated */
+    qsort(first, (size_t)(last - first), sizeof(vg_entry), vg_cmp);
 }
 
 /* PCL: filters/impl/voxel_grid.hpp applyFilter() (downsample_all_data_, no field filter,
@@ -1012,7 +1292,8 @@ int orc_voxel_grid(const float* in4, int n, float leaf, float* out4)
         e[i].idx = (unsigned int)(ijk0 * mul[0] + ijk1 * mul[1] + ijk2 * mul[2]);
         e[i].pt = i;
     }
-    qsort(e, (size_t)n, sizeof(vg_entry), vg_cmp);
+    if (g_dbg_variant & 8u) qsort(e, (size_t)n, sizeof(vg_entry), vg_cmp);      /* diagnosis: input order inside a voxel */
+    else msvc_sort(e, e + n, (ptrdiff_t)n);
     int m = 0, i = 0;
     while (i < n) {
         int j = i;
@@ -1164,6 +1445,7 @@ int orc_piecewise_icp_loop(const float* cloud1, int n1, float* cloud2, int n2,
         for (int i = 0; i < m2; ++i) {
             float s1 = CTstd1[mCT[i]], s2 = BPstd2[i];
             float LoD = (float)(1.96 * (double)sqrtf(s1 * s1 + s2 * s2));
+            if (g_dbg_variant & 4u) LoD = (float)(1.96 * sqrt((double)(s1 * s1 + s2 * s2)));
             if (LoD > maxLoD) LoD = maxLoD; else if (LoD < minLoD) LoD = minLoD;
             LoDet[i] = LoD;
             if (LoD < LoDet_min) LoDet_min = LoD;
@@ -1221,7 +1503,15 @@ int orc_piecewise_icp_loop(const float* cloud1, int n1, float* cloud2, int n2,
             int CTpass = 1;
             if (currDT <= LoDet[i]) { if (LoDet[i] < P2PlCT[i]) CTpass = 0; }
             else { if (currDT < P2PlCT[i]) CTpass = 0; }
-            if (CTpass && BPpass && (P2PtCT[i] < DTctct)) {
+            int is_stable = CTpass && BPpass && (P2PtCT[i] < DTctct);
+            if (g_dbg_rel >= 0.0) {
+                float thr = currDT <= LoDet[i] ? LoDet[i] : currDT;
+                dbg_record(k, i, 0, P2PlCT[i], thr, is_stable);
+                for (int kk = 0; kk < 6; ++kk) dbg_record(k, i, 1 + kk, P2PlBP[6 * i + kk], thr, is_stable);
+                dbg_record(k, i, 7, P2PtCT[i], DTctct, is_stable);
+            }
+            if (g_dbg_nflip && dbg_flipped(k, i)) is_stable = !is_stable;
+            if (is_stable) {
                 int np = off2[i + 1] - off2[i];
                 memcpy(stPC + 4 * (size_t)nsp, pat2 + 4 * (size_t)off2[i], sizeof(float) * 4 * (size_t)np);
                 nsp += np;
@@ -1236,7 +1526,9 @@ int orc_piecewise_icp_loop(const float* cloud1, int n1, float* cloud2, int n2,
         /* (5) 875-877 */
         float Tk[16];
         double ti0 = now_s();
+        g_dbg_cur_outer = k;
         int n_in = orc_p2p_icp(ct1, ct1n, m1, stCT, stN, ns, 1e-6, Tk, &io->n_corr);
+        g_dbg_cur_outer = -2;
         if (io->faithful_cost) { orc_kdtree* extra = orc_kdtree_build(ct1, m1); orc_kdtree_free(extra); } /* Registration::initCompute tree */
         io->t_inner_s += now_s() - ti0;
         io->n_inner[k] = n_in; io->n_inner_total += n_in;

@@ -150,6 +150,21 @@ int orc_piecewise_icp_loop(const float* cloud1_4, int n1, float* cloud2_4, int n
                            float* ct2_4, float* bp2_4,
                            orc_loop_io* io);
 
+/* ---- diagnosis hooks (tools/rootcause_golden.py) --------------------------------------- */
+typedef struct { int outer, patch, which; float dist, thr, rel; int stable; } orc_dbg_rec;
+/* rel_margin >= 0 records every decision of R.cpp:828-853 with |dist-thr|/thr <= rel_margin (which: 0 CT plane, 1..6 BP
+ * plane, 7 CT point distance); flips = (outer, patch) pairs whose verdict is inverted; variant bits: 1 eigen33 trig through
+ * sinf/cosf/atan2f, 2 NN ties to the highest index, 4 LoD through a double sqrt, 8 voxel-grid points summed in input order
+ * instead of the order MSVC's std::sort leaves them in, 16 / 64 the plane-fit / patch-feature scatter matrix accumulated in double
+ * and rounded once instead of summed in float, 32 Eigen's float eigen-solver for the plane fit.  orc_debug_config(-1, NULL, 0, 0) = off. */
+void orc_debug_config(double rel_margin, const int* flips, int nflip, unsigned variant);
+void orc_debug_force_inner(int outer, int count);
+/* patch-selection side: records (outer = kind, patch = supervoxel, which = point) for kind 0 refinement |d| < 2 sigma
+ * (S.cpp:220-225), 1 variation gate, 2 planarity gate (S.cpp:127); flips = (kind, supervoxel, point) triples, kind 3 drops
+ * the supervoxel.  Applies to the next orc_select_patches calls until switched off with (-1, NULL, 0). */
+void orc_debug_select_config(double rel_margin, const int* flips, int nflip);
+int  orc_debug_records(orc_dbg_rec* out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

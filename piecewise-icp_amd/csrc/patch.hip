@@ -43,7 +43,11 @@ __device__ inline bool point_normal(const float4* __restrict__ p, int n, float* 
     return true;
 }
 
-// scatter (double accumulation of float demeaned coords) of the kept points; returns the float mean
+// scatter of the kept points' demeaned float coordinates; returns the float mean.  The reference forms it as a float GEMM
+// (pcl::PCA: alpha = D D^T, common/impl/pca.hpp; calPatchFeature / calPatchNormal: cloud_mat^T cloud_mat, S.cpp:246, C.cpp:311)
+// whose inner dimension is the points: every element is a FLOAT sum over the points in order.  Accumulating in double and
+// rounding once flips refinement decisions |d| < 2 sigma (S.cpp:220-225) at ~1e-6 relative margins: 3 of the reference's 57
+// result files then sit at 3e-7 .. 9e-7 rad instead of <= 2e-8 (tools/rootcause_golden.py, oracle variant 16).
 template <bool FILTER>
 __device__ inline void mean_and_scatter(const float4* __restrict__ p, const unsigned char* __restrict__ keep,
                                         int n, int cnt, float* mean, double* S) {
@@ -54,13 +58,13 @@ __device__ inline void mean_and_scatter(const float4* __restrict__ p, const unsi
         c0 += v.x; c1 += v.y; c2 += v.z;
     }
     c0 /= (float)cnt; c1 /= (float)cnt; c2 /= (float)cnt;
-    double s0 = 0, s1 = 0, s2 = 0, s4 = 0, s5 = 0, s8 = 0;
+    float s0 = 0, s1 = 0, s2 = 0, s4 = 0, s5 = 0, s8 = 0;
     for (int i = 0; i < n; ++i) {
         if (FILTER && !keep[i]) continue;
         float4 v = p[i];
         float dx = v.x - c0, dy = v.y - c1, dz = v.z - c2;
-        s0 += (double)dx * dx; s1 += (double)dx * dy; s2 += (double)dx * dz;
-        s4 += (double)dy * dy; s5 += (double)dy * dz; s8 += (double)dz * dz;
+        s0 += dx * dx; s1 += dx * dy; s2 += dx * dz;
+        s4 += dy * dy; s5 += dy * dz; s8 += dz * dz;
     }
     mean[0] = c0; mean[1] = c1; mean[2] = c2;
     S[0] = s0; S[1] = s1; S[2] = s2; S[3] = s1; S[4] = s4; S[5] = s5; S[6] = s2; S[7] = s5; S[8] = s8;

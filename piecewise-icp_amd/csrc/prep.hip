@@ -4,7 +4,9 @@
 // ijk = floor(p * inverse_leaf) - min_b, linear index i + j*dx + k*dx*dy, float centroid per occupied voxel, output
 // in ascending index order) and SORfilter CommonFunc.cpp:442-452 -> pcl::StatisticalOutlierRemoval (mean distance to
 // the k nearest other points, global mean + sample stddev, keep d <= mean + mult*stddev).
-// Points of a voxel are summed in input order (stable sort), exactly like the host version (host/preprocess.cpp).
+// Points of a voxel are summed in the order pcl::VoxelGrid's std::sort leaves them in for the reference's released build
+// (host/msvc_sort.h: a sequential procedure, run on the host on the 4-byte keys while the device sorts and scans), or in
+// input order with PWICP_VOXEL_ORDER=input - exactly like the host version (host/preprocess.cpp).
 #include <hipcub/hipcub.hpp>
 
 #include <cfloat>
@@ -12,6 +14,7 @@
 #include <vector>
 
 #include "common.h"
+#include "../host/preprocess.h"
 
 namespace {
 
@@ -136,11 +139,34 @@ int pw_preprocess_dev(pwicp_context* ctx, const float4* d_in, int n, bool downsa
     HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys.p, keys_s.p, vals.p, order.p, n, 0, end_bit, ctx->stream));
     DevBuf<unsigned char> tsort;
     HIPCHK(ctx, tsort.reserve(tb));
+    // the reference build's order inside a voxel: keys to the host (4 B per point) before the device sort is queued, the
+    // sequential sort there while the device sorts / scans, the permutation back (4 B per point)
+    const bool msvc = pwhost::voxel_order_is_msvc();
+    std::vector<pwhost::VoxelEntry> he;
+    if (msvc) {
+        std::vector<unsigned> hk((size_t)n);
+        HIPCHK(ctx, hipMemcpyAsync(hk.data(), keys.p, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        he.resize((size_t)n);
+        for (int i = 0; i < n; ++i) he[(size_t)i] = pwhost::VoxelEntry{hk[(size_t)i], i};
+    }
     HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(tsort.p, tb, keys.p, keys_s.p, vals.p, order.p, n, 0, end_bit, ctx->stream));
     hipLaunchKernelGGL(k_vg_heads, dim3(div_up(n + 1, kBlock)), dim3(kBlock), 0, ctx->stream, keys_s.p, n, head.p);
     PWCHK(pw_exclusive_scan(ctx, head.p, (long long)n + 1, &tmp));
     m = 0;
     HIPCHK(ctx, hipMemcpyAsync(&m, head.p + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<int> ho;                       // lives until the synchronisation below
+    if (msvc) {
+        if (pwhost::voxel_sort_msvc(he.data(), he.size())) {
+            ho.resize((size_t)n);
+            for (int i = 0; i < n; ++i) ho[(size_t)i] = he[(size_t)i].pt;
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(order.p, ho.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            fprintf(stderr, "[pwicp] voxel grid: std::sort's depth budget ran out on this input; the points of a voxel are summed in "
+                            "input order instead.\n");
+        }
+    }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, start.reserve((size_t)m + 1));
     HIPCHK(ctx, vox.reserve((size_t)m));

@@ -11,14 +11,30 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <cstdio>
 #include <vector>
 
 #include "kdtree.h"
+#include "msvc_sort.h"
+#include "parallel.h"
+#include "preprocess.h"
 #include "pwicp.h"
 
 namespace pwhost {
+
+// PWICP_VOXEL_ORDER = msvc (default) | input: the order the points of one voxel are summed in (msvc_sort.h)
+bool voxel_order_is_msvc() {
+    const char* e = std::getenv("PWICP_VOXEL_ORDER");
+    return !(e && std::strcmp(e, "input") == 0);
+}
+
+// (voxel index, point) entries -> the order pcl::VoxelGrid's std::sort leaves them in.  false: the sort's depth budget ran
+// out (adversarial input); `e` then holds a permutation in an unspecified state and the caller sorts it stably instead.
+bool voxel_sort_msvc(VoxelEntry* e, size_t n) {
+    return msvc_order::sort(e, e + n, [](const VoxelEntry& a, const VoxelEntry& b) { return a.idx < b.idx; }, host_threads());
+}
 
 // returns the number of output points; out must hold n points
 int voxel_grid(const float* in4, int n, float leaf, float* out4) {
@@ -47,17 +63,30 @@ int voxel_grid(const float* in4, int n, float leaf, float* out4) {
         divb[d] = (int)std::floor(mx[d] * inv) - minb[d] + 1;
     }
     const int mul1 = divb[0], mul2 = divb[0] * divb[1];
-    struct Entry { unsigned idx; int pt; };
+    using Entry = VoxelEntry;
     std::vector<Entry> e((size_t)n);
-    for (int i = 0; i < n; ++i) {
-        const float* p = in4 + 4 * (size_t)i;
-        const int i0 = (int)(std::floor(p[0] * inv) - (float)minb[0]);
-        const int i1 = (int)(std::floor(p[1] * inv) - (float)minb[1]);
-        const int i2 = (int)(std::floor(p[2] * inv) - (float)minb[2]);
-        e[(size_t)i] = Entry{(unsigned)(i0 + i1 * mul1 + i2 * mul2), i};
+    auto fill = [&] {
+        for (int i = 0; i < n; ++i) {
+            const float* p = in4 + 4 * (size_t)i;
+            const int i0 = (int)(std::floor(p[0] * inv) - (float)minb[0]);
+            const int i1 = (int)(std::floor(p[1] * inv) - (float)minb[1]);
+            const int i2 = (int)(std::floor(p[2] * inv) - (float)minb[2]);
+            e[(size_t)i] = Entry{(unsigned)(i0 + i1 * mul1 + i2 * mul2), i};
+        }
+    };
+    fill();
+    // PCL sorts with std::sort (unstable): the points of a voxel in the order the reference's build leaves them in, or
+    // (PWICP_VOXEL_ORDER=input) in input order
+    bool sorted = false;
+    if (voxel_order_is_msvc()) {
+        sorted = voxel_sort_msvc(e.data(), e.size());
+        if (!sorted) {
+            std::fprintf(stderr, "[pwicp] voxel grid: std::sort's depth budget ran out on this input; the points of a voxel are "
+                                 "summed in input order instead.\n");
+            fill();
+        }
     }
-    // PCL sorts with std::sort (unstable); points inside a voxel are taken in input order here
-    std::stable_sort(e.begin(), e.end(), [](const Entry& a, const Entry& b) { return a.idx < b.idx; });
+    if (!sorted) std::stable_sort(e.begin(), e.end(), [](const Entry& a, const Entry& b) { return a.idx < b.idx; });
     int m = 0;
     for (size_t i = 0; i < e.size();) {
         size_t j = i;

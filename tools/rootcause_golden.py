@@ -1,0 +1,171 @@
+"""Root-cause search for the golden pairs the oracle misses by more than float print precision (Direct2Ref e8, e19).
+
+For one pair (target epoch t, source epoch e, reference result file):
+  1. run the oracle with the decision recorder on (oracle/pwicp_oracle.h: orc_debug_config) and list every
+     classification decision of R.cpp:828-853 whose distance sits within REL of its threshold;
+  2. re-run with each such decision (and each arithmetic variant / forced inner-iteration count) changed alone and
+     report the distance of the result to the reference's file.
+A single change that brings the pair to float print precision of the reference's result names the cause.
+
+  python tools/rootcause_golden.py 8 [19 ...]      (needs /root/reference for epochs 3..20; run in the build container)
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "piecewise-icp_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import _golden as G          # noqa: E402
+import _oracle as O          # noqa: E402
+from pwicp_amd.pcd import read_pcd   # noqa: E402
+
+
+class Rec(C.Structure):
+    _fields_ = [("outer", C.c_int), ("patch", C.c_int), ("which", C.c_int), ("dist", C.c_float), ("thr", C.c_float),
+                ("rel", C.c_float), ("stable", C.c_int)]
+
+
+L = O.lib()
+L.orc_debug_config.argtypes = [C.c_double, C.POINTER(C.c_int), C.c_int, C.c_uint]
+L.orc_debug_force_inner.argtypes = [C.c_int, C.c_int]
+L.orc_debug_select_config.argtypes = [C.c_double, C.POINTER(C.c_int), C.c_int]
+L.orc_debug_records.argtypes = [C.POINTER(Rec), C.c_int]
+L.orc_debug_records.restype = C.c_int
+
+_prep = {}
+
+
+def cloud(e):
+    if e not in _prep:
+        _prep[e] = G.preprocess_4d(O, read_pcd(G.epoch_path(e)))
+    return _prep[e]
+
+
+class Case:
+    def __init__(self, t, e, mode):
+        self.t, self.e = t, e
+        r1, r2, self.shift = G.reduce_pair(cloud(t), cloud(e))
+        self.r1, self.r2 = r1, r2
+        self.lab1 = O.ref_frontend(r1, 0.05)
+        self.lab2 = O.ref_frontend(r2, 0.05)
+        self.Tg, self.Vg, self.stds = G.parse_transmatrix_file(
+            os.path.join(G.REF_ROOT, "results/4DPCReg", "%d_%s_TransMatrix.txt" % (e, mode)))
+
+    def select_records(self, rel):
+        """Near-threshold decisions of the source cloud's patch selection (kind, supervoxel, point, value, thr, rel, verdict)."""
+        L.orc_debug_select_config(rel, None, 0)
+        O.select_patches(self.r2, *self.lab2)
+        n = L.orc_debug_records(None, 0)
+        buf = (Rec * max(n, 1))()
+        L.orc_debug_records(buf, n)
+        L.orc_debug_select_config(-1.0, None, 0)
+        return [(r.outer, r.patch, r.which, r.dist, r.thr, r.rel, r.stable) for r in buf[:n]]
+
+    def run(self, rel=-1.0, flips=(), variant=0, inner=None, sel_flips=()):
+        variant |= int(os.environ.get("VARIANT", "0"))
+        fl = np.array(flips, np.int32).reshape(-1)
+        L.orc_debug_config(-1.0, None, 0, variant)
+        P1 = O.select_patches(self.r1, *self.lab1)
+        sf = np.array(sel_flips, np.int32).reshape(-1)
+        L.orc_debug_select_config(-1.0, sf.ctypes.data_as(C.POINTER(C.c_int)), len(sf) // 3)
+        P2 = O.select_patches(self.r2, *self.lab2)
+        L.orc_debug_select_config(-1.0, None, 0)
+        L.orc_debug_config(rel, fl.ctypes.data_as(C.POINTER(C.c_int)), len(fl) // 2, variant)
+        L.orc_debug_force_inner(*(inner if inner else (-1, 0)))
+        io = O.run_loop(self.r1, self.r2, P1, P2, 0.005, 0.005, 0.05, 0.05, 0.05, 0.004)
+        recs = []
+        if rel >= 0:
+            n = L.orc_debug_records(None, 0)
+            buf = (Rec * n)()
+            L.orc_debug_records(buf, n)
+            recs = [(r.outer, r.patch, r.which, r.dist, r.thr, r.rel, r.stable) for r in buf]
+        L.orc_debug_config(-1.0, None, 0, 0)
+        L.orc_debug_force_inner(-1, 0)
+        Tf = G.final_matrix(io.T16, self.shift)
+        da = float(np.abs(G.euler(Tf) - G.euler(self.Tg)).max())
+        dt = float(np.abs(Tf[:3, 3].astype(float) - self.Tg[:3, 3]).max())
+        V = np.array(io.VCM).reshape(6, 6)
+        mine = np.concatenate([1000 * 63.6619772368 * np.sqrt(np.diag(V)[:3]), 1000 * np.sqrt(np.diag(V)[3:])])
+        dstd = float(np.abs(mine / self.stds - 1).max())
+        return dict(da=da, dt=dt, dstd=dstd, outer=io.n_outer, inner=list(io.n_inner[:io.n_outer]),
+                    stable=list(io.n_stable[:io.n_outer]), status=io.status), recs
+
+
+def fmt(r):
+    return "d_angle %.2e rad  d_trans %.2e m  d_sigma %.1e  outer %d inner %s stable %s" % (
+        r["da"], r["dt"], r["dstd"], r["outer"], r["inner"], r["stable"])
+
+
+def search(t, e, mode, rel):
+    c = Case(t, e, mode)
+    base, recs = c.run(rel=rel)
+    print("== %s: epoch %d -> %d" % (mode, e, t))
+    print("   base        : " + fmt(base))
+    hits = []
+    for v, name in ((1, "eigen33 trig through sinf/cosf/atan2f"), (2, "NN ties to the highest index"), (4, "LoD through a double sqrt"),
+                    (7, "all three")):
+        r, _ = c.run(variant=v)
+        print("   variant %d (%s): %s" % (v, name, fmt(r)))
+        if r["da"] < 5e-7 and r["dt"] < 5e-7:
+            hits.append(("variant %d" % v, r))
+    for k in range(base["outer"]):
+        for cnt in (base["inner"][k] - 1, base["inner"][k] + 1):
+            if cnt < 1:
+                continue
+            r, _ = c.run(inner=(k, cnt))
+            tag = "inner count of outer %d forced %d -> %d" % (k, base["inner"][k], cnt)
+            print("   %s: %s" % (tag, fmt(r)))
+            if r["da"] < 5e-7 and r["dt"] < 5e-7:
+                hits.append((tag, r))
+    # decisions near their threshold: one candidate per (outer, patch), the tightest comparison of the patch
+    cand = {}
+    for (ko, pi, which, dist, thr, rl, st) in recs:
+        key = (ko, pi)
+        if key not in cand or rl < cand[key][2]:
+            cand[key] = (which, dist, rl, thr, st)
+    print("   %d decisions within %.0e of their threshold" % (len(cand), rel))
+    for (ko, pi), (which, dist, rl, thr, st) in sorted(cand.items(), key=lambda kv: kv[1][2]):
+        r, _ = c.run(flips=[(ko, pi)])
+        tag = "flip outer %d patch %d (%s dist %.9g vs thr %.9g, rel %.1e, was %s)" % (
+            ko, pi, ["CT-plane", "BP1", "BP2", "BP3", "BP4", "BP5", "BP6", "CT-point"][which], dist, thr, rl, "stable" if st else "unstable")
+        ok = r["da"] < 5e-7 and r["dt"] < 5e-7
+        print("   %s%s: %s" % ("** " if ok else "", tag, fmt(r)))
+        if ok:
+            hits.append((tag, r))
+    # the source cloud's patch selection (S.cpp:109-127, 220-225): near-threshold refinement / gate decisions, one at a time
+    srecs = c.select_records(float(os.environ.get("SEL_REL", "1e-3")))
+    print("   %d patch-selection decisions of the source cloud near their threshold" % len(srecs))
+    for (kind, sv, k, val, thr, rl, verdict) in sorted(srecs, key=lambda r: r[5]):
+        r, _ = c.run(sel_flips=[(kind, sv, k)])
+        tag = "select: %s of supervoxel %d%s (value %.9g vs %.9g, rel %.1e, was %s)" % (
+            ["refinement", "variation gate", "planarity gate"][kind], sv, " point %d" % k if kind == 0 else "", val, thr, rl,
+            "kept" if verdict else "rejected")
+        ok = r["da"] < 5e-7 and r["dt"] < 5e-7
+        if ok or r["da"] < 0.5 * base["da"]:
+            print("   %s%s: %s" % ("** " if ok else "", tag, fmt(r)))
+        if ok:
+            hits.append((tag, r))
+    if os.environ.get("DROP_ALL"):
+        for sv in range(c.lab2[1]):
+            r, _ = c.run(sel_flips=[(3, sv, 0)])
+            ok = r["da"] < 5e-7 and r["dt"] < 5e-7
+            if ok or r["da"] < 0.3 * base["da"]:
+                print("   %sdrop supervoxel %d: %s" % ("** " if ok else "", sv, fmt(r)))
+            if ok:
+                hits.append(("drop supervoxel %d" % sv, r))
+    print("   => %d single changes reach float print precision of the reference's file" % len(hits))
+    for tag, r in hits:
+        print("      " + tag)
+    return base, hits
+
+
+if __name__ == "__main__":
+    rel = float(os.environ.get("REL", "2e-3"))
+    mode = os.environ.get("MODE", "Direct2Ref")
+    for a in sys.argv[1:]:
+        e = int(a)
+        t = 1 if mode == "Direct2Ref" else int(os.environ["TARGET"])
+        search(t, e, mode, rel)
