@@ -307,6 +307,10 @@ PWICP_API int pwicp_abs_error_of_trans_para(const char* transMatFile, const char
 /* matrix2angle (C.cpp:385-407; decl C.h:172) and calBoundingBoxCornerChange (C.cpp:410-419; decl C.h:183): host arithmetic */
 PWICP_API void  pwicp_matrix2angle(const float* transMat16, float* rotAngle3);
 PWICP_API float pwicp_bbox_corner_change(const double* boundingBox6, const float* transMat16);
+/* The per-pair result file <prefix>TransMatrix.txt as PiecewiseICP_pair_call / Piecewise_ICP_4D write it (R.cpp:341-388,
+ * 492-539): 4x4 (fixed, 12 digits), angles in gon and translation (10 digits), 6x6 VCM (12 digits), standard deviations in
+ * mgon / mm (10 digits).  Layout known-answer test: tests/test_host_stages.py feeds the reference's own numbers through it. */
+PWICP_API int pwicp_write_trans_matrix_file(const char* path, const float* transMat16, const double* VCM36);
 
 /* ---- the 4D series as a handle: independent pairs on any GPU (R.cpp:89-187) -------------------------------
  * PiecewiseICP_4D_call is open + run_pair over all pairs + write_results + close on one GPU.  On a multi-GPU node

@@ -488,6 +488,10 @@ PWICP_API int pwicp_abs_error_of_trans_para(const char* transMatFile, const char
 
 // matrix2angle (C.cpp:385-407; decl C.h:172): rotation angles [rad] about x, y, z of a row-major 4x4
 PWICP_API void pwicp_matrix2angle(const float* T16, float* rotAngle3) { matrix2angle(T16, rotAngle3); }
+PWICP_API int pwicp_write_trans_matrix_file(const char* path, const float* T16, const double* VCM36) {
+    if (!path || !T16 || !VCM36) return PWICP_E_INVALID;
+    return write_transmatrix_file(path, T16, VCM36) ? PWICP_OK : PWICP_E_INVALID;
+}
 
 // ---- 4D series as a handle: the pairs of R.cpp:89-187 are independent, so any subset can run on any GPU ---------
 }  // extern "C"

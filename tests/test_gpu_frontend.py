@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import _data
+import _golden as G
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -67,6 +68,41 @@ def test_device_labels_equal_serial_labels_golden_epochs(ctx, epoch):
     cloud = (cloud - cloud.mean(axis=0)).astype(np.float32)
     nsv = _assert_same(ctx, cloud, 0.05, 0.005)
     assert nsv > 100
+
+
+def _device_labels(ctx, cloud, sv, spacing):
+    os.environ["PWICP_FRONTEND"] = "device"
+    try:
+        return ctx.frontend_segment(cloud, sv, 45, spacing)
+    finally:
+        os.environ.pop("PWICP_FRONTEND", None)
+
+
+@pytest.mark.parametrize("epoch", list(range(1, 21)))
+def test_device_labels_equal_the_references_compiled_front_end_golden_epochs(ctx, oracle, epoch):
+    """Directly against the REFERENCE'S OWN front end (oracle/_ref: /root/reference/codelibrary compiled by oracle/Makefile;
+    what Segmentation.cpp:18-68 runs), not against the product's serial passes: each of the reference's 20 scans, preprocessed
+    and reduced as the 4D entry point does (VoxelGrid 5 mm, SOR 14 / 5.0, minus the float centroid; R.cpp:412-436)."""
+    if not oracle.ref_frontend_available():
+        pytest.skip("oracle/_ref not built")
+    from pwicp_amd.pcd import read_pcd
+    cloud = G.preprocess_4d(oracle, read_pcd(G.epoch_path(epoch)))
+    red, _, _ = G.reduce_pair(cloud, cloud)
+    ld, nd = _device_labels(ctx, red, 0.05, 0.005)
+    lr, nr = oracle.ref_frontend(red, 0.05)
+    assert nd == nr
+    assert np.array_equal(ld, lr), "%d of %d labels differ" % (int((ld != lr).sum()), len(lr))
+
+
+def test_device_labels_equal_the_references_compiled_front_end_300k(ctx, oracle):
+    """300 k synthetic points (the bench generator), device pipeline against oracle/_ref."""
+    if not oracle.ref_frontend_available():
+        pytest.skip("oracle/_ref not built")
+    tgt, src, _ = _data.pair(300000)
+    for cloud in (tgt, src):
+        ld, nd = _device_labels(ctx, cloud, 10 * _data.R, _data.R)
+        lr, nr = oracle.ref_frontend(cloud, 10 * _data.R)
+        assert nd == nr and np.array_equal(ld, lr)
 
 
 def test_one_million_points(ctx):

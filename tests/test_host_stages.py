@@ -418,6 +418,9 @@ def test_composition_and_error_entry_points_reproduce_reference_files(tmp_path):
     rc = L.pwicp_trans_to_reference_epoch(os.path.join(gold, "TransMatrices.txt").encode(), -1, str(pair_file).encode(), n,
                                           out_tm.encode(), out_tp.encode(), stamps, T, V)
     assert rc == 0 and list(stamps) == list(range(2, 21))
+    # byte for byte (the reference's files were written on Windows: CRLF line ends)
+    for mine, theirs in ((out_tm, "TransMatrices_toRef.txt"), (out_tp, "TransParameters_toRef.txt")):
+        assert open(mine, "rb").read() == open(os.path.join(gold, theirs), "rb").read().replace(b"\r", b""), theirs
     Tr, Vr = _read_matrices(os.path.join(gold, "TransMatrices_toRef.txt"), n)
     Tm, Vm = _read_matrices(out_tm, n)
     for i in range(n):
@@ -430,7 +433,63 @@ def test_composition_and_error_entry_points_reproduce_reference_files(tmp_path):
     err = str(tmp_path / "err.txt")
     assert L.pwicp_abs_error_of_trans_para(os.path.join(gold, "TransMatrices_toRef.txt").encode(),
                                            os.path.join(gold, "defined_transformations.txt").encode(), 20, 0, err.encode()) == 0
+    assert open(err, "rb").read() == open(os.path.join(gold, "TransPara_AbsError.txt"), "rb").read().replace(b"\r", b"")
     a = np.loadtxt(err, skiprows=1)
     b = np.loadtxt(os.path.join(gold, "TransPara_AbsError.txt"), skiprows=1)
     assert a.shape == b.shape == (19, 6)
     assert np.allclose(a, b, rtol=2e-3, atol=2e-3)          # mgon / mm, printed with 6 significant digits by the reference
+
+
+def test_result_file_writers_reproduce_the_references_files_byte_for_byte(tmp_path):
+    """Layout known-answer test of the text writers (R.cpp:341-388 / 492-539, 152-167): the reference's own numbers, parsed from
+    its 57 checked-in <e>_{Direct2Ref,Adaptive,Fixed}_TransMatrix.txt files, written again by the product's writer.  Every line
+    must come back byte for byte (CRLF aside) - labels, blank lines, trailing blanks, `fixed` with 12 / 10 digits, the gon
+    conversion of matrix2angle - except the six Std_ lines, whose inputs (the full-precision VCM) the files only hold to 12
+    decimals: there the label / unit / digit layout must match and the value agree to 3 digits.  TransMatrices.txt (id line,
+    4 + 6 rows per pair) is reproduced in full through the direct-to-reference composition (a pass-through in pairMode 0)."""
+    import ctypes as C
+    import re
+    import pwicp_amd as P
+    L = P.load_library()
+    gold = os.path.join(G.GOLD, "reference_results")
+    L.pwicp_write_trans_matrix_file.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_double)]
+    out = str(tmp_path / "tm.txt")
+    std_line = re.compile(rb"^Std_(R|t)[xyz] = \d+\.\d{10} (mgon|mm)$")
+    for mode in ("Direct2Ref", "Adaptive", "Fixed"):
+        for e in range(2, 21):
+            f = os.path.join(gold, "%d_%s_TransMatrix.txt" % (e, mode))
+            T, V, _ = G.parse_transmatrix_file(f)
+            T32 = np.ascontiguousarray(T, np.float32).reshape(16)
+            V64 = np.ascontiguousarray(V, np.float64).reshape(36)
+            assert L.pwicp_write_trans_matrix_file(out.encode(), T32.ctypes.data_as(C.POINTER(C.c_float)),
+                                                   V64.ctypes.data_as(C.POINTER(C.c_double))) == 0
+            theirs = open(f, "rb").read().replace(b"\r", b"").split(b"\n")
+            mine = open(out, "rb").read().split(b"\n")
+            assert len(mine) == len(theirs) == 31
+            n_std = 0
+            for a, b in zip(mine, theirs):
+                if b.startswith(b"Std_"):
+                    n_std += 1
+                    assert std_line.match(a) and std_line.match(b) and a.split(b"=")[0] == b.split(b"=")[0] and a.split()[-1] == b.split()[-1]
+                    assert abs(float(a.split()[2]) / float(b.split()[2]) - 1) < 2e-3
+                else:
+                    assert a == b, (mode, e, a, b)
+            assert n_std == 6
+    # TransMatrices.txt through reader + writer (pairMode 0: the matrices to the reference epoch are the matrices themselves)
+    n = 19
+    stamps = (C.c_int32 * n)()
+    T = (C.c_float * (16 * n))()
+    V = (C.c_double * (36 * n))()
+    L.pwicp_trans_to_reference_epoch.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p,
+                                                 C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_double)]
+    out_tm, out_tp = str(tmp_path / "tms.txt"), str(tmp_path / "tps.txt")
+    assert L.pwicp_trans_to_reference_epoch(os.path.join(gold, "TransMatrices.txt").encode(), 0, b"", n, out_tm.encode(),
+                                            out_tp.encode(), stamps, T, V) == 0
+    assert open(out_tm, "rb").read() == open(os.path.join(gold, "TransMatrices.txt"), "rb").read().replace(b"\r", b"")
+    # TransParameters.txt: header and row layout (its sigmas come from full-precision VCMs the text files do not hold)
+    theirs = open(os.path.join(gold, "TransParameters.txt"), "rb").read().replace(b"\r", b"").split(b"\n")
+    mine = open(out_tp, "rb").read().split(b"\n")
+    assert mine[0] == theirs[0] and len(mine) == len(theirs)
+    row = re.compile(rb"^\d+( -?\d+\.\d{10}){12}$")
+    for a, b in zip(mine[1:20], theirs[1:20]):
+        assert row.match(a) and row.match(b) and a.split()[:7] == b.split()[:7]
