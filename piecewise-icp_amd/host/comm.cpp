@@ -4,15 +4,24 @@
 //
 // Reference: the pair loop of PiecewiseICP_4D_call (src/Registration.cpp:89-187) is sequential in one process; its
 // iterations are independent, which is what this shards: pair p -> rank p mod world, results gathered once.
-// Rendezvous: the ncclUniqueId travels through a file (single node): rank 0 writes <id_file>.tmp and renames it, the other
-// ranks poll for it.
+// Rendezvous: the ncclUniqueId travels through a file (single node).  Rank 0 removes whatever is left under that name,
+// creates <id_file>.tmp exclusively (O_EXCL | O_NOFOLLOW, mode 0600), writes {magic, job token, time, id} and renames it;
+// the other ranks poll and accept only a file that carries THEIR job token and a fresh time stamp, so a file left behind by a
+// crashed run or written by another job is never taken for this job's id.  The job token is what all ranks of one launch
+// share: $PWICP_JOB_ID, else $TORCHELASTIC_RUN_ID + the launcher's pid (getppid()).  Rank 0 removes the file on every failure
+// path of the initialisation and in pwicp_comm_destroy.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
+#include <cstdint>
 #include <cstdio>
+#include <ctime>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -50,6 +59,57 @@ struct Rccl {
 };
 Rccl g_rccl;
 
+// what every rank of one launch shares and no other launch does
+uint64_t job_token() {
+    std::string t;
+    if (const char* e = std::getenv("PWICP_JOB_ID")) t = e;
+    else {
+        if (const char* r = std::getenv("TORCHELASTIC_RUN_ID")) t = r;
+        t += "/ppid=" + std::to_string((long)getppid());
+    }
+    for (const char* k : {"MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE"})
+        if (const char* e = std::getenv(k)) { t += "/"; t += e; }
+    uint64_t h = 1469598103934665603ull;                 // FNV-1a
+    for (unsigned char c : t) { h ^= c; h *= 1099511628211ull; }
+    return h;
+}
+
+struct IdFile {                  // content of the rendezvous file
+    uint64_t magic, token;
+    int64_t written_at;          // seconds since the epoch
+    ncclUniqueId id;
+};
+constexpr uint64_t kIdMagic = 0x5057494350494431ull;     // "PWICPID1"
+constexpr int64_t kIdMaxAgeSeconds = 600;
+
+bool write_id_file(const std::string& path, const ncclUniqueId& id) {
+    const std::string tmp = path + ".tmp";
+    (void)unlink(path.c_str());
+    (void)unlink(tmp.c_str());
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    if (fd < 0) return false;
+    IdFile f;
+    std::memset(&f, 0, sizeof(f));
+    f.magic = kIdMagic; f.token = job_token(); f.written_at = (int64_t)std::time(nullptr); f.id = id;
+    const bool ok = write(fd, &f, sizeof(f)) == (ssize_t)sizeof(f);
+    close(fd);
+    if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) { (void)unlink(tmp.c_str()); return false; }
+    return true;
+}
+
+// 1: taken, 0: nothing (acceptable) there yet
+int read_id_file(const std::string& path, ncclUniqueId* id) {
+    const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0) return 0;
+    IdFile f;
+    const bool ok = read(fd, &f, sizeof(f)) == (ssize_t)sizeof(f);
+    close(fd);
+    if (!ok || f.magic != kIdMagic || f.token != job_token()) return 0;                 // another job's, or a torn write
+    if ((int64_t)std::time(nullptr) - f.written_at > kIdMaxAgeSeconds) return 0;        // left behind by an earlier run
+    *id = f.id;
+    return 1;
+}
+
 }  // namespace
 
 struct pwicp_comm {
@@ -57,6 +117,16 @@ struct pwicp_comm {
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
     std::string id_file;
+    void* stage = nullptr;       // device staging of the host-buffer collectives, grow-only
+    size_t stage_bytes = 0;
+    void* staging(size_t bytes) {
+        if (bytes <= stage_bytes) return stage;
+        if (stage) { (void)hipFree(stage); stage = nullptr; stage_bytes = 0; }
+        const size_t want = std::max<size_t>(bytes, 1 << 16);
+        if (hipMalloc(&stage, want) != hipSuccess) { stage = nullptr; return nullptr; }
+        stage_bytes = want;
+        return stage;
+    }
 };
 
 extern "C" {
@@ -70,25 +140,17 @@ PWICP_API int pwicp_comm_init(int rank, int world, int device, const char* id_fi
     std::memset(&id, 0, sizeof(id));
     const std::string path = id_file ? id_file : "";
     if (rank == 0) {
+        if (world > 1) { (void)unlink(path.c_str()); (void)unlink((path + ".tmp").c_str()); }     // nothing stale may be picked up
         if (g_rccl.GetUniqueId(&id) != ncclSuccess) return PWICP_E_NO_DEVICE;
-        if (world > 1) {
-            const std::string tmp = path + ".tmp";
-            FILE* f = std::fopen(tmp.c_str(), "wb");
-            if (!f || std::fwrite(&id, sizeof(id), 1, f) != 1) { if (f) std::fclose(f); return PWICP_E_INTERNAL; }
-            std::fclose(f);
-            if (std::rename(tmp.c_str(), path.c_str()) != 0) return PWICP_E_INTERNAL;
+        if (world > 1 && !write_id_file(path, id)) {
+            std::cerr << "Error: cannot create the RCCL id file " << path << "\n";
+            return PWICP_E_INTERNAL;
         }
     } else {
         const auto t0 = std::chrono::steady_clock::now();
-        for (;;) {
-            FILE* f = std::fopen(path.c_str(), "rb");
-            if (f) {
-                const size_t got = std::fread(&id, sizeof(id), 1, f);
-                std::fclose(f);
-                if (got == 1) break;
-            }
+        while (!read_id_file(path, &id)) {
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) {
-                std::cerr << "Error: rank " << rank << " never saw the RCCL id file " << path << "\n";
+                std::cerr << "Error: rank " << rank << " never saw this job's RCCL id file " << path << "\n";
                 return PWICP_E_INTERNAL;
             }
             std::this_thread::sleep_for(std::chrono::milliseconds(20));
@@ -99,10 +161,16 @@ PWICP_API int pwicp_comm_init(int rank, int world, int device, const char* id_fi
     const ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
     if (r != ncclSuccess) {
         std::cerr << "Error: ncclCommInitRank failed: " << (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?") << "\n";
+        if (rank == 0 && world > 1) (void)unlink(path.c_str());
         delete c;
         return PWICP_E_NO_DEVICE;
     }
-    if (hipStreamCreate(&c->stream) != hipSuccess) { g_rccl.CommDestroy(c->comm); delete c; return PWICP_E_NO_DEVICE; }
+    if (hipStreamCreate(&c->stream) != hipSuccess) {
+        g_rccl.CommDestroy(c->comm);
+        if (rank == 0 && world > 1) (void)unlink(path.c_str());
+        delete c;
+        return PWICP_E_NO_DEVICE;
+    }
     *out = c;
     return PWICP_OK;
 }
@@ -112,6 +180,7 @@ PWICP_API void pwicp_comm_destroy(pwicp_comm* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->comm) g_rccl.CommDestroy(c->comm);
+    if (c->stage) (void)hipFree(c->stage);
     if (c->rank == 0 && c->world > 1 && !c->id_file.empty()) std::remove(c->id_file.c_str());
     delete c;
 }
@@ -123,29 +192,29 @@ PWICP_API int pwicp_comm_world(const pwicp_comm* c) { return c ? c->world : 0; }
 PWICP_API int pwicp_comm_allgather(pwicp_comm* c, const void* send, size_t bytes, void* recv) {
     if (!c || !send || !recv || bytes == 0) return PWICP_E_INVALID;
     if (hipSetDevice(c->device) != hipSuccess) return PWICP_E_NO_DEVICE;
-    void *ds = nullptr, *dr = nullptr;
+    // one staging block: [send | recv]; 256-byte aligned halves
+    const size_t off = (bytes + 255) / 256 * 256;
+    char* st = (char*)c->staging(off + bytes * (size_t)c->world);
+    if (!st) return PWICP_E_NOMEM;
+    void *ds = st, *dr = st + off;
     int rc = PWICP_OK;
-    if (hipMalloc(&ds, bytes) != hipSuccess || hipMalloc(&dr, bytes * (size_t)c->world) != hipSuccess) rc = PWICP_E_NOMEM;
-    if (rc == PWICP_OK && hipMemcpyAsync(ds, send, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = PWICP_E_NO_DEVICE;
+    if (hipMemcpyAsync(ds, send, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = PWICP_E_NO_DEVICE;
     if (rc == PWICP_OK && g_rccl.AllGather(ds, dr, bytes, ncclChar, c->comm, c->stream) != ncclSuccess) rc = PWICP_E_INTERNAL;
     if (rc == PWICP_OK && hipMemcpyAsync(recv, dr, bytes * (size_t)c->world, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = PWICP_E_NO_DEVICE;
     if (hipStreamSynchronize(c->stream) != hipSuccess && rc == PWICP_OK) rc = PWICP_E_NO_DEVICE;
-    if (ds) (void)hipFree(ds);
-    if (dr) (void)hipFree(dr);
     return rc;
 }
 
 PWICP_API int pwicp_comm_broadcast(pwicp_comm* c, void* buf, size_t bytes, int root) {
     if (!c || !buf || bytes == 0 || root < 0 || root >= c->world) return PWICP_E_INVALID;
     if (hipSetDevice(c->device) != hipSuccess) return PWICP_E_NO_DEVICE;
-    void* d = nullptr;
+    void* d = c->staging(bytes);
+    if (!d) return PWICP_E_NOMEM;
     int rc = PWICP_OK;
-    if (hipMalloc(&d, bytes) != hipSuccess) rc = PWICP_E_NOMEM;
-    if (rc == PWICP_OK && c->rank == root && hipMemcpyAsync(d, buf, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = PWICP_E_NO_DEVICE;
+    if (c->rank == root && hipMemcpyAsync(d, buf, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = PWICP_E_NO_DEVICE;
     if (rc == PWICP_OK && g_rccl.Broadcast(d, d, bytes, ncclChar, root, c->comm, c->stream) != ncclSuccess) rc = PWICP_E_INTERNAL;
     if (rc == PWICP_OK && hipMemcpyAsync(buf, d, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = PWICP_E_NO_DEVICE;
     if (hipStreamSynchronize(c->stream) != hipSuccess && rc == PWICP_OK) rc = PWICP_E_NO_DEVICE;
-    if (d) (void)hipFree(d);
     return rc;
 }
 
@@ -182,7 +251,8 @@ PWICP_API bool pwicp_series_run_distributed(const char* confile, int startEpoch,
             }
             if (!agree(ok)) break;
             if (pwicp_comm_broadcast(comm, &n_t, sizeof(n_t), 0) != PWICP_OK) { ok = false; }
-            if (ok) targets.resize((size_t)std::max(n_t, 1));
+            if (!agree(ok)) break;               // a rank whose first broadcast failed must not leave the others in the second
+            targets.resize((size_t)std::max(n_t, 1));
             if (ok && pwicp_comm_broadcast(comm, targets.data(), sizeof(int32_t) * (size_t)n_t, 0) != PWICP_OK) ok = false;
             if (!agree(ok)) break;
         }
