@@ -22,6 +22,8 @@ struct pwicp_context {
     std::string err;
     int n_cu = 256;
     std::shared_ptr<void> scratch;        // grow-only work buffers a stage keeps between calls (csrc/frontend.hip), freed with the context
+    std::shared_ptr<void> host_slot;      // what the host stages keep with a context between calls (host/registration.cpp: the
+                                          // auxiliary contexts of the front ends), freed with the context
     void set_err(const char* where, hipError_t e) {
         char buf[512];
         snprintf(buf, sizeof(buf), "%s: %s", where, hipGetErrorString(e));
@@ -37,7 +39,7 @@ struct pwicp_context {
         hipError_t e__ = (expr);                                            \
         if (e__ != hipSuccess) {                                            \
             (ctx)->set_err(__FILE__ ":" PW_STR(__LINE__) " " #expr, e__);   \
-            return PWICP_E_NO_DEVICE;                                       \
+            return e__ == hipErrorOutOfMemory ? PWICP_E_NOMEM : PWICP_E_NO_DEVICE; \
         }                                                                   \
     } while (0)
 #define PWCHK(expr)                        \

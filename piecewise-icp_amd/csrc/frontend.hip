@@ -1534,6 +1534,15 @@ int segment_from_device_graph(pwicp_context* ctx, FeTrace& tr, const float* clou
 
 }  // namespace
 
+void pw_frontend_release_workspace(pwicp_context* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->scratch.reset();
+}
+
+std::shared_ptr<void>* pw_context_host_slot(pwicp_context* ctx) { return ctx ? &ctx->host_slot : nullptr; }
+
 // The whole front end of one cloud (S.cpp:18-68).  Device: k-NN graph, neighbourhood scatter, occupied cells, fusion,
 // refinement, relabel.  Host: only the closed-form eigen step of the normals (libm's pow / acos / cos decide label bits).
 int pw_frontend_segment_device(pwicp_context* ctx, const float* cloud_xyz4, int n, int k, float cell_edge, float sv_resolution,
@@ -1613,10 +1622,19 @@ int pw_frontend_segment_device(pwicp_context* ctx, const float* cloud_xyz4, int 
         HIPCHK(ctx, cnt.reserve(1));
         HIPCHK(ctx, hipMemsetAsync(table.p, 0xff, sizeof(unsigned long long) * cap, st));
         HIPCHK(ctx, hipMemsetAsync(cnt.p, 0, sizeof(int), st));
+        if (std::max(s1, std::max(s2, s3)) > (1 << 21)) {
+            // the 64-bit cell key packs 21 bits per axis: beyond that (extent / resolution > 2 M cells on an axis; GridSample
+            // allows INT_MAX) the cells are counted by the host pass on the downloaded points
+            std::vector<FePt> hP((size_t)n);
+            HIPCHK(ctx, hipMemcpyAsync(hP.data(), dP.p, sizeof(FePt) * (size_t)n, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            n_sv = pwhost::fe_count_occupied_cells(hP.data(), n, res);
+        } else {
         hipLaunchKernelGGL(k_fe_count_cells, grid1(n), dim3(256), 0, st, dP.p, n, mn[0], mn[1], mn[2], res, s1, s2, s3, table.p,
                            (unsigned long long)(cap - 1), cnt.p);
         HIPCHK(ctx, hipMemcpyAsync(&n_sv, cnt.p, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
+        }
     }
     tr.lap("occupied cells");
     return segment_from_device_graph(ctx, tr, cloud_xyz4, dP.p, d_nb.p, k, n, res, n_sv, labels, n_supervoxels);

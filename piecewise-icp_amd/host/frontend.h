@@ -3,6 +3,7 @@
 #pragma once
 
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 namespace pwhost {
@@ -32,3 +33,7 @@ void fe_refine_host(const FePt* P, const int32_t* nb, int k, int n, double resol
 struct pwicp_context;
 int pw_frontend_segment_device(pwicp_context* ctx, const float* cloud_xyz4, int n, int k, float cell_edge, float sv_resolution,
                                int32_t* labels, int* n_supervoxels);
+// frees the grow-only device / pinned work space the front end keeps with `ctx` (it is rebuilt by the next call)
+void pw_frontend_release_workspace(pwicp_context* ctx);
+// a slot the host stages may hang helpers on that should live as long as the context (destroyed with it)
+std::shared_ptr<void>* pw_context_host_slot(pwicp_context* ctx);

@@ -10,6 +10,7 @@
 // Pipeline per pair: load PCD -> VoxelGrid + SOR -> subtract the target centroid -> supervoxel labels (host front
 // end) -> pwicp_pair_create / pwicp_pair_run (the fine-registration loop on the GPU) -> T_final = S^-1 T S -> files.
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -149,7 +150,21 @@ bool prepare_labels(Prepared* c, AuxContexts* aux) {
         pwicp_context* ctx = aux->acquire();
         if (!ctx) { std::cerr << "Error: no usable HIP device (pwicp has no CPU fallback).\n"; return false; }
         c->lab.resize((size_t)c->m);
-        const int rc = pw_frontend_segment_device(ctx, c->p.data(), c->m, kNN, 2.0f * c->Res, c->SVRes, c->lab.data(), &c->nsv);
+        // the device pipeline indexes its lists with 32 bits (n * k < 2^31) and wants ~1 KB of work space per point; a cloud
+        // beyond either limit takes the serial passes of the same front end (host/frontend.cpp: same labels) from a device
+        // k-NN graph instead of failing - what the fusion does anyway when a search outgrows its queue
+        const bool fits = (long long)c->m * kNN <= (long long)INT_MAX - 64;
+        int rc = fits ? pw_frontend_segment_device(ctx, c->p.data(), c->m, kNN, 2.0f * c->Res, c->SVRes, c->lab.data(), &c->nsv)
+                      : PWICP_E_NOMEM;
+        if (rc == PWICP_E_NOMEM) {
+            std::cerr << "[pwicp] front end: " << (fits ? "device work space does not fit" : "cloud beyond the 32-bit list limit of the device pipeline")
+                      << " (" << c->m << " points); serial fusion / refinement on the host for this cloud.\n";
+            pw_frontend_release_workspace(ctx);
+            rc = c->nb.reserve((size_t)c->m * kNN) ? PWICP_OK : PWICP_E_NOMEM;
+            if (rc == PWICP_OK) rc = pwicp_knn(ctx, c->p.data(), c->m, kNN, 2.0f * c->Res, c->nb.data());
+            if (rc == PWICP_OK) rc = segment_from_knn(c->p.data(), c->m, c->nb.data(), kNN, c->SVRes, c->lab.data(), &c->nsv);
+            c->nb.release();
+        }
         if (rc != PWICP_OK) std::cerr << "Error: supervoxel segmentation failed: " << pwicp_last_error(ctx) << "\n";
         aux->release(ctx);
         c->segmented = rc == PWICP_OK;
@@ -212,7 +227,11 @@ bool register_pair(pwicp_context* ctx, const std::vector<float>& cloud1, const s
     std::cout << "PC-1 avg. point spacing: " << Res1 << "\t PC-2 avg. point spacing: " << Res2 << std::endl << std::endl;
     const float SVRes1 = cfg.isSetResSVsize ? cfg.SVsize1 : Res1 * 10, SVRes2 = cfg.isSetResSVsize ? cfg.SVsize2 : Res2 * 10;   // R.cpp:635-640
     Prepared t, s;
-    AuxContexts aux(pwicp_context_device(ctx));
+    // the streams (and GB-sized work spaces) of the front ends are kept with the context, not rebuilt per call
+    std::shared_ptr<void>* slot = pw_context_host_slot(ctx);
+    if (!slot) return false;
+    if (!*slot) *slot = std::shared_ptr<void>(new AuxContexts(pwicp_context_device(ctx)), [](void* p) { delete static_cast<AuxContexts*>(p); });
+    AuxContexts& aux = *static_cast<AuxContexts*>(slot->get());
     if (!prepare_gpu(ctx, cloud1, Res1, SVRes1, sor_mult, nullptr, &t)) return false;
     bool ok1 = true;
     std::thread th([&] { ok1 = prepare_labels(&t, &aux); });    // the target's front end runs beside the source's preparation and front end
