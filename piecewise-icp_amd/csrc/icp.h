@@ -1,5 +1,6 @@
 // Inner ICP / VCM device work buffers and launch wrappers (icp.hip).
 #pragma once
+#include "classify_dev.h"
 #include "common.h"
 
 struct IcpState {
@@ -38,11 +39,16 @@ struct IcpWork {
     DevBuf<IcpState> state;
     DevBuf<unsigned> counter;      // blocks finished in the current launch (last one solves)
     DevBuf<double> qx, vcm;
+    DevBuf<unsigned long long> agg; // per-block aggregates of the fused classification launch (k_classify_icp0)
+    unsigned epoch = 0;            // tag of the current fused launch's aggregates
     int reserve(pwicp_context* ctx, int ns_max);
 };
 
 int pw_icp_enqueue(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
                    int ns_max, const unsigned* ns_dev, double euclid_eps, int n_iter, const IcpMail* mail = nullptr);
+// classification + order-preserving compaction of the stable patches + inner-ICP iteration 0, one launch (icp.hip)
+int pw_classify_icp0_launch(pwicp_context* ctx, const ClassifyArgs& a, int* d_stable, float4* d_stCT, float4* d_stN, IcpWork* w,
+                            unsigned* d_slot, double euclid_eps, const IcpMail* mail = nullptr);
 int pw_icp_run(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w, int ns,
                double euclid_eps, float* T16, int* iters_out);
 int pw_vcm_enqueue(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,

@@ -14,6 +14,7 @@
 //                and — in the last launch of a batch — the iteration record to the host mailbox.
 // Launches after convergence are no-ops (done flag), so iterations are enqueued in small batches.
 // calTransParaVCM is two launches of the same shape (k_vcm_normal, k_vcm_finish).
+#include "classify_dev.h"
 #include "common.h"
 #include "devmath.h"
 #include "icp.h"
@@ -25,6 +26,18 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kNSums = 28;    // 21 ATA (upper triangle) + 6 ATb + 1 sum(d2)
+
+// -DPWICP_KTRACE: wall-clock stamps (s_memrealtime, 10 ns) of the phases of the fused launch, read by tools/ktrace.py
+#ifdef PWICP_KTRACE
+__device__ unsigned long long pw_ktrace[32];
+#define KT_STAMP(slot_) do { if ((threadIdx.x & 63) == 0) pw_ktrace[slot_] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define KT_MIN(slot_) do { if (threadIdx.x == 0) atomicMin(&pw_ktrace[slot_], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
+#define KT_MAX(slot_) do { if (threadIdx.x == 0) atomicMax(&pw_ktrace[slot_], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
+#else
+#define KT_STAMP(slot_) do { } while (0)
+#define KT_MIN(slot_) do { } while (0)
+#define KT_MAX(slot_) do { } while (0)
+#endif
 
 __device__ __forceinline__ void block_reduce_store(double* v, int nv, double* __restrict__ partial_out) {
     __shared__ double sh[kBlock / 64][kNSums];
@@ -73,7 +86,23 @@ __device__ __forceinline__ void icp_send_mail(const IcpMail& m, const IcpState* 
 constexpr int kAccBlock = 1024;                       // 128 points per block: few partials for the solve kernel
 constexpr int kAccPts = kAccBlock / kGroup;
 
-__device__ void icp_solve_tail(IcpState* st, const double* partials, int ns, double mse_rel);
+__device__ __forceinline__ void icp_solve_tail(IcpState* st, const double* partials, int nblocks, int ns, double mse_rel, bool first);
+
+// Stores that other blocks / the mailbox wave read back in the SAME launch go through device-coherent (write-through) atomics
+// and are read back with device-coherent atomic loads; the writer drains its store queue (s_waitcnt vmcnt(0)) before it
+// signals (block counter, mailbox sequence number).  That is what stands in for a release / acquire fence pair here: a fence
+// writes the L2 back and invalidates the L1 (~3.5 us a pair on MI355X), which is as long as the rest of the tail.
+// Data handled this way - and ONLY to be touched this way inside a launch: the block partials (`partials`), the block
+// aggregates of the fused classification (`agg`), the slot words [0..3] and the whole IcpState.  gfx9 counts stores in vmcnt
+// (no separate vscnt), which the drain relies on: this file is gfx950 only (see the static_assert below).
+#if !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
+#error "icp.hip relies on gfx9 memory-counter behaviour (stores counted by vmcnt): build for gfx950 only"
+#endif
+template <typename T>
+__device__ __forceinline__ void coh_store(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ T coh_load(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // One inner iteration in ONE launch: every block accumulates its 128 points; the block that finishes last (device
 // counter) reduces the partials in a fixed order and solves the 6x6 system — the former second kernel, whose launch
@@ -144,19 +173,20 @@ __global__ void __launch_bounds__(kAccBlock) k_icp_iter(GridDesc g, const float4
     // are write-through stores read back with device-coherent loads, so no fence (= L2 write-back + L1 invalidate, ~3.5 us
     // a pair) is needed on either side: draining the store queue before the count is the release.
     if (threadIdx.x >= 64) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    drain_stores();
     unsigned last = 0;
+    const unsigned nact = (unsigned)((ns + kAccPts - 1) / kAccPts);
     if (threadIdx.x == 0) {
-        const unsigned nact = (unsigned)((ns + kAccPts - 1) / kAccPts);
         const unsigned prev = atomicAdd(counter, 1u);
         last = (prev == nact - 1u) ? 1u : 0u;
         if (last) *counter = 0u;                             // re-armed for the next launch
     }
     last = (unsigned)__shfl((int)last, 0);
     if (!last) return;
-    icp_solve_tail(st, partials, ns, mse_rel);
+    icp_solve_tail(st, partials, (int)nact, ns, mse_rel, false);
     if (mail.dst) {
-        __threadfence();
+        drain_stores();                                      // the state went out through coherent stores (icp_solve_tail)
+        wave_sync();
         icp_send_mail(mail, st);
     }
 }
@@ -211,8 +241,10 @@ __device__ __forceinline__ void inv6_wave(double (*A)[6], double (*inv)[6], int*
 
 // fixed-order sum of the block partials, 6x6 LU inverse, x = inv*ATb, T from (alpha,beta,gamma,t), convergence tests of
 // pcl::registration::DefaultConvergenceCriteria.  Runs on ONE wave (threadIdx.x < 64).
-__device__ void icp_solve_tail(IcpState* st, const double* partials, int ns, double mse_rel) {
-    const int nblocks = (ns + kAccPts - 1) / kAccPts;
+// `first`: iteration 0 of a call (the state is not read: final = identity, no previous MSE).
+// (inlined on purpose: a call makes the kernel use scratch memory, and a dispatch that needs scratch behind one that does not -
+// or the other way round - costs ~6 us of dispatch latency on MI355X: two such bubbles per outer iteration)
+__device__ __forceinline__ void icp_solve_tail(IcpState* st, const double* partials, int nblocks, int ns, double mse_rel, bool first) {
     __shared__ double sums[kNSums], half[2][kNSums];
     __shared__ double A[6][6], inv[6][6], x[6], sc[6];
     __shared__ int piv[8];
@@ -237,6 +269,7 @@ __device__ void icp_solve_tail(IcpState* st, const double* partials, int ns, dou
         half[h][k] = s;
     }
     wave_sync();
+    KT_STAMP(6);
     if (t < kNSums) sums[t] = half[0][t] + half[1][t];
     wave_sync();
     if (t < 36) {           // symmetric fill from the 21 upper-triangle sums
@@ -245,6 +278,7 @@ __device__ void icp_solve_tail(IcpState* st, const double* partials, int ns, dou
     }
     wave_sync();
     inv6_wave(A, inv, piv, &singular);
+    KT_STAMP(7);
     if (t < 6) {
         double s = 0.0;
         for (int c = 0; c < 6; ++c) s += inv[t][c] * sums[21 + c];
@@ -267,7 +301,8 @@ __device__ void icp_solve_tail(IcpState* st, const double* partials, int ns, dou
         T[3] = (float)x[3]; T[7] = (float)x[4]; T[11] = (float)x[5];
         T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
     }
-    if (t < 16) F[t] = st->Tfinal[t];
+    KT_STAMP(8);
+    if (t < 16) F[t] = first ? ((t % 5 == 0) ? 1.f : 0.f) : st->Tfinal[t];
     wave_sync();
     if (t < 16) {           // final = T * final (Eigen order), one element per lane
         const int i = t / 4, j = t % 4;
@@ -275,21 +310,227 @@ __device__ void icp_solve_tail(IcpState* st, const double* partials, int ns, dou
         s = s + T[4 * i + 1] * F[4 + j];
         s = s + T[4 * i + 2] * F[8 + j];
         s = s + T[4 * i + 3] * F[12 + j];
-        st->Tfinal[t] = s;
-        st->T[t] = T[t];
+        coh_store(&st->Tfinal[t], s);
+        coh_store(&st->T[t], T[t]);
     }
     if (t != 0) return;
-    const int iters = st->iters + 1;
-    st->iters = iters;
+    const int iters = (first ? 0 : st->iters) + 1;
+    const double prev_mse = first ? 1.7976931348623157e308 : st->prev_mse;
+    coh_store(&st->iters, iters);
+    if (first) { coh_store(&st->reason, 0); coh_store(&st->pad, 0); }
     // pcl::registration::DefaultConvergenceCriteria<float>::hasConverged()
-    if (iters >= 100) { st->done = 1; st->reason = 1; return; }
+    int done = 0, reason = 0;
     const double cos_angle = 0.5 * (double)(T[0] + T[5] + T[10] - 1.0f);
     const double translation_sqr = (double)(T[3] * T[3] + T[7] * T[7] + T[11] * T[11]);
-    if (cos_angle >= 1.0 - 1e-8 && translation_sqr <= 1e-8) { st->done = 1; st->reason = 2; return; }
     const double mse = sums[27] / (double)ns;
-    if (fabs(mse - st->prev_mse) < 1e-12) { st->done = 1; st->reason = 3; return; }
-    if (fabs(mse - st->prev_mse) / st->prev_mse < mse_rel) { st->done = 1; st->reason = 4; return; }
-    st->prev_mse = mse;
+    if (iters >= 100) { done = 1; reason = 1; }
+    else if (cos_angle >= 1.0 - 1e-8 && translation_sqr <= 1e-8) { done = 1; reason = 2; }
+    else if (fabs(mse - prev_mse) < 1e-12) { done = 1; reason = 3; }
+    else if (fabs(mse - prev_mse) / prev_mse < mse_rel) { done = 1; reason = 4; }
+    if (done) coh_store(&st->reason, reason);
+    else coh_store(&st->prev_mse, mse);
+    if (first && done) coh_store(&st->prev_mse, prev_mse);
+    if (first || done) coh_store(&st->done, done);
+}
+
+// ---- classification + compaction + inner-ICP iteration 0 in ONE launch -------------------------------------------------------
+// Steps (2)-(5a) of an outer iteration (R.cpp:750-877) used to be three launches (classify, compact, first k_icp_iter); the
+// chain of dependent launches is what an outer iteration costs at 10^4 patches, so they are one launch now:
+//   classify   one lane per source patch (classify_dev.h): stable flag, LoD min / max into the slot;
+//   compact    order-preserving: wave scan, block scan, and the block's base = the stable counts of all blocks before it, read
+//              from their published aggregates (one 64-bit word per block: epoch | stable points | stable patches; a block
+//              only ever waits for blocks with smaller indices, which were dispatched before it);
+//   ICP it. 0  the correspondences of PCL's first inner iteration ARE the centroid matches the front launch has just found
+//              (same queries - the untransformed stable centroids - against the same target-centroid grid), so the LLS row of
+//              a stable patch is formed by its own lane without another search; 28 sums per block in a fixed order (xor tree
+//              in the wave, waves in order), blocks in order by the block that finishes last, which also writes the totals
+//              into the slot, solves the 6x6 system (icp_solve_tail, first = true) and - when no further k_icp_iter launch
+//              was enqueued behind it - sends the batch's mailbox message.
+// `epoch` tags the aggregates of THIS launch (a per-pair launch counter, never 0): words left by earlier launches do not match.
+constexpr int kClsBlock = 256;
+constexpr int kClsSegs = 9;                                   // 28 sums x 9 segments = 252 of the block's 256 threads
+constexpr int kClsSegLen = (kClsBlock + kClsSegs - 1) / kClsSegs;
+
+
+__device__ __forceinline__ unsigned long long agg_pack(unsigned epoch, int n, int pts) {
+    return ((unsigned long long)(epoch & 0xffffu) << 48) | ((unsigned long long)(unsigned)pts << 16) | (unsigned long long)(unsigned)n;
+}
+
+__global__ void __launch_bounds__(kClsBlock) k_classify_icp0(ClassifyArgs a, int* __restrict__ stable, float4* __restrict__ stCT,
+                                                             float4* __restrict__ stN, float4* __restrict__ wsrc,
+                                                             float4* __restrict__ wsrcn, unsigned* __restrict__ slot,
+                                                             unsigned long long* __restrict__ agg, unsigned epoch, IcpState* st,
+                                                             double* __restrict__ partials, unsigned* __restrict__ counter,
+                                                             double mse_rel, IcpMail mail) {
+    __shared__ int s_n[kClsBlock / 64], s_p[kClsBlock / 64], s_b[kClsBlock / 64];
+    __shared__ float s_lod[kClsBlock / 64][2];
+    __shared__ float s_row[kClsBlock][8];
+    __shared__ double s_part[kClsSegs][kNSums];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int me = blockIdx.x, nb = gridDim.x;
+    const int i = me * kClsBlock + tid;
+    if (blockIdx.x == 0 && threadIdx.x == 0) KT_STAMP(0);
+    float lod = 0.0f;
+    int f = 0, np = 0;
+    if (i < a.m2) {
+        f = pwdev::classify_patch(a, i, &lod);
+        stable[i] = f;
+        np = a.off2[i + 1] - a.off2[i];
+    }
+    // block aggregate: stable patches / their points, LoD min / max
+    int in = f;                                      // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(in, o);
+        if (lane >= o) in += up;
+    }
+    int pts = f ? np : 0;
+    float lo = (i < a.m2) ? lod : INFINITY, hi = (i < a.m2) ? lod : 0.0f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        pts += __shfl_xor(pts, o);
+        lo = fminf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
+    if (lane == 63) s_n[wave] = in;
+    if (lane == 0) { s_p[wave] = pts; s_lod[wave][0] = lo; s_lod[wave][1] = hi; }
+    __syncthreads();
+    KT_MAX(1);
+    int blk_n = 0, blk_p = 0, wave_off = 0;
+#pragma unroll
+    for (int w = 0; w < kClsBlock / 64; ++w) {
+        if (w < wave) wave_off += s_n[w];
+        blk_n += s_n[w]; blk_p += s_p[w];
+    }
+    if (tid == 0) {
+        float blo = INFINITY, bhi = 0.0f;
+        for (int w = 0; w < kClsBlock / 64; ++w) { blo = fminf(blo, s_lod[w][0]); bhi = fmaxf(bhi, s_lod[w][1]); }
+        if (bhi > 0.0f) {                                // positive floats order like their bit patterns
+            const unsigned r0 = atomicMin(&slot[0], __float_as_uint(blo));
+            const unsigned r1 = atomicMax(&slot[1], __float_as_uint(bhi));
+            asm volatile("" ::"v"(r0), "v"(r1));        // PERFORMED before this block counts itself below
+        }
+        coh_store(&agg[me], agg_pack(epoch, blk_n, blk_p));
+    }
+    // The LLS rows of inner iteration 0 and their 28 sums need no position: they go first, the wait for the preceding blocks'
+    // aggregates (published about now by all of them) comes after.  Row = [a b c nx ny nz | d | d2], float-valued as PCL forms
+    // it; all 0 for a lane without a stable patch.
+    {
+        float row[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (f) {
+            const float4 c = a.ct2[i];
+            const int j = max(a.mCT[i], 0);
+            const float4 t = a.ct1[j], tn = a.ct1n[j];
+            const float sx = c.x, sy = c.y, sz = c.z, dx = t.x, dy = t.y, dz = t.z, nx = tn.x, ny = tn.y, nz = tn.z;
+            row[0] = nz * sy - ny * sz;
+            row[1] = nx * sz - nz * sx;
+            row[2] = ny * sx - nx * sy;
+            row[3] = nx; row[4] = ny; row[5] = nz;
+            row[6] = nx * dx + ny * dy + nz * dz - nx * sx - ny * sy - nz * sz;
+            row[7] = a.dCT[i];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s_row[tid][e] = row[e];
+    }
+    __syncthreads();
+    // thread (k, seg): sum k of the 28 (21 upper-triangle products row by row, 6 row * d, sum of d2 - the order of k_icp_iter)
+    // over the patches of segment seg, in patch order; then the segments in order: a fixed summation order
+    if (tid < kNSums * kClsSegs) {
+        const int k = tid % kNSums, seg = tid / kNSums;
+        int p_ = 0, q_ = 0;
+        if (k < 21) {
+            int kk = k;
+            while (kk >= 6 - p_) { kk -= 6 - p_; ++p_; }
+            q_ = p_ + kk;
+        } else if (k < 27) { p_ = k - 21; q_ = 6; }
+        else { p_ = 7; q_ = -1; }
+        double acc = 0.0;
+        const int lo = seg * kClsSegLen, hi = min(lo + kClsSegLen, kClsBlock);
+        for (int r = lo; r < hi; ++r) {
+            const float u = s_row[r][p_];
+            double v;
+            if (q_ < 0) v = (double)u;                                   // d2
+            else {
+                const float w = s_row[r][q_];
+                // PCL's ATA / ATb: products among the normal's components are float products (widened afterwards), everything
+                // that involves a, b, c or d is a double product of the widened float values
+                v = (k < 21 && p_ >= 3) ? (double)(u * w) : (double)u * (double)w;
+            }
+            acc += v;
+        }
+        s_part[seg][k] = acc;
+    }
+    __syncthreads();
+    if (tid < kNSums) {
+        double acc = s_part[0][tid];
+#pragma unroll
+        for (int g = 1; g < kClsSegs; ++g) acc += s_part[g][tid];
+        coh_store(&partials[(size_t)me * kNSums + tid], acc);
+    }
+    // base: stable patches of the blocks before this one
+    int bn = 0;
+    for (int b = tid; b < me; b += kClsBlock) {
+        unsigned long long v = coh_load(&agg[b]);
+        while ((unsigned)(v >> 48) != (epoch & 0xffffu)) { __builtin_amdgcn_s_sleep(1); v = coh_load(&agg[b]); }
+        bn += (int)(v & 0xffffu);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bn += __shfl_xor(bn, o);
+    if (lane == 0) s_b[wave] = bn;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < kClsBlock / 64; ++w) base += s_b[w];
+    KT_MAX(2);
+    // compacted outputs (generateCentroidCloudWithPatchNormals semantics for the normal: (0,0,1) unless > 6 points and valid)
+    if (f) {
+        const float4 c = a.ct2[i];
+        float4 n = a.nrm2[i];
+        if (!(np > 6 && n.w != 0.0f)) n = make_float4(0.f, 0.f, 1.f, 0.f);
+        n.w = 0.f;
+        const int pos = base + wave_off + in - 1;
+        stCT[pos] = c; stN[pos] = n;
+        wsrc[pos] = c; wsrcn[pos] = n;
+    }
+    if (tid >= 64) return;
+    KT_MAX(3);
+    drain_stores();
+    unsigned last = 0;
+    if (tid == 0) {
+        const unsigned prev = atomicAdd(counter, 1u);
+        last = (prev == (unsigned)nb - 1u) ? 1u : 0u;
+        if (last) *counter = 0u;
+    }
+    last = (unsigned)__shfl((int)last, 0);
+    if (!last) return;
+    KT_STAMP(4);
+    // totals (every aggregate is published by now), slot words, state, solve
+    int tn = 0, tp = 0;
+    for (int b = tid; b < nb; b += 64) {
+        const unsigned long long v = coh_load(&agg[b]);
+        tn += (int)(v & 0xffffu); tp += (int)((v >> 16) & 0xffffffffu);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { tn += __shfl_xor(tn, o); tp += __shfl_xor(tp, o); }
+    if (tid == 0) { coh_store(&slot[2], (unsigned)tn); coh_store(&slot[3], (unsigned)tp); }
+    if (tn < 3) {                  // min_number_correspondences_ = 3: no estimate (the host stops at < 4 stable patches anyway)
+        if (tid < 16) { coh_store(&st->T[tid], (tid % 5 == 0) ? 1.f : 0.f); coh_store(&st->Tfinal[tid], (tid % 5 == 0) ? 1.f : 0.f); }
+        if (tid == 0) {
+            coh_store(&st->iters, 0); coh_store(&st->reason, 0); coh_store(&st->pad, 0);
+            coh_store(&st->prev_mse, 1.7976931348623157e308);
+            coh_store(&st->done, 1);
+        }
+    } else {
+        KT_STAMP(5);
+        icp_solve_tail(st, partials, nb, tn, mse_rel, true);
+    }
+    KT_STAMP(9);
+    if (mail.dst) {
+        drain_stores();
+        wave_sync();
+        icp_send_mail(mail, st);
+    }
+    KT_STAMP(10);
 }
 
 __global__ void k_icp_init(IcpState* st) {
@@ -481,6 +722,35 @@ int IcpWork::reserve(pwicp_context* ctx, int ns_max) {
     HIPCHK(ctx, hipMemsetAsync(counter.p, 0, sizeof(unsigned), ctx->stream));
     HIPCHK(ctx, qx.reserve(48));
     HIPCHK(ctx, vcm.reserve(36));
+    HIPCHK(ctx, agg.reserve((size_t)div_up(std::max(ns_max, 1), kClsBlock) + 1));
+    HIPCHK(ctx, hipMemsetAsync(agg.p, 0, sizeof(unsigned long long) * ((size_t)div_up(std::max(ns_max, 1), kClsBlock) + 1), ctx->stream));
+    return PWICP_OK;
+}
+
+#ifdef PWICP_KTRACE
+extern "C" __attribute__((visibility("default"))) int pwicp_debug_ktrace(unsigned long long* out32, int reset) {
+    if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(pw_ktrace), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[32];
+        for (int i = 0; i < 32; ++i) z[i] = 0ull;
+        z[0] = ~0ull;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pw_ktrace), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
+// classification + compaction + inner-ICP iteration 0 (k_classify_icp0); `mail`: sent by this launch (no k_icp_iter follows
+// in the batch)
+int pw_classify_icp0_launch(pwicp_context* ctx, const ClassifyArgs& a, int* d_stable, float4* d_stCT, float4* d_stN, IcpWork* w,
+                            unsigned* d_slot, double euclid_eps, const IcpMail* mail) {
+    if (a.m2 <= 0) return PWICP_OK;
+    w->epoch = (w->epoch % 0xffffu) + 1u;          // 1 .. 65535, never 0 (the buffer is zeroed once)
+    IcpMail none{};
+    hipLaunchKernelGGL(k_classify_icp0, dim3(div_up(a.m2, kClsBlock)), dim3(kClsBlock), 0, ctx->stream, a, d_stable, d_stCT, d_stN,
+                       w->src.p, w->srcn.p, d_slot, w->agg.p, w->epoch, w->state.p, w->partials.p, w->counter.p, euclid_eps,
+                       mail ? *mail : none);
+    HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }
 

@@ -41,152 +41,6 @@ inline float ord2f_host(unsigned u) {
 // scal layout (unsigned words): [0] LoDmin bits, [1] LoDmax bits, [2] n stable, [3] n stable points,
 //                               [4..6] bbox min (ordered), [7..9] bbox max (ordered)
 
-// Steps (2)-(4) of PwICP_singleIteration for one source patch per lane (R.cpp:750-862).
-__global__ void __launch_bounds__(kBlock) k_classify(
-    int m2, const int* __restrict__ mCT, const float* __restrict__ dCT, const int* __restrict__ mBP,
-    const float* __restrict__ dBP, const float* __restrict__ ctstd1, const float* __restrict__ bpstd2,
-    const float4* __restrict__ nrm1, const float4* __restrict__ ct1, const float4* __restrict__ ct2,
-    const float4* __restrict__ bp2, const int* __restrict__ off2, float currDT, float DTmin, float DTctct,
-    int* __restrict__ stable, int* __restrict__ blk_cnt, unsigned* __restrict__ scal) {
-    __shared__ int s_cnt[kBlock / 64][2];
-    __shared__ float s_lod[kBlock / 64][2];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    float lod_min = INFINITY, lod_max = 0.0f;
-    int st_flag = 0, st_pts = 0;
-    if (i < m2) {
-        // (2) level of detection, R.cpp:756-766
-        const float maxLoD = DTmin * 2.0f, minLoD = DTmin;
-        const int j = max(mCT[i], 0);                  // (-1 = empty target: rejected on the host before the launch)
-        const float s1 = ctstd1[j], s2 = bpstd2[i];
-        float LoD = (float)(1.96 * (double)sqrtf(s1 * s1 + s2 * s2));
-        if (LoD > maxLoD) LoD = maxLoD; else if (LoD < minLoD) LoD = minLoD;
-        lod_min = LoD; lod_max = LoD;
-        // (3) point-to-plane distances with the matched TARGET patch normal, R.cpp:781-812
-        const float4 q = ct2[i];
-        float4 n = nrm1[j], t = ct1[j];
-        float resCT;
-        if (n.w != 0.0f) {
-            const float dx = t.x - q.x, dy = t.y - q.y, dz = t.z - q.z;
-            resCT = fabsf(dx * n.x + dy * n.y + dz * n.z);
-        } else resCT = sqrtf(dCT[i]);
-        const float p2pt = sqrtf(dCT[i]);
-        // (4) R.cpp:826-862; `thr < dist` fails, exactly the reference's comparisons
-        const float thr = (currDT <= LoD) ? LoD : currDT;
-        bool pass = !(thr < resCT);
-        // the six boundary points: all index loads, then all gathers, in flight together (the kernel is a chain of
-        // dependent round trips, not throughput)
-        int jb[6];
-        float4 b[6], nn[6], tt[6];
-        float db[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { jb[k] = max(mBP[6 * i + k], 0); b[k] = bp2[6 * i + k]; db[k] = dBP[6 * i + k]; }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { nn[k] = nrm1[jb[k]]; tt[k] = ct1[jb[k]]; }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            float res;
-            if (nn[k].w != 0.0f) {
-                const float dx = tt[k].x - b[k].x, dy = tt[k].y - b[k].y, dz = tt[k].z - b[k].z;
-                res = fabsf(dx * nn[k].x + dy * nn[k].y + dz * nn[k].z);
-            } else res = sqrtf(db[k]);
-            if (thr < res) pass = false;
-        }
-        st_flag = (pass && (p2pt < DTctct)) ? 1 : 0;
-        stable[i] = st_flag;
-        st_pts = st_flag ? (off2[i + 1] - off2[i]) : 0;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        lod_min = fminf(lod_min, __shfl_xor(lod_min, o));
-        lod_max = fmaxf(lod_max, __shfl_xor(lod_max, o));
-        st_flag += __shfl_xor(st_flag, o);
-        st_pts += __shfl_xor(st_pts, o);
-    }
-    // stable patches / points of this block, for the parallel compaction that follows
-    if ((threadIdx.x & 63) == 0) {
-        s_cnt[threadIdx.x >> 6][0] = st_flag; s_cnt[threadIdx.x >> 6][1] = st_pts;
-        s_lod[threadIdx.x >> 6][0] = lod_min; s_lod[threadIdx.x >> 6][1] = lod_max;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int a = 0, b = 0;
-        float lo = INFINITY, hi = 0.0f;
-        for (int w = 0; w < kBlock / 64; ++w) {
-            a += s_cnt[w][0]; b += s_cnt[w][1];
-            lo = fminf(lo, s_lod[w][0]); hi = fmaxf(hi, s_lod[w][1]);
-        }
-        blk_cnt[2 * blockIdx.x] = a;
-        blk_cnt[2 * blockIdx.x + 1] = b;
-        if (hi > 0.0f) {                                  // one atomic pair per block: same-line atomics serialise
-            atomicMin(&scal[0], __float_as_uint(lo));     // positive floats order like their bit patterns
-            atomicMax(&scal[1], __float_as_uint(hi));
-        }
-    }
-}
-
-// Order-preserving compaction of the stable patches, one block per 256 patches (same grid as k_classify, which
-// left the per-block counts in blk_cnt): base = sum of the preceding blocks' counts, then a block-local scan.
-// Outputs: stable centroids with normals (generateCentroidCloudWithPatchNormals semantics:
-// (0,0,1) unless > 6 points and a valid normal), the ICP working copies.  Block 0 also writes the totals into the
-// iteration's scalar slot and resets the inner-ICP state.
-__global__ void __launch_bounds__(kBlock) k_compact(int m2, const int* __restrict__ stable, const int* __restrict__ off2,
-                                                    const float4* __restrict__ ct2, const float4* __restrict__ nrm2,
-                                                    const int* __restrict__ blk_cnt, float4* __restrict__ stCT,
-                                                    float4* __restrict__ stN, float4* __restrict__ wsrc,
-                                                    float4* __restrict__ wsrcn, unsigned* __restrict__ scal,
-                                                    IcpState* __restrict__ st) {
-    __shared__ int s_red[kBlock / 64][3];
-    __shared__ int s_w[kBlock / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nb = gridDim.x, me = blockIdx.x;
-    // own data first (independent of the counts: both loads are in flight together)
-    const int i = me * kBlock + threadIdx.x;
-    const int f = (i < m2) ? stable[i] : 0;
-    const int np = (i < m2) ? (off2[i + 1] - off2[i]) : 0;
-    float4 c = make_float4(0.f, 0.f, 0.f, 0.f), n = make_float4(0.f, 0.f, 1.f, 0.f);
-    if (f) { c = ct2[i]; n = nrm2[i]; }
-    int bn = 0, tn = 0, tp = 0;
-    for (int b = threadIdx.x; b < nb; b += kBlock) {
-        const int a0 = blk_cnt[2 * b];
-        tn += a0; tp += blk_cnt[2 * b + 1];
-        if (b < me) bn += a0;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { bn += __shfl_xor(bn, o); tn += __shfl_xor(tn, o); tp += __shfl_xor(tp, o); }
-    int in = f;                                      // inclusive scan inside the wave
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int a0 = __shfl_up(in, o);
-        if (lane >= o) in += a0;
-    }
-    if (lane == 0) { s_red[wave][0] = bn; s_red[wave][1] = tn; s_red[wave][2] = tp; }
-    if (lane == 63) s_w[wave] = in;
-    __syncthreads();
-    int base_n = 0, tot_n = 0, tot_p = 0, on = 0;
-#pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w) {
-        base_n += s_red[w][0]; tot_n += s_red[w][1]; tot_p += s_red[w][2];
-        if (w < wave) on += s_w[w];
-    }
-    if (f) {
-        const int pos = base_n + on + in - f;
-        if (!(np > 6 && n.w != 0.0f)) n = make_float4(0.f, 0.f, 1.f, 0.f);
-        n.w = 0.f;
-        stCT[pos] = c; stN[pos] = n;
-        wsrc[pos] = c; wsrcn[pos] = n;
-    }
-    if (me == 0 && threadIdx.x == 0) {
-        scal[2] = (unsigned)tot_n;
-        scal[3] = (unsigned)tot_p;
-        for (int k = 0; k < 16; ++k) {
-            st->T[k] = (k % 5 == 0) ? 1.f : 0.f;
-            st->Tfinal[k] = (k % 5 == 0) ? 1.f : 0.f;
-        }
-        st->iters = 0; st->done = (tot_n < 3) ? 1 : 0; st->reason = 0; st->pad = 0;
-        st->prev_mse = 1.7976931348623157e308;
-    }
-}
-
 // target centroids with normals for the ICP / VCM (C.cpp:357-382)
 __global__ void k_with_norm(int m, const int* __restrict__ off, const float4* __restrict__ nrm,
                             float4* __restrict__ out) {
@@ -496,7 +350,7 @@ struct pwicp_pair {
     const GridLevel* dense_lv = nullptr;   // small-cell level of the target this pair's dense search uses (pw_dense_level_for)
     DevBuf<int> all_stable;  // all-ones flags (bench replay over every patch)
     // per-iteration work
-    DevBuf<int> mCTBP, stable, blk_cnt;   // matches of the 7*m2 centroid+boundary queries
+    DevBuf<int> mCTBP, stable;   // matches of the 7*m2 centroid+boundary queries
     DevBuf<float> dCTBP, d2dense;
     DevBuf<float4> stCT, stN;
     IcpWork icp;
@@ -586,7 +440,6 @@ int finish_create(pwicp_pair* pr) {
     HIPCHK(ctx, pr->mCTBP.reserve(M2 * 7));
     HIPCHK(ctx, pr->dCTBP.reserve(M2 * 7));
     HIPCHK(ctx, pr->stable.reserve(M2));
-    HIPCHK(ctx, pr->blk_cnt.reserve(2 * (size_t)div_up((long long)M2, kBlock) + 2));
     HIPCHK(ctx, pr->stable0.reserve(M2 + 1));
     HIPCHK(ctx, pr->stCT.reserve(M2));
     HIPCHK(ctx, pr->stN.reserve(M2));
@@ -861,6 +714,21 @@ int pwicp_pair_num_patch_points(const pwicp_pair* pr, int* tot1, int* tot2) {
 constexpr int kSelMailSeq = 4, kSelMailPayload = 8;      // mailbox words of the percentile selection
 
 // waits until the mailbox sequence word reaches `seq` (spin, then fall back to a stream synchronisation)
+// PWICP_HOST_TRACE=1: host-side time stamps of pwicp_pair_run's enqueues and mailbox waits (stderr, us since the loop began)
+struct HostTrace {
+    bool on = getenv("PWICP_HOST_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    std::vector<std::pair<const char*, double>> ev;
+    void operator()(const char* what) {
+        if (on) ev.push_back({what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count()});
+    }
+    ~HostTrace() {
+        if (!on) return;
+        double prev = 0;
+        for (auto& e : ev) { fprintf(stderr, "[host] %8.1f us (+%6.1f)  %s\n", e.second, e.second - prev, e.first); prev = e.second; }
+    }
+};
+
 static int mail_wait(pwicp_pair* pr, unsigned seq, int word = 0) {
     pwicp_context* ctx = pr->ctx;
     const auto t0 = std::chrono::steady_clock::now();
@@ -982,6 +850,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     // derived on the device from the slot's stable-point count (speculative enqueue, before the host knows the count).
     unsigned sel_seq = 0;
     auto enqueue_dense_tail = [&](unsigned* slot, int nsp, bool rank_dev, bool with_front) -> int {
+        // (a dispatch with events attached - hipExtLaunchKernelGGL - was measured too: the same two ~5 us bubbles as the records)
         const bool ev = (pr->profiling & PWICP_PROF_DENSE) != 0;
         if (ev) {
             ev_kind.push_back({n_ev, 0});
@@ -1020,6 +889,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     static int speculate = -1;             // PWICP_SPECULATE_DENSE=0: never enqueue the first dense search ahead of the ICP result
     if (speculate < 0) { const char* e = getenv("PWICP_SPECULATE_DENSE"); speculate = e ? atoi(e) : 1; }
     const auto t0 = std::chrono::steady_clock::now();
+    HostTrace ht;
     while (!stage3) {                                                   // R.cpp:680
         const int k = res->n_outer;
         if (k >= PWICP_MAX_OUTER) { status = PWICP_E_NOT_CONVERGED; break; }     // Stage 3 never reached: no VCM, not a success
@@ -1027,19 +897,19 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         if (4 > m2 || 1 > pr->tgt->P1.m) { status = PWICP_E_TOO_FEW_PATCHES; break; }   // R.cpp:728-731; an empty target has no match
         unsigned* const slot = pr->scal.p + (size_t)kSlot * k;
 
-        if (!front_ready) PWCHK(enqueue_front(nullptr, true));
+        ht("iteration begins");
+        if (!front_ready) { PWCHK(enqueue_front(nullptr, true)); ht("front enqueued"); }
         front_ready = false;
         const float4* const ct2 = pr->src_ctbp();
         const float4* const bp2 = pr->src_ctbp() + m2;
         res->n_corr += (long long)m2 + nbp2;
         // (2)-(4)
         const float DTctct = currDT + 1 * (prm.SVRes1 + prm.SVRes2);   // R.cpp:817
-        hipLaunchKernelGGL(k_classify, dim3(div_up(m2, kBlock)), dim3(kBlock), 0, ctx->stream, m2, pr->mCTBP.p,
-                           pr->dCTBP.p, pr->mCTBP.p + m2, pr->dCTBP.p + m2, pr->tgt->P1.ctstd.p, pr->P2.bpstd.p, pr->tgt->nrm1.p,
-                           pr->tgt->P1.ct.p, ct2, bp2, pr->P2.off.p, currDT, DTmin, DTctct, pr->stable.p, pr->blk_cnt.p, slot);
-        hipLaunchKernelGGL(k_compact, dim3(div_up(m2, kBlock)), dim3(kBlock), 0, ctx->stream, m2, pr->stable.p, pr->P2.off.p,
-                           ct2, pr->nrm2.p, pr->blk_cnt.p, pr->stCT.p, pr->stN.p, pr->icp.src.p, pr->icp.srcn.p, slot,
-                           pr->icp.state.p);
+        ClassifyArgs cls;
+        cls.m2 = m2; cls.mCT = pr->mCTBP.p; cls.dCT = pr->dCTBP.p; cls.mBP = pr->mCTBP.p + m2; cls.dBP = pr->dCTBP.p + m2;
+        cls.ctstd1 = pr->tgt->P1.ctstd.p; cls.bpstd2 = pr->P2.bpstd.p; cls.nrm1 = pr->tgt->nrm1.p; cls.ct1 = pr->tgt->P1.ct.p;
+        cls.ct1n = pr->tgt->ct1n.p; cls.ct2 = ct2; cls.bp2 = bp2; cls.nrm2 = pr->nrm2.p; cls.off2 = pr->P2.off.p;
+        cls.currDT = currDT; cls.DTmin = DTmin; cls.DTctct = DTctct;
         // (5) R.cpp:875-877: inner ICP enqueued right behind, its point count read from the slot on the device;
         // ONE host round trip returns the counts, LoD_min and the ICP state together.  Once Stage 2 is reached the
         // dense search (7) cannot run any more, so the transform and — unless this looks like the last iteration
@@ -1062,6 +932,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
             // (~15 us).  PCL's ICP needs 3-8 iterations in the first outer iteration and about half as many as the
             // time before afterwards, hence 4, then half of the previous count, then 2 at a time.
             int batch = (k == 0) ? 4 : std::max(1, (prev_inner + 1) / 2);
+            bool first_batch = true;
             for (;;) {
                 // (an event record costs a ~6 us bubble on the stream: the inner-loop timing is opt-in)
                 const bool ev = (pr->profiling & PWICP_PROF_INNER) != 0;
@@ -1076,7 +947,17 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                 mail.a = slot; mail.na = kSlot;
                 mail.b = k > 0 ? slot - kSlot + 4 : slot + 4; mail.nb = 6;
                 mail.dst = pr->mail_d + 16; mail.seq_ptr = pr->mail_d; mail.seq = seq;
-                PWCHK(pw_icp_enqueue(ctx, pr->tgt->g_ct1.d, pr->tgt->P1.ct.p, pr->tgt->ct1n.p, &pr->icp, m2, slot + 2, 1e-6, batch, &mail));
+                // the first batch opens with the fused launch: classification, compaction and inner iteration 0 (whose
+                // correspondences are the front's centroid matches); it carries the message when nothing follows it
+                int n_iter = batch;
+                if (first_batch) {
+                    n_iter = batch - 1;
+                    PWCHK(pw_classify_icp0_launch(ctx, cls, pr->stable.p, pr->stCT.p, pr->stN.p, &pr->icp, slot, 1e-6, n_iter == 0 ? &mail : nullptr));
+                    first_batch = false;
+                }
+                if (n_iter > 0)
+                    PWCHK(pw_icp_enqueue(ctx, pr->tgt->g_ct1.d, pr->tgt->P1.ct.p, pr->tgt->ct1n.p, &pr->icp, m2, slot + 2, 1e-6, n_iter, &mail));
+                ht("classify+icp batch enqueued");
                 if (ev) {
                     HIPCHK(ctx, hipEventRecord(pr->event(n_ev + 1), ctx->stream));
                     n_ev += 2;
@@ -1087,7 +968,9 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                 }
                 const bool spec_now = spec_dense && !spec_done;
                 if (spec_now) { PWCHK(enqueue_dense_tail(slot, 0, /*rank_dev*/ true, /*with_front*/ true)); spec_done = true; }
+                ht("early transform / front / dense enqueued");
                 PWCHK(mail_wait(pr, seq));
+                ht("icp mail arrived");
                 memcpy(hs, pr->mail_h + 16, sizeof(hs));
                 memcpy(hb, pr->mail_h + 16 + kSlot, sizeof(hb));
                 memcpy(&hst, pr->mail_h + 16 + kSlot + 6, sizeof(IcpState));
@@ -1142,6 +1025,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
             if (pr->profiling & PWICP_PROF_REPLAY) { pr->ns0 = ns; pr->nsp0 = nsp; }
             double Dist75 = 0;
             PWCHK(select_p75_finish(pr, sel_seq, &Dist75));
+            ht("percentile mail arrived");
             res->n_corr += nsp; res->n_corr_dense += nsp; res->n_dense_nn_launches++;
             res->d75[k] = Dist75;
             if ((double)currDT > Dist75) currDT = (float)Dist75; else stage2 = true;
@@ -1164,7 +1048,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
             xf_enqueued = spec_xf_valid;
             front_ready = spec_xf_valid && !stage3;
         }
-        if (!xf_enqueued) enqueue_transform(slot);                      // (8)
+        if (!xf_enqueued) { enqueue_transform(slot); ht("transform enqueued (late)"); }                      // (8)
         pr->lazy = false;                   // a valid transform is on the stream: from here on the working arrays are the source state
         pr->dirty = true;
         // (9) R.cpp:958-961: stable centroids as copied BEFORE the update (R.cpp:868)
@@ -1186,6 +1070,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     unsigned long long ex = 0;
     if (vcm_pending) {
         PWCHK(mail_wait(pr, vcm_seq));
+        ht("vcm mail arrived");
         memcpy(res->VCM, pr->mail_h + 16, 36 * sizeof(double));
         memcpy(&ex, pr->mail_h + 16 + 72, sizeof(ex));
     } else {                                              // the loop ended without Stage 3 (error / iteration cap)
@@ -1242,11 +1127,13 @@ int pwicp_pair_step(pwicp_pair* pr, pwicp_step* sp) {
                           pr->dCTBP.p));
     // (2)-(4) R.cpp:750-871
     const float DTctct = currDT_in + 1 * (prm.SVRes1 + prm.SVRes2);
-    hipLaunchKernelGGL(k_classify, dim3(div_up(m2, kBlock)), dim3(kBlock), 0, ctx->stream, m2, pr->mCTBP.p, pr->dCTBP.p,
-                       pr->mCTBP.p + m2, pr->dCTBP.p + m2, pr->tgt->P1.ctstd.p, pr->P2.bpstd.p, pr->tgt->nrm1.p, pr->tgt->P1.ct.p, ct2,
-                       bp2, pr->P2.off.p, currDT_in, DTmin, DTctct, pr->stable.p, pr->blk_cnt.p, slot);
-    hipLaunchKernelGGL(k_compact, dim3(div_up(m2, kBlock)), dim3(kBlock), 0, ctx->stream, m2, pr->stable.p, pr->P2.off.p, ct2,
-                       pr->nrm2.p, pr->blk_cnt.p, pr->stCT.p, pr->stN.p, pr->icp.src.p, pr->icp.srcn.p, slot, pr->icp.state.p);
+    ClassifyArgs cls;
+    cls.m2 = m2; cls.mCT = pr->mCTBP.p; cls.dCT = pr->dCTBP.p; cls.mBP = pr->mCTBP.p + m2; cls.dBP = pr->dCTBP.p + m2;
+    cls.ctstd1 = pr->tgt->P1.ctstd.p; cls.bpstd2 = pr->P2.bpstd.p; cls.nrm1 = pr->tgt->nrm1.p; cls.ct1 = pr->tgt->P1.ct.p;
+    cls.ct1n = pr->tgt->ct1n.p; cls.ct2 = ct2; cls.bp2 = bp2; cls.nrm2 = pr->nrm2.p; cls.off2 = pr->P2.off.p;
+    cls.currDT = currDT_in; cls.DTmin = DTmin; cls.DTctct = DTctct;
+    // the same fused launch as pwicp_pair_run (classification, compaction, inner iteration 0): identical sums, identical T
+    PWCHK(pw_classify_icp0_launch(ctx, cls, pr->stable.p, pr->stCT.p, pr->stN.p, &pr->icp, slot, 1e-6, nullptr));
     unsigned hs[kSlot];
     HIPCHK(ctx, hipMemcpyAsync(hs, slot, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1258,7 +1145,7 @@ int pwicp_pair_step(pwicp_pair* pr, pwicp_step* sp) {
     // (5) R.cpp:875-877
     IcpState hst;
     for (;;) {
-        PWCHK(pw_icp_enqueue(ctx, pr->tgt->g_ct1.d, pr->tgt->P1.ct.p, pr->tgt->ct1n.p, &pr->icp, ns, nullptr, 1e-6, 4, nullptr));
+        PWCHK(pw_icp_enqueue(ctx, pr->tgt->g_ct1.d, pr->tgt->P1.ct.p, pr->tgt->ct1n.p, &pr->icp, ns, nullptr, 1e-6, 3, nullptr));
         HIPCHK(ctx, hipMemcpyAsync(&hst, pr->icp.state.p, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         if (hst.done || hst.iters >= 100) break;

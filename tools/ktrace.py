@@ -1,0 +1,26 @@
+"""Phase stamps of the fused classification launch (build with `make -C piecewise-icp_amd EXTRA=-DPWICP_KTRACE`): runs the
+bench pair a few times and prints, for the LAST k_classify_icp0 launch of a run, the wall-clock offsets of its phases."""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "piecewise-icp_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import pwicp_amd as P
+import _data
+L = P.load_library()
+L.pwicp_debug_ktrace.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+ctx = P.Context(0)
+tgt, src, _ = _data.pair(n)
+l1, n1 = ctx.frontend_segment(tgt, 10 * _data.R, 45, _data.R)
+l2, n2 = ctx.frontend_segment(src, 10 * _data.R, 45, _data.R)
+pair = P.Pair(ctx, tgt, l1, n1, src, l2, n2, _data.params())
+names = ["first block starts", "classified (last block to get there)", "base known (last)", "partials stored (last)", "last block identified",
+         "totals done, tail starts", "tail: partials summed", "tail: 6x6 inverted", "tail: T formed", "tail done", "mail sent"]
+for rep in range(4):
+    pair.reset()
+    L.pwicp_debug_ktrace(None, 1)
+    pair.run(check=False)
+    buf = (C.c_ulonglong * 32)()
+    L.pwicp_debug_ktrace(buf, 0)
+    t0 = buf[0]
+    print("run %d: " % rep + " | ".join("%s +%.2f us" % (names[i], (buf[i] - t0) / 100.0) for i in range(1, 11)))
