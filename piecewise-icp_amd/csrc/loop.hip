@@ -16,21 +16,15 @@
 #include "nn_device.h"
 #include "patch.h"
 #include "select_dev.h"
+#include "xform_dev.h"
 
 using namespace pwdev;
 
-struct Mat4 {
-    float m[16];
-};
 
 namespace {
 
 constexpr int kBlock = 256;
 
-__device__ __forceinline__ unsigned f2ord_dev(float f) {
-    unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
 inline float ord2f_host(unsigned u) {
     u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
     float f;
@@ -52,7 +46,6 @@ __global__ void k_with_norm(int m, const int* __restrict__ off, const float4* __
     out[i] = n;
 }
 
-constexpr int kBoxParts = 64;
 // (8) R.cpp:943-954 in ONE launch: blocks [0, nb_cloud) transform cloud2 and reduce its new bounding box (for the
 // next iteration's octree box, R.cpp:881-886); the remaining blocks transform centroids+boundary points and
 // the patch points.  min/max are exact whatever the reduction order.
@@ -98,86 +91,7 @@ __global__ void __launch_bounds__(kBlock) k_transform_all(const float4* cloud_in
         }
         return;
     }
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    {
-        const int stride = nb_cloud * kBlock;
-        for (int i = bid * kBlock + threadIdx.x; i < n; i += 4 * stride) {
-            float4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (i + u * stride < n) v[u] = cloud_in[i + u * stride];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (i + u * stride < n) {
-                    const float4 w = xform_point(T.m, v[u]);
-                    cloud[i + u * stride] = w;
-                    mn[0] = fminf(mn[0], w.x); mx[0] = fmaxf(mx[0], w.x);
-                    mn[1] = fminf(mn[1], w.y); mx[1] = fmaxf(mx[1], w.y);
-                    mn[2] = fminf(mn[2], w.z); mx[2] = fmaxf(mx[2], w.z);
-                }
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            mn[d] = fminf(mn[d], __shfl_xor(mn[d], o));
-            mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], o));
-        }
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0)
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { sh[wave][d] = mn[d]; sh[wave][3 + d] = mx[d]; }
-    __syncthreads();
-    if (threadIdx.x >= 64) return;
-    unsigned* part = bbox_part + (bid & (kBoxParts - 1)) * 32;
-    if (threadIdx.x < 3) {
-        float a = sh[0][threadIdx.x], b = sh[0][3 + threadIdx.x];
-        for (int w = 1; w < kBlock / 64; ++w) { a = fminf(a, sh[w][threadIdx.x]); b = fmaxf(b, sh[w][3 + threadIdx.x]); }
-        // 64 partial boxes, one 128-byte line each: same-line atomics from all XCDs serialise (~5 ns apiece)
-        const unsigned r0 = atomicMin(&part[threadIdx.x], f2ord_dev(a));
-        const unsigned r1 = atomicMax(&part[3 + threadIdx.x], f2ord_dev(b));
-        asm volatile("" ::"v"(r0), "v"(r1));      // wait until both have been PERFORMED (see below)
-    }
-    // Fold in the same launch: the block that completes a partial box counts it, the block that completes the last
-    // partial box folds all of them into the slot and re-arms the buffer (two levels, so that no counter line sees
-    // more than ~nb_cloud/64 + 64 atomics).  The box atomics have to be PERFORMED before the count: they are
-    // device-coherent read-modify-writes, so waiting for their return values (above) is enough.  A device-scope fence
-    // would also do, but it writes the L2 back, which is ruinous in a launch that has just written the whole cloud;
-    // a mere acknowledgement wait is NOT enough (the update may still be on its way to the coherence point).
-    unsigned last = 0;
-    if (threadIdx.x == 0) {
-        const int pidx = bid & (kBoxParts - 1);
-        const unsigned np = (unsigned)((nb_cloud - pidx + kBoxParts - 1) / kBoxParts);
-        if (atomicAdd(&part[8], 1u) == np - 1u) {
-            const unsigned nparts = (unsigned)min(nb_cloud, kBoxParts);
-            if (atomicAdd(&bbox_part[kBoxParts * 32], 1u) == nparts - 1u) last = 1u;
-        }
-    }
-    last = (unsigned)__shfl((int)last, 0);
-    if (!last) return;
-    const int t = threadIdx.x;
-    unsigned umn[3], umx[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        umn[d] = __hip_atomic_load(&bbox_part[t * 32 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        umx[d] = __hip_atomic_load(&bbox_part[t * 32 + 3 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            umn[d] = min(umn[d], (unsigned)__shfl_xor((int)umn[d], o));
-            umx[d] = max(umx[d], (unsigned)__shfl_xor((int)umx[d], o));
-        }
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { bbox_part[t * 32 + d] = 0xffffffffu; bbox_part[t * 32 + 3 + d] = 0u; }
-    bbox_part[t * 32 + 8] = 0u;
-    if (t == 0) {
-        bbox_part[kBoxParts * 32] = 0u;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { slot[4 + d] = umn[d]; slot[7 + d] = umx[d]; }
-    }
+    xf_cloud_block(T, cloud_in, cloud, n, bid, nb_cloud, bbox_part, slot, sh);
 }
 
 // arms the partial boxes and their counters (once, at pair creation; afterwards the folding block re-arms them)
@@ -844,6 +758,12 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                            (const IcpState*)pr->icp.state.p, (const unsigned*)(slot + 2), pr->bbox_part.p, slot, nb_cloud + nb_rest,
                            fs ? *fs : none);
     };
+    // (8) and the front of the NEXT iteration in one launch (patch.hip: k_xf_front): every role only needs T
+    auto enqueue_xf_front = [&](unsigned* slot, const FusedSelect* fs = nullptr) -> int {
+        return pw_xf_front_launch(ctx, pr->src_pat(), pr->P2.pat.p, pr->P2.off.p, m2, pr->nrm2.p, pr->tgt->g_ct1.d, pr->src_ctbp(),
+                                  pr->ctbp2.p, 7 * m2, pr->mCTBP.p, pr->dCTBP.p, pr->src_cloud(), pr->cloud2.p, pr->n2,
+                                  (const IcpState*)pr->icp.state.p, (const unsigned*)(slot + 2), pr->bbox_part.p, slot, fs);
+    };
     // (7) of a Stage-1 iteration: dense NN of the stable patches' points against the full target cloud (C.cpp:266-281) with the
     // percentile selection riding on the launches that follow (select_dev.h): pass 0 in the dense kernel, pass 1 beside the
     // transform, pass 2 beside the next front (or on its own when no front follows).  `rank_dev`: the rank of the percentile is
@@ -880,10 +800,10 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         static int nb1 = -1;
         if (nb1 < 0) { const char* e = getenv("PWICP_FS_BLOCKS1"); nb1 = e ? std::max(atoi(e), 1) : 64; }
         fs.nblk = nb1;
-        enqueue_transform(slot, fused ? &fs : nullptr);
+        if (with_front) PWCHK(enqueue_xf_front(slot, fused ? &fs : nullptr));
+        else enqueue_transform(slot, fused ? &fs : nullptr);
         fs.nblk = kFsBlocks;
-        if (with_front) PWCHK(enqueue_front(fused ? &fs : nullptr));
-        else if (fused) PWCHK(pw_fs_pass_launch(ctx, 2, fs));
+        if (fused && !with_front) PWCHK(pw_fs_pass_launch(ctx, 2, fs));      // (with a front: pass 2 on the merged launch's last blocks)
         return PWICP_OK;
     };
     static int speculate = -1;             // PWICP_SPECULATE_DENSE=0: never enqueue the first dense search ahead of the ICP result
@@ -962,9 +882,9 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                     HIPCHK(ctx, hipEventRecord(pr->event(n_ev + 1), ctx->stream));
                     n_ev += 2;
                 }
-                if (early_xf) {
-                    enqueue_transform(slot);                 // no-op on the device while the ICP has not converged
-                    if (early_front) PWCHK(enqueue_front());
+                if (early_xf) {                              // no-op on the device while the ICP has not converged
+                    if (early_front) PWCHK(enqueue_xf_front(slot));
+                    else enqueue_transform(slot);
                 }
                 const bool spec_now = spec_dense && !spec_done;
                 if (spec_now) { PWCHK(enqueue_dense_tail(slot, 0, /*rank_dev*/ true, /*with_front*/ true)); spec_done = true; }
@@ -1048,7 +968,11 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
             xf_enqueued = spec_xf_valid;
             front_ready = spec_xf_valid && !stage3;
         }
-        if (!xf_enqueued) { enqueue_transform(slot); ht("transform enqueued (late)"); }                      // (8)
+        if (!xf_enqueued) {                                              // (8)
+            if (!stage3) { PWCHK(enqueue_xf_front(slot)); front_ready = true; }
+            else enqueue_transform(slot);
+            ht("transform enqueued (late)");
+        }
         pr->lazy = false;                   // a valid transform is on the stream: from here on the working arrays are the source state
         pr->dirty = true;
         // (9) R.cpp:958-961: stable centroids as copied BEFORE the update (R.cpp:868)

@@ -18,6 +18,13 @@ int pw_patch_normals_launch(pwicp_context* ctx, const float4* d_pat, const int* 
 // source patch normals + 1-NN of (centroids | boundary points) among the target centroids, one launch
 int pw_front_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, int m, float4* d_nrm, const GridDesc& g,
                     const float4* d_q, int nq, int* d_idx, float* d_d2, const struct FusedSelect* fs = nullptr);
+// transform update + the next iteration's front in one launch (k_xf_front); *_in: the arrays the moved values are read from
+// (== the output arrays except in the first update of a run on a lazily reset pair)
+struct IcpState;
+int pw_xf_front_launch(pwicp_context* ctx, const float4* d_pat_in, float4* d_pat, const int* d_off, int m, float4* d_nrm,
+                       const GridDesc& g, const float4* d_ctbp_in, float4* d_ctbp, int nq, int* d_idx, float* d_d2,
+                       const float4* d_cloud_in, float4* d_cloud, int n, const IcpState* d_state, const unsigned* d_ns,
+                       unsigned* d_bbox_part, unsigned* d_slot, const struct FusedSelect* fs = nullptr);
 int pw_patch_stats_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, int m, float4* ct, float4* bp,
                           float* bpstd, float* ctstd);
 int pw_select_patches_dev(pwicp_context* ctx, const float4* d_cloud, int n, const int* d_labels, int nsv,

@@ -13,8 +13,10 @@
 #include "common.h"
 #include "devmath.h"
 #include "nn_device.h"
+#include "icp.h"
 #include "select_dev.h"
 #include "patch.h"
+#include "xform_dev.h"
 
 using namespace pwdev;
 
@@ -160,8 +162,12 @@ __device__ inline void ct_bp(const float4* __restrict__ p, const unsigned char* 
 constexpr int kAhead = 4;
 constexpr int kTilePts = kGroup * kAhead;            // 32 points per pass (16 KiB of LDS per 256-thread block)
 constexpr int kTileStride = kTilePts + 1;            // float4 units; +1: the 8 tiles of a wave start on different banks
-__device__ __forceinline__ void patch_normal_group(const float4* __restrict__ pat, const int* __restrict__ off, int i, int sub,
-                                                   float4* __restrict__ nrm_out, float4* __restrict__ tile) {
+// XF: the points are read from pat_in, moved by T on the way (pcl::transformPointCloud: xform_point, the same float
+// operations as the stand-alone transform launch) and written to `pat`; the sums run over the moved points.
+template <bool XF = false>
+__device__ __forceinline__ void patch_normal_group(const float4* pat, const int* __restrict__ off, int i, int sub,
+                                                   float4* __restrict__ nrm_out, float4* __restrict__ tile,
+                                                   const float4* pat_in = nullptr, const float* T = nullptr, float4* pat_w = nullptr) {
     const int lo = off[i], hi = off[i + 1];
     const int gbase = (int)(__lane_id() & ~(unsigned)(kGroup - 1));       // first lane of this group within the wave
     // operand components of this lane's sum (w = 1 turns a plain sum into the same mul-then-add)
@@ -173,6 +179,10 @@ __device__ __forceinline__ void patch_normal_group(const float4* __restrict__ pa
 #pragma unroll
     for (int u = 0; u < kAhead; ++u) {
         const int j = lo + u * kGroup + sub;
+        if (XF) {
+            nxt[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < hi) { nxt[u] = xform_point(T, pat_in[j]); pat_w[j] = nxt[u]; }
+        } else
         nxt[u] = (j < hi) ? pat[j] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     for (int base = lo; base < hi; base += kTilePts) {
@@ -185,6 +195,10 @@ __device__ __forceinline__ void patch_normal_group(const float4* __restrict__ pa
 #pragma unroll
         for (int u = 0; u < kAhead; ++u) {
             const int j = base + kTilePts + u * kGroup + sub;
+            if (XF) {
+                nxt[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j < hi) { nxt[u] = xform_point(T, pat_in[j]); pat_w[j] = nxt[u]; }
+            } else
             nxt[u] = (j < hi) ? pat[j] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");          // the tile is private to this group (one wave)
@@ -222,6 +236,10 @@ __device__ __forceinline__ void patch_normal_group(const float4* __restrict__ pa
             nv[0] = e[0]; nv[1] = e[1]; nv[2] = e[2];
             ok = true;
         } else {
+            if (XF) {                                    // the group's own writes of the moved points, read back
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+                __builtin_amdgcn_wave_barrier();
+            }
             ok = cal_patch_normal(pat + lo, n, nv);      // takes the SVD-fallback branch (C.cpp:303-326)
         }
     }
@@ -272,6 +290,66 @@ __global__ void __launch_bounds__(kFrontBlock) k_front(const float4* __restrict_
         idx[i] = b.found() ? b.idx() : -1;
         d2[i] = b.d2();
     }
+}
+
+// Transform update (R.cpp:943-954) AND the front of the next outer iteration (R.cpp:737-747, 824) in ONE launch.  Every role
+// only needs T (read from the ICP state on the device, guarded like k_transform_all), so nothing waits for anything:
+//   normal blocks   move the points of their patches (pat_in -> pat) on the way into the covariance sums;
+//   query blocks    move centroids / boundary points (ctbp_in -> ctbp) and search the moved point among the target centroids;
+//   cloud blocks    move the full cloud and fold its new bounding box (xf_cloud_block);
+//   first / last    blocks: passes 1 / 2 of the percentile selection when a dense search has just run (select_dev.h).
+// The moved values are the same float expressions as in the stand-alone launches (xform_point), so normals, matches and
+// distances are bit-identical to transform-then-front; the two launches cost 14 + 17 us back to back, this one ~24 us.
+// (Alternating query and cloud blocks in the grid, or 6 / 8 waves per SIMD through launch bounds: no gain, measured.)
+__global__ void __launch_bounds__(kFrontBlock) k_xf_front(const float4* pat_in, float4* pat, const int* __restrict__ off, int m,
+                                                          float4* __restrict__ nrm_out, int nb_nrm, GridDesc g,
+                                                          const float4* ctbp_in, float4* ctbp, int nq, int* __restrict__ idx,
+                                                          float* __restrict__ d2, int nb_nn,
+                                                          const float4* cloud_in, float4* cloud, int n, int nb_cloud,
+                                                          const IcpState* __restrict__ st, const unsigned* __restrict__ ns_dev,
+                                                          unsigned* __restrict__ bbox_part, unsigned* __restrict__ slot, FusedSelect fs,
+                                                          int nblk2) {
+    __shared__ float4 tiles[(kFrontBlock / kGroup) * kTileStride];
+    static_assert(kFrontBlock == kXfBlock, "xf_cloud_block is written for this block size");
+    const int nsel = fs.scratch ? fs.nblk : 0;
+    if ((int)blockIdx.x < nsel) {
+        static_assert(sizeof(tiles) >= kFsBins * sizeof(unsigned), "tile buffer too small for the selection bins");
+        fs_pass_embedded<1>((unsigned*)tiles, fs, (int)blockIdx.x, fs.mail.seq);
+        return;
+    }
+    if (fs.scratch && (int)blockIdx.x >= nsel + nb_nrm + nb_nn + nb_cloud) {      // pass 2 on the LAST blocks of the grid
+        FusedSelect f2 = fs;
+        f2.nblk = nblk2;
+        fs_pass_embedded<2>((unsigned*)tiles, f2, (int)blockIdx.x - (nsel + nb_nrm + nb_nn + nb_cloud), fs.mail.seq);
+        return;
+    }
+    if (!st->done || *ns_dev < 4u) return;
+    Mat4 T;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) T.m[i] = st->Tfinal[i];
+    int bid = (int)blockIdx.x - nsel;
+    if (bid < nb_nrm) {
+        const int t = bid * kFrontBlock + threadIdx.x;
+        const int i = t / kGroup;
+        if (i < m) patch_normal_group<true>(pat, off, i, t % kGroup, nrm_out, tiles + (threadIdx.x / kGroup) * kTileStride, pat_in, T.m, pat);
+        return;
+    }
+    bid -= nb_nrm;
+    if (bid < nb_nn) {
+        const int t = bid * kFrontBlock + threadIdx.x;
+        const int i = t / kGroup, sub = t % kGroup;
+        if (i >= nq) return;                        // a whole group is in or out of range together
+        const float4 v = xform_point(T.m, ctbp_in[i]);
+        if (sub == 0) ctbp[i] = v;
+        const NNBest b = nn_query_group(g, v.x, v.y, v.z, sub);
+        if (sub == 0) {
+            idx[i] = b.found() ? b.idx() : -1;
+            d2[i] = b.d2();
+        }
+        return;
+    }
+    bid -= nb_nn;
+    xf_cloud_block(T, cloud_in, cloud, n, bid, nb_cloud, bbox_part, slot, (float (*)[6])tiles);
 }
 
 // CT / BP / sigma of already selected patches
@@ -433,6 +511,22 @@ int pw_front_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, i
     const bool sel = fs && fs->scratch;
     hipLaunchKernelGGL(k_front, dim3(nb_nrm + nb_nn + (sel ? fs->nblk : 0)), dim3(kFrontBlock), 0, ctx->stream, d_pat, d_off, m, d_nrm,
                        nb_nrm, g, d_q, nq, d_idx, d_d2, nb_nrm + nb_nn, sel ? *fs : none);
+    HIPCHK(ctx, hipGetLastError());
+    return PWICP_OK;
+}
+
+int pw_xf_front_launch(pwicp_context* ctx, const float4* d_pat_in, float4* d_pat, const int* d_off, int m, float4* d_nrm,
+                       const GridDesc& g, const float4* d_ctbp_in, float4* d_ctbp, int nq, int* d_idx, float* d_d2,
+                       const float4* d_cloud_in, float4* d_cloud, int n, const IcpState* d_state, const unsigned* d_ns,
+                       unsigned* d_bbox_part, unsigned* d_slot, const FusedSelect* fs) {
+    const int nb_nrm = div_up((long long)m * kGroup, kFrontBlock);
+    const int nb_nn = div_up((long long)nq * kGroup, kFrontBlock);
+    const int nb_cloud = std::min(div_up(n, kFrontBlock), ctx->n_cu * 8);
+    FusedSelect none{};
+    const bool sel = fs && fs->scratch;
+    hipLaunchKernelGGL(k_xf_front, dim3(nb_nrm + nb_nn + nb_cloud + (sel ? fs->nblk + kFsBlocks : 0)), dim3(kFrontBlock), 0, ctx->stream,
+                       d_pat_in, d_pat, d_off, m, d_nrm, nb_nrm, g, d_ctbp_in, d_ctbp, nq, d_idx, d_d2, nb_nn, d_cloud_in, d_cloud, n,
+                       nb_cloud, d_state, d_ns, d_bbox_part, d_slot, sel ? *fs : none, kFsBlocks);
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }

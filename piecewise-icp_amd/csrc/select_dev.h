@@ -16,7 +16,8 @@
 
 constexpr int kFsBins = 2048;
 constexpr int kFsRep = 8;                 // replicas of the pass-0 bins in global memory (same-address atomics serialise)
-constexpr int kFsCtl = 16;                // control words: [0] prefix, [1] rank remaining, [2..4] finished blocks of pass 0..2
+constexpr int kFsCtl = 16;                // control words: [0] prefix, [1] rank remaining, [2..4] finished blocks of pass 0..2,
+                                          // [5] tag of the selection whose pass 1 has finished (passes 1 and 2 in ONE launch)
 constexpr int kFsWords = kFsCtl + (kFsRep + 2) * kFsBins;
 constexpr int kFsBlocks = 128;            // blocks devoted to an embedded pass
 
@@ -105,15 +106,27 @@ __device__ __forceinline__ void fs_pick0(unsigned* h, const FusedSelect& fs, uns
 }
 
 // ---- passes 1 and 2 on `fs.nblk` blocks of some other launch; `bidx` = index of this block among them --------------------
+// chain != 0: passes 1 and 2 run in the SAME launch (k_xf_front: pass 1 on the first blocks of the grid, pass 2 on the last).
+// The wave that picks pass 1's bin publishes prefix / rank through device-coherent stores and then the tag `chain`; the blocks
+// of pass 2 wait for the tag.  They only ever wait for blocks with smaller indices (dispatched before them), and by the time
+// the last blocks of a grid of thousands are dispatched the first ones have long finished.
 template <int PASS>
-__device__ __forceinline__ void fs_pass_embedded(unsigned* h, const FusedSelect& fs, int bidx) {
+__device__ __forceinline__ void fs_pass_embedded(unsigned* h, const FusedSelect& fs, int bidx, unsigned chain = 0u) {
     __shared__ unsigned s_last;
     unsigned prefix, k_in;
     if (PASS == 1) {
         fs_pick0(h, fs, &prefix, &k_in);               // from the bins the dense kernel left; leaves h zeroed
     } else {
         for (int t = threadIdx.x; t < kFsBins; t += blockDim.x) h[t] = 0u;
-        prefix = fs.scratch[0]; k_in = fs.scratch[1];  // written by pass 1 (previous launch)
+        if (chain) {
+            if (threadIdx.x == 0)
+                while (__hip_atomic_load(&fs.scratch[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != chain) __builtin_amdgcn_s_sleep(2);
+            __syncthreads();
+            prefix = __hip_atomic_load(&fs.scratch[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            k_in = __hip_atomic_load(&fs.scratch[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            prefix = fs.scratch[0]; k_in = fs.scratch[1];  // written by pass 1 (previous launch)
+        }
     }
     __syncthreads();
     const int stride = fs.nblk * (int)blockDim.x;
@@ -171,8 +184,8 @@ __device__ __forceinline__ void fs_pass_embedded(unsigned* h, const FusedSelect&
                 const unsigned bin = (unsigned)(lane * 32 + b);
                 const unsigned pf = (PASS == 1) ? (prefix | (bin << 10)) : (prefix | bin);
                 value = pf;
-                fs.scratch[0] = (PASS == 2) ? 0u : pf;
-                fs.scratch[1] = (PASS == 2) ? 0u : k - run;
+                __hip_atomic_store(&fs.scratch[0], (PASS == 2) ? 0u : pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&fs.scratch[1], (PASS == 2) ? 0u : k - run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (PASS == 2 && fs.out) fs.out[0] = __uint_as_float(pf);
             }
             run += c;
@@ -185,6 +198,11 @@ __device__ __forceinline__ void fs_pass_embedded(unsigned* h, const FusedSelect&
         for (int w = lane; w < kFsRep * kFsBins; w += 64) g0[w] = 0u;
     }
     if (lane == 0) fs.scratch[2 + PASS] = 0u;
+    if (PASS == 1 && chain) {                          // prefix / rank performed (write-through stores drained), then the tag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) __hip_atomic_store(&fs.scratch[5], chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (PASS == 2 && fs.mail.dst) {
         const unsigned long long m = __ballot(mine);
         const int src = m ? (int)__ffsll((long long)m) - 1 : 0;
