@@ -53,5 +53,10 @@ int pw_icp_run(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const
                double euclid_eps, float* T16, int* iters_out);
 int pw_vcm_enqueue(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
                    const float4* d_src, int ns, const VcmMail* mail = nullptr);
+// the run's last transform update + the VCM in one launch (icp.hip: k_xf_vcm)
+int pw_xf_vcm_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
+                     const float4* d_stct, int ns_max, const VcmMail* mail, unsigned stage3_bits, const float4* d_cloud_in,
+                     const float4* d_ctbp_in, const float4* d_pat_in, float4* d_cloud, int n, float4* d_ctbp, int n_ctbp, float4* d_pat,
+                     int n_pat, unsigned* d_bbox_part, unsigned* d_slot);
 int pw_vcm_run(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
                const float4* d_src, int ns, double* VCM36);

@@ -19,6 +19,7 @@
 #include "devmath.h"
 #include "icp.h"
 #include "nn_device.h"
+#include "xform_dev.h"
 
 using namespace pwdev;
 
@@ -556,22 +557,35 @@ __device__ __forceinline__ void vcm_row(float4 q, float4 p, float4 n, double* a,
     *L = Nx * (Px - Qx) + Ny * (Py - Qy) + Nz * (Pz - Qz);
 }
 
-// VCM step 1 in one launch: normal equations (group-cooperative like k_icp_iter: 8 lanes share a point's NN search and
-// each keeps 4 of the 27 sums) and, on the block that finishes last, Qxx = (A^T A)^-1 and x = Qxx A^T L.
-__global__ void __launch_bounds__(kAccBlock) k_vcm_normal(GridDesc g, const float4* __restrict__ tgt,
-                                                          const float4* __restrict__ tgt_n,
-                                                          const float4* __restrict__ src, int ns, int* __restrict__ match,
-                                                          double* __restrict__ partials, unsigned* __restrict__ counter,
-                                                          double* __restrict__ QX) {
-    __shared__ double sh[kAccBlock / 64][32];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = threadIdx.x % kGroup;
-    const int i = blockIdx.x * kAccPts + threadIdx.x / kGroup;
+// calTransParaVCM (R.cpp:1273-1343) in ONE launch of 1024-thread blocks, `bid` of `nb_max`:
+//   every block   NN of its 128 stable centroids among the target centroids (group-cooperative like k_icp_iter: 8 lanes share a
+//                 point's search and each keeps 4 of the 27 sums), one partial per block;
+//   last block    (device counter) Qxx = (A^T A)^-1 and x = Qxx A^T L on its first wave, then - all 1024 threads - the residuals
+//                 v = A x - L of ALL points (matches read back through device-coherent loads), v^T v in a fixed order,
+//                 sigma0^2 Qxx (R.cpp:1330-1340) and, when asked, the run's closing mailbox message.
+// (Two launches before: the second one's start-up cost as much as its work.)  ns: *ns_dev when ns_dev != nullptr.
+constexpr int kVcmBlock = kAccBlock;
+
+__device__ __forceinline__ void vcm_block(const GridDesc& g, const float4* __restrict__ tgt, const float4* __restrict__ tgt_n,
+                                          const float4* __restrict__ src, int ns, int* __restrict__ match,
+                                          double* __restrict__ partials, unsigned* __restrict__ counter,
+                                          double* __restrict__ vcm, const VcmMail& mail, int bid) {
+    __shared__ double sh[kVcmBlock / 64][32];
+    __shared__ double sums[kVSums];
+    __shared__ double A[6][6], Q[6][6], xs[6];
+    __shared__ int piv[8];
+    __shared__ bool singular;
+    __shared__ unsigned s_last;
+    const int nact = (ns + kAccPts - 1) / kAccPts;
+    if (bid >= nact) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = tid % kGroup;
+    const int i = bid * kAccPts + tid / kGroup;
     double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
     if (i < ns) {
         const float4 q = src[i];
         const NNBest b = nn_query_group(g, q.x, q.y, q.z, sub);
         const int bi = b.idx();
-        if (sub == 0) match[i] = bi;
+        if (sub == 0) coh_store(&match[i], bi);
         double a[6], L;
         vcm_row(q, tgt[bi], tgt_n[bi], a, &L);
         // sum k (0..26; 21 upper-triangle products row by row, then a[r]*L) lives on lane sub = k % 8 as its (k / 8)-th value
@@ -592,100 +606,72 @@ __global__ void __launch_bounds__(kAccBlock) k_vcm_normal(GridDesc g, const floa
     }
     if (lane < kGroup) { sh[wave][lane] = w0; sh[wave][8 + lane] = w1; sh[wave][16 + lane] = w2; sh[wave][24 + lane] = w3; }
     __syncthreads();
-    if (threadIdx.x < kVSums) {
-        double acc = sh[0][threadIdx.x];
-        for (int w = 1; w < kAccBlock / 64; ++w) acc += sh[w][threadIdx.x];
-        partials[(size_t)blockIdx.x * kNSums + threadIdx.x] = acc;
+    if (tid < kVSums) {
+        double acc = sh[0][tid];
+        for (int w = 1; w < kVcmBlock / 64; ++w) acc += sh[w][tid];
+        coh_store(&partials[(size_t)bid * kNSums + tid], acc);
     }
-    if (threadIdx.x >= 64) return;
-    __threadfence();
-    unsigned last = 0;
-    if (threadIdx.x == 0) {
-        last = (atomicAdd(counter, 1u) == gridDim.x - 1u) ? 1u : 0u;
-        if (last) *counter = 0u;
+    drain_stores();                         // every wave: its matches (and wave 0's partials) performed ...
+    __syncthreads();                        // ... before the block counts itself
+    if (tid == 0) {
+        const unsigned prev = atomicAdd(counter, 1u);
+        s_last = (prev == (unsigned)nact - 1u) ? 1u : 0u;
+        if (s_last) *counter = 0u;
     }
-    last = (unsigned)__shfl((int)last, 0);
-    if (!last) return;
-    __threadfence();
-    // ---- solve (one wave) ----
-    __shared__ double sums[kVSums];
-    __shared__ double A[6][6], Q[6][6];
-    __shared__ int piv[8];
-    __shared__ bool singular;
-    const int t = threadIdx.x, nblocks = gridDim.x;
-    if (t < kVSums) {
-        double s = 0.0;
-        int bk = 0;
-        for (; bk + 8 <= nblocks; bk += 8) {
-            double v[8];
+    __syncthreads();
+    if (!s_last) return;
+    // ---- solve (wave 0), the other waves wait ----
+    if (tid < 64) {
+        const int t = tid;
+        if (t < kVSums) {
+            double s = 0.0;
+            int bk = 0;
+            for (; bk + 8 <= nact; bk += 8) {
+                double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)(bk + u) * kNSums + t];
+                for (int u = 0; u < 8; ++u) v[u] = coh_load(&partials[(size_t)(bk + u) * kNSums + t]);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; bk < nact; ++bk) s += coh_load(&partials[(size_t)bk * kNSums + t]);
+            sums[t] = s;
         }
-        for (; bk < nblocks; ++bk) s += partials[(size_t)bk * kNSums + t];
-        sums[t] = s;
+        wave_sync();
+        if (t < 36) {
+            const int r0 = t / 6, c0 = t % 6, r = min(r0, c0), c = max(r0, c0);
+            A[r0][c0] = sums[r * 6 - r * (r - 1) / 2 + (c - r)];
+        }
+        wave_sync();
+        inv6_wave(A, Q, piv, &singular);
+        if (t < 6) {
+            double s = 0;
+            for (int c = 0; c < 6; ++c) s += Q[t][c] * sums[21 + c];
+            xs[t] = s;
+        }
     }
-    wave_sync();
-    if (t < 36) {
-        const int r0 = t / 6, c0 = t % 6, r = min(r0, c0), c = max(r0, c0);
-        A[r0][c0] = sums[r * 6 - r * (r - 1) / 2 + (c - r)];
-    }
-    wave_sync();
-    inv6_wave(A, Q, piv, &singular);
-    if (t < 36) QX[t] = Q[t / 6][t % 6];
-    if (t < 6) {
-        double s = 0;
-        for (int c = 0; c < 6; ++c) s += Q[t][c] * sums[21 + c];
-        QX[36 + t] = s;
-    }
-}
-
-// VCM step 2 in one launch: residuals v = A x - L, v^T v; the block that finishes last forms sigma0^2 * Qxx
-// (R.cpp:1330-1340) and, when asked, publishes it together with the run's diagnostic counter to the host mailbox.
-__global__ void __launch_bounds__(kBlock) k_vcm_finish(const float4* __restrict__ tgt, const float4* __restrict__ tgt_n,
-                                                       const float4* __restrict__ src, int ns,
-                                                       const int* __restrict__ match, const double* __restrict__ QX,
-                                                       double* __restrict__ partials, unsigned* __restrict__ counter,
-                                                       double* __restrict__ vcm, VcmMail mail) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    double v[kNSums];
-    v[0] = 0.0;
-    if (i < ns) {
+    __syncthreads();
+    // ---- residuals of all points on the whole block: thread t takes points t, t + 1024, ... ; fixed summation order ----
+    double vv = 0.0;
+    for (int p = tid; p < ns; p += kVcmBlock) {
+        const int bi = coh_load(&match[p]);
         double a[6], L;
-        vcm_row(src[i], tgt[match[i]], tgt_n[match[i]], a, &L);
+        vcm_row(src[p], tgt[bi], tgt_n[bi], a, &L);
         double r = 0;
-        for (int c = 0; c < 6; ++c) r += a[c] * QX[36 + c];
+        for (int c = 0; c < 6; ++c) r += a[c] * xs[c];
         r -= L;
-        v[0] = r * r;
+        vv += r * r;
     }
-    block_reduce_store(v, 1, partials + (size_t)blockIdx.x * kNSums);
-    if (threadIdx.x >= 64) return;
-    __threadfence();
-    unsigned last = 0;
-    if (threadIdx.x == 0) {
-        last = (atomicAdd(counter, 1u) == gridDim.x - 1u) ? 1u : 0u;
-        if (last) *counter = 0u;
-    }
-    last = (unsigned)__shfl((int)last, 0);
-    if (!last) return;
-    __threadfence();
-    const int t = threadIdx.x, nblocks = gridDim.x;
-    double vtpv = 0.0;
-    {   // block order, eight loads in flight; every lane computes the same sum
-        int bk = 0;
-        for (; bk + 8 <= nblocks; bk += 8) {
-            double w[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) w[u] = partials[(size_t)(bk + u) * kNSums];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) vtpv += w[u];
-        }
-        for (; bk < nblocks; ++bk) vtpv += partials[(size_t)bk * kNSums];
-    }
+    for (int o = 32; o > 0; o >>= 1) vv += __shfl_xor(vv, o);
+    if (lane == 0) sh[wave][0] = vv;
+    __syncthreads();
+    if (tid >= 64) return;
+    double vtpv = sh[0][0];
+    for (int w = 1; w < kVcmBlock / 64; ++w) vtpv += sh[w][0];
+    const int t = tid;
     const double STD0 = sqrt(vtpv / (double)(ns - 6));
     double out = 0.0;
-    if (t < 36) { out = STD0 * STD0 * QX[t]; vcm[t] = out; }
+    if (t < 36) { out = STD0 * STD0 * Q[t / 6][t % 6]; vcm[t] = out; }
     if (!mail.dst) return;
     // message: 36 doubles | the folded diagnostic counter (256 partial counters, 128 bytes apart) | seq
     unsigned long long ex = 0;
@@ -706,6 +692,43 @@ __global__ void __launch_bounds__(kBlock) k_vcm_finish(const float4* __restrict_
     __threadfence_system();
     wave_sync();
     if (t == 0) __hip_atomic_store(mail.seq_ptr, mail.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void __launch_bounds__(kVcmBlock) k_vcm(GridDesc g, const float4* __restrict__ tgt, const float4* __restrict__ tgt_n,
+                                                   const float4* __restrict__ src, int ns, int* __restrict__ match,
+                                                   double* __restrict__ partials, unsigned* __restrict__ counter,
+                                                   double* __restrict__ vcm, VcmMail mail) {
+    vcm_block(g, tgt, tgt_n, src, ns, match, partials, counter, vcm, mail, (int)blockIdx.x);
+}
+
+// The LAST update of a run (R.cpp:943-954) and calTransParaVCM (R.cpp:958-961) in one launch: the VCM works on the stable
+// centroids as they were BEFORE the update (R.cpp:868) and on the static target, so it does not wait for the transform - the
+// two used to be 14 + 16 + 8 us back to back.  Blocks [0, nb_vcm) are the VCM, the rest the transform (guarded by the ICP's done
+// flag like k_transform_all).  `stage3_bits` != 0: the launch was enqueued BEFORE the host has seen this iteration's result, on
+// the guess that it is the last one; the VCM then only runs if the iteration really reaches Stage 3, which in Stage 2 is
+// exactly `currDT == LoDet_min` (R.cpp:896) - both are known here (slot word 0).
+__global__ void __launch_bounds__(kVcmBlock) k_xf_vcm(GridDesc g, const float4* __restrict__ tgt, const float4* __restrict__ tgt_n,
+                                                      const float4* __restrict__ stct, int* __restrict__ match,
+                                                      double* __restrict__ partials, unsigned* __restrict__ counter,
+                                                      double* __restrict__ vcm, VcmMail mail, int nb_vcm, unsigned stage3_bits,
+                                                      const float4* cloud_in, const float4* ctbp_in, const float4* pat_in,
+                                                      float4* cloud, int n, int nb_cloud, float4* ctbp, int n_ctbp, float4* pat,
+                                                      int n_pat, const IcpState* __restrict__ st, const unsigned* __restrict__ slot_ro,
+                                                      unsigned* __restrict__ bbox_part, unsigned* __restrict__ slot, int nb_rest) {
+    __shared__ float shb[kVcmBlock / 64][6];
+    if (!st->done || slot_ro[2] < 4u) return;
+    int bid = (int)blockIdx.x;
+    if (bid < nb_vcm) {
+        if (stage3_bits && coh_load(&slot_ro[0]) != stage3_bits) return;
+        vcm_block(g, tgt, tgt_n, stct, (int)slot_ro[2], match, partials, counter, vcm, mail, bid);
+        return;
+    }
+    bid -= nb_vcm;
+    Mat4 T;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) T.m[i] = st->Tfinal[i];
+    if (bid < nb_rest) { xf_rest_block<kVcmBlock>(T, ctbp_in, ctbp, n_ctbp, pat_in, pat, n_pat, bid, nb_rest); return; }
+    xf_cloud_block<kVcmBlock>(T, cloud_in, cloud, n, bid - nb_rest, nb_cloud, bbox_part, slot, shb);
 }
 
 }  // namespace
@@ -795,10 +818,25 @@ int pw_vcm_enqueue(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, c
                    const float4* d_src, int ns, const VcmMail* mail) {
     if (ns <= 0) return PWICP_OK;
     VcmMail none{};
-    hipLaunchKernelGGL(k_vcm_normal, dim3(div_up(ns, kAccPts)), dim3(kAccBlock), 0, ctx->stream, g, d_tgt, d_tgt_n, d_src, ns,
-                       w->match.p, w->partials.p, w->counter.p, w->qx.p);
-    hipLaunchKernelGGL(k_vcm_finish, dim3(div_up(ns, kBlock)), dim3(kBlock), 0, ctx->stream, d_tgt, d_tgt_n, d_src, ns,
-                       w->match.p, w->qx.p, w->partials.p, w->counter.p, w->vcm.p, mail ? *mail : none);
+    hipLaunchKernelGGL(k_vcm, dim3(div_up(ns, kAccPts)), dim3(kVcmBlock), 0, ctx->stream, g, d_tgt, d_tgt_n, d_src, ns, w->match.p,
+                       w->partials.p, w->counter.p, w->vcm.p, mail ? *mail : none);
+    HIPCHK(ctx, hipGetLastError());
+    return PWICP_OK;
+}
+
+// the run's last transform + the VCM in one launch (k_xf_vcm); ns_max bounds the VCM's grid, the count itself is slot word 2
+int pw_xf_vcm_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
+                     const float4* d_stct, int ns_max, const VcmMail* mail, unsigned stage3_bits, const float4* d_cloud_in,
+                     const float4* d_ctbp_in, const float4* d_pat_in, float4* d_cloud, int n, float4* d_ctbp, int n_ctbp, float4* d_pat,
+                     int n_pat, unsigned* d_bbox_part, unsigned* d_slot) {
+    const int nb_vcm = div_up(std::max(ns_max, 1), kAccPts);
+    const int nb_cloud = std::min(div_up(n, kVcmBlock), ctx->n_cu * 2);
+    const int nb_rest = std::min(div_up(n_ctbp + n_pat, kVcmBlock), ctx->n_cu * 2);
+    VcmMail none{};
+    hipLaunchKernelGGL(k_xf_vcm, dim3(nb_vcm + nb_rest + nb_cloud), dim3(kVcmBlock), 0, ctx->stream, g, d_tgt, d_tgt_n, d_stct,
+                       w->match.p, w->partials.p, w->counter.p, w->vcm.p, mail ? *mail : none, nb_vcm, stage3_bits, d_cloud_in,
+                       d_ctbp_in, d_pat_in, d_cloud, n, nb_cloud, d_ctbp, n_ctbp, d_pat, n_pat, (const IcpState*)w->state.p,
+                       (const unsigned*)d_slot, d_bbox_part, d_slot, nb_rest);
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }

@@ -75,20 +75,7 @@ __global__ void __launch_bounds__(kBlock) k_transform_all(const float4* cloud_in
 #pragma unroll
     for (int i = 0; i < 16; ++i) T.m[i] = st->Tfinal[i];
     if (bid >= nb_cloud) {
-        const int nb = nb_work - nb_cloud, stride = nb * kBlock, ntot = n_ctbp + n_pat;
-        for (int i = (bid - nb_cloud) * kBlock + threadIdx.x; i < ntot; i += 4 * stride) {
-            float4* q[4];
-            float4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = i + u * stride;
-                q[u] = (j < n_ctbp) ? (ctbp + j) : (pat + (j - n_ctbp));
-                if (j < ntot) v[u] = (j < n_ctbp) ? ctbp_in[j] : pat_in[j - n_ctbp];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (i + u * stride < ntot) *q[u] = xform_point(T.m, v[u]);
-        }
+        xf_rest_block(T, ctbp_in, ctbp, n_ctbp, pat_in, pat, n_pat, bid - nb_cloud, nb_work - nb_cloud);
         return;
     }
     xf_cloud_block(T, cloud_in, cloud, n, bid, nb_cloud, bbox_part, slot, sh);
@@ -281,7 +268,7 @@ struct pwicp_pair {
     // mailbox in pinned coherent host memory: [0] sequence word, [16..] payload
     unsigned* mail_h = nullptr;
     unsigned* mail_d = nullptr;
-    unsigned mail_seq = 0, sel_mail_seq = 0;
+    unsigned mail_seq = 0, sel_mail_seq = 0, vcm_mail_seq = 0;
     ~pwicp_pair() {
         for (auto e : ev) (void)hipEventDestroy(e);
         if (mail_h) (void)hipHostFree(mail_h);
@@ -626,6 +613,7 @@ int pwicp_pair_num_patch_points(const pwicp_pair* pr, int* tot1, int* tot2) {
 }
 
 constexpr int kSelMailSeq = 4, kSelMailPayload = 8;      // mailbox words of the percentile selection
+constexpr int kVcmMailSeq = 6, kVcmMailPayload = 128;    // ... of the run's closing message (VCM | diagnostic counter)
 
 // waits until the mailbox sequence word reaches `seq` (spin, then fall back to a stream synchronisation)
 // PWICP_HOST_TRACE=1: host-side time stamps of pwicp_pair_run's enqueues and mailbox waits (stderr, us since the loop began)
@@ -723,12 +711,8 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     // tight bbox of the current source cloud: uploaded state now, then refreshed by every transform launch
     float bmin[3], bmax[3];
     for (int d = 0; d < 3; ++d) { bmin[d] = pr->bmin0[d]; bmax[d] = pr->bmax0[d]; }
-    {
-        const int n_zero = 256 * 16 + 2;
-        hipLaunchKernelGGL(k_scal_init, dim3(div_up(std::max(kSlot * (PWICP_MAX_OUTER + 1), n_zero), kBlock)), dim3(kBlock), 0,
-                           ctx->stream, pr->scal.p, PWICP_MAX_OUTER + 1, pr->examined.p, n_zero);
-    }
-
+    // (the scalar slots and the run's diagnostic counters are armed by the front launches: patch.hip front_init)
+    const int n_zero = 256 * 16 + 2;
     int status = PWICP_OK;
     int prev_inner = 2;
     bool vcm_pending = false;
@@ -740,12 +724,15 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     float prev_lod = NAN;
     // src_now: the front of the CURRENT iteration's state (pristine arrays on a lazily reset pair until the first transform);
     // false: the front of the NEXT iteration, enqueued behind a transform, reads the working arrays that transform writes
-    auto enqueue_front = [&](const FusedSelect* fs = nullptr, bool src_now = false) -> int {
+    auto enqueue_front = [&](unsigned* slot_k, const FusedSelect* fs = nullptr, bool src_now = false, bool run_start = false) -> int {
         // (1) R.cpp:737-747 — CT2 and BP2 queries against the static target-centroid grid — and the source patch
         // normals for CTcloud2_withNorm (R.cpp:824), recomputed from the transformed patch points: one launch
         // (+ pass 2 of the percentile selection on a few extra blocks when a dense search has just run)
+        FrontInit in;
+        in.slot = slot_k;
+        if (run_start) { in.zero = pr->examined.p; in.n_zero = n_zero; }
         return pw_front_launch(ctx, src_now ? pr->src_pat() : pr->P2.pat.p, pr->P2.off.p, m2, pr->nrm2.p, pr->tgt->g_ct1.d,
-                               src_now ? pr->src_ctbp() : pr->ctbp2.p, 7 * m2, pr->mCTBP.p, pr->dCTBP.p, fs);
+                               src_now ? pr->src_ctbp() : pr->ctbp2.p, 7 * m2, pr->mCTBP.p, pr->dCTBP.p, fs, &in);
     };
     auto enqueue_transform = [&](unsigned* slot, const FusedSelect* fs = nullptr) {
         // (8) R.cpp:943-954: cloud2 (+ its new bbox into this slot), centroids + boundary points, patch points
@@ -760,9 +747,23 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     };
     // (8) and the front of the NEXT iteration in one launch (patch.hip: k_xf_front): every role only needs T
     auto enqueue_xf_front = [&](unsigned* slot, const FusedSelect* fs = nullptr) -> int {
+        FrontInit in;
+        in.slot = slot + kSlot;                 // the front is the next iteration's
         return pw_xf_front_launch(ctx, pr->src_pat(), pr->P2.pat.p, pr->P2.off.p, m2, pr->nrm2.p, pr->tgt->g_ct1.d, pr->src_ctbp(),
                                   pr->ctbp2.p, 7 * m2, pr->mCTBP.p, pr->dCTBP.p, pr->src_cloud(), pr->cloud2.p, pr->n2,
-                                  (const IcpState*)pr->icp.state.p, (const unsigned*)(slot + 2), pr->bbox_part.p, slot, fs);
+                                  (const IcpState*)pr->icp.state.p, (const unsigned*)(slot + 2), pr->bbox_part.p, slot, fs, &in);
+    };
+    // the run's LAST update and the VCM (9) in one launch (icp.hip: k_xf_vcm).  guess: enqueued before the host has seen the
+    // iteration's result; the VCM part then only runs if the iteration reaches Stage 3 (currDT == LoDet_min, R.cpp:896)
+    auto enqueue_xf_vcm = [&](unsigned* slot, float currDT_now, bool guess, unsigned seq) -> int {
+        VcmMail vm;
+        vm.examined = pr->examined.p;
+        vm.dst = pr->mail_d + kVcmMailPayload; vm.seq_ptr = pr->mail_d + kVcmMailSeq; vm.seq = seq;
+        unsigned bits = 0;
+        if (guess) memcpy(&bits, &currDT_now, 4);
+        return pw_xf_vcm_launch(ctx, pr->tgt->g_ct1.d, pr->tgt->P1.ct.p, pr->tgt->ct1n.p, &pr->icp, pr->stCT.p, m2, &vm, bits,
+                                pr->src_cloud(), pr->src_ctbp(), pr->src_pat(), pr->cloud2.p, pr->n2, pr->ctbp2.p, 7 * m2, pr->P2.pat.p,
+                                pr->P2.tot, pr->bbox_part.p, slot);
     };
     // (7) of a Stage-1 iteration: dense NN of the stable patches' points against the full target cloud (C.cpp:266-281) with the
     // percentile selection riding on the launches that follow (select_dev.h): pass 0 in the dense kernel, pass 1 beside the
@@ -818,7 +819,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         unsigned* const slot = pr->scal.p + (size_t)kSlot * k;
 
         ht("iteration begins");
-        if (!front_ready) { PWCHK(enqueue_front(nullptr, true)); ht("front enqueued"); }
+        if (!front_ready) { PWCHK(enqueue_front(slot, nullptr, true, k == 0)); ht("front enqueued"); }
         front_ready = false;
         const float4* const ct2 = pr->src_ctbp();
         const float4* const bp2 = pr->src_ctbp() + m2;
@@ -837,6 +838,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         const bool early_xf = stage2;
         const bool early_front = stage2 && !(currDT == prev_lod);
         bool xf_enqueued = false;
+        unsigned vcm_guess_seq = 0;        // != 0: the update went out merged with a guarded VCM (k_xf_vcm) under this mailbox tag
         // First iteration, still Stage 1: the dense search will almost certainly be needed (the clouds have just moved by the
         // whole initial misalignment), and it reads the PRE-transform positions, which do not change while the ICP iterates.
         // So it goes out right behind the first ICP batch, with the transform and the next front behind it, instead of after
@@ -884,7 +886,10 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                 }
                 if (early_xf) {                              // no-op on the device while the ICP has not converged
                     if (early_front) PWCHK(enqueue_xf_front(slot));
-                    else enqueue_transform(slot);
+                    else {                                   // looks like the last iteration: the update together with the VCM
+                        if (!vcm_guess_seq) vcm_guess_seq = ++pr->vcm_mail_seq;
+                        PWCHK(enqueue_xf_vcm(slot, currDT, true, vcm_guess_seq));
+                    }
                 }
                 const bool spec_now = spec_dense && !spec_done;
                 if (spec_now) { PWCHK(enqueue_dense_tail(slot, 0, /*rank_dev*/ true, /*with_front*/ true)); spec_done = true; }
@@ -968,20 +973,31 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
             xf_enqueued = spec_xf_valid;
             front_ready = spec_xf_valid && !stage3;
         }
-        if (!xf_enqueued) {                                              // (8)
+        // (8) the update, (9) R.cpp:958-961 the VCM of the last iteration on the stable centroids as copied BEFORE the update
+        // (R.cpp:868); its launch also sends the run's closing message (VCM | diagnostic counter)
+        bool vcm_done = false;
+        if (xf_enqueued && vcm_guess_seq && stage3) {      // went out merged and guarded: the device has taken the same decision
+            vcm_seq = vcm_guess_seq;
+            vcm_done = true;
+        }
+        if (!xf_enqueued) {
             if (!stage3) { PWCHK(enqueue_xf_front(slot)); front_ready = true; }
-            else enqueue_transform(slot);
+            else {
+                vcm_seq = ++pr->vcm_mail_seq;
+                PWCHK(enqueue_xf_vcm(slot, currDT, false, vcm_seq));
+                vcm_done = true;
+            }
             ht("transform enqueued (late)");
         }
         pr->lazy = false;                   // a valid transform is on the stream: from here on the working arrays are the source state
         pr->dirty = true;
-        // (9) R.cpp:958-961: stable centroids as copied BEFORE the update (R.cpp:868)
         if (stage3) {
-            // last iteration: the VCM's final launch also sends the run's closing message (VCM | diagnostic counter)
-            VcmMail vm;
-            vm.examined = pr->examined.p;
-            vm.dst = pr->mail_d + 16; vm.seq_ptr = pr->mail_d; vm.seq = vcm_seq = ++pr->mail_seq;
-            PWCHK(pw_vcm_enqueue(ctx, pr->tgt->g_ct1.d, pr->tgt->P1.ct.p, pr->tgt->ct1n.p, &pr->icp, pr->stCT.p, ns, &vm));
+            if (!vcm_done) {                                // the update went out with the next front (wrong guess): VCM on its own
+                VcmMail vm;
+                vm.examined = pr->examined.p;
+                vm.dst = pr->mail_d + kVcmMailPayload; vm.seq_ptr = pr->mail_d + kVcmMailSeq; vm.seq = vcm_seq = ++pr->vcm_mail_seq;
+                PWCHK(pw_vcm_enqueue(ctx, pr->tgt->g_ct1.d, pr->tgt->P1.ct.p, pr->tgt->ct1n.p, &pr->icp, pr->stCT.p, ns, &vm));
+            }
             vcm_pending = true;
             res->n_corr += ns;
         }
@@ -993,10 +1009,10 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     // closing message: the VCM (R.cpp:958-961) and the diagnostic counter; its arrival also means the stream is idle
     unsigned long long ex = 0;
     if (vcm_pending) {
-        PWCHK(mail_wait(pr, vcm_seq));
+        PWCHK(mail_wait(pr, vcm_seq, kVcmMailSeq));
         ht("vcm mail arrived");
-        memcpy(res->VCM, pr->mail_h + 16, 36 * sizeof(double));
-        memcpy(&ex, pr->mail_h + 16 + 72, sizeof(ex));
+        memcpy(res->VCM, pr->mail_h + kVcmMailPayload, 36 * sizeof(double));
+        memcpy(&ex, pr->mail_h + kVcmMailPayload + 72, sizeof(ex));
     } else {                                              // the loop ended without Stage 3 (error / iteration cap)
         hipLaunchKernelGGL(k_fold_examined, dim3(1), dim3(64), 0, ctx->stream, pr->examined.p);
         const unsigned seq = ++pr->mail_seq;

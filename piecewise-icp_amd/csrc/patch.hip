@@ -255,6 +255,15 @@ __global__ void __launch_bounds__(kFrontBlock) k_patch_normals(const float4* __r
     if (i < m) patch_normal_group(pat, off, i, t % kGroup, nrm_out, tiles + (threadIdx.x / kGroup) * kTileStride);   // a whole group is in or out of range together
 }
 
+// What the launches of an outer iteration expect to find armed, done by the front launch that precedes them instead of by a
+// launch of its own: words [0] / [1] of the iteration's scalar slot (atomicMin / atomicMax targets of the classification) and,
+// at the start of a run, the diagnostic counters.  Idempotent: a front launch that is enqueued twice arms twice.
+__device__ __forceinline__ void front_init(const FrontInit& in) {
+    if (in.slot && blockIdx.x == 0 && threadIdx.x < 2) in.slot[threadIdx.x] = threadIdx.x == 0 ? 0xffffffffu : 0u;
+    if (in.zero && blockIdx.x < 16)
+        for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < in.n_zero; i += 16 * (int)blockDim.x) in.zero[i] = 0ull;
+}
+
 // The "front" of an outer iteration in ONE launch: blocks [0, nb_nrm) compute the source patch normals (R.cpp:824),
 // the remaining blocks the 1-NN of the source centroids and boundary points among the target centroids
 // (R.cpp:737-747), 8 lanes per query.  The two are independent, each is a chain of dependent memory round trips that
@@ -263,8 +272,9 @@ __global__ void __launch_bounds__(kFrontBlock) k_patch_normals(const float4* __r
 __global__ void __launch_bounds__(kFrontBlock) k_front(const float4* __restrict__ pat, const int* __restrict__ off, int m,
                                                        float4* __restrict__ nrm_out, int nb_nrm, GridDesc g,
                                                        const float4* __restrict__ q, int nq, int* __restrict__ idx,
-                                                       float* __restrict__ d2, int nb_work, FusedSelect fs) {
+                                                       float* __restrict__ d2, int nb_work, FusedSelect fs, FrontInit init) {
     __shared__ float4 tiles[(kFrontBlock / kGroup) * kTileStride];
+    front_init(init);
     const int nsel = fs.scratch ? fs.nblk : 0;
     if ((int)blockIdx.x < nsel) {
         // leading blocks: pass 2 of the percentile selection of the PREVIOUS iteration's dense search (select_dev.h); the
@@ -297,7 +307,7 @@ __global__ void __launch_bounds__(kFrontBlock) k_front(const float4* __restrict_
 //   normal blocks   move the points of their patches (pat_in -> pat) on the way into the covariance sums;
 //   query blocks    move centroids / boundary points (ctbp_in -> ctbp) and search the moved point among the target centroids;
 //   cloud blocks    move the full cloud and fold its new bounding box (xf_cloud_block);
-//   first / last    blocks: passes 1 / 2 of the percentile selection when a dense search has just run (select_dev.h).
+//   first blocks    passes 1 and 2 of the percentile selection when a dense search has just run (select_dev.h).
 // The moved values are the same float expressions as in the stand-alone launches (xform_point), so normals, matches and
 // distances are bit-identical to transform-then-front; the two launches cost 14 + 17 us back to back, this one ~24 us.
 // (Alternating query and cloud blocks in the grid, or 6 / 8 waves per SIMD through launch bounds: no gain, measured.)
@@ -308,8 +318,9 @@ __global__ void __launch_bounds__(kFrontBlock) k_xf_front(const float4* pat_in, 
                                                           const float4* cloud_in, float4* cloud, int n, int nb_cloud,
                                                           const IcpState* __restrict__ st, const unsigned* __restrict__ ns_dev,
                                                           unsigned* __restrict__ bbox_part, unsigned* __restrict__ slot, FusedSelect fs,
-                                                          int nblk2) {
+                                                          int nblk2, FrontInit init) {
     __shared__ float4 tiles[(kFrontBlock / kGroup) * kTileStride];
+    front_init(init);
     static_assert(kFrontBlock == kXfBlock, "xf_cloud_block is written for this block size");
     const int nsel = fs.scratch ? fs.nblk : 0;
     if ((int)blockIdx.x < nsel) {
@@ -317,17 +328,21 @@ __global__ void __launch_bounds__(kFrontBlock) k_xf_front(const float4* pat_in, 
         fs_pass_embedded<1>((unsigned*)tiles, fs, (int)blockIdx.x, fs.mail.seq);
         return;
     }
-    if (fs.scratch && (int)blockIdx.x >= nsel + nb_nrm + nb_nn + nb_cloud) {      // pass 2 on the LAST blocks of the grid
+    const int nsel2 = fs.scratch ? nblk2 : 0;
+    if ((int)blockIdx.x < nsel + nsel2) {
+        // pass 2 right behind pass 1 in the grid (its blocks wait for pass 1's tag: blocks with smaller indices, dispatched
+        // before them): the percentile reaches the host while the rest of the launch is still running, so the next
+        // classification - which needs it as its threshold - is enqueued without the device going idle
         FusedSelect f2 = fs;
         f2.nblk = nblk2;
-        fs_pass_embedded<2>((unsigned*)tiles, f2, (int)blockIdx.x - (nsel + nb_nrm + nb_nn + nb_cloud), fs.mail.seq);
+        fs_pass_embedded<2>((unsigned*)tiles, f2, (int)blockIdx.x - nsel, fs.mail.seq);
         return;
     }
     if (!st->done || *ns_dev < 4u) return;
     Mat4 T;
 #pragma unroll
     for (int i = 0; i < 16; ++i) T.m[i] = st->Tfinal[i];
-    int bid = (int)blockIdx.x - nsel;
+    int bid = (int)blockIdx.x - nsel - nsel2;
     if (bid < nb_nrm) {
         const int t = bid * kFrontBlock + threadIdx.x;
         const int i = t / kGroup;
@@ -493,7 +508,7 @@ int pw_patch_normals_launch(pwicp_context* ctx, const float4* d_pat, const int* 
 }
 
 int pw_front_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, int m, float4* d_nrm, const GridDesc& g,
-                    const float4* d_q, int nq, int* d_idx, float* d_d2, const FusedSelect* fs) {
+                    const float4* d_q, int nq, int* d_idx, float* d_d2, const FusedSelect* fs, const FrontInit* init) {
     if (m <= 0 || nq <= 0) {
         if (fs && fs->scratch) return pw_fs_pass_launch(ctx, 2, *fs);
         return PWICP_OK;
@@ -510,7 +525,7 @@ int pw_front_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, i
     FusedSelect none{};
     const bool sel = fs && fs->scratch;
     hipLaunchKernelGGL(k_front, dim3(nb_nrm + nb_nn + (sel ? fs->nblk : 0)), dim3(kFrontBlock), 0, ctx->stream, d_pat, d_off, m, d_nrm,
-                       nb_nrm, g, d_q, nq, d_idx, d_d2, nb_nrm + nb_nn, sel ? *fs : none);
+                       nb_nrm, g, d_q, nq, d_idx, d_d2, nb_nrm + nb_nn, sel ? *fs : none, init ? *init : FrontInit{});
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }
@@ -518,7 +533,7 @@ int pw_front_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, i
 int pw_xf_front_launch(pwicp_context* ctx, const float4* d_pat_in, float4* d_pat, const int* d_off, int m, float4* d_nrm,
                        const GridDesc& g, const float4* d_ctbp_in, float4* d_ctbp, int nq, int* d_idx, float* d_d2,
                        const float4* d_cloud_in, float4* d_cloud, int n, const IcpState* d_state, const unsigned* d_ns,
-                       unsigned* d_bbox_part, unsigned* d_slot, const FusedSelect* fs) {
+                       unsigned* d_bbox_part, unsigned* d_slot, const FusedSelect* fs, const FrontInit* init) {
     const int nb_nrm = div_up((long long)m * kGroup, kFrontBlock);
     const int nb_nn = div_up((long long)nq * kGroup, kFrontBlock);
     const int nb_cloud = std::min(div_up(n, kFrontBlock), ctx->n_cu * 8);
@@ -526,7 +541,7 @@ int pw_xf_front_launch(pwicp_context* ctx, const float4* d_pat_in, float4* d_pat
     const bool sel = fs && fs->scratch;
     hipLaunchKernelGGL(k_xf_front, dim3(nb_nrm + nb_nn + nb_cloud + (sel ? fs->nblk + kFsBlocks : 0)), dim3(kFrontBlock), 0, ctx->stream,
                        d_pat_in, d_pat, d_off, m, d_nrm, nb_nrm, g, d_ctbp_in, d_ctbp, nq, d_idx, d_d2, nb_nn, d_cloud_in, d_cloud, n,
-                       nb_cloud, d_state, d_ns, d_bbox_part, d_slot, sel ? *fs : none, kFsBlocks);
+                       nb_cloud, d_state, d_ns, d_bbox_part, d_slot, sel ? *fs : none, kFsBlocks, init ? *init : FrontInit{});
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }

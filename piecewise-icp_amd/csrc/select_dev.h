@@ -106,10 +106,10 @@ __device__ __forceinline__ void fs_pick0(unsigned* h, const FusedSelect& fs, uns
 }
 
 // ---- passes 1 and 2 on `fs.nblk` blocks of some other launch; `bidx` = index of this block among them --------------------
-// chain != 0: passes 1 and 2 run in the SAME launch (k_xf_front: pass 1 on the first blocks of the grid, pass 2 on the last).
+// chain != 0: passes 1 and 2 run in the SAME launch (k_xf_front: pass 1 on the first blocks of the grid, pass 2 on the next).
 // The wave that picks pass 1's bin publishes prefix / rank through device-coherent stores and then the tag `chain`; the blocks
-// of pass 2 wait for the tag.  They only ever wait for blocks with smaller indices (dispatched before them), and by the time
-// the last blocks of a grid of thousands are dispatched the first ones have long finished.
+// of pass 2 wait for the tag (one lane polls, the block sleeps at a barrier).  They only ever wait for blocks with smaller
+// indices, which were dispatched before them.
 template <int PASS>
 __device__ __forceinline__ void fs_pass_embedded(unsigned* h, const FusedSelect& fs, int bidx, unsigned chain = 0u) {
     __shared__ unsigned s_last;

@@ -12,17 +12,38 @@ struct Mat4 {
 namespace pwdev {
 
 constexpr int kBoxParts = 64;
-constexpr int kXfBlock = 256;
+constexpr int kXfBlock = 256;             // block size of k_transform_all / k_xf_front (k_xf_vcm: 1024)
 
 __device__ __forceinline__ unsigned f2ord_dev(float f) {
     unsigned u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// block `bid` of `nb_cloud` blocks of kXfBlock threads; `sh`: kXfBlock / 64 x 6 floats of LDS
+// centroids + boundary points and the patch points: block `bid` of `nb` blocks of BLOCK threads
+template <int BLOCK = kXfBlock>
+__device__ __forceinline__ void xf_rest_block(const Mat4& T, const float4* ctbp_in, float4* ctbp, int n_ctbp, const float4* pat_in,
+                                              float4* pat, int n_pat, int bid, int nb) {
+    const int stride = nb * BLOCK, ntot = n_ctbp + n_pat;
+    for (int i = bid * BLOCK + (int)threadIdx.x; i < ntot; i += 4 * stride) {
+        float4* q[4];
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = i + u * stride;
+            q[u] = (j < n_ctbp) ? (ctbp + j) : (pat + (j - n_ctbp));
+            if (j < ntot) v[u] = (j < n_ctbp) ? ctbp_in[j] : pat_in[j - n_ctbp];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * stride < ntot) *q[u] = xform_point(T.m, v[u]);
+    }
+}
+
+// block `bid` of `nb_cloud` blocks of BLOCK threads; `sh`: BLOCK / 64 x 6 floats of LDS
+template <int BLOCK = kXfBlock>
 __device__ __forceinline__ void xf_cloud_block(const Mat4& T, const float4* cloud_in, float4* cloud, int n, int bid, int nb_cloud,
                                                unsigned* __restrict__ bbox_part, unsigned* __restrict__ slot, float (*sh)[6]) {
-    constexpr int kBlock = kXfBlock;
+    constexpr int kBlock = BLOCK;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     {
         const int stride = nb_cloud * kBlock;

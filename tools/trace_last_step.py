@@ -8,7 +8,7 @@ def short(n):
     m = re.search(r"(k_\w+|__amd_\w+|rocprim|hipcub)", n)
     return m.group(1) if m else n[:30]
 seq = [(short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows]
-idx = [i for i, s in enumerate(seq) if s[0] == "k_scal_init"]
+idx = [i for i, s in enumerate(seq) if s[0] == "k_scal_init" or (s[0] == "k_front" and (i == 0 or seq[i - 1][0] != "k_xf_front"))]
 i0 = idx[-1]
 prev_end = seq[i0][1]
 busy = 0
