@@ -157,6 +157,78 @@ def series_workload(args, ctx, P, rank, world):
     ctx.close()
 
 
+def series_end_to_end(args, P, rank, world, local_rank, dist, dev, barrier):
+    """BASELINE configs[3] end to end, beside the loop-only figure: ONE Direct2Ref series of `--series-epochs` source epochs of
+    `--points` points (PCD files written by rank 0), its pairs dealt p -> rank p mod world, every rank going from the files through
+    preprocessing, front end, registration (pwicp_series_run_pairs); then the series' one exchange (all-gather of the 384-byte
+    records).  Strong scaling of a fixed series: what contends on a node - scan I/O, host threads of the front ends, PCIe uploads
+    from pageable memory - shows here and not in the loop-only line.  Returns a dict for the main JSON line (rank 0), else None."""
+    import shutil
+    import tempfile
+    from pwicp_amd import fourd, synth
+    from pwicp_amd.pcd import write_pcd_binary
+    r, n, E = R_SPACING, args.points, args.series_epochs
+    root = os.environ.get("PWICP_BENCH_TMP") or ("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir())
+    d = os.path.join(root, "pwicp_bench_series_%s" % os.environ.get("MASTER_PORT", str(os.getppid())))
+    inp = os.path.join(d, "scans")
+    cfg = os.path.join(d, "cfg.txt")
+    if rank == 0:
+        shutil.rmtree(d, ignore_errors=True)
+        os.makedirs(inp)
+        t, _ = synth.make_tile(n, r)
+        write_pcd_binary(os.path.join(inp, "Epoch_001.pcd"), t.astype(np.float32))
+        for e in range(1, E + 1):
+            s, _ = synth.make_source(n, r, epoch=e)
+            write_pcd_binary(os.path.join(inp, "Epoch_%03d.pcd" % (e + 1)), s.astype(np.float32))
+        with open(cfg, "w") as f:
+            f.write("string FolderFilePath1: %s\nstring FolderFilePath2: %s\nbool isSetResSVsize (yes-1, no-0): 1\n"
+                    "float PCres1 (m): %g\nfloat PCres2 (m): %g\nfloat SVsize1 (m): %g\nfloat SVsize2 (m): %g\n"
+                    "bool isSetDTinit (yes-1, no-0): 1\nfloat DTinit (m): %g\nfloat DTmin (m): %g\nbool isVisual (yes-1, no-0): 0"
+                    % (inp, os.path.join(d, "out_"), r, r, 10 * r, 10 * r, 10 * r, 0.8 * r))
+    barrier()
+    out = None
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    saved = os.dup(1)
+    try:
+        os.dup2(devnull, 1)                      # the entry point prints the reference's progress lines on stdout
+        series = P.Series(cfg, 0, E + 1, 0, 0.75, local_rank)
+        mine = [p for p in range(E) if p % world == rank]
+        barrier()
+        t0 = time.perf_counter()
+        recs = series.run_pairs(mine) if mine else np.zeros(0, fourd.RECORD)
+        if dist is not None:
+            table = fourd.gather_records([recs[k:k + 1] for k in range(len(recs))], E, world, dist=dist, device=dev)
+            assert len(table) == E, "record gather incomplete"
+        barrier()
+        wall = time.perf_counter() - t0
+        stages = series.stage_times()
+        series.close()
+    finally:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)           # what the library has buffered for stdout goes to /dev/null too
+        os.dup2(saved, 1)
+        os.close(saved)
+        os.close(devnull)
+    import torch
+    tmax = wall
+    if dist is not None:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tmax = float(t.item())
+    ok = bool(np.all(recs["status"] == 0)) if len(recs) else True
+    if rank == 0:
+        out = {"metric": "pairs/sec, PCD files -> transforms (Direct2Ref series of %d source epochs x %d pts, pairs dealt over the GPUs)" % (E, n),
+               "value": round(E / tmax, 3), "unit": "pairs/s", "scaling": "strong", "n_gpus": world, "pairs": E, "wall_s": round(tmax, 3),
+               "all_pairs_ok": ok,
+               "rank0_stage_wall_ms": {k: round(v, 1) for k, v in stages.items() if k.endswith("_ms")},
+               "rank0_scan_bytes_to_gpu": stages["scan_bytes"],
+               "note": "stages of rank 0 (its share of the pairs + the shared target): reading scans, GPU preparation (voxel grid incl. the "
+                       "host-side std::sort order, SOR, reduction), what is left of the front ends after that, registrations; the "
+                       "front end of a cloud (~100 ms per 1 M points of device time) is what a pair costs, the loop is 0.35 ms of it"}
+        shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
 def frontend_workload(args, ctx, P, rank, world):
     """the segmentation front end of ONE cloud (S.cpp:18-68: k-NN-45 graph, PCA normals, supervoxel fusion,
     boundary refinement) through pwicp_frontend_segment_dev, timed host buffer in -> labels out.  The device pipeline
@@ -219,6 +291,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=1000000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--series-epochs", type=int, default=8,
+                    help="source epochs of the end-to-end series measured beside the loop-only figure (BASELINE configs[3]); 0: skip")
     ap.add_argument("--no-inner-timing", action="store_true",
                     help="skip the two extra untimed steps that time the inner ICP with HIP events (kernel-trace runs: the last "
                          "step of the process is then a step as timed)")
@@ -319,6 +393,9 @@ def main():
         corr_total = float(c.item())
 
     res = results[-1]
+    series_line = None
+    if args.series_epochs > 0:
+        series_line = series_end_to_end(args, P, rank, world, local_rank, dist, dev, barrier)
     # inner-iteration timing needs two more HIP events per ICP call (a ~6 us stream bubble each): measured on two
     # extra, untimed steps so that the timed region carries only the dense-NN events of the roofline figure
     pair.set_profiling(1 | 2)
@@ -398,6 +475,7 @@ def main():
             # (one after the other here), then upload + patch selection + grids
             "frontend_s": round(FRONTEND_S, 3), "setup_s": round(t_setup, 3),
             "roofline": roofline,
+            "series_end_to_end": series_line,
         }
         if world == 1 and not args.no_cpu_baseline:
             io, io_mt, mt_cores = cpu_baseline(tgt, l1, n1, src, l2, n2)

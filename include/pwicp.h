@@ -337,10 +337,19 @@ PWICP_API int pwicp_series_num_scans(const pwicp_series* s);     /* Epoch_### fi
 PWICP_API int pwicp_series_pair_epochs(const pwicp_series* s, int pair, int* target_index, int* source_index,
                                        long* source_stamp);
 PWICP_API int pwicp_series_adaptive_targets(const pwicp_series* s, int32_t* targets, int n);
+/* The adaptive pair map in pieces (a multi-process run shards the independent overlap ratios, R.cpp:593-614, and replays the
+ * sequential target scan, R.cpp:552-589, from the gathered table): open the series with adaptive_targets = NULL and
+ * n_adaptive = -1 (deferred), compute any (target, source) file-index pairs with pwicp_series_overlap_ratios, then hand the
+ * table (#files x #files floats, [i * #files + j], NaN = unknown: computed on the spot) to pwicp_series_adaptive_from_ratios. */
+PWICP_API int pwicp_series_overlap_ratios(pwicp_series* s, const int32_t* target_source_pairs, int n_pairs, float* ratios);
+PWICP_API int pwicp_series_adaptive_from_ratios(pwicp_series* s, const float* ratio_table, float overlapThd, int write_pair_file);
 PWICP_API int pwicp_series_run_pair(pwicp_series* s, int pair, pwicp_pair_record* rec);
 /* Any subset of the pairs, pipelined: scans read and supervoxels computed on host threads for several pairs at once,
  * GPU stages one after the other.  Same records as n calls of pwicp_series_run_pair. */
 PWICP_API int pwicp_series_run_pairs(pwicp_series* s, const int32_t* pairs, int n_pairs, pwicp_pair_record* recs);
+/* wall time per stage of the pairs run so far, ms5 = {read scans, GPU preparation, front ends (rest), registrations} in ms and
+ * the raw scan bytes handed to the GPU */
+PWICP_API int pwicp_series_stage_times(pwicp_series* s, double* ms5);
 PWICP_API int pwicp_series_write_results(pwicp_series* s, const pwicp_pair_record* recs, int n_recs);
 /* Several GPUs inside ONE process: n >= 1 HIP device ids (duplicates allowed: two workers sharing a GPU, for functional
  * tests on a 1-GPU box).  pwicp_series_run_pairs then deals the pairs of a call to the devices (pair k -> device k mod n),

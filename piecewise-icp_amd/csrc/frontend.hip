@@ -1009,6 +1009,8 @@ struct FeWorkspace {
         dflag, cflag, dtmin, Wa, Wb, dq, dq2, ovf, o_sz, o_ran, o_absn, o_adjn, o_dirty, o_oldabsn, alive, newlen, cut, arenaA, arenaB, sa, ctr;
     DevBuf<long long> offA, offB, rec_ptr, o_ptr, o_oldptr;
     DevBuf<unsigned long long> big;     // [0] absorbed in the round, [16 * (1 + r)] bump pointer of arena region r
+    int sa_factor = 3;                  // list arena = sa_factor * n * k entries (doubled, once, when a round overflows it)
+    bool sa_overflow = false;           // set by fusion_device when it gave up because of the arena
     FeWorkspace() = default;
     FeWorkspace(const FeWorkspace&) = delete;
     FeWorkspace& operator=(const FeWorkspace&) = delete;
@@ -1246,9 +1248,11 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     for (DevBuf<long long>* b : {&ws.offA, &ws.offB, &ws.rec_ptr, &ws.o_ptr, &ws.o_oldptr}) HIPCHK(ctx, b->reserve(N));
     HIPCHK(ctx, ws.ctr.reserve(16));
     HIPCHK(ctx, ws.big.reserve(16 * (kFusArenas + 1)));
-    // lists of changed outcomes are appended, nothing is freed inside a round: 14 % of 16 n k entries at most on the clouds
-    // measured (the round after the first one); 6 n k = 1.1 GB per 1 M points, overflow = the device pass gives up
-    const unsigned long long sa_cap = 6ull * (unsigned long long)n * (unsigned long long)k;
+    // lists of changed outcomes are appended, nothing is freed inside a round: 2.2 n k entries at most on the clouds measured
+    // (the round after the first one).  3 n k = 0.54 GB per 1 M points; a round that overflows it is retried once with 6 n k
+    // (segment_from_device_graph), beyond that the device pass gives up
+    const unsigned long long sa_cap = (unsigned long long)ws.sa_factor * (unsigned long long)n * (unsigned long long)k;
+    ws.sa_overflow = false;
     HIPCHK(ctx, ws.sa.reserve((size_t)sa_cap));
     hipLaunchKernelGGL(k_fus_first_round, grid1(n), dim3(256), 0, st, n, k, ws.root0.p, ws.s0.p, ws.lenA.p, ws.offA.p, ws.cenA.p);
     int* len0 = ws.lenA.p; int* len1 = ws.lenB.p;
@@ -1352,6 +1356,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
                 runs += h_ctr[7];
                 if (h_ctr[8] || h_ctr[9]) {
                     if (trace) fprintf(stderr, "[pwicp front end/dev]   fusion gives up in round %d (%s overflow)\n", round, h_ctr[8] ? "queue" : "arena");
+                    ws.sa_overflow = !h_ctr[8] && h_ctr[9];
                     *gave_up = true;
                     return PWICP_OK;
                 }
@@ -1384,6 +1389,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
             HIPCHK(ctx, hipStreamSynchronize(st));
             if (h_ctr[8] || h_ctr[9]) {
                 if (trace) fprintf(stderr, "[pwicp front end/dev]   fusion gives up in round %d (%s overflow)\n", round, h_ctr[8] ? "queue" : "arena");
+                ws.sa_overflow = !h_ctr[8] && h_ctr[9];
                 *gave_up = true;
                 return PWICP_OK;
             }
@@ -1489,6 +1495,12 @@ int segment_from_device_graph(pwicp_context* ctx, FeTrace& tr, const float* clou
     bool host_fusion = getenv("PWICP_FUSION") && std::string(getenv("PWICP_FUSION")) == "host";
     if (!host_fusion) {
         PWCHK(fusion_device(ctx, dP, d_nb, k, n, res, n_sv, d_lab.p, &d_roots, &n_roots, &host_fusion));
+        FeWorkspace& fws = *workspace_of(ctx);
+        if (host_fusion && fws.sa_overflow && fws.sa_factor < 6) {       // the list arena was too small for this cloud: once more, doubled
+            fws.sa_factor = 6;
+            if (getenv("PWICP_TRACE")) fprintf(stderr, "[pwicp front end/dev]   list arena doubled, fusion restarted\n");
+            PWCHK(fusion_device(ctx, dP, d_nb, k, n, res, n_sv, d_lab.p, &d_roots, &n_roots, &host_fusion));
+        }
         tr.lap("fusion");
     }
     if (host_fusion) {                                  // (serial host pass: $PWICP_FUSION=host, or the device pass gave up)

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "common.h"
+#include "../host/io.h"
 #include "../host/preprocess.h"
 
 namespace {
@@ -93,6 +94,7 @@ int pw_preprocess_dev(pwicp_context* ctx, const float4* d_in, int n, bool downsa
                       DevBuf<float4>* d_out, int* m_out) {
     *m_out = 0;
     if (n <= 0) return PWICP_OK;
+    pwhost::StageTimer tm;                  // PWICP_TRACE=1
     float mn[3], mx[3];
     PWCHK(pw_bbox(ctx, d_in, n, mn, mx));
     DevBuf<float4> vox;
@@ -149,6 +151,7 @@ int pw_preprocess_dev(pwicp_context* ctx, const float4* d_in, int n, bool downsa
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         he.resize((size_t)n);
         for (int i = 0; i < n; ++i) he[(size_t)i] = pwhost::VoxelEntry{hk[(size_t)i], i};
+        tm.lap("  prep: bbox, voxel keys down");
     }
     HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(tsort.p, tb, keys.p, keys_s.p, vals.p, order.p, n, 0, end_bit, ctx->stream));
     hipLaunchKernelGGL(k_vg_heads, dim3(div_up(n + 1, kBlock)), dim3(kBlock), 0, ctx->stream, keys_s.p, n, head.p);
@@ -157,7 +160,9 @@ int pw_preprocess_dev(pwicp_context* ctx, const float4* d_in, int n, bool downsa
     HIPCHK(ctx, hipMemcpyAsync(&m, head.p + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     std::vector<int> ho;                       // lives until the synchronisation below
     if (msvc) {
-        if (pwhost::voxel_sort_msvc(he.data(), he.size())) {
+        const bool sorted = pwhost::voxel_sort_msvc(he.data(), he.size());
+        tm.lap("  prep: std::sort order (host)");
+        if (sorted) {
             ho.resize((size_t)n);
             for (int i = 0; i < n; ++i) ho[(size_t)i] = he[(size_t)i].pt;
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -174,6 +179,7 @@ int pw_preprocess_dev(pwicp_context* ctx, const float4* d_in, int n, bool downsa
     hipLaunchKernelGGL(k_vg_centroids, dim3(div_up(m, kBlock)), dim3(kBlock), 0, ctx->stream, d_in, order.p, start.p, m, n, vox.p);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));          // the sort temporaries die with this scope
     sor_in = vox.p;
+    tm.lap("  prep: voxel centroids");
     }
     // ---- statistical outlier removal ---------------------------------------------------------------------------------
     Grid g;
@@ -185,6 +191,7 @@ int pw_preprocess_dev(pwicp_context* ctx, const float4* d_in, int n, bool downsa
     std::vector<float> hd((size_t)m);
     HIPCHK(ctx, hipMemcpyAsync(hd.data(), dist.p, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    tm.lap("  prep: SOR grid + 14-NN mean distances down");
     double sum = 0, sq = 0;
     for (int i = 0; i < m; ++i) { sum += hd[(size_t)i]; sq += (double)(hd[(size_t)i] * hd[(size_t)i]); }
     const double mean = sum / (double)m;
@@ -202,6 +209,7 @@ int pw_preprocess_dev(pwicp_context* ctx, const float4* d_in, int n, bool downsa
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipGetLastError());
     *m_out = kept;
+    tm.lap("  prep: SOR statistics (host) + compaction");
     return PWICP_OK;
 }
 

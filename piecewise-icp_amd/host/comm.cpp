@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <ctime>
@@ -219,8 +220,8 @@ PWICP_API int pwicp_comm_broadcast(pwicp_comm* c, void* buf, size_t bytes, int r
 }
 
 // One rank of a 4D series sharded over `world` processes (one GPU each): PiecewiseICP_4D_call (R.cpp:17-215) with its pair
-// loop (R.cpp:89-187) dealt out as pair p -> rank p mod world.  In adaptive mode rank 0 determines the pair map
-// (calAdaptivePairSequence, R.cpp:552-589) and broadcasts it; every rank runs its pairs; ONE all-gather of the 384-byte
+// loop (R.cpp:89-187) dealt out as pair p -> rank p mod world.  In adaptive mode the overlap ratios behind the pair map are
+// dealt out too and every rank replays calAdaptivePairSequence (R.cpp:552-589) on the gathered table; every rank runs its pairs; ONE all-gather of the 384-byte
 // records; rank 0 writes the reference's result files.  Every collective is preceded by an agreement on the ranks' status
 // (a 4-byte all-gather), so a rank that failed locally makes all ranks return false instead of leaving them in a collective.
 PWICP_API bool pwicp_series_run_distributed(const char* confile, int startEpoch, int epochNum, int pairMode, float overlapThd,
@@ -241,19 +242,36 @@ PWICP_API bool pwicp_series_run_distributed(const char* confile, int startEpoch,
     int32_t n_t = 0;
     do {
         if (pairMode < 0 && world > 1) {
-            if (rank == 0) {
-                ok = pwicp_series_open(confile, startEpoch, epochNum, pairMode, overlapThd, device, nullptr, 0, &s) == PWICP_OK;
-                if (ok) {
-                    n_t = pwicp_series_num_scans(s) - startEpoch - 1;
-                    targets.resize((size_t)std::max(n_t, 1));
-                    ok = n_t > 0 && pwicp_series_adaptive_targets(s, targets.data(), n_t) == PWICP_OK;
-                }
+            // adaptive mode: the overlap ratios of the candidate pairs (source j against the targets j-W .. j-1, R.cpp:593-614) are
+            // independent - dealt to the ranks, all-gathered as one #files x #files table - and every rank replays the
+            // sequential target scan (R.cpp:552-589) on the same table: the same map everywhere, nothing to broadcast.  A
+            // ratio the scan needs beyond the window is computed on the spot (by every rank alike).
+            ok = pwicp_series_open(confile, startEpoch, epochNum, pairMode, overlapThd, device, nullptr, -1, &s) == PWICP_OK;
+            if (!agree(ok)) break;
+            const int nf = pwicp_series_num_scans(s);
+            int W = 6;
+            if (const char* e = getenv("PWICP_ADAPTIVE_WINDOW")) W = std::max(1, atoi(e));
+            std::vector<float> mine_tab((size_t)nf * nf, NAN);
+            {
+                std::vector<int32_t> ij;
+                int p = 0;
+                for (int j = startEpoch + 1; j < nf; ++j)
+                    for (int i = std::max(startEpoch, j - W); i < j; ++i, ++p)
+                        if (p % world == rank) { ij.push_back(i); ij.push_back(j); }
+                std::vector<float> r(ij.size() / 2 + 1);
+                ok = pwicp_series_overlap_ratios(s, ij.data(), (int)(ij.size() / 2), r.data()) == PWICP_OK;
+                for (size_t k = 0; ok && k < ij.size() / 2; ++k) mine_tab[(size_t)ij[2 * k] * nf + ij[2 * k + 1]] = r[k];
             }
             if (!agree(ok)) break;
-            if (pwicp_comm_broadcast(comm, &n_t, sizeof(n_t), 0) != PWICP_OK) { ok = false; }
-            if (!agree(ok)) break;               // a rank whose first broadcast failed must not leave the others in the second
-            targets.resize((size_t)std::max(n_t, 1));
-            if (ok && pwicp_comm_broadcast(comm, targets.data(), sizeof(int32_t) * (size_t)n_t, 0) != PWICP_OK) ok = false;
+            std::vector<float> all_tab((size_t)nf * nf * world);
+            ok = pwicp_comm_allgather(comm, mine_tab.data(), sizeof(float) * mine_tab.size(), all_tab.data()) == PWICP_OK;
+            if (!agree(ok)) break;
+            for (int r = 0; r < world; ++r)
+                for (size_t k = 0; k < mine_tab.size(); ++k) {
+                    const float v = all_tab[(size_t)r * mine_tab.size() + k];
+                    if (v == v) mine_tab[k] = v;
+                }
+            ok = pwicp_series_adaptive_from_ratios(s, mine_tab.data(), overlapThd, rank == 0 ? 1 : 0) == PWICP_OK;
             if (!agree(ok)) break;
         }
         if (!s) ok = pwicp_series_open(confile, startEpoch, epochNum, pairMode, overlapThd, device, targets.empty() ? nullptr : targets.data(),

@@ -546,6 +546,11 @@ struct pwicp_series {
     std::vector<long> times;
     int startEpoch = 0, epochNum = 0, pairMode = 0, device = 0;
     std::map<int, int> regPairs;          // adaptive mode: source -> target, relative to startEpoch (R.cpp:570)
+    bool adaptive_deferred = false;       // adaptive mode opened without its pair map (a sharded computation supplies it)
+    std::mutex stage_mu;
+    double stage_ms[4] = {0, 0, 0, 0};    // wall time spent so far: reading scans | GPU preparation | front ends (rest) | registrations
+    long long stage_bytes = 0;            // bytes of raw scans handed to the GPU
+    std::vector<std::vector<float>> scan_cache;   // raw scans read for the overlap ratios, dropped once the map is known
     std::vector<std::unique_ptr<SeriesWorker>> workers;      // [0] = `device`; more after pwicp_series_set_devices
 
     SeriesWorker* w0() {
@@ -563,29 +568,43 @@ struct pwicp_series {
 
 namespace {
 
-// calAdaptivePairSequence (R.cpp:552-589) with the overlap ratio on the GPU (R.cpp:593-614)
-bool adaptive_pair_sequence(pwicp_series* s, float overlapThd, const std::string& pairFile) {
+// calOverlapRatioByC2Cdist (R.cpp:593-614) of the raw scans i (target) and j (source), on the GPU; scans cached in the series
+bool series_overlap(pwicp_series* s, int i, int j, float* ratio) {
     if (!s->w0()->need_ctx()) return false;
-    pwicp_context* const ctx0 = s->w0()->ctx;
+    const int fileCount = (int)s->files.size();
+    if (i < 0 || j < 0 || i >= fileCount || j >= fileCount) return false;
+    if ((int)s->scan_cache.size() != fileCount) s->scan_cache.assign((size_t)fileCount, {});
+    auto cloud = [&](int f) -> std::vector<float>& { if (s->scan_cache[(size_t)f].empty()) load_pcd(s->files[(size_t)f], &s->scan_cache[(size_t)f]); return s->scan_cache[(size_t)f]; };
+    std::vector<float>&a = cloud(i), &b = cloud(j);
+    return pwicp_overlap_ratio(s->w0()->ctx, a.data(), (int)(a.size() / 4), b.data(), (int)(b.size() / 4), s->cfg.DTinit, ratio) == PWICP_OK;
+}
+
+// calAdaptivePairSequence (R.cpp:552-589).  table (optional): fileCount x fileCount overlap ratios computed elsewhere, entry
+// [i * fileCount + j] for target i, source j, NaN = not computed; whatever the scan needs beyond it is computed on the spot.
+bool adaptive_pair_sequence(pwicp_series* s, float overlapThd, const std::string& pairFile, const float* table = nullptr) {
     const int fileCount = (int)s->files.size(), startEpoch = s->startEpoch;
     int idxTarget = startEpoch;
-    std::vector<std::vector<float>> cache((size_t)fileCount);
-    auto cloud = [&](int i) -> std::vector<float>& { if (cache[(size_t)i].empty()) load_pcd(s->files[(size_t)i], &cache[(size_t)i]); return cache[(size_t)i]; };
+    s->regPairs.clear();
     for (int j = startEpoch + 1; j < fileCount; ++j) {
         float ratio = 0;
         for (int i = idxTarget; i < j; ++i) {
-            std::vector<float>&a = cloud(i), &b = cloud(j);
-            if (pwicp_overlap_ratio(ctx0, a.data(), (int)(a.size() / 4), b.data(), (int)(b.size() / 4), s->cfg.DTinit, &ratio) != PWICP_OK) return false;
+            const float known = table ? table[(size_t)i * fileCount + j] : NAN;
+            if (known == known) ratio = known;
+            else if (!series_overlap(s, i, j, &ratio)) return false;
             idxTarget = i;
             if (ratio > overlapThd) break;
         }
         s->regPairs[j - startEpoch] = idxTarget - startEpoch;
         std::cout << "Pair: " << idxTarget - startEpoch << " - " << j - startEpoch << ";  Overlap ratio = " << 100 * ratio << "% \n";
-        if (idxTarget > startEpoch) cache[(size_t)idxTarget - 1].clear();        // scans before the current target are never read again
+        if (idxTarget > startEpoch && !s->scan_cache.empty()) std::vector<float>().swap(s->scan_cache[(size_t)idxTarget - 1]);   // never read again
     }
-    std::ofstream pf(pairFile);
-    if (!pf) { std::cerr << "Error: Cannot open adaptivePairFile!\n"; return false; }
-    for (auto& kv : s->regPairs) pf << kv.first << " " << kv.second << std::endl;
+    std::vector<std::vector<float>>().swap(s->scan_cache);
+    if (!pairFile.empty()) {
+        std::ofstream pf(pairFile);
+        if (!pf) { std::cerr << "Error: Cannot open adaptivePairFile!\n"; return false; }
+        for (auto& kv : s->regPairs) pf << kv.first << " " << kv.second << std::endl;
+    }
+    s->adaptive_deferred = false;
     return true;
 }
 
@@ -606,9 +625,11 @@ PWICP_API int pwicp_series_open(const char* confile, int startEpoch, int epochNu
     if (startEpoch < 0 || epochNum > fileCount || startEpoch >= epochNum) { std::cerr << "Error: epoch range outside the folder content.\n"; return PWICP_E_INVALID; }
     s->startEpoch = startEpoch; s->epochNum = epochNum; s->pairMode = pairMode; s->device = device;
     if (pairMode < 0) {
-        if (adaptive_targets) {                       // map computed elsewhere (rank 0 of a multi-GPU run)
+        if (adaptive_targets) {                       // map computed elsewhere
             if (n_adaptive != fileCount - startEpoch - 1) { std::cerr << "Error: adaptive pair map has the wrong length.\n"; return PWICP_E_INVALID; }
             for (int k = 0; k < n_adaptive; ++k) s->regPairs[k + 1] = adaptive_targets[k];
+        } else if (n_adaptive < 0) {                  // deferred: pwicp_series_overlap_ratios / pwicp_series_adaptive_from_ratios follow
+            s->adaptive_deferred = true;
         } else {
             std::cout << "--->>> Adaptive pair sequence determination... \n";
             if (!adaptive_pair_sequence(s.get(), overlapThd, "RegPairFile.txt")) { for (auto& w : s->workers) w->close(); return PWICP_E_INTERNAL; }
@@ -635,6 +656,36 @@ PWICP_API int pwicp_series_pair_epochs(const pwicp_series* s, int pair, int* tar
     return PWICP_OK;
 }
 
+// The adaptive pair map in pieces, for a computation sharded over processes (host/comm.cpp, pwicp_amd/series.py): the overlap
+// ratios of candidate pairs are independent of each other (R.cpp:593-614), only the scan that picks the targets is sequential
+// (R.cpp:552-589).  ij: n pairs of file indices (target, source).
+PWICP_API int pwicp_series_overlap_ratios(pwicp_series* s, const int32_t* ij, int n, float* ratios) {
+    if (!s || !ij || !ratios || n < 0) return PWICP_E_INVALID;
+    for (int k = 0; k < n; ++k)
+        if (!series_overlap(s, ij[2 * k], ij[2 * k + 1], &ratios[k])) return s->w0()->ctx ? PWICP_E_INVALID : PWICP_E_NO_DEVICE;
+    return PWICP_OK;
+}
+
+// table: #files x #files ratios, [i * #files + j] for target i and source j, NaN where unknown (computed on the spot if the scan
+// gets there).  write_pair_file != 0: RegPairFile.txt in the working directory, as the reference does (R.cpp:578-586).
+PWICP_API int pwicp_series_adaptive_from_ratios(pwicp_series* s, const float* table, float overlapThd, int write_pair_file) {
+    if (!s || s->pairMode >= 0) return PWICP_E_INVALID;
+    std::cout << "--->>> Adaptive pair sequence determination... \n";
+    return adaptive_pair_sequence(s, overlapThd, write_pair_file ? "RegPairFile.txt" : "", table) ? PWICP_OK : PWICP_E_INTERNAL;
+}
+
+// wall time the pairs run so far have spent per stage (ms): [0] reading scans, [1] GPU preparation (voxel grid, SOR, reduction;
+// the front ends of earlier clouds run beside it on their own streams), [2] what was left of the front ends after that,
+// [3] registrations (upload, patches, loop); [4] = raw scan bytes handed to the GPU.  With several devices the stages of the
+// workers overlap: the entries are sums over the workers.
+PWICP_API int pwicp_series_stage_times(pwicp_series* s, double* ms5) {
+    if (!s || !ms5) return PWICP_E_INVALID;
+    std::lock_guard<std::mutex> g(s->stage_mu);
+    for (int k = 0; k < 4; ++k) ms5[k] = s->stage_ms[k];
+    ms5[4] = (double)s->stage_bytes;
+    return PWICP_OK;
+}
+
 // adaptive map as n = (#files - startEpoch - 1) targets, entry k = target of source k+1 (relative to startEpoch)
 PWICP_API int pwicp_series_adaptive_targets(const pwicp_series* s, int32_t* targets, int n) {
     if (!s || !targets || n != (int)s->regPairs.size()) return PWICP_E_INVALID;
@@ -656,6 +707,7 @@ static int run_pairs_on(pwicp_series* s, SeriesWorker* w, const int32_t* pairs, 
         if (pairs[k] < 0 || pairs[k] >= s->num_pairs()) return PWICP_E_INVALID;
     }
     if (n_pairs == 0) return PWICP_OK;
+    if (s->adaptive_deferred) { std::cerr << "Error: the adaptive pair map of this series has not been determined yet.\n"; return PWICP_E_INVALID; }
     if (!w->need_ctx()) { for (int k = 0; k < n_pairs; ++k) recs[k].status = PWICP_E_NO_DEVICE; return PWICP_E_NO_DEVICE; }
     const ConfigPara& cfg = s->cfg;
     const double sor_mult = 5.0;                                           // R.cpp:415-416
@@ -665,6 +717,13 @@ static int run_pairs_on(pwicp_series* s, SeriesWorker* w, const int32_t* pairs, 
         const int w1 = std::min(n_pairs, w0 + window), nw = w1 - w0;
         const auto t0 = std::chrono::steady_clock::now();
         StageTimer tm;
+        auto t_stage = std::chrono::steady_clock::now();
+        auto stage = [&](int which) {
+            const auto now = std::chrono::steady_clock::now();
+            std::lock_guard<std::mutex> g(s->stage_mu);
+            s->stage_ms[which] += std::chrono::duration<double, std::milli>(now - t_stage).count();
+            t_stage = now;
+        };
         // ---- scans of this window: sources, and targets that are not prepared yet -------------------------------
         std::vector<int> refIdx((size_t)nw);
         std::vector<std::vector<float>> raw2((size_t)nw);
@@ -682,6 +741,14 @@ static int run_pairs_on(pwicp_series* s, SeriesWorker* w, const int32_t* pairs, 
             for (auto& t : th) t.join();
         }
         tm.lap("read scans (host threads)");
+        stage(0);
+        {
+            long long b = 0;
+            for (auto& v : raw2) b += (long long)v.size() * 4;
+            for (auto& kv : raw1) b += (long long)kv.second.size() * 4;
+            std::lock_guard<std::mutex> g(s->stage_mu);
+            s->stage_bytes += b;
+        }
         // ---- GPU parts one after the other; the host part of a cloud starts on its own thread as soon as its k-NN graph
         //      is down, so the serial host passes of earlier clouds run while the GPU prepares the later ones -------------
         std::vector<char> ok((size_t)nw, 1);
@@ -721,12 +788,14 @@ static int run_pairs_on(pwicp_series* s, SeriesWorker* w, const int32_t* pairs, 
             std::vector<float>().swap(raw2[(size_t)k]);
         }
         tm.lap("voxel grid + SOR, k-NN graphs (GPU)");
+        stage(1);
         for (auto& t : th) t.join();
         {
             size_t ti = 0;
             for (auto& kv : raw1) { if (!okt[ti]) w->targets.erase(kv.first); ++ti; }
         }
         tm.lap("normals + supervoxels (host threads, rest)");
+        stage(2);
         // ---- registrations ---------------------------------------------------------------------------------------------
         const double t_setup_each = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / nw;
         for (int k = 0; k < nw; ++k) {
@@ -754,6 +823,7 @@ static int run_pairs_on(pwicp_series* s, SeriesWorker* w, const int32_t* pairs, 
             std::vector<float>().swap(src[(size_t)k].p);                                                     // release early
         }
         tm.lap("registrations (GPU)");
+        stage(3);
         // keep the reference epoch and the targets of this window, drop older ones
         for (auto it = w->targets.begin(); it != w->targets.end();) {
             bool used = it->first == s->startEpoch;

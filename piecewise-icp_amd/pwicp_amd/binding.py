@@ -107,6 +107,9 @@ def load_library():
     L.pwicp_series_num_scans.argtypes = [vp]
     L.pwicp_series_pair_epochs.argtypes = [vp, C.c_int, ip, ip, C.POINTER(C.c_long)]
     L.pwicp_series_adaptive_targets.argtypes = [vp, ip, C.c_int]
+    L.pwicp_series_stage_times.argtypes = [vp, C.POINTER(C.c_double)]
+    L.pwicp_series_overlap_ratios.argtypes = [vp, ip, C.c_int, fp]
+    L.pwicp_series_adaptive_from_ratios.argtypes = [vp, fp, C.c_float, C.c_int]
     L.pwicp_series_run_pair.argtypes = [vp, C.c_int, vp]
     L.pwicp_series_run_pairs.argtypes = [vp, ip, C.c_int, vp]
     L.pwicp_series_write_results.argtypes = [vp, vp, C.c_int]
@@ -215,7 +218,9 @@ class Series:
         self._L = load_library()
         h = C.c_void_p()
         at, n_at = None, 0
-        if adaptive_targets is not None:
+        if isinstance(adaptive_targets, str) and adaptive_targets == "deferred":
+            n_at = -1                  # adaptive map supplied later: overlap_ratios() + adaptive_from_ratios()
+        elif adaptive_targets is not None:
             self._at = np.ascontiguousarray(adaptive_targets, np.int32)
             at, n_at = _p(self._at, ip), len(self._at)
         rc = self._L.pwicp_series_open(str(confile).encode(), int(startEpoch), int(epochNum), int(pairMode),
@@ -258,6 +263,32 @@ class Series:
     @property
     def num_scans(self):
         return int(self._L.pwicp_series_num_scans(self._h))
+
+    def stage_times(self):
+        """Wall time per stage of the pairs run so far (ms) and the raw scan bytes handed to the GPU."""
+        v = (C.c_double * 5)()
+        if self._L.pwicp_series_stage_times(self._h, v) != 0:
+            raise PwicpError(-2, "pwicp_series_stage_times")
+        return {"read_scans_ms": v[0], "gpu_preparation_ms": v[1], "front_ends_rest_ms": v[2], "registrations_ms": v[3], "scan_bytes": int(v[4])}
+
+    def overlap_ratios(self, pairs):
+        """calOverlapRatioByC2Cdist (R.cpp:593-614) for (target, source) file-index pairs; returns float32 ratios."""
+        ij = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        out = np.empty(len(ij), np.float32)
+        rc = self._L.pwicp_series_overlap_ratios(self._h, _p(ij, ip), len(ij), _p(out, fp))
+        if rc != 0:
+            raise PwicpError(rc, "pwicp_series_overlap_ratios")
+        return out
+
+    def adaptive_from_ratios(self, table, overlapThd=0.75, write_pair_file=False):
+        """calAdaptivePairSequence (R.cpp:552-589) replayed on a (#files x #files) table of overlap ratios (NaN = unknown)."""
+        t = np.ascontiguousarray(table, np.float32)
+        n = self.num_scans
+        if t.shape != (n, n):
+            raise ValueError("ratio table must be (%d, %d)" % (n, n))
+        rc = self._L.pwicp_series_adaptive_from_ratios(self._h, _p(t, fp), float(overlapThd), 1 if write_pair_file else 0)
+        if rc != 0:
+            raise PwicpError(rc, "pwicp_series_adaptive_from_ratios")
 
     def adaptive_targets(self):
         """Adaptive pair map: entry k = target of source k+1, both relative to startEpoch."""

@@ -7,7 +7,8 @@ one process per GPU.
 (without a launcher: one GPU, same as the exported C entry point).  Every rank opens the same configuration, runs the
 pairs p with p mod world == rank through libpwicp.so, the 384-byte records are all-gathered (backend nccl = RCCL over
 xGMI; gloo for debugging) and rank 0 writes the reference's result files and the composition to the reference epoch.
-In adaptive mode rank 0 determines the pair map (dense NN of raw scans on its GPU, R.cpp:552-589) and broadcasts it.
+In adaptive mode the overlap ratios behind the pair map (dense NN of raw scans, R.cpp:593-614) are dealt to the ranks and
+every rank replays the target scan (R.cpp:552-589) on the gathered table.
 In Direct2Ref mode every rank prepares the shared target scan once (preprocessing + supervoxels), not once per pair."""
 import argparse
 import os
@@ -57,28 +58,43 @@ def run_series(confile, start_epoch, epoch_num, pair_mode, overlap_thd=0.75, bac
     ok = False
     series = None
     try:
-        # ---- phase 1: open the series (adaptive mode: rank 0 determines the pair map, the others receive it) -----
+        # ---- phase 1: open the series.  Adaptive mode: the overlap ratios of the candidate pairs (source j against the targets
+        # j-W .. j-1) are independent (R.cpp:593-614): dealt to the ranks, all-gathered as one table, and every rank replays the
+        # sequential target scan (R.cpp:552-589) on it - the same map on every rank, nothing to broadcast --------------------
         targets, good = None, True
         if pair_mode < 0 and world > 1:
             import torch
-            if rank == 0:
-                try:
-                    series = Series(confile, start_epoch, epoch_num, pair_mode, overlap_thd, device)
-                    targets = series.adaptive_targets()
-                except Exception as e:                      # noqa: BLE001 - reported, then agreed on by all ranks
-                    print("pwicp series: rank 0 failed to open the series: %s" % e, file=sys.stderr)
-                    good = False
+            table = None
+            try:
+                series = Series(confile, start_epoch, epoch_num, pair_mode, overlap_thd, device, "deferred")
+                nf = series.num_scans
+                W = max(1, int(os.environ.get("PWICP_ADAPTIVE_WINDOW", "6")))
+                cand = [(i, j) for j in range(start_epoch + 1, nf) for i in range(max(start_epoch, j - W), j)]
+                mine_ij = [c for p, c in enumerate(cand) if p % world == rank]
+                table = np.full((nf, nf), np.nan, np.float32)
+                if mine_ij:
+                    r = series.overlap_ratios(mine_ij)
+                    for (i, j), v in zip(mine_ij, r):
+                        table[i, j] = v
+            except Exception as e:                          # noqa: BLE001 - reported, then agreed on by all ranks
+                print("pwicp series: rank %d failed on its share of the overlap ratios: %s" % (rank, e), file=sys.stderr)
+                good = False
             if not _agree(dist, dev, good):
                 return False
-            n_t = torch.zeros(1, dtype=torch.int32, device=dev)
-            if rank == 0:
-                n_t[0] = len(targets)
-            dist.broadcast(n_t, src=0)
-            t = torch.zeros(int(n_t.item()), dtype=torch.int32, device=dev)
-            if rank == 0:
-                t.copy_(torch.from_numpy(targets))
-            dist.broadcast(t, src=0)
-            targets = t.cpu().numpy()
+            t = torch.from_numpy(table).to(dev)
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(parts, t)
+            for part in parts:
+                a = part.cpu().numpy()
+                known = ~np.isnan(a)
+                table[known] = a[known]
+            try:
+                series.adaptive_from_ratios(table, overlap_thd, write_pair_file=(rank == 0))
+            except Exception as e:                          # noqa: BLE001
+                print("pwicp series: rank %d failed to determine the pair map: %s" % (rank, e), file=sys.stderr)
+                good = False
+            if not _agree(dist, dev, good):
+                return False
         if series is None:
             try:
                 series = Series(confile, start_epoch, epoch_num, pair_mode, overlap_thd, device, targets)
