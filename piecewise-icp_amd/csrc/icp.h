@@ -44,8 +44,11 @@ struct IcpWork {
     int reserve(pwicp_context* ctx, int ns_max);
 };
 
+// fs (optional): passes 1 and 2 of a percentile selection ride on the first two launches (n_iter >= 2)
+struct FusedSelect;
 int pw_icp_enqueue(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
-                   int ns_max, const unsigned* ns_dev, double euclid_eps, int n_iter, const IcpMail* mail = nullptr);
+                   int ns_max, const unsigned* ns_dev, double euclid_eps, int n_iter, const IcpMail* mail = nullptr,
+                   const FusedSelect* fs = nullptr);
 // classification + order-preserving compaction of the stable patches + inner-ICP iteration 0, one launch (icp.hip)
 int pw_classify_icp0_launch(pwicp_context* ctx, const ClassifyArgs& a, int* d_stable, float4* d_stCT, float4* d_stN, IcpWork* w,
                             unsigned* d_slot, double euclid_eps, const IcpMail* mail = nullptr);

@@ -19,6 +19,7 @@
 #include "devmath.h"
 #include "icp.h"
 #include "nn_device.h"
+#include "select_dev.h"
 #include "xform_dev.h"
 
 using namespace pwdev;
@@ -114,20 +115,33 @@ __global__ void __launch_bounds__(kAccBlock) k_icp_iter(GridDesc g, const float4
                                                         float4* __restrict__ srcn, int ns_host,
                                                         const unsigned* __restrict__ ns_dev, IcpState* st,
                                                         double* __restrict__ partials, unsigned* __restrict__ counter,
-                                                        double mse_rel, IcpMail mail) {
+                                                        double mse_rel, IcpMail mail, FusedSelect fs, int fs_pass) {
     __shared__ double sh[kAccBlock / 64][32];
+    // Leading blocks (first iteration of a run only): pass 1 or 2 of the percentile selection of the dense search that was
+    // enqueued just BEFORE this ICP batch (loop.hip: the search does not depend on the ICP).  The ICP leaves most of the chip
+    // idle, so the passes cost it nothing, and the percentile reaches the host together with the ICP's result instead of
+    // at the end of the update launch that follows.
+    const int nsel = fs.scratch ? fs.nblk : 0;
+    if ((int)blockIdx.x < nsel) {
+        __shared__ unsigned s_hist[kFsBins];
+        if (threadIdx.x >= 256) return;
+        if (fs_pass == 1) fs_pass_embedded<1>(s_hist, fs, (int)blockIdx.x, 0u, 256);
+        else fs_pass_embedded<2>(s_hist, fs, (int)blockIdx.x, 0u, 256);
+        return;
+    }
+    const int bx = (int)blockIdx.x - nsel;
     if (st->done) {                 // converged in an earlier launch of the batch: only the message is left to do
-        if (mail.dst && blockIdx.x == 0) icp_send_mail(mail, st);
+        if (mail.dst && bx == 0) icp_send_mail(mail, st);
         return;
     }
     const int ns = ns_dev ? (int)*ns_dev : ns_host;          // the count may live on the device (no host sync)
     if (ns <= 0) {
-        if (mail.dst && blockIdx.x == 0) icp_send_mail(mail, st);
+        if (mail.dst && bx == 0) icp_send_mail(mail, st);
         return;
     }
-    if ((int)(blockIdx.x * kAccPts) >= ns) return;
+    if ((int)(bx * kAccPts) >= ns) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = threadIdx.x % kGroup;
-    const int i = blockIdx.x * kAccPts + threadIdx.x / kGroup;
+    const int i = bx * kAccPts + threadIdx.x / kGroup;
     double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
     if (i < ns) {
         float4 p = src[i], nrm = srcn[i];
@@ -167,7 +181,7 @@ __global__ void __launch_bounds__(kAccBlock) k_icp_iter(GridDesc g, const float4
         double acc = sh[0][threadIdx.x];
         for (int w = 1; w < kAccBlock / 64; ++w) acc += sh[w][threadIdx.x];
         // write-through (device-coherent) store: the partial sums reach the coherence point without a cache write-back
-        __hip_atomic_store(&partials[(size_t)blockIdx.x * kNSums + threadIdx.x], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&partials[(size_t)bx * kNSums + threadIdx.x], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // last active block -> solve.  Only wave 0 (which stored the partials) goes on: drain its stores, count, and if it
     // is the last one the solve on that single wave (wave-level synchronisation only, see icp_solve_tail).  The partials
@@ -780,14 +794,17 @@ int pw_classify_icp0_launch(pwicp_context* ctx, const ClassifyArgs& a, int* d_st
 // Enqueues n_iter inner iterations (accumulate + solve each) on the stream; no host synchronisation.  The number
 // of source points is ns_host, or *ns_dev when ns_dev != nullptr (then ns_max bounds the launch grid).
 int pw_icp_enqueue(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
-                   int ns_max, const unsigned* ns_dev, double euclid_eps, int n_iter, const IcpMail* mail) {
+                   int ns_max, const unsigned* ns_dev, double euclid_eps, int n_iter, const IcpMail* mail, const FusedSelect* fs) {
     if (ns_max <= 0) return PWICP_OK;
     const int nb = div_up(ns_max, kAccPts);
     IcpMail none{};
-    for (int k = 0; k < n_iter; ++k)
-        hipLaunchKernelGGL(k_icp_iter, dim3(nb), dim3(kAccBlock), 0, ctx->stream, g, d_tgt, d_tgt_n, w->src.p, w->srcn.p,
-                           ns_max, ns_dev, w->state.p, w->partials.p, w->counter.p, euclid_eps,
-                           (mail && k == n_iter - 1) ? *mail : none);
+    FusedSelect nofs{};
+    for (int k = 0; k < n_iter; ++k) {
+        const bool sel = fs && fs->scratch && k < 2;           // passes 1 and 2 on the first two launches (the caller enqueues >= 2)
+        hipLaunchKernelGGL(k_icp_iter, dim3(nb + (sel ? fs->nblk : 0)), dim3(kAccBlock), 0, ctx->stream, g, d_tgt, d_tgt_n, w->src.p,
+                           w->srcn.p, ns_max, ns_dev, w->state.p, w->partials.p, w->counter.p, euclid_eps,
+                           (mail && k == n_iter - 1) ? *mail : none, sel ? *fs : nofs, k + 1);
+    }
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }

@@ -770,7 +770,10 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     // transform, pass 2 beside the next front (or on its own when no front follows).  `rank_dev`: the rank of the percentile is
     // derived on the device from the slot's stable-point count (speculative enqueue, before the host knows the count).
     unsigned sel_seq = 0;
-    auto enqueue_dense_tail = [&](unsigned* slot, int nsp, bool rank_dev, bool with_front) -> int {
+    // ahead_of_icp (out): only the search is enqueued and *ahead_of_icp describes the selection whose passes 1 / 2 the caller puts
+    // on the ICP launches that follow (first iteration: the search does not depend on the ICP, and the percentile then arrives
+    // with the ICP's result); the update + front go out behind the ICP as usual, without selection blocks
+    auto enqueue_dense_tail = [&](unsigned* slot, int nsp, bool rank_dev, bool with_front, FusedSelect* ahead_of_icp = nullptr) -> int {
         // (a dispatch with events attached - hipExtLaunchKernelGGL - was measured too: the same two ~5 us bubbles as the records)
         const bool ev = (pr->profiling & PWICP_PROF_DENSE) != 0;
         if (ev) {
@@ -796,6 +799,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         }
         if (res->n_dense_nn_launches == 0 && (pr->profiling & PWICP_PROF_REPLAY))      // remember the first launch for stand-alone replays
             HIPCHK(ctx, hipMemcpyAsync(pr->stable0.p, pr->stable.p, (size_t)m2 * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+        if (ahead_of_icp) { *ahead_of_icp = fs; return PWICP_OK; }       // (only taken with `fused`)
         if (!fused) PWCHK(select_p75_enqueue(pr, pr->P2.tot, nsp, &sel_seq));
         // the percentile only steers the threshold: transform and next front go out while it travels
         static int nb1 = -1;
@@ -872,13 +876,19 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                 // the first batch opens with the fused launch: classification, compaction and inner iteration 0 (whose
                 // correspondences are the front's centroid matches); it carries the message when nothing follows it
                 int n_iter = batch;
+                FusedSelect fs_icp{};
+                const bool spec_now = spec_dense && !spec_done;
                 if (first_batch) {
                     n_iter = batch - 1;
                     PWCHK(pw_classify_icp0_launch(ctx, cls, pr->stable.p, pr->stCT.p, pr->stN.p, &pr->icp, slot, 1e-6, n_iter == 0 ? &mail : nullptr));
                     first_batch = false;
+                    // first iteration: the dense search right behind the classification (it needs the stable flags, not the ICP),
+                    // passes 1 / 2 of its percentile on the ICP launches (n_iter = 3 here)
+                    if (spec_now && n_iter >= 2) PWCHK(enqueue_dense_tail(slot, 0, /*rank_dev*/ true, /*with_front*/ true, &fs_icp));
                 }
                 if (n_iter > 0)
-                    PWCHK(pw_icp_enqueue(ctx, pr->tgt->g_ct1.d, pr->tgt->P1.ct.p, pr->tgt->ct1n.p, &pr->icp, m2, slot + 2, 1e-6, n_iter, &mail));
+                    PWCHK(pw_icp_enqueue(ctx, pr->tgt->g_ct1.d, pr->tgt->P1.ct.p, pr->tgt->ct1n.p, &pr->icp, m2, slot + 2, 1e-6, n_iter, &mail,
+                                         fs_icp.scratch ? &fs_icp : nullptr));
                 ht("classify+icp batch enqueued");
                 if (ev) {
                     HIPCHK(ctx, hipEventRecord(pr->event(n_ev + 1), ctx->stream));
@@ -891,8 +901,11 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                         PWCHK(enqueue_xf_vcm(slot, currDT, true, vcm_guess_seq));
                     }
                 }
-                const bool spec_now = spec_dense && !spec_done;
-                if (spec_now) { PWCHK(enqueue_dense_tail(slot, 0, /*rank_dev*/ true, /*with_front*/ true)); spec_done = true; }
+                if (spec_now) {
+                    if (fs_icp.scratch) PWCHK(enqueue_xf_front(slot));          // the search and its selection are already on the stream
+                    else PWCHK(enqueue_dense_tail(slot, 0, /*rank_dev*/ true, /*with_front*/ true));
+                    spec_done = true;
+                }
                 ht("early transform / front / dense enqueued");
                 PWCHK(mail_wait(pr, seq));
                 ht("icp mail arrived");

@@ -110,14 +110,17 @@ __device__ __forceinline__ void fs_pick0(unsigned* h, const FusedSelect& fs, uns
 // The wave that picks pass 1's bin publishes prefix / rank through device-coherent stores and then the tag `chain`; the blocks
 // of pass 2 wait for the tag (one lane polls, the block sleeps at a barrier).  They only ever wait for blocks with smaller
 // indices, which were dispatched before them.
+// nt: threads of the block that take part (256 for pass 1, whose pick is written for 256 threads; the caller has retired the
+// others of a larger block before the call: a barrier only waits for waves that are still alive).  0: blockDim.x.
 template <int PASS>
-__device__ __forceinline__ void fs_pass_embedded(unsigned* h, const FusedSelect& fs, int bidx, unsigned chain = 0u) {
+__device__ __forceinline__ void fs_pass_embedded(unsigned* h, const FusedSelect& fs, int bidx, unsigned chain = 0u, int nt_ = 0) {
     __shared__ unsigned s_last;
+    const int nt = nt_ > 0 ? nt_ : (int)blockDim.x;
     unsigned prefix, k_in;
     if (PASS == 1) {
         fs_pick0(h, fs, &prefix, &k_in);               // from the bins the dense kernel left; leaves h zeroed
     } else {
-        for (int t = threadIdx.x; t < kFsBins; t += blockDim.x) h[t] = 0u;
+        for (int t = threadIdx.x; t < kFsBins; t += nt) h[t] = 0u;
         if (chain) {
             if (threadIdx.x == 0)
                 while (__hip_atomic_load(&fs.scratch[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != chain) __builtin_amdgcn_s_sleep(2);
@@ -129,9 +132,9 @@ __device__ __forceinline__ void fs_pass_embedded(unsigned* h, const FusedSelect&
         }
     }
     __syncthreads();
-    const int stride = fs.nblk * (int)blockDim.x;
+    const int stride = fs.nblk * nt;
     // (the pass is a chain of memory round trips, not bandwidth: eight loads in flight per lane)
-    for (int i0 = bidx * (int)blockDim.x + (int)threadIdx.x; i0 < fs.n; i0 += 8 * stride) {
+    for (int i0 = bidx * nt + (int)threadIdx.x; i0 < fs.n; i0 += 8 * stride) {
         unsigned u[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) u[j] = (i0 + j * stride < fs.n) ? __float_as_uint(fs.vals[i0 + j * stride]) : 0xffffffffu;
@@ -148,7 +151,7 @@ __device__ __forceinline__ void fs_pass_embedded(unsigned* h, const FusedSelect&
     __syncthreads();
     unsigned* gh = fs.scratch + kFsCtl + (kFsRep + PASS - 1) * kFsBins;
     unsigned seen = 0;
-    for (int t = threadIdx.x; t < kFsBins; t += blockDim.x) {
+    for (int t = threadIdx.x; t < kFsBins; t += nt) {
         const unsigned v = h[t];
         if (v) seen |= atomicAdd(&gh[t], v);
     }
