@@ -362,7 +362,8 @@ __device__ __forceinline__ void icp_solve_tail(IcpState* st, const double* parti
 //              into the slot, solves the 6x6 system (icp_solve_tail, first = true) and - when no further k_icp_iter launch
 //              was enqueued behind it - sends the batch's mailbox message.
 // `epoch` tags the aggregates of THIS launch (a per-pair launch counter, never 0): words left by earlier launches do not match.
-constexpr int kClsBlock = 256;
+constexpr int kClsBlock = 256;                                // patches per block ...
+constexpr int kClsThreads = kClsBlock + 64;                   // ... on waves 1-4; wave 0 is the block's service wave (see below)
 constexpr int kClsSegs = 9;                                   // 28 sums x 9 segments = 252 of the block's 256 threads
 constexpr int kClsSegLen = (kClsBlock + kClsSegs - 1) / kClsSegs;
 
@@ -371,19 +372,24 @@ __device__ __forceinline__ unsigned long long agg_pack(unsigned epoch, int n, in
     return ((unsigned long long)(epoch & 0xffffu) << 48) | ((unsigned long long)(unsigned)pts << 16) | (unsigned long long)(unsigned)n;
 }
 
-__global__ void __launch_bounds__(kClsBlock) k_classify_icp0(ClassifyArgs a, int* __restrict__ stable, float4* __restrict__ stCT,
+__global__ void __launch_bounds__(kClsThreads) k_classify_icp0(ClassifyArgs a, int* __restrict__ stable, float4* __restrict__ stCT,
                                                              float4* __restrict__ stN, float4* __restrict__ wsrc,
                                                              float4* __restrict__ wsrcn, unsigned* __restrict__ slot,
                                                              unsigned long long* __restrict__ agg, unsigned epoch, IcpState* st,
                                                              double* __restrict__ partials, unsigned* __restrict__ counter,
                                                              double mse_rel, IcpMail mail) {
-    __shared__ int s_n[kClsBlock / 64], s_p[kClsBlock / 64], s_b[kClsBlock / 64];
+    __shared__ int s_n[kClsBlock / 64], s_p[kClsBlock / 64];
     __shared__ float s_lod[kClsBlock / 64][2];
     __shared__ float s_row[kClsBlock][8];
     __shared__ double s_part[kClsSegs][kNSums];
+    // Wave 0 classifies nothing: it is the block's SERVICE wave (aggregate, final partial sums, block count, and on the block
+    // that finishes last the totals, the solve and the mailbox message), so that nothing the other four waves still have to do
+    // - the look-back for the compaction base, the compacted outputs - is between the last partial sum and the solve.
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool svc = wave == 0;
+    const int ptid = tid - 64, pw = wave - 1;          // patch lane / patch wave (negative on the service wave)
     const int me = blockIdx.x, nb = gridDim.x;
-    const int i = me * kClsBlock + tid;
+    const int i = svc ? a.m2 : me * kClsBlock + ptid;
     if (blockIdx.x == 0 && threadIdx.x == 0) KT_STAMP(0);
     float lod = 0.0f;
     int f = 0, np = 0;
@@ -407,14 +413,14 @@ __global__ void __launch_bounds__(kClsBlock) k_classify_icp0(ClassifyArgs a, int
         lo = fminf(lo, __shfl_xor(lo, o));
         hi = fmaxf(hi, __shfl_xor(hi, o));
     }
-    if (lane == 63) s_n[wave] = in;
-    if (lane == 0) { s_p[wave] = pts; s_lod[wave][0] = lo; s_lod[wave][1] = hi; }
+    if (!svc && lane == 63) s_n[pw] = in;
+    if (!svc && lane == 0) { s_p[pw] = pts; s_lod[pw][0] = lo; s_lod[pw][1] = hi; }
     __syncthreads();
     KT_MAX(1);
     int blk_n = 0, blk_p = 0, wave_off = 0;
 #pragma unroll
     for (int w = 0; w < kClsBlock / 64; ++w) {
-        if (w < wave) wave_off += s_n[w];
+        if (w < pw) wave_off += s_n[w];
         blk_n += s_n[w]; blk_p += s_p[w];
     }
     if (tid == 0) {
@@ -444,8 +450,10 @@ __global__ void __launch_bounds__(kClsBlock) k_classify_icp0(ClassifyArgs a, int
             row[6] = nx * dx + ny * dy + nz * dz - nx * sx - ny * sy - nz * sz;
             row[7] = a.dCT[i];
         }
+        if (!svc) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s_row[tid][e] = row[e];
+            for (int e = 0; e < 8; ++e) s_row[ptid][e] = row[e];
+        }
     }
     __syncthreads();
     // thread (k, seg): sum k of the 28 (21 upper-triangle products row by row, 6 row * d, sum of d2 - the order of k_icp_iter)
@@ -482,22 +490,62 @@ __global__ void __launch_bounds__(kClsBlock) k_classify_icp0(ClassifyArgs a, int
         for (int g = 1; g < kClsSegs; ++g) acc += s_part[g][tid];
         coh_store(&partials[(size_t)me * kNSums + tid], acc);
     }
-    // base: stable patches of the blocks before this one
-    int bn = 0;
-    for (int b = tid; b < me; b += kClsBlock) {
+    // The block's share of iteration 0 is done: count it, and let the block that finishes last go on with the totals and the solve
+    // at once - the positions of the compacted outputs (below) are not on the way to T.
+    if (svc) {
+        KT_MAX(3);
+        drain_stores();
+        unsigned last = 0;
+        if (tid == 0) {
+            const unsigned prev = atomicAdd(counter, 1u);
+            last = (prev == (unsigned)nb - 1u) ? 1u : 0u;
+            if (last) *counter = 0u;
+        }
+        last = (unsigned)__shfl((int)last, 0);
+        if (last) {
+            KT_STAMP(4);
+            // totals (every aggregate is published by now), slot words, state, solve
+            int tn = 0, tp = 0;
+            for (int b = tid; b < nb; b += 64) {
+                const unsigned long long v = coh_load(&agg[b]);
+                tn += (int)(v & 0xffffu); tp += (int)((v >> 16) & 0xffffffffu);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { tn += __shfl_xor(tn, o); tp += __shfl_xor(tp, o); }
+            if (tid == 0) { coh_store(&slot[2], (unsigned)tn); coh_store(&slot[3], (unsigned)tp); }
+            if (tn < 3) {              // min_number_correspondences_ = 3: no estimate (the host stops at < 4 stable patches anyway)
+                if (tid < 16) { coh_store(&st->T[tid], (tid % 5 == 0) ? 1.f : 0.f); coh_store(&st->Tfinal[tid], (tid % 5 == 0) ? 1.f : 0.f); }
+                if (tid == 0) {
+                    coh_store(&st->iters, 0); coh_store(&st->reason, 0); coh_store(&st->pad, 0);
+                    coh_store(&st->prev_mse, 1.7976931348623157e308);
+                    coh_store(&st->done, 1);
+                }
+            } else {
+                KT_STAMP(5);
+                icp_solve_tail(st, partials, nb, tn, mse_rel, true);
+            }
+            KT_STAMP(9);
+            if (mail.dst) {
+                drain_stores();
+                wave_sync();
+                icp_send_mail(mail, st);
+            }
+            KT_STAMP(10);
+        }
+        return;
+    }
+    // base of the compacted outputs: the stable patches of the blocks before this one (every wave for itself: no block barrier
+    // that the wave in the solve would keep the others waiting at), then the outputs (generateCentroidCloudWithPatchNormals
+    // semantics for the normal: (0,0,1) unless > 6 points and valid)
+    int base = 0;
+    for (int b = lane; b < me; b += 64) {
         unsigned long long v = coh_load(&agg[b]);
         while ((unsigned)(v >> 48) != (epoch & 0xffffu)) { __builtin_amdgcn_s_sleep(1); v = coh_load(&agg[b]); }
-        bn += (int)(v & 0xffffu);
+        base += (int)(v & 0xffffu);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) bn += __shfl_xor(bn, o);
-    if (lane == 0) s_b[wave] = bn;
-    __syncthreads();
-    int base = 0;
-#pragma unroll
-    for (int w = 0; w < kClsBlock / 64; ++w) base += s_b[w];
+    for (int o = 32; o > 0; o >>= 1) base += __shfl_xor(base, o);
     KT_MAX(2);
-    // compacted outputs (generateCentroidCloudWithPatchNormals semantics for the normal: (0,0,1) unless > 6 points and valid)
     if (f) {
         const float4 c = a.ct2[i];
         float4 n = a.nrm2[i];
@@ -507,45 +555,6 @@ __global__ void __launch_bounds__(kClsBlock) k_classify_icp0(ClassifyArgs a, int
         stCT[pos] = c; stN[pos] = n;
         wsrc[pos] = c; wsrcn[pos] = n;
     }
-    if (tid >= 64) return;
-    KT_MAX(3);
-    drain_stores();
-    unsigned last = 0;
-    if (tid == 0) {
-        const unsigned prev = atomicAdd(counter, 1u);
-        last = (prev == (unsigned)nb - 1u) ? 1u : 0u;
-        if (last) *counter = 0u;
-    }
-    last = (unsigned)__shfl((int)last, 0);
-    if (!last) return;
-    KT_STAMP(4);
-    // totals (every aggregate is published by now), slot words, state, solve
-    int tn = 0, tp = 0;
-    for (int b = tid; b < nb; b += 64) {
-        const unsigned long long v = coh_load(&agg[b]);
-        tn += (int)(v & 0xffffu); tp += (int)((v >> 16) & 0xffffffffu);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { tn += __shfl_xor(tn, o); tp += __shfl_xor(tp, o); }
-    if (tid == 0) { coh_store(&slot[2], (unsigned)tn); coh_store(&slot[3], (unsigned)tp); }
-    if (tn < 3) {                  // min_number_correspondences_ = 3: no estimate (the host stops at < 4 stable patches anyway)
-        if (tid < 16) { coh_store(&st->T[tid], (tid % 5 == 0) ? 1.f : 0.f); coh_store(&st->Tfinal[tid], (tid % 5 == 0) ? 1.f : 0.f); }
-        if (tid == 0) {
-            coh_store(&st->iters, 0); coh_store(&st->reason, 0); coh_store(&st->pad, 0);
-            coh_store(&st->prev_mse, 1.7976931348623157e308);
-            coh_store(&st->done, 1);
-        }
-    } else {
-        KT_STAMP(5);
-        icp_solve_tail(st, partials, nb, tn, mse_rel, true);
-    }
-    KT_STAMP(9);
-    if (mail.dst) {
-        drain_stores();
-        wave_sync();
-        icp_send_mail(mail, st);
-    }
-    KT_STAMP(10);
 }
 
 __global__ void k_icp_init(IcpState* st) {
@@ -784,7 +793,7 @@ int pw_classify_icp0_launch(pwicp_context* ctx, const ClassifyArgs& a, int* d_st
     if (a.m2 <= 0) return PWICP_OK;
     w->epoch = (w->epoch % 0xffffu) + 1u;          // 1 .. 65535, never 0 (the buffer is zeroed once)
     IcpMail none{};
-    hipLaunchKernelGGL(k_classify_icp0, dim3(div_up(a.m2, kClsBlock)), dim3(kClsBlock), 0, ctx->stream, a, d_stable, d_stCT, d_stN,
+    hipLaunchKernelGGL(k_classify_icp0, dim3(div_up(a.m2, kClsBlock)), dim3(kClsThreads), 0, ctx->stream, a, d_stable, d_stCT, d_stN,
                        w->src.p, w->srcn.p, d_slot, w->agg.p, w->epoch, w->state.p, w->partials.p, w->counter.p, euclid_eps,
                        mail ? *mail : none);
     HIPCHK(ctx, hipGetLastError());
