@@ -88,7 +88,10 @@ __device__ __forceinline__ void icp_send_mail(const IcpMail& m, const IcpState* 
 constexpr int kAccBlock = 1024;                       // 128 points per block: few partials for the solve kernel
 constexpr int kAccPts = kAccBlock / kGroup;
 
-__device__ __forceinline__ void icp_solve_tail(IcpState* st, const double* partials, int nblocks, int ns, double mse_rel, bool first);
+struct TailPrev { float F; int iters; double mse; };        // what a tail needs of the previous iteration's state
+__device__ __forceinline__ TailPrev tail_prefetch(const IcpState* st, bool first);
+__device__ __forceinline__ void icp_solve_tail(IcpState* st, const double* sums, int ns, double mse_rel, bool first, TailPrev pv);
+__device__ __forceinline__ void tail_sums_block(const double* partials, int nblocks, double (*segs)[32], double* sums);
 
 // Stores that other blocks / the mailbox wave read back in the SAME launch go through device-coherent (write-through) atomics
 // and are read back with device-coherent atomic loads; the writer drains its store queue (s_waitcnt vmcnt(0)) before it
@@ -140,6 +143,7 @@ __global__ void __launch_bounds__(kAccBlock) k_icp_iter(GridDesc g, const float4
         return;
     }
     if ((int)(bx * kAccPts) >= ns) return;
+    if (bx == 0 && threadIdx.x == 0) KT_STAMP(16);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = threadIdx.x % kGroup;
     const int i = bx * kAccPts + threadIdx.x / kGroup;
     double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
@@ -151,6 +155,7 @@ __global__ void __launch_bounds__(kAccBlock) k_icp_iter(GridDesc g, const float4
             if (sub == 0) { src[i] = p; srcn[i] = nrm; }
         }
         const NNBest b = nn_query_group(g, p.x, p.y, p.z, sub);
+        KT_MAX(17);
         const int bi = b.idx();
         const float4 t = tgt[bi], n = tgt_n[bi];
         const float sx = p.x, sy = p.y, sz = p.z, dx = t.x, dy = t.y, dz = t.z, nx = n.x, ny = n.y, nz = n.z;
@@ -183,22 +188,32 @@ __global__ void __launch_bounds__(kAccBlock) k_icp_iter(GridDesc g, const float4
         // write-through (device-coherent) store: the partial sums reach the coherence point without a cache write-back
         __hip_atomic_store(&partials[(size_t)bx * kNSums + threadIdx.x], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // last active block -> solve.  Only wave 0 (which stored the partials) goes on: drain its stores, count, and if it
-    // is the last one the solve on that single wave (wave-level synchronisation only, see icp_solve_tail).  The partials
-    // are write-through stores read back with device-coherent loads, so no fence (= L2 write-back + L1 invalidate, ~3.5 us
-    // a pair) is needed on either side: draining the store queue before the count is the release.
-    if (threadIdx.x >= 64) return;
-    drain_stores();
-    unsigned last = 0;
+    // last active block -> solve.  Wave 0 (which stored the partials) drains its stores and counts the block; the block that
+    // turns out to be the last one sums the partials of all blocks with ALL its waves (one round trip of loads), then its first
+    // wave solves (wave-level synchronisation only, see icp_solve_tail).  The partials are write-through stores read back with
+    // device-coherent loads, so no fence (= L2 write-back + L1 invalidate, ~3.5 us a pair) is needed on either side: draining
+    // the store queue before the count is the release.
+    __shared__ unsigned s_last;
+    __shared__ double s_sums[kNSums];
     const unsigned nact = (unsigned)((ns + kAccPts - 1) / kAccPts);
-    if (threadIdx.x == 0) {
-        const unsigned prev = atomicAdd(counter, 1u);
-        last = (prev == nact - 1u) ? 1u : 0u;
-        if (last) *counter = 0u;                             // re-armed for the next launch
+    if (threadIdx.x < 64) {
+        drain_stores();
+        KT_MAX(18);
+        if (threadIdx.x == 0) {
+            const unsigned prev = atomicAdd(counter, 1u);
+            const unsigned last = (prev == nact - 1u) ? 1u : 0u;
+            if (last) *counter = 0u;                         // re-armed for the next launch
+            s_last = last;
+        }
     }
-    last = (unsigned)__shfl((int)last, 0);
-    if (!last) return;
-    icp_solve_tail(st, partials, (int)nact, ns, mse_rel, false);
+    __syncthreads();
+    if (!s_last) return;
+    KT_STAMP(19);
+    const TailPrev pv = tail_prefetch(st, false);
+    tail_sums_block(partials, (int)nact, sh, s_sums);
+    if (threadIdx.x >= 64) return;
+    icp_solve_tail(st, s_sums, ns, mse_rel, false, pv);
+    KT_STAMP(25);
     if (mail.dst) {
         drain_stores();                                      // the state went out through coherent stores (icp_solve_tail)
         wave_sync();
@@ -206,71 +221,84 @@ __global__ void __launch_bounds__(kAccBlock) k_icp_iter(GridDesc g, const float4
     }
 }
 
-// 6x6 inverse by LU with partial pivoting on ONE wave, operands in LDS.  Element (i,j) is owned by lane 6*i+j; every
-// element goes through exactly the operations of the serial algorithm (devmath.h inv6) in the same order, so the
-// result is bit-identical — only independent elements are updated side by side.  A is destroyed; inv receives A^-1.
-__device__ __forceinline__ void inv6_wave(double (*A)[6], double (*inv)[6], int* piv, bool* singular) {
+// value of lane `lane` (wave-uniform index) in every lane: v_readlane, no LDS round trip
+__device__ __forceinline__ double lane_bcast(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// 6x6 inverse by LU with partial pivoting on ONE wave, operands in registers.  Lane j < 6 holds column j of A, lane 6 + c
+// column c of the identity: the elimination of [A | I] row by row IS the serial algorithm (devmath.h inv6) - the row swaps
+// applied to the identity are its `piv`, the updates of the identity's columns its forward substitution (same operands, same
+// order: y_i loses L_i0 y_0, then L_i1 y_1, ...), the back substitution runs on lanes 6..11 with U broadcast from lanes 0..5 -
+// so the result is bit-identical; what is gone are the LDS round trips between the steps (v_readlane broadcasts instead:
+// every index below is a compile-time constant after unrolling).  A is read from LDS, inv written to LDS.
+__device__ __forceinline__ void inv6_wave(double (*A)[6], double (*inv)[6], bool* singular) {
     const int t = threadIdx.x;
-    if (t < 6) piv[t] = t;
-    if (t == 0) *singular = false;
-    wave_sync();
+    const int col = t < 6 ? t : 0;
+    double a[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) a[i] = (t < 6) ? A[i][col] : ((t - 6 == i) ? 1.0 : 0.0);
+    bool sing = false;
+#pragma unroll
     for (int k = 0; k < 6; ++k) {
-        if (t == 0) {
-            int p = k;
-            double best = fabs(A[k][k]);
-            for (int i = k + 1; i < 6; ++i)
-                if (fabs(A[i][k]) > best) { best = fabs(A[i][k]); p = i; }
-            if (best == 0.0) *singular = true;
-            piv[6] = p;                                   // scratch: pivot row of this step
-        }
-        wave_sync();
-        const int p = piv[6];
-        if (p != k && t < 6) { const double tmp = A[k][t]; A[k][t] = A[p][t]; A[p][t] = tmp; }
-        if (p != k && t == 6) { const int tp = piv[k]; piv[k] = piv[p]; piv[p] = tp; }
-        wave_sync();
-        if (t > k && t < 6) A[t][k] = A[t][k] / A[k][k];
-        wave_sync();
-        if (t < 36) {
-            const int i = t / 6, j = t % 6;
-            if (i > k && j > k) A[i][j] = A[i][j] - A[i][k] * A[k][j];
-        }
-        wave_sync();
-    }
-    if (t < 6) {          // column t of the inverse: forward then back substitution (independent columns)
-        double y[6];
-        for (int i = 0; i < 6; ++i) {
-            double s = (piv[i] == t) ? 1.0 : 0.0;
-            for (int j = 0; j < i; ++j) s = s - A[i][j] * y[j];
-            y[i] = s;
-        }
-        for (int i = 5; i >= 0; --i) {
-            double s = y[i];
-            for (int j = i + 1; j < 6; ++j) s = s - A[i][j] * inv[j][t];
-            inv[i][t] = s / A[i][i];
+        // pivot of column k (lane k), rows k..5: first maximum of |.|
+        int p = k;
+        double best = fabs(a[k]);
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i)
+            if (fabs(a[i]) > best) { best = fabs(a[i]); p = i; }
+        p = __builtin_amdgcn_readlane(p, k);
+        if (lane_bcast(best, k) == 0.0) sing = true;
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i)
+            if (p == i) { const double tmp = a[k]; a[k] = a[i]; a[i] = tmp; }          // wave-uniform branch
+        // multipliers (lane k keeps them as L), then row i loses l_i * row k in the columns right of k and in the identity's
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) {
+            const double q = a[i] / a[k];
+            const double l = lane_bcast(q, k);
+            const double upd = a[i] - l * a[k];
+            a[i] = (t == k) ? q : ((t > k) ? upd : a[i]);
         }
     }
-    wave_sync();
-    if (*singular && t < 36) inv[t / 6][t % 6] = NAN;
+    // back substitution on lanes 6..11 (x overwrites y from the bottom up); U(i, j) = a[i] of lane j
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double sacc = a[i];
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) sacc = sacc - lane_bcast(a[i], j) * a[j];
+        const double x = sacc / lane_bcast(a[i], i);
+        if (t >= 6) a[i] = x;
+    }
+    if (t >= 6 && t < 12) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) inv[i][t - 6] = sing ? (double)NAN : a[i];
+    }
+    if (t == 0) *singular = sing;
     wave_sync();
 }
 
-// fixed-order sum of the block partials, 6x6 LU inverse, x = inv*ATb, T from (alpha,beta,gamma,t), convergence tests of
-// pcl::registration::DefaultConvergenceCriteria.  Runs on ONE wave (threadIdx.x < 64).
-// `first`: iteration 0 of a call (the state is not read: final = identity, no previous MSE).
-// (inlined on purpose: a call makes the kernel use scratch memory, and a dispatch that needs scratch behind one that does not -
-// or the other way round - costs ~6 us of dispatch latency on MI355X: two such bubbles per outer iteration)
-__device__ __forceinline__ void icp_solve_tail(IcpState* st, const double* partials, int nblocks, int ns, double mse_rel, bool first) {
-    __shared__ double sums[kNSums], half[2][kNSums];
-    __shared__ double A[6][6], inv[6][6], x[6], sc[6];
-    __shared__ int piv[8];
-    __shared__ bool singular;
-    __shared__ float T[16], F[16];
+// requested at the START of a tail (with the partial sums): two dependent round trips less after T
+__device__ __forceinline__ TailPrev tail_prefetch(const IcpState* st, bool first) {
+    TailPrev pv{0.f, 0, 1.7976931348623157e308};
+    if (!first) {
+        if (threadIdx.x < 16) pv.F = st->Tfinal[threadIdx.x];
+        if (threadIdx.x == 0) { pv.iters = st->iters; pv.mse = st->prev_mse; }
+    }
+    return pv;
+}
+
+// the 28 sums over the block partials on ONE wave: two lanes per sum (even / odd blocks), then one add - a fixed order
+__device__ __forceinline__ void tail_sums_wave(const double* partials, int nblocks, double* sums) {
+    __shared__ double half[2][kNSums];
     const int t = threadIdx.x;
-    if (t < 2 * kNSums) {      // two lanes per sum (even / odd blocks), then one add: a fixed summation order
+    if (t < 2 * kNSums) {
         const int k = t % kNSums, h = t / kNSums;
         double s = 0.0;
-        // (written by other blocks of this launch: visible after the acquire fence in the caller.)  Many loads in
-        // flight, then the adds in block order: the summation order stays fixed, the latency is paid once per pass
+        // (written by other blocks of this launch through coherent stores.)  Many loads in flight, then the adds in block
+        // order: the summation order stays fixed, the latency is paid once per pass
         int b = h;
         for (; b < nblocks; b += 64) {            // 32 guarded loads in flight (typical launches: one pass)
             double v[32];
@@ -284,23 +312,68 @@ __device__ __forceinline__ void icp_solve_tail(IcpState* st, const double* parti
         half[h][k] = s;
     }
     wave_sync();
-    KT_STAMP(6);
     if (t < kNSums) sums[t] = half[0][t] + half[1][t];
     wave_sync();
+}
+
+// the same on a whole block of >= kTailSegs * 28 threads (the block that finished last, all of its waves still there):
+// thread (k, seg) takes the blocks seg, seg + kTailSegs, ..., then the segments in order.  One round trip of loads for up to
+// 4 * kTailSegs blocks instead of one per 64.  `segs` : kTailSegs x 32 doubles of LDS.  Ends with a block barrier.
+constexpr int kTailSegs = 16;
+__device__ __forceinline__ void tail_sums_block(const double* partials, int nblocks, double (*segs)[32], double* sums) {
+    const int t = threadIdx.x;
+    if (t < kTailSegs * kNSums) {
+        const int k = t % kNSums, seg = t / kNSums;
+        double s = 0.0;
+        for (int b = seg; b < nblocks; b += 8 * kTailSegs) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = (b + u * kTailSegs < nblocks) ? __hip_atomic_load(&partials[(size_t)(b + u * kTailSegs) * kNSums + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (b + u * kTailSegs < nblocks) s += v[u];
+        }
+        segs[seg][k] = s;
+    }
+    __syncthreads();
+    if (t < kNSums) {
+        double s = segs[0][t];
+#pragma unroll
+        for (int g = 1; g < kTailSegs; ++g) s += segs[g][t];
+        sums[t] = s;
+    }
+    __syncthreads();
+}
+
+// 6x6 LU inverse of the summed system, x = inv*ATb, T from (alpha,beta,gamma,t), convergence tests of
+// pcl::registration::DefaultConvergenceCriteria.  Runs on ONE wave (threadIdx.x < 64); `sums`: the 28 sums in LDS.
+// `first`: iteration 0 of a call (the state is not read: final = identity, no previous MSE).
+// (inlined on purpose: a call makes the kernel use scratch memory, and a dispatch that needs scratch behind one that does not -
+// or the other way round - costs ~6 us of dispatch latency on MI355X: two such bubbles per outer iteration)
+__device__ __forceinline__ void icp_solve_tail(IcpState* st, const double* sums, int ns, double mse_rel, bool first, TailPrev pv) {
+    __shared__ double A[6][6], inv[6][6], x[6], sc[6];
+    __shared__ bool singular;
+    __shared__ float T[16], F[16];
+    const int t = threadIdx.x;
+    const float F_prev = pv.F;
+    const int iters_prev = pv.iters;
+    const double mse_prev = pv.mse;
+    KT_STAMP(first ? 6 : 22);
     if (t < 36) {           // symmetric fill from the 21 upper-triangle sums
         const int i = t / 6, j = t % 6, r = min(i, j), c = max(i, j);
         A[i][j] = sums[r * 6 - r * (r - 1) / 2 + (c - r)];
     }
     wave_sync();
-    inv6_wave(A, inv, piv, &singular);
-    KT_STAMP(7);
+    inv6_wave(A, inv, &singular);
+    KT_STAMP(first ? 7 : 23);
     if (t < 6) {
         double s = 0.0;
         for (int c = 0; c < 6; ++c) s += inv[t][c] * sums[21 + c];
         x[t] = s;
     }
     wave_sync();
-    if (t < 3) { sc[t] = cos(x[t]); sc[3 + t] = sin(x[t]); }     // alpha, beta, gamma
+    if (t < 3) { double sn, cs; sincos(x[t], &sn, &cs); sc[t] = cs; sc[3 + t] = sn; }     // alpha, beta, gamma (sincos: one argument reduction, the values of sin() and cos())
     wave_sync();
     if (t == 0) {
         const double ca = sc[0], cb = sc[1], cg = sc[2], sa = sc[3], sb = sc[4], sg = sc[5];
@@ -316,8 +389,8 @@ __device__ __forceinline__ void icp_solve_tail(IcpState* st, const double* parti
         T[3] = (float)x[3]; T[7] = (float)x[4]; T[11] = (float)x[5];
         T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
     }
-    KT_STAMP(8);
-    if (t < 16) F[t] = first ? ((t % 5 == 0) ? 1.f : 0.f) : st->Tfinal[t];
+    KT_STAMP(first ? 8 : 24);
+    if (t < 16) F[t] = first ? ((t % 5 == 0) ? 1.f : 0.f) : F_prev;
     wave_sync();
     if (t < 16) {           // final = T * final (Eigen order), one element per lane
         const int i = t / 4, j = t % 4;
@@ -329,8 +402,8 @@ __device__ __forceinline__ void icp_solve_tail(IcpState* st, const double* parti
         coh_store(&st->T[t], T[t]);
     }
     if (t != 0) return;
-    const int iters = (first ? 0 : st->iters) + 1;
-    const double prev_mse = first ? 1.7976931348623157e308 : st->prev_mse;
+    const int iters = iters_prev + 1;
+    const double prev_mse = mse_prev;
     coh_store(&st->iters, iters);
     if (first) { coh_store(&st->reason, 0); coh_store(&st->pad, 0); }
     // pcl::registration::DefaultConvergenceCriteria<float>::hasConverged()
@@ -504,9 +577,13 @@ __global__ void __launch_bounds__(kClsThreads) k_classify_icp0(ClassifyArgs a, i
         last = (unsigned)__shfl((int)last, 0);
         if (last) {
             KT_STAMP(4);
-            // totals (every aggregate is published by now), slot words, state, solve
-            int tn = 0, tp = 0;
-            for (int b = tid; b < nb; b += 64) {
+            // totals (every aggregate is published by now), slot words, state, solve.  The aggregates and the partials are
+            // requested together: one round trip
+            __shared__ double s_sums[kNSums];
+            const unsigned long long agg0 = (tid < nb) ? coh_load(&agg[tid]) : 0ull;
+            tail_sums_wave(partials, nb, s_sums);
+            int tn = (int)(agg0 & 0xffffu), tp = (int)((agg0 >> 16) & 0xffffffffu);
+            for (int b = tid + 64; b < nb; b += 64) {
                 const unsigned long long v = coh_load(&agg[b]);
                 tn += (int)(v & 0xffffu); tp += (int)((v >> 16) & 0xffffffffu);
             }
@@ -522,7 +599,7 @@ __global__ void __launch_bounds__(kClsThreads) k_classify_icp0(ClassifyArgs a, i
                 }
             } else {
                 KT_STAMP(5);
-                icp_solve_tail(st, partials, nb, tn, mse_rel, true);
+                icp_solve_tail(st, s_sums, tn, mse_rel, true, TailPrev{0.f, 0, 1.7976931348623157e308});
             }
             KT_STAMP(9);
             if (mail.dst) {
@@ -596,7 +673,6 @@ __device__ __forceinline__ void vcm_block(const GridDesc& g, const float4* __res
     __shared__ double sh[kVcmBlock / 64][32];
     __shared__ double sums[kVSums];
     __shared__ double A[6][6], Q[6][6], xs[6];
-    __shared__ int piv[8];
     __shared__ bool singular;
     __shared__ unsigned s_last;
     const int nact = (ns + kAccPts - 1) / kAccPts;
@@ -665,7 +741,7 @@ __device__ __forceinline__ void vcm_block(const GridDesc& g, const float4* __res
             A[r0][c0] = sums[r * 6 - r * (r - 1) / 2 + (c - r)];
         }
         wave_sync();
-        inv6_wave(A, Q, piv, &singular);
+        inv6_wave(A, Q, &singular);
         if (t < 6) {
             double s = 0;
             for (int c = 0; c < 6; ++c) s += Q[t][c] * sums[21 + c];
