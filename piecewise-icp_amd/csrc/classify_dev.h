@@ -19,8 +19,11 @@ struct ClassifyArgs {
 
 namespace pwdev {
 
-// returns the stable flag; *lod = the patch's level of detection
-__device__ __forceinline__ int classify_patch(const ClassifyArgs& a, int i, float* lod) {
+// what inner-ICP iteration 0 needs of a patch, gathered in the same two round trips as the classification's own operands
+struct ClassifyRow { float4 q, t, tn; float dct; };
+
+// returns the stable flag; *lod = the patch's level of detection; *row (optional): the operands of the patch's LLS row
+__device__ __forceinline__ int classify_patch(const ClassifyArgs& a, int i, float* lod, ClassifyRow* row = nullptr) {
     // (2) level of detection, R.cpp:756-766
     const float maxLoD = a.DTmin * 2.0f, minLoD = a.DTmin;
     const int j = max(a.mCT[i], 0);                  // (-1 = empty target: rejected on the host before the launch)
@@ -32,6 +35,7 @@ __device__ __forceinline__ int classify_patch(const ClassifyArgs& a, int i, floa
     const float4 q = a.ct2[i];
     const float4 n = a.nrm1[j], t = a.ct1[j];
     const float dct = a.dCT[i];
+    if (row) { row->q = q; row->t = t; row->tn = a.ct1n[j]; row->dct = dct; }
     float resCT;
     if (n.w != 0.0f) {
         const float dx = t.x - q.x, dy = t.y - q.y, dz = t.z - q.z;

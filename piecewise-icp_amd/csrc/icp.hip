@@ -466,10 +466,11 @@ __global__ void __launch_bounds__(kClsThreads) k_classify_icp0(ClassifyArgs a, i
     if (blockIdx.x == 0 && threadIdx.x == 0) KT_STAMP(0);
     float lod = 0.0f;
     int f = 0, np = 0;
+    pwdev::ClassifyRow cr;
     if (i < a.m2) {
-        f = pwdev::classify_patch(a, i, &lod);
-        stable[i] = f;
         np = a.off2[i + 1] - a.off2[i];
+        f = pwdev::classify_patch(a, i, &lod, &cr);
+        stable[i] = f;
     }
     // block aggregate: stable patches / their points, LoD min / max
     int in = f;                                      // inclusive scan inside the wave
@@ -512,16 +513,14 @@ __global__ void __launch_bounds__(kClsThreads) k_classify_icp0(ClassifyArgs a, i
     {
         float row[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (f) {
-            const float4 c = a.ct2[i];
-            const int j = max(a.mCT[i], 0);
-            const float4 t = a.ct1[j], tn = a.ct1n[j];
+            const float4 c = cr.q, t = cr.t, tn = cr.tn;
             const float sx = c.x, sy = c.y, sz = c.z, dx = t.x, dy = t.y, dz = t.z, nx = tn.x, ny = tn.y, nz = tn.z;
             row[0] = nz * sy - ny * sz;
             row[1] = nx * sz - nz * sx;
             row[2] = ny * sx - nx * sy;
             row[3] = nx; row[4] = ny; row[5] = nz;
             row[6] = nx * dx + ny * dy + nz * dz - nx * sx - ny * sy - nz * sz;
-            row[7] = a.dCT[i];
+            row[7] = cr.dct;
         }
         if (!svc) {
 #pragma unroll

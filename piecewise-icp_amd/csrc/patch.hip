@@ -25,6 +25,26 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kFrontBlock = 256;     // a multiple of kGroup
 
+// -DPWICP_KTRACE: start / end stamp of every block of the LAST k_xf_front launch (s_memrealtime, 10 ns; plain stores, no
+// atomics: 20 k same-address atomics would take longer than the kernel), reduced per role by tools/ktrace_front.py
+#ifdef PWICP_KTRACE
+constexpr int kFtBlocks = 8192;
+__device__ unsigned long long pw_fblk[3 * kFtBlocks];          // begin | end (thread 0's wave) | role
+#define FT_ROLE_BEGIN(r_) do { if (threadIdx.x == 0 && blockIdx.x < kFtBlocks) { pw_fblk[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime(); pw_fblk[3 * blockIdx.x + 2] = (r_); } } while (0)
+#define FT_ROLE_END(r_) do { if (threadIdx.x == 0 && blockIdx.x < kFtBlocks) pw_fblk[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" __attribute__((visibility("default"))) int pwicp_debug_ftrace(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(pw_fblk), sizeof(unsigned long long) * 3 * kFtBlocks) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long z[3 * kFtBlocks];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pw_fblk), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define FT_ROLE_BEGIN(r_) do { } while (0)
+#define FT_ROLE_END(r_) do { } while (0)
+#endif
+
 // pcl::computeMeanAndCovarianceMatrix (float, single pass) + solvePlaneParameters; false if n < 3
 __device__ inline bool point_normal(const float4* __restrict__ p, int n, float* nrm) {
     if (n < 3) return false;
@@ -160,6 +180,7 @@ __device__ inline void ct_bp(const float4* __restrict__ p, const unsigned char* 
 //   lane:      0    1    2    3    4    5    6    7
 //   sum:       xx   xy   xz   yy   yz   zz   x    y (and z)
 constexpr int kAhead = 4;
+constexpr int kSumBatch = 8;                          // LDS reads in flight per lane while summing (8 costs the kernel two registers too many for 8 waves per SIMD)
 constexpr int kTilePts = kGroup * kAhead;            // 32 points per pass (16 KiB of LDS per 256-thread block)
 constexpr int kTileStride = kTilePts + 1;            // float4 units; +1: the 8 tiles of a wave start on different banks
 // XF: the points are read from pat_in, moved by T on the way (pcl::transformPointCloud: xform_point, the same float
@@ -205,12 +226,12 @@ __device__ __forceinline__ void patch_normal_group(const float4* pat, const int*
         __builtin_amdgcn_wave_barrier();
         const int cnt = min(kTilePts, hi - base);
         int t = 0;
-        for (; t + 8 <= cnt; t += 8) {
-            float p[8], q[8], z[8];
+        for (; t + kSumBatch <= cnt; t += kSumBatch) {
+            float p[kSumBatch], q[kSumBatch], z[kSumBatch];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { p[u] = tw[(t + u) * 4 + c1]; q[u] = tw[(t + u) * 4 + c2]; z[u] = tw[(t + u) * 4 + 2]; }
+            for (int u = 0; u < kSumBatch; ++u) { p[u] = tw[(t + u) * 4 + c1]; q[u] = tw[(t + u) * 4 + c2]; z[u] = tw[(t + u) * 4 + 2]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { acc += p[u] * q[u]; acc8 += z[u]; }
+            for (int u = 0; u < kSumBatch; ++u) { acc += p[u] * q[u]; acc8 += z[u]; }
         }
         for (; t < cnt; ++t) { acc += tw[t * 4 + c1] * tw[t * 4 + c2]; acc8 += tw[t * 4 + 2]; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -269,14 +290,19 @@ __device__ __forceinline__ void front_init(const FrontInit& in) {
 // (R.cpp:737-747), 8 lanes per query.  The two are independent, each is a chain of dependent memory round trips that
 // fills a fraction of the chip, and back to back they cost 16 + 17 us per iteration; side by side ~17 us.
 // The normal blocks come first in the grid so that the longer chain starts first.
+// SEL: the instantiation that can carry a selection pass on its leading blocks.  The pick of a pass is what needs the most
+// registers in these kernels (87 VGPRs = 5 waves per SIMD against 64 = 8 without it), and the launches are bound by how many
+// of their ~5000 short blocks are resident at a time - so the launches that carry no pass (all of them on the usual,
+// speculative schedule) run the instantiation without the role.
+template <bool SEL>
 __global__ void __launch_bounds__(kFrontBlock) k_front(const float4* __restrict__ pat, const int* __restrict__ off, int m,
                                                        float4* __restrict__ nrm_out, int nb_nrm, GridDesc g,
                                                        const float4* __restrict__ q, int nq, int* __restrict__ idx,
                                                        float* __restrict__ d2, int nb_work, FusedSelect fs, FrontInit init) {
     __shared__ float4 tiles[(kFrontBlock / kGroup) * kTileStride];
     front_init(init);
-    const int nsel = fs.scratch ? fs.nblk : 0;
-    if ((int)blockIdx.x < nsel) {
+    const int nsel = (SEL && fs.scratch) ? fs.nblk : 0;
+    if (SEL && (int)blockIdx.x < nsel) {
         // leading blocks: pass 2 of the percentile selection of the PREVIOUS iteration's dense search (select_dev.h); the
         // bins live in the tile buffer
         static_assert(sizeof(tiles) >= kFsBins * sizeof(unsigned), "tile buffer too small for the selection bins");
@@ -311,6 +337,7 @@ __global__ void __launch_bounds__(kFrontBlock) k_front(const float4* __restrict_
 // The moved values are the same float expressions as in the stand-alone launches (xform_point), so normals, matches and
 // distances are bit-identical to transform-then-front; the two launches cost 14 + 17 us back to back, this one ~24 us.
 // (Alternating query and cloud blocks in the grid, or 6 / 8 waves per SIMD through launch bounds: no gain, measured.)
+template <bool SEL>
 __global__ void __launch_bounds__(kFrontBlock) k_xf_front(const float4* pat_in, float4* pat, const int* __restrict__ off, int m,
                                                           float4* __restrict__ nrm_out, int nb_nrm, GridDesc g,
                                                           const float4* ctbp_in, float4* ctbp, int nq, int* __restrict__ idx,
@@ -322,14 +349,14 @@ __global__ void __launch_bounds__(kFrontBlock) k_xf_front(const float4* pat_in, 
     __shared__ float4 tiles[(kFrontBlock / kGroup) * kTileStride];
     front_init(init);
     static_assert(kFrontBlock == kXfBlock, "xf_cloud_block is written for this block size");
-    const int nsel = fs.scratch ? fs.nblk : 0;
-    if ((int)blockIdx.x < nsel) {
+    const int nsel = (SEL && fs.scratch) ? fs.nblk : 0;
+    if (SEL && (int)blockIdx.x < nsel) {
         static_assert(sizeof(tiles) >= kFsBins * sizeof(unsigned), "tile buffer too small for the selection bins");
         fs_pass_embedded<1>((unsigned*)tiles, fs, (int)blockIdx.x, fs.mail.seq);
         return;
     }
-    const int nsel2 = fs.scratch ? nblk2 : 0;
-    if ((int)blockIdx.x < nsel + nsel2) {
+    const int nsel2 = (SEL && fs.scratch) ? nblk2 : 0;
+    if (SEL && (int)blockIdx.x < nsel + nsel2) {
         // pass 2 right behind pass 1 in the grid (its blocks wait for pass 1's tag: blocks with smaller indices, dispatched
         // before them): the percentile reaches the host while the rest of the launch is still running, so the next
         // classification - which needs it as its threshold - is enqueued without the device going idle
@@ -344,9 +371,11 @@ __global__ void __launch_bounds__(kFrontBlock) k_xf_front(const float4* pat_in, 
     for (int i = 0; i < 16; ++i) T.m[i] = st->Tfinal[i];
     int bid = (int)blockIdx.x - nsel - nsel2;
     if (bid < nb_nrm) {
+        FT_ROLE_BEGIN(0);
         const int t = bid * kFrontBlock + threadIdx.x;
         const int i = t / kGroup;
         if (i < m) patch_normal_group<true>(pat, off, i, t % kGroup, nrm_out, tiles + (threadIdx.x / kGroup) * kTileStride, pat_in, T.m, pat);
+        FT_ROLE_END(0);
         return;
     }
     bid -= nb_nrm;
@@ -354,6 +383,7 @@ __global__ void __launch_bounds__(kFrontBlock) k_xf_front(const float4* pat_in, 
         const int t = bid * kFrontBlock + threadIdx.x;
         const int i = t / kGroup, sub = t % kGroup;
         if (i >= nq) return;                        // a whole group is in or out of range together
+        FT_ROLE_BEGIN(1);
         const float4 v = xform_point(T.m, ctbp_in[i]);
         if (sub == 0) ctbp[i] = v;
         const NNBest b = nn_query_group(g, v.x, v.y, v.z, sub);
@@ -361,10 +391,13 @@ __global__ void __launch_bounds__(kFrontBlock) k_xf_front(const float4* pat_in, 
             idx[i] = b.found() ? b.idx() : -1;
             d2[i] = b.d2();
         }
+        FT_ROLE_END(1);
         return;
     }
     bid -= nb_nn;
+    FT_ROLE_BEGIN(2);
     xf_cloud_block(T, cloud_in, cloud, n, bid, nb_cloud, bbox_part, slot, (float (*)[6])tiles);
+    FT_ROLE_END(2);
 }
 
 // CT / BP / sigma of already selected patches
@@ -524,8 +557,12 @@ int pw_front_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, i
     const int nb_nn = div_up((long long)nq * kGroup, kFrontBlock);
     FusedSelect none{};
     const bool sel = fs && fs->scratch;
-    hipLaunchKernelGGL(k_front, dim3(nb_nrm + nb_nn + (sel ? fs->nblk : 0)), dim3(kFrontBlock), 0, ctx->stream, d_pat, d_off, m, d_nrm,
-                       nb_nrm, g, d_q, nq, d_idx, d_d2, nb_nrm + nb_nn, sel ? *fs : none, init ? *init : FrontInit{});
+    if (sel)
+        hipLaunchKernelGGL(k_front<true>, dim3(nb_nrm + nb_nn + fs->nblk), dim3(kFrontBlock), 0, ctx->stream, d_pat, d_off, m, d_nrm,
+                           nb_nrm, g, d_q, nq, d_idx, d_d2, nb_nrm + nb_nn, *fs, init ? *init : FrontInit{});
+    else
+        hipLaunchKernelGGL(k_front<false>, dim3(nb_nrm + nb_nn), dim3(kFrontBlock), 0, ctx->stream, d_pat, d_off, m, d_nrm,
+                           nb_nrm, g, d_q, nq, d_idx, d_d2, nb_nrm + nb_nn, none, init ? *init : FrontInit{});
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }
@@ -539,9 +576,14 @@ int pw_xf_front_launch(pwicp_context* ctx, const float4* d_pat_in, float4* d_pat
     const int nb_cloud = std::min(div_up(n, kFrontBlock), ctx->n_cu * 8);
     FusedSelect none{};
     const bool sel = fs && fs->scratch;
-    hipLaunchKernelGGL(k_xf_front, dim3(nb_nrm + nb_nn + nb_cloud + (sel ? fs->nblk + kFsBlocks : 0)), dim3(kFrontBlock), 0, ctx->stream,
-                       d_pat_in, d_pat, d_off, m, d_nrm, nb_nrm, g, d_ctbp_in, d_ctbp, nq, d_idx, d_d2, nb_nn, d_cloud_in, d_cloud, n,
-                       nb_cloud, d_state, d_ns, d_bbox_part, d_slot, sel ? *fs : none, kFsBlocks, init ? *init : FrontInit{});
+    if (sel)
+        hipLaunchKernelGGL(k_xf_front<true>, dim3(nb_nrm + nb_nn + nb_cloud + fs->nblk + kFsBlocks), dim3(kFrontBlock), 0, ctx->stream,
+                           d_pat_in, d_pat, d_off, m, d_nrm, nb_nrm, g, d_ctbp_in, d_ctbp, nq, d_idx, d_d2, nb_nn, d_cloud_in, d_cloud, n,
+                           nb_cloud, d_state, d_ns, d_bbox_part, d_slot, *fs, kFsBlocks, init ? *init : FrontInit{});
+    else
+        hipLaunchKernelGGL(k_xf_front<false>, dim3(nb_nrm + nb_nn + nb_cloud), dim3(kFrontBlock), 0, ctx->stream,
+                           d_pat_in, d_pat, d_off, m, d_nrm, nb_nrm, g, d_ctbp_in, d_ctbp, nq, d_idx, d_d2, nb_nn, d_cloud_in, d_cloud, n,
+                           nb_cloud, d_state, d_ns, d_bbox_part, d_slot, none, kFsBlocks, init ? *init : FrontInit{});
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }
