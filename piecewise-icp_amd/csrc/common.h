@@ -154,6 +154,19 @@ float pw_estimate_cell_edge(const float* xyz4, int n);     // cell edge of a sta
 int pw_knn_mean_dist_launch(pwicp_context* ctx, const GridDesc& g, int mean_k, float* d_mean);
 // k-th smallest (0-based) of the non-sentinel entries of n non-negative floats; result written to d_out[0]; scratch >= 3*2048+8 uints
 // optional host-mailbox message of a selection: the selected value's bits -> dst[0], then seq (system-scope release)
+// ---- device -> host mailbox hand-over (pinned, host-coherent memory) --------------------------------------------------------
+// The payload words go out as system-scope write-through stores, every lane that stored drains its store queue (gfx9 counts
+// stores in vmcnt; a system-scope store is acknowledged by the fabric), then ONE lane stores the sequence word.  That is the
+// part of __threadfence_system() a mailbox needs; the other part - writing the whole L2 back and invalidating the L1 - costs
+// 1.5-3 us behind a launch that has just rewritten the clouds, for words that never were in a cache.  gfx950 only (see icp.hip).
+#if defined(__HIPCC__)
+__device__ __forceinline__ void mail_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void mail_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }     // every lane that called mail_store
+__device__ __forceinline__ void mail_publish(unsigned* seq_ptr, unsigned seq) {                        // one lane, after the drain
+    __hip_atomic_store(seq_ptr, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
+
 struct SelectMail {
     unsigned* dst = nullptr;
     unsigned* seq_ptr = nullptr;

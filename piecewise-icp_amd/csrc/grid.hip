@@ -627,9 +627,9 @@ __global__ void k_select_pass(const float* __restrict__ v, int n, int k0, unsign
         const int src = m ? (int)__ffsll((long long)m) - 1 : 0;
         value = (unsigned)__shfl((int)value, src);
         if (lane == 0) {
-            mail.dst[0] = value;
-            __threadfence_system();
-            __hip_atomic_store(mail.seq_ptr, mail.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            mail_store(&mail.dst[0], value);
+            mail_drain();
+            mail_publish(mail.seq_ptr, mail.seq);
         }
     }
 }

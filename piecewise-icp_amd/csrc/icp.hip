@@ -35,7 +35,22 @@ __device__ unsigned long long pw_ktrace[32];
 #define KT_STAMP(slot_) do { if ((threadIdx.x & 63) == 0) pw_ktrace[slot_] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define KT_MIN(slot_) do { if (threadIdx.x == 0) atomicMin(&pw_ktrace[slot_], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
 #define KT_MAX(slot_) do { if (threadIdx.x == 0) atomicMax(&pw_ktrace[slot_], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
+// start / end / role of every block of the last k_xf_vcm launch (plain stores), tools/ktrace_front.py
+constexpr int kVtBlocks = 4096;
+__device__ unsigned long long pw_vblk[3 * kVtBlocks];
+#define VT_BEGIN(r_) do { if (threadIdx.x == 0 && blockIdx.x < kVtBlocks) { pw_vblk[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime(); pw_vblk[3 * blockIdx.x + 2] = (r_); } } while (0)
+#define VT_END() do { if (threadIdx.x == 0 && blockIdx.x < kVtBlocks) pw_vblk[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" __attribute__((visibility("default"))) int pwicp_debug_vtrace(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(pw_vblk), sizeof(unsigned long long) * 3 * kVtBlocks) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long z[3 * kVtBlocks];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pw_vblk), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
 #else
+#define VT_BEGIN(r_) do { } while (0)
+#define VT_END() do { } while (0)
 #define KT_STAMP(slot_) do { } while (0)
 #define KT_MIN(slot_) do { } while (0)
 #define KT_MAX(slot_) do { } while (0)
@@ -73,12 +88,12 @@ __device__ __forceinline__ void icp_send_mail(const IcpMail& m, const IcpState* 
     if (t >= 64) return;
     const unsigned* c = (const unsigned*)st;
     const int nc = (int)(sizeof(IcpState) / 4);
-    for (int i = t; i < m.na; i += 64) m.dst[i] = __hip_atomic_load(&m.a[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int i = t; i < m.nb; i += 64) m.dst[m.na + i] = __hip_atomic_load(&m.b[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int i = t; i < nc; i += 64) m.dst[m.na + m.nb + i] = __hip_atomic_load(&c[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence_system();
+    for (int i = t; i < m.na; i += 64) mail_store(&m.dst[i], __hip_atomic_load(&m.a[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    for (int i = t; i < m.nb; i += 64) mail_store(&m.dst[m.na + i], __hip_atomic_load(&m.b[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    for (int i = t; i < nc; i += 64) mail_store(&m.dst[m.na + m.nb + i], __hip_atomic_load(&c[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    mail_drain();
     wave_sync();
-    if (t == 0) __hip_atomic_store(m.seq_ptr, m.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (t == 0) mail_publish(m.seq_ptr, m.seq);
 }
 
 // Group-cooperative accumulate: kGroup (8) consecutive lanes share one stable centroid.  They split the rows of its
@@ -645,7 +660,7 @@ __global__ void k_icp_init(IcpState* st) {
 }
 
 // ---- VCM (R.cpp:1273-1343) ------------------------------------------------------------------------------
-constexpr int kVSums = 27;    // 21 ATA + 6 ATL
+constexpr int kVSums = 28;    // 21 ATA + 6 ATL + L^T L
 
 __device__ __forceinline__ void vcm_row(float4 q, float4 p, float4 n, double* a, double* L) {
     const double Qx = q.x, Qy = q.y, Qz = q.z, Px = p.x, Py = p.y, Pz = p.z, Nx = n.x, Ny = n.y, Nz = n.z;
@@ -659,8 +674,9 @@ __device__ __forceinline__ void vcm_row(float4 q, float4 p, float4 n, double* a,
 // calTransParaVCM (R.cpp:1273-1343) in ONE launch of 1024-thread blocks, `bid` of `nb_max`:
 //   every block   NN of its 128 stable centroids among the target centroids (group-cooperative like k_icp_iter: 8 lanes share a
 //                 point's search and each keeps 4 of the 27 sums), one partial per block;
-//   last block    (device counter) Qxx = (A^T A)^-1 and x = Qxx A^T L on its first wave, then - all 1024 threads - the residuals
-//                 v = A x - L of ALL points (matches read back through device-coherent loads), v^T v in a fixed order,
+//   last block    (device counter) the sums of the partials on all its waves, Qxx = (A^T A)^-1 and x = Qxx A^T L on its first wave,
+//                 v^T v = L^T L - x^T A^T L from the sums (the residual pass over ALL points - one CU reading 0.5 MB: 9 us -
+//                 only when those two terms cancel, see below),
 //                 sigma0^2 Qxx (R.cpp:1330-1340) and, when asked, the run's closing mailbox message.
 // (Two launches before: the second one's start-up cost as much as its work.)  ns: *ns_dev when ns_dev != nullptr.
 constexpr int kVcmBlock = kAccBlock;
@@ -670,7 +686,7 @@ __device__ __forceinline__ void vcm_block(const GridDesc& g, const float4* __res
                                           double* __restrict__ partials, unsigned* __restrict__ counter,
                                           double* __restrict__ vcm, const VcmMail& mail, int bid) {
     __shared__ double sh[kVcmBlock / 64][32];
-    __shared__ double sums[kVSums];
+    __shared__ double sums[kNSums];
     __shared__ double A[6][6], Q[6][6], xs[6];
     __shared__ bool singular;
     __shared__ unsigned s_last;
@@ -686,12 +702,12 @@ __device__ __forceinline__ void vcm_block(const GridDesc& g, const float4* __res
         if (sub == 0) coh_store(&match[i], bi);
         double a[6], L;
         vcm_row(q, tgt[bi], tgt_n[bi], a, &L);
-        // sum k (0..26; 21 upper-triangle products row by row, then a[r]*L) lives on lane sub = k % 8 as its (k / 8)-th value
+        // sum k (0..27; 21 upper-triangle products row by row, then a[r]*L, then L*L) lives on lane sub = k % 8 as its (k / 8)-th value
         switch (sub) {
             case 0: w0 = a[0] * a[0]; w1 = a[1] * a[3]; w2 = a[3] * a[4]; w3 = a[3] * L; break;    // 0, 8, 16, 24
             case 1: w0 = a[0] * a[1]; w1 = a[1] * a[4]; w2 = a[3] * a[5]; w3 = a[4] * L; break;    // 1, 9, 17, 25
             case 2: w0 = a[0] * a[2]; w1 = a[1] * a[5]; w2 = a[4] * a[4]; w3 = a[5] * L; break;    // 2, 10, 18, 26
-            case 3: w0 = a[0] * a[3]; w1 = a[2] * a[2]; w2 = a[4] * a[5]; break;                   // 3, 11, 19
+            case 3: w0 = a[0] * a[3]; w1 = a[2] * a[2]; w2 = a[4] * a[5]; w3 = L * L; break;       // 3, 11, 19, 27
             case 4: w0 = a[0] * a[4]; w1 = a[2] * a[3]; w2 = a[5] * a[5]; break;                   // 4, 12, 20
             case 5: w0 = a[0] * a[5]; w1 = a[2] * a[4]; w2 = a[0] * L; break;                      // 5, 13, 21
             case 6: w0 = a[1] * a[1]; w1 = a[2] * a[5]; w2 = a[1] * L; break;                      // 6, 14, 22
@@ -718,23 +734,18 @@ __device__ __forceinline__ void vcm_block(const GridDesc& g, const float4* __res
     }
     __syncthreads();
     if (!s_last) return;
-    // ---- solve (wave 0), the other waves wait ----
+    KT_STAMP(26);
+    // ---- the block that finished last: the sums of the partials on all its waves (one round trip), the solve on wave 0 ----
+    __shared__ double s_vv;
+    __shared__ int s_explicit;
+    // (the diagnostic counters of the closing message: requested now, they come from HBM)
+    unsigned long long ex = 0;
+    if (mail.dst && tid < 64)
+        for (int k = tid; k < 256; k += 64) ex += mail.examined[(size_t)k * 16];
+    tail_sums_block(partials, nact, sh, sums);
+    KT_STAMP(27);
     if (tid < 64) {
         const int t = tid;
-        if (t < kVSums) {
-            double s = 0.0;
-            int bk = 0;
-            for (; bk + 8 <= nact; bk += 8) {
-                double v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = coh_load(&partials[(size_t)(bk + u) * kNSums + t]);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) s += v[u];
-            }
-            for (; bk < nact; ++bk) s += coh_load(&partials[(size_t)bk * kNSums + t]);
-            sums[t] = s;
-        }
-        wave_sync();
         if (t < 36) {
             const int r0 = t / 6, c0 = t % 6, r = min(r0, c0), c = max(r0, c0);
             A[r0][c0] = sums[r * 6 - r * (r - 1) / 2 + (c - r)];
@@ -746,10 +757,23 @@ __device__ __forceinline__ void vcm_block(const GridDesc& g, const float4* __res
             for (int c = 0; c < 6; ++c) s += Q[t][c] * sums[21 + c];
             xs[t] = s;
         }
+        wave_sync();
+        if (t == 0) {
+            // v^T v with v = A x - L, x = Qxx A^T L:  v^T v = L^T L - x^T (A^T L)  (normal equations) - no second pass over the
+            // points.  The two terms cancel when the fit explains nearly all of L; then (and only then: never at the end of a
+            // registration, where x ~ 0) the residuals are formed point by point below, as the reference does (R.cpp:1331-1333).
+            double xtl = 0.0;
+            for (int c = 0; c < 6; ++c) xtl += xs[c] * sums[21 + c];
+            const double vv_id = sums[27] - xtl;
+            s_vv = vv_id;
+            s_explicit = (vv_id > 1e-4 * sums[27]) ? 0 : 1;
+        }
+        KT_STAMP(28);
     }
     __syncthreads();
-    // ---- residuals of all points on the whole block: thread t takes points t, t + 1024, ... ; fixed summation order ----
     double vv = 0.0;
+    if (s_explicit) {
+    // ---- residuals of all points on the whole block: thread t takes points t, t + 1024, ... ; fixed summation order ----
     for (int p = tid; p < ns; p += kVcmBlock) {
         const int bi = coh_load(&match[p]);
         double a[6], L;
@@ -759,6 +783,8 @@ __device__ __forceinline__ void vcm_block(const GridDesc& g, const float4* __res
         r -= L;
         vv += r * r;
     }
+    }
+    KT_STAMP(29);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) vv += __shfl_xor(vv, o);
     if (lane == 0) sh[wave][0] = vv;
@@ -766,30 +792,31 @@ __device__ __forceinline__ void vcm_block(const GridDesc& g, const float4* __res
     if (tid >= 64) return;
     double vtpv = sh[0][0];
     for (int w = 1; w < kVcmBlock / 64; ++w) vtpv += sh[w][0];
+    if (!s_explicit) vtpv = s_vv;
     const int t = tid;
     const double STD0 = sqrt(vtpv / (double)(ns - 6));
     double out = 0.0;
     if (t < 36) { out = STD0 * STD0 * Q[t / 6][t % 6]; vcm[t] = out; }
+    KT_STAMP(30);
     if (!mail.dst) return;
     // message: 36 doubles | the folded diagnostic counter (256 partial counters, 128 bytes apart) | seq
-    unsigned long long ex = 0;
-    for (int k = t; k < 256; k += 64) ex += mail.examined[(size_t)k * 16];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ex += __shfl_xor(ex, o);
     if (t < 36) {
         unsigned lo, hi;
         memcpy(&lo, &out, 4);
         memcpy(&hi, (const char*)&out + 4, 4);
-        mail.dst[2 * t] = lo;
-        mail.dst[2 * t + 1] = hi;
+        mail_store(&mail.dst[2 * t], lo);
+        mail_store(&mail.dst[2 * t + 1], hi);
     }
     if (t == 0) {
-        mail.dst[72] = (unsigned)(ex & 0xffffffffull);
-        mail.dst[73] = (unsigned)(ex >> 32);
+        mail_store(&mail.dst[72], (unsigned)(ex & 0xffffffffull));
+        mail_store(&mail.dst[73], (unsigned)(ex >> 32));
     }
-    __threadfence_system();
+    mail_drain();
     wave_sync();
-    if (t == 0) __hip_atomic_store(mail.seq_ptr, mail.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (t == 0) mail_publish(mail.seq_ptr, mail.seq);
+    KT_STAMP(31);
 }
 
 __global__ void __launch_bounds__(kVcmBlock) k_vcm(GridDesc g, const float4* __restrict__ tgt, const float4* __restrict__ tgt_n,
@@ -818,15 +845,19 @@ __global__ void __launch_bounds__(kVcmBlock) k_xf_vcm(GridDesc g, const float4* 
     int bid = (int)blockIdx.x;
     if (bid < nb_vcm) {
         if (stage3_bits && coh_load(&slot_ro[0]) != stage3_bits) return;
+        VT_BEGIN(0);
         vcm_block(g, tgt, tgt_n, stct, (int)slot_ro[2], match, partials, counter, vcm, mail, bid);
+        VT_END();
         return;
     }
     bid -= nb_vcm;
     Mat4 T;
 #pragma unroll
     for (int i = 0; i < 16; ++i) T.m[i] = st->Tfinal[i];
-    if (bid < nb_rest) { xf_rest_block<kVcmBlock>(T, ctbp_in, ctbp, n_ctbp, pat_in, pat, n_pat, bid, nb_rest); return; }
+    if (bid < nb_rest) { VT_BEGIN(1); xf_rest_block<kVcmBlock>(T, ctbp_in, ctbp, n_ctbp, pat_in, pat, n_pat, bid, nb_rest); VT_END(); return; }
+    VT_BEGIN(2);
     xf_cloud_block<kVcmBlock>(T, cloud_in, cloud, n, bid - nb_rest, nb_cloud, bbox_part, slot, shb);
+    VT_END();
 }
 
 }  // namespace

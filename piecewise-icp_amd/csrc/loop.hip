@@ -91,18 +91,18 @@ __global__ void __launch_bounds__(64) k_bbox_arm(unsigned* __restrict__ bbox_par
 }
 
 // Device -> host mailbox: copies up to three word ranges into pinned, coherent host memory and then publishes a
-// sequence number with a system-scope release.  The host spins on the sequence word instead of paying a
+// sequence number (common.h: mail_store / mail_drain / mail_publish).  The host spins on the sequence word instead of paying a
 // hipMemcpy + hipStreamSynchronize round trip per outer iteration (stream order guarantees the producers ran).
 __global__ void __launch_bounds__(64) k_mail(const unsigned* __restrict__ a, int na, const unsigned* __restrict__ b, int nb,
                                              const unsigned* __restrict__ c, int nc, unsigned* __restrict__ dst,
                                              unsigned* seq_ptr, unsigned seq) {
     const int t = threadIdx.x;
-    for (int i = t; i < na; i += 64) dst[i] = a[i];
-    for (int i = t; i < nb; i += 64) dst[na + i] = b[i];
-    for (int i = t; i < nc; i += 64) dst[na + nb + i] = c[i];
-    __threadfence_system();
+    for (int i = t; i < na; i += 64) mail_store(&dst[i], a[i]);
+    for (int i = t; i < nb; i += 64) mail_store(&dst[na + i], b[i]);
+    for (int i = t; i < nc; i += 64) mail_store(&dst[na + nb + i], c[i]);
+    mail_drain();
     __syncthreads();
-    if (t == 0) __hip_atomic_store(seq_ptr, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (t == 0) mail_publish(seq_ptr, seq);
 }
 
 // sums the 256 spread diagnostic counters into ctr[256*16] (one wave)

@@ -211,9 +211,9 @@ __device__ __forceinline__ void fs_pass_embedded(unsigned* h, const FusedSelect&
         const int src = m ? (int)__ffsll((long long)m) - 1 : 0;
         value = (unsigned)__shfl((int)value, src);
         if (lane == 0) {
-            fs.mail.dst[0] = value;
-            __threadfence_system();
-            __hip_atomic_store(fs.mail.seq_ptr, fs.mail.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            mail_store(&fs.mail.dst[0], value);
+            mail_drain();
+            mail_publish(fs.mail.seq_ptr, fs.mail.seq);
         }
     }
 }

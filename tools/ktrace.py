@@ -29,3 +29,6 @@ for rep in range(4):
               23: "tail: 6x6 inverted", 24: "tail: T formed", 25: "tail done"}
     if buf[16]:
         print("   k_icp_iter: " + " | ".join("%s +%.2f us" % (inames[i], (buf[i] - buf[16]) / 100.0) for i in sorted(inames)))
+    if buf[26]:
+        vn = {27: "partials summed", 28: "solved (wave 0)", 29: "residual loop done (last wave to write)", 30: "VCM formed", 31: "mail sent"}
+        print("   vcm tail: " + " | ".join("%s +%.2f us" % (vn[i], (buf[i] - buf[26]) / 100.0) for i in sorted(vn)))
