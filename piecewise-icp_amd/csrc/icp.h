@@ -54,8 +54,9 @@ int pw_classify_icp0_launch(pwicp_context* ctx, const ClassifyArgs& a, int* d_st
                             unsigned* d_slot, double euclid_eps, const IcpMail* mail = nullptr);
 int pw_icp_run(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w, int ns,
                double euclid_eps, float* T16, int* iters_out);
+// have_match: d_src are the stable centroids the last pw_classify_icp0_launch on `w` compacted (their matches are in w->match)
 int pw_vcm_enqueue(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
-                   const float4* d_src, int ns, const VcmMail* mail = nullptr);
+                   const float4* d_src, int ns, const VcmMail* mail = nullptr, bool have_match = false);
 // the run's last transform update + the VCM in one launch (icp.hip: k_xf_vcm)
 int pw_xf_vcm_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
                      const float4* d_stct, int ns_max, const VcmMail* mail, unsigned stage3_bits, const float4* d_cloud_in,

@@ -462,7 +462,7 @@ __device__ __forceinline__ unsigned long long agg_pack(unsigned epoch, int n, in
 
 __global__ void __launch_bounds__(kClsThreads) k_classify_icp0(ClassifyArgs a, int* __restrict__ stable, float4* __restrict__ stCT,
                                                              float4* __restrict__ stN, float4* __restrict__ wsrc,
-                                                             float4* __restrict__ wsrcn, unsigned* __restrict__ slot,
+                                                             float4* __restrict__ wsrcn, int* __restrict__ wmatch, unsigned* __restrict__ slot,
                                                              unsigned long long* __restrict__ agg, unsigned epoch, IcpState* st,
                                                              double* __restrict__ partials, unsigned* __restrict__ counter,
                                                              double mse_rel, IcpMail mail) {
@@ -645,6 +645,7 @@ __global__ void __launch_bounds__(kClsThreads) k_classify_icp0(ClassifyArgs a, i
         const int pos = base + wave_off + in - 1;
         stCT[pos] = c; stN[pos] = n;
         wsrc[pos] = c; wsrcn[pos] = n;
+        wmatch[pos] = max(a.mCT[i], 0);              // the stable centroid's nearest target centroid (front launch): the VCM's match
     }
 }
 
@@ -684,7 +685,7 @@ constexpr int kVcmBlock = kAccBlock;
 __device__ __forceinline__ void vcm_block(const GridDesc& g, const float4* __restrict__ tgt, const float4* __restrict__ tgt_n,
                                           const float4* __restrict__ src, int ns, int* __restrict__ match,
                                           double* __restrict__ partials, unsigned* __restrict__ counter,
-                                          double* __restrict__ vcm, const VcmMail& mail, int bid) {
+                                          double* __restrict__ vcm, const VcmMail& mail, int bid, bool have_match) {
     __shared__ double sh[kVcmBlock / 64][32];
     __shared__ double sums[kNSums];
     __shared__ double A[6][6], Q[6][6], xs[6];
@@ -697,9 +698,15 @@ __device__ __forceinline__ void vcm_block(const GridDesc& g, const float4* __res
     double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
     if (i < ns) {
         const float4 q = src[i];
-        const NNBest b = nn_query_group(g, q.x, q.y, q.z, sub);
-        const int bi = b.idx();
-        if (sub == 0) coh_store(&match[i], bi);
+        // have_match: the stable centroids are the ones the fused classification has just compacted, and it left their nearest
+        // target centroids (the front launch's matches: same points, same target, R.cpp:1292 would find them again) in `match`
+        int bi;
+        if (have_match) bi = match[i];
+        else {
+            const NNBest b = nn_query_group(g, q.x, q.y, q.z, sub);
+            bi = b.idx();
+            if (sub == 0) coh_store(&match[i], bi);
+        }
         double a[6], L;
         vcm_row(q, tgt[bi], tgt_n[bi], a, &L);
         // sum k (0..27; 21 upper-triangle products row by row, then a[r]*L, then L*L) lives on lane sub = k % 8 as its (k / 8)-th value
@@ -767,6 +774,9 @@ __device__ __forceinline__ void vcm_block(const GridDesc& g, const float4* __res
             const double vv_id = sums[27] - xtl;
             s_vv = vv_id;
             s_explicit = (vv_id > 1e-4 * sums[27]) ? 0 : 1;
+#ifdef PWICP_KTRACE
+            pw_ktrace[20] = (unsigned long long)s_explicit; pw_ktrace[21] = (unsigned long long)__double_as_longlong(vv_id / sums[27]);
+#endif
         }
         KT_STAMP(28);
     }
@@ -822,8 +832,8 @@ __device__ __forceinline__ void vcm_block(const GridDesc& g, const float4* __res
 __global__ void __launch_bounds__(kVcmBlock) k_vcm(GridDesc g, const float4* __restrict__ tgt, const float4* __restrict__ tgt_n,
                                                    const float4* __restrict__ src, int ns, int* __restrict__ match,
                                                    double* __restrict__ partials, unsigned* __restrict__ counter,
-                                                   double* __restrict__ vcm, VcmMail mail) {
-    vcm_block(g, tgt, tgt_n, src, ns, match, partials, counter, vcm, mail, (int)blockIdx.x);
+                                                   double* __restrict__ vcm, VcmMail mail, int have_match) {
+    vcm_block(g, tgt, tgt_n, src, ns, match, partials, counter, vcm, mail, (int)blockIdx.x, have_match != 0);
 }
 
 // The LAST update of a run (R.cpp:943-954) and calTransParaVCM (R.cpp:958-961) in one launch: the VCM works on the stable
@@ -846,7 +856,7 @@ __global__ void __launch_bounds__(kVcmBlock) k_xf_vcm(GridDesc g, const float4* 
     if (bid < nb_vcm) {
         if (stage3_bits && coh_load(&slot_ro[0]) != stage3_bits) return;
         VT_BEGIN(0);
-        vcm_block(g, tgt, tgt_n, stct, (int)slot_ro[2], match, partials, counter, vcm, mail, bid);
+        vcm_block(g, tgt, tgt_n, stct, (int)slot_ro[2], match, partials, counter, vcm, mail, bid, true);
         VT_END();
         return;
     }
@@ -900,7 +910,7 @@ int pw_classify_icp0_launch(pwicp_context* ctx, const ClassifyArgs& a, int* d_st
     w->epoch = (w->epoch % 0xffffu) + 1u;          // 1 .. 65535, never 0 (the buffer is zeroed once)
     IcpMail none{};
     hipLaunchKernelGGL(k_classify_icp0, dim3(div_up(a.m2, kClsBlock)), dim3(kClsThreads), 0, ctx->stream, a, d_stable, d_stCT, d_stN,
-                       w->src.p, w->srcn.p, d_slot, w->agg.p, w->epoch, w->state.p, w->partials.p, w->counter.p, euclid_eps,
+                       w->src.p, w->srcn.p, w->match.p, d_slot, w->agg.p, w->epoch, w->state.p, w->partials.p, w->counter.p, euclid_eps,
                        mail ? *mail : none);
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
@@ -947,11 +957,11 @@ int pw_icp_run(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const
 
 // enqueue only: the 6x6 result is left in w->vcm (device)
 int pw_vcm_enqueue(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
-                   const float4* d_src, int ns, const VcmMail* mail) {
+                   const float4* d_src, int ns, const VcmMail* mail, bool have_match) {
     if (ns <= 0) return PWICP_OK;
     VcmMail none{};
     hipLaunchKernelGGL(k_vcm, dim3(div_up(ns, kAccPts)), dim3(kVcmBlock), 0, ctx->stream, g, d_tgt, d_tgt_n, d_src, ns, w->match.p,
-                       w->partials.p, w->counter.p, w->vcm.p, mail ? *mail : none);
+                       w->partials.p, w->counter.p, w->vcm.p, mail ? *mail : none, have_match ? 1 : 0);
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }
@@ -962,7 +972,9 @@ int pw_xf_vcm_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt,
                      const float4* d_ctbp_in, const float4* d_pat_in, float4* d_cloud, int n, float4* d_ctbp, int n_ctbp, float4* d_pat,
                      int n_pat, unsigned* d_bbox_part, unsigned* d_slot) {
     const int nb_vcm = div_up(std::max(ns_max, 1), kAccPts);
-    const int nb_cloud = std::min(div_up(n, kVcmBlock), ctx->n_cu * 2);
+    // (a cloud block ends with the bounding-box fold, ~3 us of dependent atomics: one block per CU, 4 k points each, not two)
+    static const int cloud_mul = getenv("PWICP_XFVCM_CLOUD_MUL") ? atoi(getenv("PWICP_XFVCM_CLOUD_MUL")) : 1;
+    const int nb_cloud = std::min(div_up(n, kVcmBlock), ctx->n_cu * std::max(cloud_mul, 1));
     const int nb_rest = std::min(div_up(n_ctbp + n_pat, kVcmBlock), ctx->n_cu * 2);
     VcmMail none{};
     hipLaunchKernelGGL(k_xf_vcm, dim3(nb_vcm + nb_rest + nb_cloud), dim3(kVcmBlock), 0, ctx->stream, g, d_tgt, d_tgt_n, d_stct,

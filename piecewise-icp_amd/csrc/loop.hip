@@ -1009,7 +1009,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                 VcmMail vm;
                 vm.examined = pr->examined.p;
                 vm.dst = pr->mail_d + kVcmMailPayload; vm.seq_ptr = pr->mail_d + kVcmMailSeq; vm.seq = vcm_seq = ++pr->vcm_mail_seq;
-                PWCHK(pw_vcm_enqueue(ctx, pr->tgt->g_ct1.d, pr->tgt->P1.ct.p, pr->tgt->ct1n.p, &pr->icp, pr->stCT.p, ns, &vm));
+                PWCHK(pw_vcm_enqueue(ctx, pr->tgt->g_ct1.d, pr->tgt->P1.ct.p, pr->tgt->ct1n.p, &pr->icp, pr->stCT.p, ns, &vm, /*have_match*/ true));
             }
             vcm_pending = true;
             res->n_corr += ns;
