@@ -96,6 +96,29 @@ __device__ __forceinline__ void icp_send_mail(const IcpMail& m, const IcpState* 
     if (t == 0) mail_publish(m.seq_ptr, m.seq);
 }
 
+// The same message without reading anything back: the word ranges a | b are requested when a tail STARTS (they are final by
+// then: slot words of earlier launches, or atomics that were performed before the last block was counted), the state words
+// come from the tail's LDS copy (icp_solve_tail: state_words).  Saves the drain of the state stores and a round trip of coherent
+// loads at the end of every launch that carries a message (~1.3 us each).  One wave; na + nb <= 64.
+constexpr int kStateWords = (int)(sizeof(IcpState) / 4);
+__device__ __forceinline__ unsigned mail_prefetch(const IcpMail& m) {
+    const int t = threadIdx.x;
+    unsigned v = 0;
+    if (m.dst) {
+        if (t < m.na) v = __hip_atomic_load(&m.a[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (t < m.na + m.nb) v = __hip_atomic_load(&m.b[t - m.na], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return v;
+}
+__device__ __forceinline__ void icp_send_mail_fast(const IcpMail& m, unsigned pre, const unsigned* state_words) {
+    const int t = threadIdx.x;
+    if (t < m.na + m.nb) mail_store(&m.dst[t], pre);
+    if (t < kStateWords) mail_store(&m.dst[m.na + m.nb + t], state_words[t]);
+    mail_drain();
+    wave_sync();
+    if (t == 0) mail_publish(m.seq_ptr, m.seq);
+}
+
 // Group-cooperative accumulate: kGroup (8) consecutive lanes share one stable centroid.  They split the rows of its
 // nearest-neighbour search (nn_query_group: the search is a chain of dependent memory round trips at this size),
 // then each lane keeps 4 of the 28 sums of the point's LLS row, so the reduction over the wave's 8 points needs
@@ -105,7 +128,7 @@ constexpr int kAccPts = kAccBlock / kGroup;
 
 struct TailPrev { float F; int iters; double mse; };        // what a tail needs of the previous iteration's state
 __device__ __forceinline__ TailPrev tail_prefetch(const IcpState* st, bool first);
-__device__ __forceinline__ void icp_solve_tail(IcpState* st, const double* sums, int ns, double mse_rel, bool first, TailPrev pv);
+__device__ __forceinline__ void icp_solve_tail(IcpState* st, const double* sums, int ns, double mse_rel, bool first, TailPrev pv, unsigned* state_words);
 __device__ __forceinline__ void tail_sums_block(const double* partials, int nblocks, double (*segs)[32], double* sums);
 
 // Stores that other blocks / the mailbox wave read back in the SAME launch go through device-coherent (write-through) atomics
@@ -224,12 +247,16 @@ __global__ void __launch_bounds__(kAccBlock) k_icp_iter(GridDesc g, const float4
     __syncthreads();
     if (!s_last) return;
     KT_STAMP(19);
+    __shared__ unsigned s_state[kStateWords];
+    const bool fast_mail = mail.dst && mail.na + mail.nb <= 64;
     const TailPrev pv = tail_prefetch(st, false);
+    const unsigned pre = (fast_mail && threadIdx.x < 64) ? mail_prefetch(mail) : 0u;
     tail_sums_block(partials, (int)nact, sh, s_sums);
     if (threadIdx.x >= 64) return;
-    icp_solve_tail(st, s_sums, ns, mse_rel, false, pv);
+    icp_solve_tail(st, s_sums, ns, mse_rel, false, pv, s_state);
     KT_STAMP(25);
-    if (mail.dst) {
+    if (fast_mail) icp_send_mail_fast(mail, pre, s_state);
+    else if (mail.dst) {
         drain_stores();                                      // the state went out through coherent stores (icp_solve_tail)
         wave_sync();
         icp_send_mail(mail, st);
@@ -366,7 +393,7 @@ __device__ __forceinline__ void tail_sums_block(const double* partials, int nblo
 // `first`: iteration 0 of a call (the state is not read: final = identity, no previous MSE).
 // (inlined on purpose: a call makes the kernel use scratch memory, and a dispatch that needs scratch behind one that does not -
 // or the other way round - costs ~6 us of dispatch latency on MI355X: two such bubbles per outer iteration)
-__device__ __forceinline__ void icp_solve_tail(IcpState* st, const double* sums, int ns, double mse_rel, bool first, TailPrev pv) {
+__device__ __forceinline__ void icp_solve_tail(IcpState* st, const double* sums, int ns, double mse_rel, bool first, TailPrev pv, unsigned* state_words) {
     __shared__ double A[6][6], inv[6][6], x[6], sc[6];
     __shared__ bool singular;
     __shared__ float T[16], F[16];
@@ -415,8 +442,10 @@ __device__ __forceinline__ void icp_solve_tail(IcpState* st, const double* sums,
         s = s + T[4 * i + 3] * F[12 + j];
         coh_store(&st->Tfinal[t], s);
         coh_store(&st->T[t], T[t]);
+        state_words[t] = __float_as_uint(T[t]);           // the state as the mailbox message carries it (IcpState layout)
+        state_words[16 + t] = __float_as_uint(s);
     }
-    if (t != 0) return;
+    if (t == 0) {
     const int iters = iters_prev + 1;
     const double prev_mse = mse_prev;
     coh_store(&st->iters, iters);
@@ -434,6 +463,14 @@ __device__ __forceinline__ void icp_solve_tail(IcpState* st, const double* sums,
     else coh_store(&st->prev_mse, mse);
     if (first && done) coh_store(&st->prev_mse, prev_mse);
     if (first || done) coh_store(&st->done, done);
+    // (fields this tail leaves alone keep what an unconverged run holds: done = 0, reason = 0; prev_mse of the converged state
+    // is the one before this iteration)
+    state_words[32] = (unsigned)iters; state_words[33] = (unsigned)done; state_words[34] = (unsigned)(done ? reason : 0);
+    state_words[35] = 0u;
+    const double pm = done ? prev_mse : mse;
+    state_words[36] = (unsigned)__double2loint(pm); state_words[37] = (unsigned)__double2hiint(pm);
+    }
+    wave_sync();
 }
 
 // ---- classification + compaction + inner-ICP iteration 0 in ONE launch -------------------------------------------------------
@@ -594,6 +631,10 @@ __global__ void __launch_bounds__(kClsThreads) k_classify_icp0(ClassifyArgs a, i
             // totals (every aggregate is published by now), slot words, state, solve.  The aggregates and the partials are
             // requested together: one round trip
             __shared__ double s_sums[kNSums];
+            __shared__ unsigned s_state[kStateWords];
+            const bool fast_mail = mail.dst && mail.na + mail.nb <= 64 && mail.na >= 4;
+            bool solved = false;
+            unsigned pre = fast_mail ? mail_prefetch(mail) : 0u;
             const unsigned long long agg0 = (tid < nb) ? coh_load(&agg[tid]) : 0ull;
             tail_sums_wave(partials, nb, s_sums);
             int tn = (int)(agg0 & 0xffffu), tp = (int)((agg0 >> 16) & 0xffffffffu);
@@ -613,10 +654,15 @@ __global__ void __launch_bounds__(kClsThreads) k_classify_icp0(ClassifyArgs a, i
                 }
             } else {
                 KT_STAMP(5);
-                icp_solve_tail(st, s_sums, tn, mse_rel, true, TailPrev{0.f, 0, 1.7976931348623157e308});
+                icp_solve_tail(st, s_sums, tn, mse_rel, true, TailPrev{0.f, 0, 1.7976931348623157e308}, s_state);
+                solved = true;
             }
             KT_STAMP(9);
-            if (mail.dst) {
+            if (solved && fast_mail) {
+                if (tid == 2) pre = (unsigned)tn;           // slot words 2 / 3 are this tail's own
+                if (tid == 3) pre = (unsigned)tp;
+                icp_send_mail_fast(mail, pre, s_state);
+            } else if (mail.dst) {
                 drain_stores();
                 wave_sync();
                 icp_send_mail(mail, st);
