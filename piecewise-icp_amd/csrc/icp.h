@@ -2,6 +2,7 @@
 #pragma once
 #include "classify_dev.h"
 #include "common.h"
+#include "stage_dev.h"
 
 struct IcpState {
     float T[16];        // last incremental transformation (row-major)
@@ -46,12 +47,13 @@ struct IcpWork {
 
 // fs (optional): passes 1 and 2 of a percentile selection ride on the first two launches (n_iter >= 2)
 struct FusedSelect;
+// sg (optional, both launch wrappers): the stage guard the converging tail evaluates (stage_dev.h)
 int pw_icp_enqueue(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
                    int ns_max, const unsigned* ns_dev, double euclid_eps, int n_iter, const IcpMail* mail = nullptr,
-                   const FusedSelect* fs = nullptr);
+                   const FusedSelect* fs = nullptr, const StageGuard* sg = nullptr);
 // classification + order-preserving compaction of the stable patches + inner-ICP iteration 0, one launch (icp.hip)
 int pw_classify_icp0_launch(pwicp_context* ctx, const ClassifyArgs& a, int* d_stable, float4* d_stCT, float4* d_stN, IcpWork* w,
-                            unsigned* d_slot, double euclid_eps, const IcpMail* mail = nullptr);
+                            unsigned* d_slot, double euclid_eps, const IcpMail* mail = nullptr, const StageGuard* sg = nullptr);
 int pw_icp_run(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w, int ns,
                double euclid_eps, float* T16, int* iters_out);
 // have_match: d_src are the stable centroids the last pw_classify_icp0_launch on `w` compacted (their matches are in w->match)

@@ -101,6 +101,7 @@ __device__ __forceinline__ void icp_send_mail(const IcpMail& m, const IcpState* 
 // come from the tail's LDS copy (icp_solve_tail: state_words).  Saves the drain of the state stores and a round trip of coherent
 // loads at the end of every launch that carries a message (~1.3 us each).  One wave; na + nb <= 64.
 constexpr int kStateWords = (int)(sizeof(IcpState) / 4);
+constexpr int kTailWords = kStateWords + 2;          // the tail's LDS copy: the state | the stage guard's two words
 __device__ __forceinline__ unsigned mail_prefetch(const IcpMail& m) {
     const int t = threadIdx.x;
     unsigned v = 0;
@@ -110,8 +111,12 @@ __device__ __forceinline__ unsigned mail_prefetch(const IcpMail& m) {
     }
     return v;
 }
-__device__ __forceinline__ void icp_send_mail_fast(const IcpMail& m, unsigned pre, const unsigned* state_words) {
+__device__ __forceinline__ void icp_send_mail_fast(const IcpMail& m, unsigned pre, const unsigned* state_words, const StageGuard& sg) {
     const int t = threadIdx.x;
+    if (sg.out) {                            // the guard's words lie in the range a (slot words): this tail has just written them
+        const int gi = (int)(sg.out - m.a);
+        if (gi >= 0 && gi + 1 < m.na) { if (t == gi) pre = state_words[kStateWords]; if (t == gi + 1) pre = state_words[kStateWords + 1]; }
+    }
     if (t < m.na + m.nb) mail_store(&m.dst[t], pre);
     if (t < kStateWords) mail_store(&m.dst[m.na + m.nb + t], state_words[t]);
     mail_drain();
@@ -128,7 +133,8 @@ constexpr int kAccPts = kAccBlock / kGroup;
 
 struct TailPrev { float F; int iters; double mse; };        // what a tail needs of the previous iteration's state
 __device__ __forceinline__ TailPrev tail_prefetch(const IcpState* st, bool first);
-__device__ __forceinline__ void icp_solve_tail(IcpState* st, const double* sums, int ns, double mse_rel, bool first, TailPrev pv, unsigned* state_words);
+__device__ __forceinline__ void icp_solve_tail(IcpState* st, const double* sums, int ns, double mse_rel, bool first, TailPrev pv, unsigned* state_words,
+                                               const StageGuard& sg);
 __device__ __forceinline__ void tail_sums_block(const double* partials, int nblocks, double (*segs)[32], double* sums);
 
 // Stores that other blocks / the mailbox wave read back in the SAME launch go through device-coherent (write-through) atomics
@@ -156,7 +162,7 @@ __global__ void __launch_bounds__(kAccBlock) k_icp_iter(GridDesc g, const float4
                                                         float4* __restrict__ srcn, int ns_host,
                                                         const unsigned* __restrict__ ns_dev, IcpState* st,
                                                         double* __restrict__ partials, unsigned* __restrict__ counter,
-                                                        double mse_rel, IcpMail mail, FusedSelect fs, int fs_pass) {
+                                                        double mse_rel, IcpMail mail, FusedSelect fs, int fs_pass, StageGuard sg) {
     __shared__ double sh[kAccBlock / 64][32];
     // Leading blocks (first iteration of a run only): pass 1 or 2 of the percentile selection of the dense search that was
     // enqueued just BEFORE this ICP batch (loop.hip: the search does not depend on the ICP).  The ICP leaves most of the chip
@@ -247,15 +253,15 @@ __global__ void __launch_bounds__(kAccBlock) k_icp_iter(GridDesc g, const float4
     __syncthreads();
     if (!s_last) return;
     KT_STAMP(19);
-    __shared__ unsigned s_state[kStateWords];
+    __shared__ unsigned s_state[kTailWords];
     const bool fast_mail = mail.dst && mail.na + mail.nb <= 64;
     const TailPrev pv = tail_prefetch(st, false);
     const unsigned pre = (fast_mail && threadIdx.x < 64) ? mail_prefetch(mail) : 0u;
     tail_sums_block(partials, (int)nact, sh, s_sums);
     if (threadIdx.x >= 64) return;
-    icp_solve_tail(st, s_sums, ns, mse_rel, false, pv, s_state);
+    icp_solve_tail(st, s_sums, ns, mse_rel, false, pv, s_state, sg);
     KT_STAMP(25);
-    if (fast_mail) icp_send_mail_fast(mail, pre, s_state);
+    if (fast_mail) icp_send_mail_fast(mail, pre, s_state, sg);
     else if (mail.dst) {
         drain_stores();                                      // the state went out through coherent stores (icp_solve_tail)
         wave_sync();
@@ -393,7 +399,8 @@ __device__ __forceinline__ void tail_sums_block(const double* partials, int nblo
 // `first`: iteration 0 of a call (the state is not read: final = identity, no previous MSE).
 // (inlined on purpose: a call makes the kernel use scratch memory, and a dispatch that needs scratch behind one that does not -
 // or the other way round - costs ~6 us of dispatch latency on MI355X: two such bubbles per outer iteration)
-__device__ __forceinline__ void icp_solve_tail(IcpState* st, const double* sums, int ns, double mse_rel, bool first, TailPrev pv, unsigned* state_words) {
+__device__ __forceinline__ void icp_solve_tail(IcpState* st, const double* sums, int ns, double mse_rel, bool first, TailPrev pv, unsigned* state_words,
+                                               const StageGuard& sg) {
     __shared__ double A[6][6], inv[6][6], x[6], sc[6];
     __shared__ bool singular;
     __shared__ float T[16], F[16];
@@ -445,6 +452,7 @@ __device__ __forceinline__ void icp_solve_tail(IcpState* st, const double* sums,
         state_words[t] = __float_as_uint(T[t]);           // the state as the mailbox message carries it (IcpState layout)
         state_words[16 + t] = __float_as_uint(s);
     }
+    wave_sync();
     if (t == 0) {
     const int iters = iters_prev + 1;
     const double prev_mse = mse_prev;
@@ -469,6 +477,20 @@ __device__ __forceinline__ void icp_solve_tail(IcpState* st, const double* sums,
     state_words[35] = 0u;
     const double pm = done ? prev_mse : mse;
     state_words[36] = (unsigned)__double2loint(pm); state_words[37] = (unsigned)__double2hiint(pm);
+    // the stage guard (stage_dev.h): the iteration's transformation is final now - does it end Stage 1 (R.cpp:881-894)?
+    state_words[kStateWords] = 0u; state_words[kStateWords + 1] = 0u;
+    if (sg.out && done) {
+        float mn[3], mx[3], Tf[16];
+        for (int d = 0; d < 3; ++d) { mn[d] = pw_ord2f(sg.bbox6[d]); mx[d] = pw_ord2f(sg.bbox6[3 + d]); }
+        for (int e = 0; e < 16; ++e) Tf[e] = __uint_as_float(state_words[16 + e]);
+        double bb[6];
+        pw_octree_bbox(mn, mx, sg.resolution, bb);
+        const float maxBB = pw_bb_corner_change(bb, Tf);
+        const unsigned flag = (maxBB < sg.DTmin) ? 1u : 0u;
+        coh_store(&sg.out[0], __float_as_uint(maxBB));
+        coh_store(&sg.out[1], flag);
+        state_words[kStateWords] = __float_as_uint(maxBB); state_words[kStateWords + 1] = flag;
+    }
     }
     wave_sync();
 }
@@ -502,7 +524,7 @@ __global__ void __launch_bounds__(kClsThreads) k_classify_icp0(ClassifyArgs a, i
                                                              float4* __restrict__ wsrcn, int* __restrict__ wmatch, unsigned* __restrict__ slot,
                                                              unsigned long long* __restrict__ agg, unsigned epoch, IcpState* st,
                                                              double* __restrict__ partials, unsigned* __restrict__ counter,
-                                                             double mse_rel, IcpMail mail) {
+                                                             double mse_rel, IcpMail mail, StageGuard sg) {
     __shared__ int s_n[kClsBlock / 64], s_p[kClsBlock / 64];
     __shared__ float s_lod[kClsBlock / 64][2];
     __shared__ float s_row[kClsBlock][8];
@@ -549,13 +571,13 @@ __global__ void __launch_bounds__(kClsThreads) k_classify_icp0(ClassifyArgs a, i
         if (w < pw) wave_off += s_n[w];
         blk_n += s_n[w]; blk_p += s_p[w];
     }
+    unsigned lod_r0 = 0, lod_r1 = 0;                     // return values of the LoD atomics: waited for only before the count
     if (tid == 0) {
         float blo = INFINITY, bhi = 0.0f;
         for (int w = 0; w < kClsBlock / 64; ++w) { blo = fminf(blo, s_lod[w][0]); bhi = fmaxf(bhi, s_lod[w][1]); }
         if (bhi > 0.0f) {                                // positive floats order like their bit patterns
-            const unsigned r0 = atomicMin(&slot[0], __float_as_uint(blo));
-            const unsigned r1 = atomicMax(&slot[1], __float_as_uint(bhi));
-            asm volatile("" ::"v"(r0), "v"(r1));        // PERFORMED before this block counts itself below
+            lod_r0 = atomicMin(&slot[0], __float_as_uint(blo));
+            lod_r1 = atomicMax(&slot[1], __float_as_uint(bhi));
         }
         coh_store(&agg[me], agg_pack(epoch, blk_n, blk_p));
     }
@@ -618,6 +640,7 @@ __global__ void __launch_bounds__(kClsThreads) k_classify_icp0(ClassifyArgs a, i
     // at once - the positions of the compacted outputs (below) are not on the way to T.
     if (svc) {
         KT_MAX(3);
+        asm volatile("" ::"v"(lod_r0), "v"(lod_r1));    // the LoD atomics PERFORMED (their values are back) before this block counts itself
         drain_stores();
         unsigned last = 0;
         if (tid == 0) {
@@ -631,7 +654,7 @@ __global__ void __launch_bounds__(kClsThreads) k_classify_icp0(ClassifyArgs a, i
             // totals (every aggregate is published by now), slot words, state, solve.  The aggregates and the partials are
             // requested together: one round trip
             __shared__ double s_sums[kNSums];
-            __shared__ unsigned s_state[kStateWords];
+            __shared__ unsigned s_state[kTailWords];
             const bool fast_mail = mail.dst && mail.na + mail.nb <= 64 && mail.na >= 4;
             bool solved = false;
             unsigned pre = fast_mail ? mail_prefetch(mail) : 0u;
@@ -654,14 +677,14 @@ __global__ void __launch_bounds__(kClsThreads) k_classify_icp0(ClassifyArgs a, i
                 }
             } else {
                 KT_STAMP(5);
-                icp_solve_tail(st, s_sums, tn, mse_rel, true, TailPrev{0.f, 0, 1.7976931348623157e308}, s_state);
+                icp_solve_tail(st, s_sums, tn, mse_rel, true, TailPrev{0.f, 0, 1.7976931348623157e308}, s_state, sg);
                 solved = true;
             }
             KT_STAMP(9);
             if (solved && fast_mail) {
                 if (tid == 2) pre = (unsigned)tn;           // slot words 2 / 3 are this tail's own
                 if (tid == 3) pre = (unsigned)tp;
-                icp_send_mail_fast(mail, pre, s_state);
+                icp_send_mail_fast(mail, pre, s_state, sg);
             } else if (mail.dst) {
                 drain_stores();
                 wave_sync();
@@ -951,13 +974,13 @@ extern "C" __attribute__((visibility("default"))) int pwicp_debug_ktrace(unsigne
 // classification + compaction + inner-ICP iteration 0 (k_classify_icp0); `mail`: sent by this launch (no k_icp_iter follows
 // in the batch)
 int pw_classify_icp0_launch(pwicp_context* ctx, const ClassifyArgs& a, int* d_stable, float4* d_stCT, float4* d_stN, IcpWork* w,
-                            unsigned* d_slot, double euclid_eps, const IcpMail* mail) {
+                            unsigned* d_slot, double euclid_eps, const IcpMail* mail, const StageGuard* sg) {
     if (a.m2 <= 0) return PWICP_OK;
     w->epoch = (w->epoch % 0xffffu) + 1u;          // 1 .. 65535, never 0 (the buffer is zeroed once)
     IcpMail none{};
     hipLaunchKernelGGL(k_classify_icp0, dim3(div_up(a.m2, kClsBlock)), dim3(kClsThreads), 0, ctx->stream, a, d_stable, d_stCT, d_stN,
                        w->src.p, w->srcn.p, w->match.p, d_slot, w->agg.p, w->epoch, w->state.p, w->partials.p, w->counter.p, euclid_eps,
-                       mail ? *mail : none);
+                       mail ? *mail : none, sg ? *sg : StageGuard{});
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }
@@ -965,7 +988,8 @@ int pw_classify_icp0_launch(pwicp_context* ctx, const ClassifyArgs& a, int* d_st
 // Enqueues n_iter inner iterations (accumulate + solve each) on the stream; no host synchronisation.  The number
 // of source points is ns_host, or *ns_dev when ns_dev != nullptr (then ns_max bounds the launch grid).
 int pw_icp_enqueue(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, const float4* d_tgt_n, IcpWork* w,
-                   int ns_max, const unsigned* ns_dev, double euclid_eps, int n_iter, const IcpMail* mail, const FusedSelect* fs) {
+                   int ns_max, const unsigned* ns_dev, double euclid_eps, int n_iter, const IcpMail* mail, const FusedSelect* fs,
+                   const StageGuard* sg) {
     if (ns_max <= 0) return PWICP_OK;
     const int nb = div_up(ns_max, kAccPts);
     IcpMail none{};
@@ -974,7 +998,7 @@ int pw_icp_enqueue(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, c
         const bool sel = fs && fs->scratch && k < 2;           // passes 1 and 2 on the first two launches (the caller enqueues >= 2)
         hipLaunchKernelGGL(k_icp_iter, dim3(nb + (sel ? fs->nblk : 0)), dim3(kAccBlock), 0, ctx->stream, g, d_tgt, d_tgt_n, w->src.p,
                            w->srcn.p, ns_max, ns_dev, w->state.p, w->partials.p, w->counter.p, euclid_eps,
-                           (mail && k == n_iter - 1) ? *mail : none, sel ? *fs : nofs, k + 1);
+                           (mail && k == n_iter - 1) ? *mail : none, sel ? *fs : nofs, k + 1, sg ? *sg : StageGuard{});
     }
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;

@@ -16,6 +16,7 @@
 #include "nn_device.h"
 #include "patch.h"
 #include "select_dev.h"
+#include "stage_dev.h"
 #include "xform_dev.h"
 
 using namespace pwdev;
@@ -173,39 +174,11 @@ __global__ void __launch_bounds__(kBlock) k_transform_bbox(float4* __restrict__ 
 // ---- host-side scalar pieces of the reference's control logic --------------------------------------------
 // pcl::octree::OctreePointCloud::defineBoundingBox + getKeyBitSize, from the tight
 // float min/max of the cloud.  resolution = double(Res2 * 2)  (R.cpp:882)
-void octree_bbox(const float* mn, const float* mx, double resolution, double* bb) {
-    const float minValue = FLT_EPSILON * 512.0f;
-    const float eps = FLT_EPSILON;
-    double lo[3], hi[3];
-    for (int d = 0; d < 3; ++d) { lo[d] = mn[d]; hi[d] = (double)(mx[d] + minValue); }
-    unsigned mk = 2;
-    for (int d = 0; d < 3; ++d) {
-        unsigned k = (unsigned)std::ceil((hi[d] - lo[d] - eps) / resolution);
-        if (k > mk) mk = k;
-    }
-    unsigned depth = (unsigned)std::ceil(std::log((double)mk) / std::log(2.0) - eps);
-    if (depth > 32) depth = 32;
-    const double side = (double)(1u << depth) * resolution;
-    for (int d = 0; d < 3; ++d) {
-        const double over = (side - (hi[d] - lo[d])) / 2.0;
-        if (over > eps) { lo[d] -= over; hi[d] += over; }
-    }
-    bb[0] = lo[0]; bb[1] = lo[1]; bb[2] = lo[2]; bb[3] = hi[0]; bb[4] = hi[1]; bb[5] = hi[2];
-}
+// (one source for the host loop and the ICP tail's stage guard: stage_dev.h)
+void octree_bbox(const float* mn, const float* mx, double resolution, double* bb) { pw_octree_bbox(mn, mx, resolution, bb); }
 
 // calBoundingBoxCornerChange, C.cpp:410-419
-float bb_corner_change(const double* bb, const float* T) {
-    float r = 0.f;
-    for (int k = 0; k < 2; ++k) {
-        const float c[3] = {(float)bb[3 * k], (float)bb[3 * k + 1], (float)bb[3 * k + 2]};
-        float t[3];
-        for (int i = 0; i < 3; ++i) t[i] = T[4 * i] * c[0] + T[4 * i + 1] * c[1] + T[4 * i + 2] * c[2] + T[4 * i + 3] * 1.0f;
-        const float dx = t[0] - c[0], dy = t[1] - c[1], dz = t[2] - c[2];
-        const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
-        if (nrm > r) r = nrm;
-    }
-    return r;
-}
+float bb_corner_change(const double* bb, const float* T) { return pw_bb_corner_change(bb, T); }
 
 }  // namespace
 
@@ -746,12 +719,12 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                            fs ? *fs : none);
     };
     // (8) and the front of the NEXT iteration in one launch (patch.hip: k_xf_front): every role only needs T
-    auto enqueue_xf_front = [&](unsigned* slot, const FusedSelect* fs = nullptr) -> int {
+    auto enqueue_xf_front = [&](unsigned* slot, const FusedSelect* fs = nullptr, const unsigned* guard = nullptr) -> int {
         FrontInit in;
         in.slot = slot + kSlot;                 // the front is the next iteration's
         return pw_xf_front_launch(ctx, pr->src_pat(), pr->P2.pat.p, pr->P2.off.p, m2, pr->nrm2.p, pr->tgt->g_ct1.d, pr->src_ctbp(),
                                   pr->ctbp2.p, 7 * m2, pr->mCTBP.p, pr->dCTBP.p, pr->src_cloud(), pr->cloud2.p, pr->n2,
-                                  (const IcpState*)pr->icp.state.p, (const unsigned*)(slot + 2), pr->bbox_part.p, slot, fs, &in);
+                                  (const IcpState*)pr->icp.state.p, (const unsigned*)(slot + 2), pr->bbox_part.p, slot, fs, &in, guard);
     };
     // the run's LAST update and the VCM (9) in one launch (icp.hip: k_xf_vcm).  guess: enqueued before the host has seen the
     // iteration's result; the VCM part then only runs if the iteration reaches Stage 3 (currDT == LoDet_min, R.cpp:896)
@@ -811,6 +784,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         if (fused && !with_front) PWCHK(pw_fs_pass_launch(ctx, 2, fs));      // (with a front: pass 2 on the merged launch's last blocks)
         return PWICP_OK;
     };
+    static const bool stage_guard = !(getenv("PWICP_STAGE_GUARD") && atoi(getenv("PWICP_STAGE_GUARD")) == 0);   // stage_dev.h
     static int speculate = -1;             // PWICP_SPECULATE_DENSE=0: never enqueue the first dense search ahead of the ICP result
     if (speculate < 0) { const char* e = getenv("PWICP_SPECULATE_DENSE"); speculate = e ? atoi(e) : 1; }
     const auto t0 = std::chrono::steady_clock::now();
@@ -851,6 +825,13 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         // front that were enqueued were no-ops / premature and are enqueued again.
         const bool spec_dense = speculate && k == 0 && !stage2 && pr->dense_lv && !pr->no_fused_select && !(pr->profiling & PWICP_PROF_REPLAY);
         bool spec_done = false, spec_xf_valid = false;
+        // Still Stage 1 after the first iteration: whether THIS iteration ends it (R.cpp:891-894) depends on its transformation.
+        // The ICP tail that converges takes that decision itself (stage_dev.h) and the update + next front go out behind the
+        // batch, guarded by its flag - a no-op of ~4 us if Stage 1 goes on, instead of a host round trip (~12 us) if it ends.
+        const bool guard_xf = stage_guard && k > 0 && !stage2 && !pr->lazy && !(pr->profiling & PWICP_PROF_REPLAY);
+        StageGuard sg{};
+        if (guard_xf) { sg.bbox6 = slot - kSlot + 4; sg.out = slot + 10; sg.resolution = (double)(prm.Res2 * 2); sg.DTmin = DTmin; }
+        bool guard_ran = false;
         unsigned hs[kSlot], hb[6];
         IcpState hst;
         {
@@ -880,7 +861,8 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                 const bool spec_now = spec_dense && !spec_done;
                 if (first_batch) {
                     n_iter = batch - 1;
-                    PWCHK(pw_classify_icp0_launch(ctx, cls, pr->stable.p, pr->stCT.p, pr->stN.p, &pr->icp, slot, 1e-6, n_iter == 0 ? &mail : nullptr));
+                    PWCHK(pw_classify_icp0_launch(ctx, cls, pr->stable.p, pr->stCT.p, pr->stN.p, &pr->icp, slot, 1e-6, n_iter == 0 ? &mail : nullptr,
+                                                  guard_xf ? &sg : nullptr));
                     first_batch = false;
                     // first iteration: the dense search right behind the classification (it needs the stable flags, not the ICP),
                     // passes 1 / 2 of its percentile on the ICP launches (n_iter = 3 here)
@@ -888,12 +870,13 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                 }
                 if (n_iter > 0)
                     PWCHK(pw_icp_enqueue(ctx, pr->tgt->g_ct1.d, pr->tgt->P1.ct.p, pr->tgt->ct1n.p, &pr->icp, m2, slot + 2, 1e-6, n_iter, &mail,
-                                         fs_icp.scratch ? &fs_icp : nullptr));
+                                         fs_icp.scratch ? &fs_icp : nullptr, guard_xf ? &sg : nullptr));
                 ht("classify+icp batch enqueued");
                 if (ev) {
                     HIPCHK(ctx, hipEventRecord(pr->event(n_ev + 1), ctx->stream));
                     n_ev += 2;
                 }
+                if (guard_xf) PWCHK(enqueue_xf_front(slot, nullptr, slot + 11));
                 if (early_xf) {                              // no-op on the device while the ICP has not converged
                     if (early_front) PWCHK(enqueue_xf_front(slot));
                     else {                                   // looks like the last iteration: the update together with the VCM
@@ -915,6 +898,8 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                 // (fewer than 4 stable patches: R.cpp:864-867 stops below; the ICP state is then meaningless)
                 if (hst.done || hst.iters >= 100 || (int)hs[2] < 4) {
                     xf_enqueued = early_xf; front_ready = early_xf && early_front;
+                    // the guarded update behind THIS batch ran iff the batch held the converged state and the tail set the flag
+                    guard_ran = guard_xf && hst.done && (int)hs[2] >= 4 && hs[11] == 1u;
                     spec_xf_valid = spec_now && hst.done && (int)hs[2] >= 4;     // the transform behind THIS batch saw the converged state
                     break;
                 }
@@ -940,7 +925,15 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         // (6) R.cpp:881-888
         double bb[6];
         octree_bbox(bmin, bmax, (double)(prm.Res2 * 2), bb);
-        const float maxBB = bb_corner_change(bb, Tk);
+        float maxBB = bb_corner_change(bb, Tk);
+        if (guard_xf && hst.done) {
+            // the device has evaluated the same expression (stage_dev.h, one source) and acted on it: its value is the record
+            float dev_maxBB;
+            memcpy(&dev_maxBB, &hs[10], 4);
+            if (memcmp(&dev_maxBB, &maxBB, 4) != 0 && getenv("PWICP_TRACE"))
+                fprintf(stderr, "[pwicp] stage guard: device maxBBchange %.9g, host %.9g\n", (double)dev_maxBB, (double)maxBB);
+            maxBB = dev_maxBB;
+        }
         res->maxBB[k] = maxBB;
 
         // (7) R.cpp:891-935, verbatim control flow
@@ -986,6 +979,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
             xf_enqueued = spec_xf_valid;
             front_ready = spec_xf_valid && !stage3;
         }
+        if (guard_ran) { xf_enqueued = true; front_ready = true; }      // (the flag is `maxBB < DTmin` itself: Stage 2 began above)
         // (8) the update, (9) R.cpp:958-961 the VCM of the last iteration on the stable centroids as copied BEFORE the update
         // (R.cpp:868); its launch also sends the run's closing message (VCM | diagnostic counter)
         bool vcm_done = false;

@@ -281,6 +281,7 @@ __global__ void __launch_bounds__(kFrontBlock) k_patch_normals(const float4* __r
 // at the start of a run, the diagnostic counters.  Idempotent: a front launch that is enqueued twice arms twice.
 __device__ __forceinline__ void front_init(const FrontInit& in) {
     if (in.slot && blockIdx.x == 0 && threadIdx.x < 2) in.slot[threadIdx.x] = threadIdx.x == 0 ? 0xffffffffu : 0u;
+    if (in.slot && blockIdx.x == 0 && threadIdx.x >= 2 && threadIdx.x < 4) in.slot[8 + threadIdx.x] = 0u;      // the stage guard's two words (stage_dev.h)
     if (in.zero && blockIdx.x < 16)
         for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < in.n_zero; i += 16 * (int)blockDim.x) in.zero[i] = 0ull;
 }
@@ -345,7 +346,7 @@ __global__ void __launch_bounds__(kFrontBlock) k_xf_front(const float4* pat_in, 
                                                           const float4* cloud_in, float4* cloud, int n, int nb_cloud,
                                                           const IcpState* __restrict__ st, const unsigned* __restrict__ ns_dev,
                                                           unsigned* __restrict__ bbox_part, unsigned* __restrict__ slot, FusedSelect fs,
-                                                          int nblk2, FrontInit init) {
+                                                          int nblk2, FrontInit init, const unsigned* __restrict__ guard) {
     __shared__ float4 tiles[(kFrontBlock / kGroup) * kTileStride];
     front_init(init);
     static_assert(kFrontBlock == kXfBlock, "xf_cloud_block is written for this block size");
@@ -366,6 +367,7 @@ __global__ void __launch_bounds__(kFrontBlock) k_xf_front(const float4* pat_in, 
         return;
     }
     if (!st->done || *ns_dev < 4u) return;
+    if (guard && *guard != 1u) return;          // enqueued on the guess that this iteration ends Stage 1: the ICP tail says otherwise
     Mat4 T;
 #pragma unroll
     for (int i = 0; i < 16; ++i) T.m[i] = st->Tfinal[i];
@@ -570,7 +572,7 @@ int pw_front_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, i
 int pw_xf_front_launch(pwicp_context* ctx, const float4* d_pat_in, float4* d_pat, const int* d_off, int m, float4* d_nrm,
                        const GridDesc& g, const float4* d_ctbp_in, float4* d_ctbp, int nq, int* d_idx, float* d_d2,
                        const float4* d_cloud_in, float4* d_cloud, int n, const IcpState* d_state, const unsigned* d_ns,
-                       unsigned* d_bbox_part, unsigned* d_slot, const FusedSelect* fs, const FrontInit* init) {
+                       unsigned* d_bbox_part, unsigned* d_slot, const FusedSelect* fs, const FrontInit* init, const unsigned* d_guard) {
     const int nb_nrm = div_up((long long)m * kGroup, kFrontBlock);
     const int nb_nn = div_up((long long)nq * kGroup, kFrontBlock);
     const int nb_cloud = std::min(div_up(n, kFrontBlock), ctx->n_cu * 8);
@@ -579,11 +581,11 @@ int pw_xf_front_launch(pwicp_context* ctx, const float4* d_pat_in, float4* d_pat
     if (sel)
         hipLaunchKernelGGL(k_xf_front<true>, dim3(nb_nrm + nb_nn + nb_cloud + fs->nblk + kFsBlocks), dim3(kFrontBlock), 0, ctx->stream,
                            d_pat_in, d_pat, d_off, m, d_nrm, nb_nrm, g, d_ctbp_in, d_ctbp, nq, d_idx, d_d2, nb_nn, d_cloud_in, d_cloud, n,
-                           nb_cloud, d_state, d_ns, d_bbox_part, d_slot, *fs, kFsBlocks, init ? *init : FrontInit{});
+                           nb_cloud, d_state, d_ns, d_bbox_part, d_slot, *fs, kFsBlocks, init ? *init : FrontInit{}, d_guard);
     else
         hipLaunchKernelGGL(k_xf_front<false>, dim3(nb_nrm + nb_nn + nb_cloud), dim3(kFrontBlock), 0, ctx->stream,
                            d_pat_in, d_pat, d_off, m, d_nrm, nb_nrm, g, d_ctbp_in, d_ctbp, nq, d_idx, d_d2, nb_nn, d_cloud_in, d_cloud, n,
-                           nb_cloud, d_state, d_ns, d_bbox_part, d_slot, none, kFsBlocks, init ? *init : FrontInit{});
+                           nb_cloud, d_state, d_ns, d_bbox_part, d_slot, none, kFsBlocks, init ? *init : FrontInit{}, d_guard);
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }
