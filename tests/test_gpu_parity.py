@@ -128,6 +128,26 @@ def test_inner_icp_and_vcm(ctx, oracle):
     assert np.allclose(Vg.reshape(36), Vo, rtol=1e-9, atol=1e-18)
 
 
+def test_vcm_when_the_fit_explains_nearly_everything(ctx, oracle):
+    """calTransParaVCM forms v^T v as L^T L - x^T A^T L unless the two terms cancel (icp.hip: vcm_block); then - this case, a
+    noise-free rigid motion: v is only the model's second-order error - it forms the residuals point by point as the reference
+    does (R.cpp:1331-1333).  Both branches have to agree with the oracle's explicit form."""
+    tgt, _, _ = _data.pair(40000)
+    lab1, n1 = _labels(tgt, "grid")
+    P1 = oracle.select_patches(tgt, lab1, n1)
+    n1v, _ = ctx.patchNormals(P1.pat, P1.off)
+    th = 1.0e-3
+    R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+    ct = np.asarray(P1.ct, np.float64)[:, :3]
+    moved = (ct @ R.T + np.array([2e-4, -1e-4, 3e-4])).astype(np.float32)
+    Vg = ctx.calTransParaVCM(P1.ct, n1v, moved)
+    Vo = np.zeros(36)
+    oracle.lib().orc_cal_trans_para_vcm(oracle._p(oracle.f4(P1.ct)), oracle._p(oracle.f4(n1v)), P1.m,
+                                        oracle._p(oracle.f4(moved)), len(moved), oracle._p(Vo, oracle.dp))
+    assert np.isfinite(Vg).all() and (np.diag(Vg.reshape(6, 6)) > 0).all()
+    assert np.allclose(Vg.reshape(36), Vo, rtol=1e-8, atol=1e-22)
+
+
 def _loop_both(ctx, oracle, tgt, src, l1, n1, l2, n2, manual=True):
     import pwicp_amd as P
     R = _data.R
