@@ -1279,7 +1279,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     int* const h_ctr = ws.h_ctr;                    // pinned: read back after every sweep
     const int gs_chunk = getenv("PWICP_FUSION_CHUNK") ? std::max(atoi(getenv("PWICP_FUSION_CHUNK")), 1) : kFusChunk;
     const int batch_sweeps = getenv("PWICP_FUSION_BATCH") ? std::max(atoi(getenv("PWICP_FUSION_BATCH")), 1) : 4;
-    const int batch_cap = 1024;
+    const int batch_cap = getenv("PWICP_FUSION_BATCH_CAP") ? std::max(atoi(getenv("PWICP_FUSION_BATCH_CAP")), 64) : 1024;
     s.nW_dev = nullptr; s.stop = nullptr;
     const int wake_all_div = getenv("PWICP_FUSION_WAKE_DIV") ? std::max(atoi(getenv("PWICP_FUSION_WAKE_DIV")), 1) : 32;
     for (;; lambda *= 2.0, ++round) {
