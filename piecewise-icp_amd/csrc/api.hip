@@ -42,6 +42,8 @@ void pwicp_destroy(pwicp_context* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->scratch.reset();
+    if (pw_tls_ctx == ctx) pw_tls_ctx = nullptr;
+    if (ctx->pool) ctx->pool->trim();           // (the pool itself lives as long as a buffer of this context does)
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -5,8 +5,11 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -16,9 +19,69 @@
 // rounds once, so the decision-relevant arithmetic (squared distances, point-to-plane
 // distances, thresholds, covariance sums) is bit-identical to the reference's x64 SSE2 build.
 
+// Per-context cache of device allocations.  hipFree waits for the whole device and hipMalloc is not cheap either: a streamed
+// 5 M-point epoch spent 2.7 ms destroying its pair and ~2 ms allocating the next one's ~40 buffers, next to a 0.9 ms loop
+// (tools/stream_pair_costs.py).  A buffer that a DevBuf releases goes back to the pool of the context it was allocated under and
+// is only ever handed out again under that context - i.e. to work on the same stream, which runs after whatever still uses
+// it.  Blocks come in size classes (<= 12.5 % above the request); the cache is capped (PWICP_POOL_MB, default 8192 per
+// context), beyond that - and when the device runs out of memory - blocks are really freed.  PWICP_POOL_MB=0: no caching.
+struct PwPool {
+    std::mutex mu;
+    std::multimap<size_t, void*> free_blocks;       // capacity -> block
+    size_t cached = 0, cap = 0;
+    PwPool() {
+        const char* e = getenv("PWICP_POOL_MB");
+        cap = (size_t)(e ? std::max(atol(e), 0L) : 8192L) << 20;
+    }
+    PwPool(const PwPool&) = delete;
+    PwPool& operator=(const PwPool&) = delete;
+    ~PwPool() { trim(); }
+    static size_t size_class(size_t bytes) {
+        if (bytes < 4096) return 4096;
+        size_t step = (size_t)1 << 9;               // granule = 2^(floor(log2 bytes) - 3), at least 512 B
+        while ((step << 4) <= bytes) step <<= 1;
+        return (bytes + step - 1) / step * step;
+    }
+    void trim() {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto& kv : free_blocks) (void)hipFree(kv.second);
+        free_blocks.clear();
+        cached = 0;
+    }
+    hipError_t take(size_t bytes, void** out, size_t* cap_out) {
+        const size_t c = size_class(bytes);
+        {
+            std::lock_guard<std::mutex> g(mu);
+            auto it = free_blocks.find(c);
+            if (it != free_blocks.end()) {
+                *out = it->second; *cap_out = c;
+                cached -= c;
+                free_blocks.erase(it);
+                return hipSuccess;
+            }
+        }
+        hipError_t e = hipMalloc(out, c);
+        if (e == hipErrorOutOfMemory) {             // give the cached blocks back and try once more
+            (void)hipGetLastError();
+            trim();
+            e = hipMalloc(out, c);
+        }
+        *cap_out = c;
+        return e;
+    }
+    void give(void* p, size_t c) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (cached + c <= cap) { free_blocks.emplace(c, p); cached += c; return; }
+        }
+        (void)hipFree(p);
+    }
+};
+
 struct pwicp_context {
     int device = 0;
     hipStream_t stream = nullptr;
+    std::shared_ptr<PwPool> pool = std::make_shared<PwPool>();
     std::string err;
     int n_cu = 256;
     std::shared_ptr<void> scratch;        // grow-only work buffers a stage keeps between calls (csrc/frontend.hip), freed with the context
@@ -34,8 +97,12 @@ struct pwicp_context {
 
 #define PW_STR2(x) #x
 #define PW_STR(x) PW_STR2(x)
+// (the context a thread is working under: DevBuf::reserve takes its pool from it.  Every entry point passes through HIPCHK
+// with its context before it allocates.)
+inline thread_local pwicp_context* pw_tls_ctx = nullptr;
 #define HIPCHK(ctx, expr)                                                   \
     do {                                                                    \
+        pw_tls_ctx = (ctx);                                                 \
         hipError_t e__ = (expr);                                            \
         if (e__ != hipSuccess) {                                            \
             (ctx)->set_err(__FILE__ ":" PW_STR(__LINE__) " " #expr, e__);   \
@@ -53,25 +120,41 @@ template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    std::shared_ptr<PwPool> pool;        // where the block came from and goes back to (null: plain hipMalloc / hipFree)
+    size_t cap_bytes = 0;
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) {
+            if (pool) pool->give(p, cap_bytes);
+            else (void)hipFree(p);
+        }
         p = nullptr;
         n = 0;
+        cap_bytes = 0;
+        pool.reset();
     }
     void swap(DevBuf& o) {
         T* tp = p; p = o.p; o.p = tp;
         size_t tn = n; n = o.n; o.n = tn;
+        pool.swap(o.pool);
+        size_t tc = cap_bytes; cap_bytes = o.cap_bytes; o.cap_bytes = tc;
     }
     // grows only; contents are NOT preserved
     hipError_t reserve(size_t count) {
         if (count <= n && p) return hipSuccess;
         release();
         if (count == 0) count = 1;
-        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        hipError_t e;
+        if (pw_tls_ctx && pw_tls_ctx->pool && pw_tls_ctx->pool->cap > 0) {
+            pool = pw_tls_ctx->pool;
+            e = pool->take(count * sizeof(T), (void**)&p, &cap_bytes);
+            if (e != hipSuccess) { p = nullptr; pool.reset(); cap_bytes = 0; }
+        } else {
+            e = hipMalloc((void**)&p, count * sizeof(T));
+        }
         if (e == hipSuccess) n = count;
         return e;
     }
