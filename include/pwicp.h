@@ -198,6 +198,12 @@ PWICP_API void pwicp_target_destroy(pwicp_target* target);
 PWICP_API int pwicp_pair_create_with_target(pwicp_target* target, const float* cloud2_xyz4, int n2,
                                             const int32_t* labels2, int n_supervoxels2, const pwicp_params* params,
                                             pwicp_pair** out);
+/* The same on a context (= stream) of the caller's choice on the target's device: the target is read-only once built, so the
+ * pairs of a streamed series can alternate between two contexts and the upload / patch selection of epoch k + 1 (one host
+ * thread) runs beside the loop of epoch k (another).  ctx == the target's own context: the call above. */
+PWICP_API int pwicp_pair_create_with_target_on(pwicp_context* ctx, pwicp_target* target, const float* cloud2_xyz4, int n2,
+                                               const int32_t* labels2, int n_supervoxels2, const pwicp_params* params,
+                                               pwicp_pair** out);
 PWICP_API void pwicp_pair_destroy(pwicp_pair* pair);
 PWICP_API int  pwicp_pair_num_patches(const pwicp_pair* pair, int* m1, int* m2);
 /* Puts the source side back into its uploaded state (the loop transforms it in place, R.cpp:943-954) so that the same pair

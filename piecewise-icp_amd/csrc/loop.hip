@@ -414,7 +414,16 @@ void pwicp_target_destroy(pwicp_target* t) {
 int pwicp_pair_create_with_target(pwicp_target* t, const float* cloud2, int n2, const int32_t* labels2, int nsv2,
                                   const pwicp_params* params, pwicp_pair** out) {
     if (!t) return PWICP_E_INVALID;
-    pwicp_context* ctx = t->ctx;
+    return pwicp_pair_create_with_target_on(t->ctx, t, cloud2, n2, labels2, nsv2, params, out);
+}
+
+int pwicp_pair_create_with_target_on(pwicp_context* ctx, pwicp_target* t, const float* cloud2, int n2, const int32_t* labels2, int nsv2,
+                                     const pwicp_params* params, pwicp_pair** out) {
+    if (!t || !ctx) return PWICP_E_INVALID;
+    if (ctx->device != t->ctx->device) {
+        ctx->set_err("pwicp_pair_create_with_target_on: the context is on another device than the target");
+        return PWICP_E_INVALID;
+    }
     if (!out || !cloud2 || !labels2 || n2 <= 0 || nsv2 < 0 || !params_ok(params) || params->Res1 != t->Res1 ||
         params->SVRes1 != t->SVRes1) {
         ctx->set_err("pwicp_pair_create_with_target: invalid argument (Res1 / SVRes1 must be the target's)");

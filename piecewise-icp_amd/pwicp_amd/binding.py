@@ -94,6 +94,7 @@ def load_library():
         ("pwicp_target_create", [vp, fp, C.c_int, ip, C.c_int, C.c_float, C.c_float, C.POINTER(vp)]),
         ("pwicp_target_destroy", [vp]),
         ("pwicp_pair_create_with_target", [vp, fp, C.c_int, ip, C.c_int, C.POINTER(Params), C.POINTER(vp)]),
+        ("pwicp_pair_create_with_target_on", [vp, vp, fp, C.c_int, ip, C.c_int, C.POINTER(Params), C.POINTER(vp)]),
     ]:
         if hasattr(L, name):
             getattr(L, name).argtypes = args
@@ -350,6 +351,7 @@ class Context:
         if rc != 0:
             raise PwicpError(rc, "pwicp_create(device %d): no usable HIP device" % device_id)
         self._h = h
+        self.device = int(self._L.pwicp_context_device(h)) if hasattr(self._L, "pwicp_context_device") else int(device_id)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -515,8 +517,9 @@ class Pair:
             self._target = target                   # keep it alive
             c2 = f4(cloud2)
             l2 = np.ascontiguousarray(labels2, np.int32)
-            ctx._chk(self._L.pwicp_pair_create_with_target(target._h, _p(c2), len(c2), _p(l2, ip), int(nsv2),
-                                                           C.byref(params), C.byref(h)))
+            # (ctx may be another context of the target's device: the pair then lives on that context's stream)
+            ctx._chk(self._L.pwicp_pair_create_with_target_on(ctx._h, target._h, _p(c2), len(c2), _p(l2, ip), int(nsv2),
+                                                              C.byref(params), C.byref(h)))
             self._h = h
             return
         c1, c2 = f4(cloud1), f4(cloud2)

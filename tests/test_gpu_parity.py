@@ -148,6 +148,45 @@ def test_vcm_when_the_fit_explains_nearly_everything(ctx, oracle):
     assert np.allclose(Vg.reshape(36), Vo, rtol=1e-8, atol=1e-22)
 
 
+def test_pairs_of_one_target_on_two_contexts(ctx):
+    """pwicp_pair_create_with_target_on: the pairs of a shared target may live on other contexts (= streams) of its device; a pair
+    created and run on a second context while another one runs on the first gives bit for bit what it gives alone."""
+    import threading
+    import pwicp_amd as P
+    tgt, s1, _ = _data.pair(60000, epoch=1)
+    _, s2, _ = _data.pair(60000, epoch=2)
+    prm = _data.params()
+    lt, nt = _labels(tgt, "grid")
+    l1, n1 = _labels(s1, "grid")
+    l2, n2 = _labels(s2, "grid")
+    T = P.Target(ctx, tgt, lt, nt, prm.Res1, prm.SVRes1)
+    alone = []
+    for s, l, n in ((s1, l1, n1), (s2, l2, n2)):
+        pr = P.Pair(ctx, None, None, 0, s, l, n, prm, target=T)
+        alone.append(pr.run())
+        pr.close()
+    ctx2 = P.Context(0)
+    out = [None, None]
+
+    def work(i, c, s, l, n):
+        for _ in range(5):
+            pr = P.Pair(c, None, None, 0, s, l, n, prm, target=T)
+            out[i] = pr.run()
+            pr.close()
+
+    th = [threading.Thread(target=work, args=(0, ctx, s1, l1, n1)), threading.Thread(target=work, args=(1, ctx2, s2, l2, n2))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for a, b in zip(alone, out):
+        assert b is not None and b.status == 0
+        assert list(a.T16) == list(b.T16) and list(a.VCM) == list(b.VCM) and a.n_outer == b.n_outer
+        assert list(a.DTseries[:a.n_outer + 1]) == list(b.DTseries[:b.n_outer + 1])
+    T.close()
+    ctx2.close()
+
+
 def _loop_both(ctx, oracle, tgt, src, l1, n1, l2, n2, manual=True):
     import pwicp_amd as P
     R = _data.R
