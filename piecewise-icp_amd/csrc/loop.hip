@@ -1038,10 +1038,23 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         memcpy(&ex, pr->mail_h + 16, sizeof(ex));
     }
     res->t_loop_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // events below must have completed
+    // The closing message has arrived: every result is on the host, and whatever the last launch still does (the cloud blocks
+    // of k_xf_vcm run a few microseconds longer than its message) is ordered before anything a later call enqueues on this
+    // stream.  So no hipStreamSynchronize here (~6 us per call) unless an event of this run is not complete yet - which the
+    // recorded ones (the dense search's, early in the run) are.  PWICP_RUN_SYNC=1: always synchronise.
+    static const bool always_sync = getenv("PWICP_RUN_SYNC") && atoi(getenv("PWICP_RUN_SYNC")) != 0;
+    bool synced = false;
+    if (always_sync || !vcm_pending || status != PWICP_OK) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); synced = true; }
     for (auto& e : ev_kind) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, pr->ev[e.first], pr->ev[e.first + 1]) == hipSuccess) {
+        hipError_t ee = hipEventElapsedTime(&ms, pr->ev[e.first], pr->ev[e.first + 1]);
+        if (ee == hipErrorNotReady && !synced) {
+            (void)hipGetLastError();
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            synced = true;
+            ee = hipEventElapsedTime(&ms, pr->ev[e.first], pr->ev[e.first + 1]);
+        }
+        if (ee == hipSuccess) {
             if (e.second == 0) res->t_dense_nn_ms += ms; else res->t_inner_ms += ms;
         }
     }
