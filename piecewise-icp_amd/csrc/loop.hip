@@ -845,9 +845,11 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         IcpState hst;
         {
             // launches enqueued ahead: a launch after convergence is a ~4 us no-op, a missing one an exposed round trip
-            // (~15 us).  PCL's ICP needs 3-8 iterations in the first outer iteration and about half as many as the
-            // time before afterwards, hence 4, then half of the previous count, then 2 at a time.
-            int batch = (k == 0) ? 4 : std::max(1, (prev_inner + 1) / 2);
+            // (~13 us).  On the reference's 57 registrations (tests/golden/oracle_vs_reference.json) the first outer iteration
+            // needs 4 (27 x), 5 (16 x), 3-8 inner iterations, a later one after n: n = 1 -> 1 (11 of 11), 2 -> 2 (44) or 1 (27),
+            // 3 -> 2 (34) or 3 (20), 4 -> 2 (17) or 3 (15), 5 -> 3 (10).  Hence 4, then 2 after 2 and half of the count (rounded
+            // up) otherwise, then 2 at a time.
+            int batch = (k == 0) ? 4 : (prev_inner == 2 ? 2 : std::max(1, (prev_inner + 1) / 2));
             bool first_batch = true;
             for (;;) {
                 // (an event record costs a ~6 us bubble on the stream: the inner-loop timing is opt-in)
