@@ -997,6 +997,9 @@ struct FeWorkspace {
     double* hN = nullptr;
     size_t h_n = 0;
     int* h_ctr = nullptr;               // pinned: counters read back after every sweep
+    unsigned* mail_h = nullptr;         // pinned, mapped, host-coherent: [0..16) words of a small read-back, [16] its sequence number
+    unsigned* mail_d = nullptr;         // the same memory as the device sees it
+    unsigned mail_seq = 0;
     // refinement
     DevBuf<double> dis, nd;
     DevBuf<unsigned long long> key;
@@ -1018,10 +1021,18 @@ struct FeWorkspace {
         if (hS) (void)hipHostFree(hS);
         if (hN) (void)hipHostFree(hN);
         if (h_ctr) (void)hipHostFree(h_ctr);
+        if (mail_h) (void)hipHostFree(mail_h);
     }
     hipError_t host_reserve(size_t n) {
         if (!h_ctr) {
             const hipError_t e = hipHostMalloc((void**)&h_ctr, sizeof(int) * 16, hipHostMallocDefault);
+            if (e != hipSuccess) return e;
+        }
+        if (!mail_h) {
+            hipError_t e = hipHostMalloc((void**)&mail_h, sizeof(unsigned) * 32, hipHostMallocMapped | hipHostMallocCoherent);
+            if (e != hipSuccess) return e;
+            memset(mail_h, 0, sizeof(unsigned) * 32);
+            e = hipHostGetDevicePointer((void**)&mail_d, mail_h, 0);
             if (e != hipSuccess) return e;
         }
         if (n <= h_n) return hipSuccess;
@@ -1041,6 +1052,48 @@ struct FeWorkspace {
 FeWorkspace* workspace_of(pwicp_context* ctx) {
     if (!ctx->scratch) ctx->scratch = std::shared_ptr<void>(new FeWorkspace, [](void* p) { delete static_cast<FeWorkspace*>(p); });
     return static_cast<FeWorkspace*>(ctx->scratch.get());
+}
+
+// Small device -> host read-backs (a counter, a flag, the 16 counters of a sweep) - a front end does ~300 of them, each a
+// copy into host memory plus a hipStreamSynchronize (the host thread sleeps and is woken by an interrupt: 30-60 us).  They go
+// through a mailbox in pinned host-coherent memory instead, as the registration loop's hand-overs do (common.h: mail_store):
+// a one-wave launch behind the producers copies the words and then a sequence number, the host spins on that word.
+// PWICP_FE_MAILBOX=0: copy + synchronise.
+__global__ void __launch_bounds__(64) k_fe_mail(const unsigned* __restrict__ src, int n, unsigned* __restrict__ dst, unsigned seq) {
+    const int t = threadIdx.x;
+    if (t < n) mail_store(&dst[t], src[t]);
+    mail_drain();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (t == 0) mail_publish(&dst[16], seq);
+}
+
+int fe_read_words(pwicp_context* ctx, FeWorkspace& ws, const void* d_src, int n_words, void* h_out) {
+    static const bool use_mail = !(getenv("PWICP_FE_MAILBOX") && atoi(getenv("PWICP_FE_MAILBOX")) == 0);
+    if (!use_mail || !ws.mail_h || n_words > 16) {
+        HIPCHK(ctx, hipMemcpyAsync(h_out, d_src, sizeof(unsigned) * (size_t)n_words, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        return PWICP_OK;
+    }
+    const unsigned seq = ++ws.mail_seq;
+    hipLaunchKernelGGL(k_fe_mail, dim3(1), dim3(64), 0, ctx->stream, (const unsigned*)d_src, n_words, ws.mail_d, seq);
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(&ws.mail_h[16], __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 0x3ff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) {
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            if (__atomic_load_n(&ws.mail_h[16], __ATOMIC_ACQUIRE) != seq) {
+                ctx->set_err("pwicp front end: device mailbox never signalled");
+                return PWICP_E_INTERNAL;
+            }
+            break;
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    memcpy(h_out, ws.mail_h, sizeof(unsigned) * (size_t)n_words);
+    return PWICP_OK;
 }
 
 // ---- k-th smallest of n doubles (exact; lambda0 = the median of the smallest neighbour metric, :98-102) ---------------------
@@ -1185,8 +1238,7 @@ int refine_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
             hipLaunchKernelGGL(k_ref_sweep, grid1(m), dim3(256), 0, st, L, m, d_nb, k, pos.p, d_lab, dis.p, dP, res, nl_prev, nl_new,
                                nd.p, flag.p);
             int changed = 0;
-            HIPCHK(ctx, hipMemcpyAsync(&changed, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipStreamSynchronize(st));
+            PWCHK(fe_read_words(ctx, *workspace_of(ctx), flag.p, 1, &changed));
             std::swap(nl_prev, nl_new);
             if (!changed) break;
         }
@@ -1196,8 +1248,7 @@ int refine_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
         hipLaunchKernelGGL(k_ref_push<1>, grid1(m), dim3(256), 0, st, L, m, d_nb, k, pos.p, d_lab, nl_prev, key.p, cnt.p, (int*)nullptr);
         PWCHK(pw_exclusive_scan(ctx, cnt.p, (long long)m + 1, &tmp));
         int m_next = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&m_next, cnt.p + m, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
+        PWCHK(fe_read_words(ctx, *workspace_of(ctx), cnt.p + m, 1, &m_next));
         if (m_next > n) { ctx->set_err("front end: refinement queue overflow"); return PWICP_E_INTERNAL; }
         hipLaunchKernelGGL(k_ref_push<2>, grid1(m), dim3(256), 0, st, L, m, d_nb, k, pos.p, d_lab, nl_prev, key.p, cnt.p, Lnext);
         hipLaunchKernelGGL(k_ref_commit, grid1(m), dim3(256), 0, st, L, m, nl_prev, nd.p, d_lab, dis.p, pos.p);
@@ -1325,8 +1376,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
                 HIPCHK(ctx, hipMemsetAsync(ws.ctr.p + 15, 0, sizeof(int), st));
                 hipLaunchKernelGGL(k_fus_ab_changed, grid1(n), dim3(256), 0, st, ws.ab.p, ws.ab_prev.p, n, ws.ctr.p + 15);
                 int differs = 0;
-                HIPCHK(ctx, hipMemcpyAsync(&differs, ws.ctr.p + 15, sizeof(int), hipMemcpyDeviceToHost, st));
-                HIPCHK(ctx, hipStreamSynchronize(st));
+                PWCHK(fe_read_words(ctx, ws, ws.ctr.p + 15, 1, &differs));
                 if (trace && differs) fprintf(stderr, "[pwicp front end/dev]   (round %d: absorbers rebuilt for the certificate differ)\n", round);
             }
             if (++sweeps > 20000) {                         // (never seen; the serial pass always terminates)
@@ -1350,8 +1400,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
                                        (const int*)ws.dq2.p);
                 }
                 s.nW_dev = nullptr; s.stop = nullptr;
-                HIPCHK(ctx, hipMemcpyAsync(h_ctr, ws.ctr.p, sizeof(int) * 16, hipMemcpyDeviceToHost, st));
-                HIPCHK(ctx, hipStreamSynchronize(st));
+                PWCHK(fe_read_words(ctx, ws, ws.ctr.p, 16, h_ctr));
                 sweeps += h_ctr[6] - 1;
                 runs += h_ctr[7];
                 if (h_ctr[8] || h_ctr[9]) {
@@ -1385,8 +1434,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
             hipLaunchKernelGGL(k_fus_wake, dim3((unsigned)std::min(1024, std::max(32, nW / 64))), dim3(256), 0, st, s, ws.dq.p, ndq, ws.dq2.p, ndq + 1);
             hipLaunchKernelGGL(k_fus_sweep_end, dim3((unsigned)std::min(256, std::max(8, nW / 256))), dim3(256), 0, st, s, ws.dq.p, ndq, ws.dq2.p,
                                ndq + 1);
-            HIPCHK(ctx, hipMemcpyAsync(h_ctr, ws.ctr.p, sizeof(int) * 16, hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipStreamSynchronize(st));
+            PWCHK(fe_read_words(ctx, ws, ws.ctr.p, 16, h_ctr));
             if (h_ctr[8] || h_ctr[9]) {
                 if (trace) fprintf(stderr, "[pwicp front end/dev]   fusion gives up in round %d (%s overflow)\n", round, h_ctr[8] ? "queue" : "arena");
                 ws.sa_overflow = !h_ctr[8] && h_ctr[9];
@@ -1406,8 +1454,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
         // absorbed in this round, per centre
         hipLaunchKernelGGL(k_fus_total_absorbed, grid1(nc), dim3(256), 0, st, cen, nc, ws.rec_absn.p, ws.newlen.p, ws.big.p);
         unsigned long long total = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&total, ws.big.p, sizeof(total), hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
+        PWCHK(fe_read_words(ctx, ws, ws.big.p, 2, &total));
         if (trace) {
             std::vector<unsigned long long> tops(16 * (kFusArenas + 1));
             (void)hipMemcpy(tops.data(), ws.big.p, sizeof(unsigned long long) * tops.size(), hipMemcpyDeviceToHost);
