@@ -375,6 +375,55 @@ def test_loop_is_deterministic_run_to_run(ctx):
     assert len(seen) == 1
 
 
+SCHEDULE_WORKER = r'''
+import hashlib, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(%(root)r, "piecewise-icp_amd")); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import pwicp_amd as P
+import _data
+ctx = P.Context(0)
+h = hashlib.sha256()
+for (n, ep, manual) in ((60000, 1, True), (60000, 3, False), (200000, 2, True)):
+    tgt, src, _ = _data.pair(n, epoch=ep)
+    l1, n1 = ctx.frontend_segment(tgt, 10 * _data.R, 45, _data.R)
+    l2, n2 = ctx.frontend_segment(src, 10 * _data.R, 45, _data.R)
+    for rep in range(2):                                  # the second pair of a size reuses the first one's pooled buffers
+        pair = P.Pair(ctx, tgt, l1, n1, src, l2, n2, _data.params(manual))
+        r = pair.run()
+        no = r.n_outer
+        for a in (np.array(r.T16, np.float32), np.array(r.VCM, np.float64), np.array(r.n_inner[:no]), np.array(r.n_stable[:no]),
+                  np.array(r.DTseries[:no + 1], np.float32), np.array(r.maxBB[:no], np.float32), np.array(r.d75[:no], np.float64),
+                  pair.download_source()):
+            h.update(np.ascontiguousarray(a).tobytes())
+        pair.close()
+print("FINGERPRINT", h.hexdigest())
+'''
+
+
+@pytest.mark.gpu
+def test_scheduling_switches_do_not_change_a_bit(tmp_path):
+    """Stage guard (the Stage-1 -> Stage-2 decision on the device), speculative first dense search, fused percentile selection,
+    the closing stream synchronisation and the allocation pool only change WHEN things are launched and where buffers come
+    from: T, VCM, every per-iteration series and the moved source cloud are bit-identical with each of them switched off."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text(SCHEDULE_WORKER % {"root": root})
+    prints = {}
+    for name, extra in (("default", {}), ("guard off", {"PWICP_STAGE_GUARD": "0"}), ("no speculation", {"PWICP_SPECULATE_DENSE": "0"}),
+                        ("selection on its own launches", {"PWICP_FUSED_SELECT": "0"}),
+                        ("no pool, closing synchronisation", {"PWICP_POOL_MB": "0", "PWICP_RUN_SYNC": "1"})):
+        env = dict(os.environ)
+        for k in ("PWICP_STAGE_GUARD", "PWICP_SPECULATE_DENSE", "PWICP_FUSED_SELECT", "PWICP_POOL_MB", "PWICP_RUN_SYNC"):
+            env.pop(k, None)
+        env.update(extra)
+        out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0 and "FINGERPRINT" in out.stdout, name + ": " + out.stdout[-2000:] + out.stderr[-2000:]
+        prints[name] = out.stdout.split("FINGERPRINT")[1].split()[0]
+    assert len(set(prints.values())) == 1, prints
+
+
 LAYOUT_WORKER = r'''
 import os, sys
 import numpy as np
