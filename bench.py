@@ -276,7 +276,7 @@ def series_end_to_end(args, P, rank, world, local_rank, dist, dev, barrier):
                "rank0_scan_bytes_to_gpu": stages["scan_bytes"],
                "note": "stages of rank 0 (its share of the pairs + the shared target): reading scans, GPU preparation (voxel grid incl. the "
                        "host-side std::sort order, SOR, reduction), what is left of the front ends after that, registrations; the "
-                       "front end of a cloud (~100 ms per 1 M points of device time) is what a pair costs, the loop is 0.35 ms of it"}
+                       "front end of a cloud (~100 ms per 1 M points of device time) is what a pair costs, the loop is 0.28 ms of it"}
         shutil.rmtree(d, ignore_errors=True)
     return out
 
@@ -500,7 +500,7 @@ def main():
                     "valu_issue_frac": (round(valu * 4.0 / (1024 * 2.4e9 * dur_s), 3) if valu else None),
                     "note": "achieved/frac = PHYSICAL HBM bytes per launch / HIP-event time / 8 TB/s; model_gbs = SURVEY 8d's algorithmic "
                             "stream (cache hits included) for reference.  The kernel is bound by vector-ALU issue and load latency, not "
-                            "by HBM: its traffic is ~1.2x the compulsory bytes (DESIGN.md 4.1)"}
+                            "by HBM: its traffic is ~1.35x the compulsory bytes (DESIGN.md 4.1)"}
         if stale:
             roofline["stale_profile"] = stale
 
