@@ -248,9 +248,10 @@ __device__ __forceinline__ NNBest nn_query(const GridDesc& gd, float qx, float q
 // group), so the lanes of a group never diverge; the result is the same exact (d2, index) minimum.
 constexpr int kGroup = 8;
 
+template <int G = kGroup>
 __device__ __forceinline__ void group_min(NNBest& b) {
 #pragma unroll
-    for (int o = 1; o < kGroup; o <<= 1) {
+    for (int o = 1; o < G; o <<= 1) {
         const unsigned long long other = __shfl_xor(b.key, o);
         b.key = other < b.key ? other : b.key;
     }
@@ -276,39 +277,49 @@ __device__ __forceinline__ unsigned scan_points4(const float4* __restrict__ pts,
 // at once (one row each), hand them round with shuffles, and then walk every row TOGETHER, points interleaved over the
 // lanes, four loads in flight each.  The chain is 1 + sum_rows ceil(n_row / 32) round trips, whatever the shape of
 // the box (the coarse boxes of stage 2 have few, long rows).
+template <int G = kGroup>
 __device__ __forceinline__ unsigned scan_box_group(const GridLevel& g, int x0, int x1, int y0, int y1, int z0, int z1, int sub,
                                                    float qx, float qy, float qz, NNBest& b) {
     unsigned cnt = 0;
     const int wy = y1 - y0 + 1;
     const int nrows = wy * (z1 - z0 + 1);
-    const int gbase = (int)(__lane_id() & ~(unsigned)(kGroup - 1));
-    for (int t0 = 0; t0 < nrows; t0 += kGroup) {
+    const int gbase = (int)(__lane_id() & ~(unsigned)(G - 1));
+    for (int t0 = 0; t0 < nrows; t0 += G) {
         int lo_s = 0, hi_s = 0;
         const int t = t0 + sub;
         if (t < nrows) row_range(g, y0 + t % wy, z0 + t / wy, x0, x1, lo_s, hi_s);
 #pragma unroll
-        for (int k = 0; k < kGroup; ++k) {
+        for (int k = 0; k < G; ++k) {
             const int lo = __shfl(lo_s, gbase + k), hi = __shfl(hi_s, gbase + k);
-            cnt += scan_points4(g.pts, lo + sub, hi, kGroup, qx, qy, qz, b);
+            cnt += scan_points4(g.pts, lo + sub, hi, G, qx, qy, qz, b);
         }
     }
     return cnt;
 }
 
+// G: lanes per query (a power of two <= 8; sub = lane % G).  8 for the launches with ~10^4 queries (ICP, VCM: the chain of
+// round trips is everything), 4 where 10^5 queries share the chip with other work (the front launches: half the waves and
+// about 0.6x the instructions per query, the chain as long - a lane's two or three rows are requested together).
+template <int G = kGroup>
 __device__ __forceinline__ NNBest nn_query_group(const GridDesc& gd, float qx, float qy, float qz, int sub) {
     NNBest b;
     b.key = kKeyInit;
     const GridLevel& g = gd.fine;
     if (g.n <= 0) return b;
-    // stage 1: the 9 stencil rows over the 8 lanes (lane 0 also takes the ninth)
+    // stage 1: the 9 stencil rows dealt over the G lanes (row r to lane r % G)
     {
         const int cx = cell_of(qx, g.ox, g.inv_h), cy = cell_of(qy, g.oy, g.inv_hy), cz = cell_of(qz, g.oz, g.inv_hz);
-        int lo0, hi0, lo1 = 0, hi1 = 0;
-        row_range(g, cy + (sub % 3) - 1, cz + (sub / 3) - 1, cx - 1, cx + 1, lo0, hi0);
-        if (sub == 0) row_range(g, cy + 1, cz + 1, cx - 1, cx + 1, lo1, hi1);
-        scan_points4(g.pts, lo0, hi0, 1, qx, qy, qz, b);
-        scan_points4(g.pts, lo1, hi1, 1, qx, qy, qz, b);
-        group_min(b);
+        constexpr int R = (9 + G - 1) / G;
+        int lo[R], hi[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int r = sub + i * G;
+            lo[i] = hi[i] = 0;
+            if (r < 9) row_range(g, cy + (r % 3) - 1, cz + (r / 3) - 1, cx - 1, cx + 1, lo[i], hi[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) scan_points4(g.pts, lo[i], hi[i], 1, qx, qy, qz, b);
+        group_min<G>(b);
         if (nn_resolved(g, 1, b)) return b;
     }
     const GridLevel& c = gd.coarse;
@@ -319,8 +330,8 @@ __device__ __forceinline__ NNBest nn_query_group(const GridDesc& gd, float qx, f
         const int y0 = max(cell_of(qy - rho, c.oy, c.inv_hy), 0), y1 = min(cell_of(qy + rho, c.oy, c.inv_hy), c.ny - 1);
         const int z0 = max(cell_of(qz - rho, c.oz, c.inv_hz), 0), z1 = min(cell_of(qz + rho, c.oz, c.inv_hz), c.nz - 1);
         if ((y1 - y0 + 1) * (z1 - z0 + 1) <= 64) {
-            if (x0 <= x1 && y0 <= y1 && z0 <= z1) scan_box_group(c, x0, x1, y0, y1, z0, z1, sub, qx, qy, qz, b);
-            group_min(b);
+            if (x0 <= x1 && y0 <= y1 && z0 <= z1) scan_box_group<G>(c, x0, x1, y0, y1, z0, z1, sub, qx, qy, qz, b);
+            group_min<G>(b);
             return b;
         }
     }
@@ -332,13 +343,13 @@ __device__ __forceinline__ NNBest nn_query_group(const GridDesc& gd, float qx, f
         const int ez = max(0, max(-cz, cz - (c.nz - 1)));
         int r = max(max(ex, ey), max(ez, 1));
         const int rcover = max(max(max(cx, c.nx - 1 - cx), max(cy, c.ny - 1 - cy)), max(cz, c.nz - 1 - cz));
-        scan_box_group(c, cx - r, cx + r, cy - r, cy + r, cz - r, cz + r, sub, qx, qy, qz, b);
-        group_min(b);
+        scan_box_group<G>(c, cx - r, cx + r, cy - r, cy + r, cz - r, cz + r, sub, qx, qy, qz, b);
+        group_min<G>(b);
         while (!nn_resolved(c, r, b) && r < rcover) {
             ++r;
             // shell of radius r: rows dealt round-robin; inner rows contribute their two end cells
             const int w = 2 * r + 1;
-            for (int t = sub; t < w * w; t += kGroup) {
+            for (int t = sub; t < w * w; t += G) {
                 const int dz = t / w - r, dy = t % w - r;
                 int lo0, hi0, lo1 = 0, hi1 = 0;
                 if (dz == -r || dz == r || dy == -r || dy == r) {
@@ -350,7 +361,7 @@ __device__ __forceinline__ NNBest nn_query_group(const GridDesc& gd, float qx, f
                 scan_points4(c.pts, lo0, hi0, 1, qx, qy, qz, b);
                 scan_points4(c.pts, lo1, hi1, 1, qx, qy, qz, b);
             }
-            group_min(b);
+            group_min<G>(b);
         }
     }
     return b;

@@ -295,7 +295,7 @@ __device__ __forceinline__ void front_init(const FrontInit& in) {
 // registers in these kernels (87 VGPRs = 5 waves per SIMD against 64 = 8 without it), and the launches are bound by how many
 // of their ~5000 short blocks are resident at a time - so the launches that carry no pass (all of them on the usual,
 // speculative schedule) run the instantiation without the role.
-template <bool SEL>
+template <bool SEL, int QG>
 __global__ void __launch_bounds__(kFrontBlock) k_front(const float4* __restrict__ pat, const int* __restrict__ off, int m,
                                                        float4* __restrict__ nrm_out, int nb_nrm, GridDesc g,
                                                        const float4* __restrict__ q, int nq, int* __restrict__ idx,
@@ -319,10 +319,10 @@ __global__ void __launch_bounds__(kFrontBlock) k_front(const float4* __restrict_
         return;
     }
     const int t = (bid - nb_nrm) * kFrontBlock + threadIdx.x;
-    const int i = t / kGroup, sub = t % kGroup;
+    const int i = t / QG, sub = t % QG;         // QG lanes per query (nn_device.h: nn_query_group)
     if (i >= nq) return;                        // a whole group is in or out of range together
     const float4 v = q[i];
-    const NNBest b = nn_query_group(g, v.x, v.y, v.z, sub);
+    const NNBest b = nn_query_group<QG>(g, v.x, v.y, v.z, sub);
     if (sub == 0) {
         idx[i] = b.found() ? b.idx() : -1;
         d2[i] = b.d2();
@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(kFrontBlock) k_front(const float4* __restrict_
 // The moved values are the same float expressions as in the stand-alone launches (xform_point), so normals, matches and
 // distances are bit-identical to transform-then-front; the two launches cost 14 + 17 us back to back, this one ~24 us.
 // (Alternating query and cloud blocks in the grid, or 6 / 8 waves per SIMD through launch bounds: no gain, measured.)
-template <bool SEL>
+template <bool SEL, int QG>
 __global__ void __launch_bounds__(kFrontBlock) k_xf_front(const float4* pat_in, float4* pat, const int* __restrict__ off, int m,
                                                           float4* __restrict__ nrm_out, int nb_nrm, GridDesc g,
                                                           const float4* ctbp_in, float4* ctbp, int nq, int* __restrict__ idx,
@@ -383,12 +383,12 @@ __global__ void __launch_bounds__(kFrontBlock) k_xf_front(const float4* pat_in, 
     bid -= nb_nrm;
     if (bid < nb_nn) {
         const int t = bid * kFrontBlock + threadIdx.x;
-        const int i = t / kGroup, sub = t % kGroup;
+        const int i = t / QG, sub = t % QG;
         if (i >= nq) return;                        // a whole group is in or out of range together
         FT_ROLE_BEGIN(1);
         const float4 v = xform_point(T.m, ctbp_in[i]);
         if (sub == 0) ctbp[i] = v;
-        const NNBest b = nn_query_group(g, v.x, v.y, v.z, sub);
+        const NNBest b = nn_query_group<QG>(g, v.x, v.y, v.z, sub);
         if (sub == 0) {
             idx[i] = b.found() ? b.idx() : -1;
             d2[i] = b.d2();
@@ -542,6 +542,15 @@ int pw_patch_normals_launch(pwicp_context* ctx, const float4* d_pat, const int* 
     return PWICP_OK;
 }
 
+// Lanes per query of the front launches' searches (nn_device.h: nn_query_group<G>).  Measured on the 1 M-point pair: k_front
+// (queries + normals: the chain of round trips decides) 17.0 us with 8 lanes, 18.0 with 4; k_xf_front (the cloud's transform
+// shares the chip: resident blocks decide) 23.2 us with 8, 21.7 with 4, 25.6 with 2.  PWICP_FRONT_QUERY_LANES = 4 / 8 forces one for both.
+static int front_query_lanes(bool with_cloud) {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PWICP_FRONT_QUERY_LANES"); v = e ? ((atoi(e) == 4 || atoi(e) == 8) ? atoi(e) : 0) : 0; }
+    return v ? v : (with_cloud ? 4 : 8);
+}
+
 int pw_front_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, int m, float4* d_nrm, const GridDesc& g,
                     const float4* d_q, int nq, int* d_idx, float* d_d2, const FusedSelect* fs, const FrontInit* init) {
     if (m <= 0 || nq <= 0) {
@@ -556,15 +565,17 @@ int pw_front_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, i
         return pw_nn_launch(ctx, g, d_q, nq, d_idx, d_d2, nullptr);
     }
     const int nb_nrm = div_up((long long)m * kGroup, kFrontBlock);
-    const int nb_nn = div_up((long long)nq * kGroup, kFrontBlock);
+    const int qg = front_query_lanes(false);
+    const int nb_nn = div_up((long long)nq * qg, kFrontBlock);
     FusedSelect none{};
     const bool sel = fs && fs->scratch;
-    if (sel)
-        hipLaunchKernelGGL(k_front<true>, dim3(nb_nrm + nb_nn + fs->nblk), dim3(kFrontBlock), 0, ctx->stream, d_pat, d_off, m, d_nrm,
-                           nb_nrm, g, d_q, nq, d_idx, d_d2, nb_nrm + nb_nn, *fs, init ? *init : FrontInit{});
-    else
-        hipLaunchKernelGGL(k_front<false>, dim3(nb_nrm + nb_nn), dim3(kFrontBlock), 0, ctx->stream, d_pat, d_off, m, d_nrm,
-                           nb_nrm, g, d_q, nq, d_idx, d_d2, nb_nrm + nb_nn, none, init ? *init : FrontInit{});
+    const FrontInit fi = init ? *init : FrontInit{};
+#define PW_FRONT(SEL_, QG_, NSEL_, FS_)                                                                                            \
+    hipLaunchKernelGGL((k_front<SEL_, QG_>), dim3(nb_nrm + nb_nn + (NSEL_)), dim3(kFrontBlock), 0, ctx->stream, d_pat, d_off, m, d_nrm,   \
+                       nb_nrm, g, d_q, nq, d_idx, d_d2, nb_nrm + nb_nn, FS_, fi)
+    if (sel) { if (qg == 4) PW_FRONT(true, 4, fs->nblk, *fs); else PW_FRONT(true, 8, fs->nblk, *fs); }
+    else { if (qg == 4) PW_FRONT(false, 4, 0, none); else PW_FRONT(false, 8, 0, none); }
+#undef PW_FRONT
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }
@@ -574,18 +585,19 @@ int pw_xf_front_launch(pwicp_context* ctx, const float4* d_pat_in, float4* d_pat
                        const float4* d_cloud_in, float4* d_cloud, int n, const IcpState* d_state, const unsigned* d_ns,
                        unsigned* d_bbox_part, unsigned* d_slot, const FusedSelect* fs, const FrontInit* init, const unsigned* d_guard) {
     const int nb_nrm = div_up((long long)m * kGroup, kFrontBlock);
-    const int nb_nn = div_up((long long)nq * kGroup, kFrontBlock);
+    const int qg = front_query_lanes(true);
+    const int nb_nn = div_up((long long)nq * qg, kFrontBlock);
     const int nb_cloud = std::min(div_up(n, kFrontBlock), ctx->n_cu * 8);
     FusedSelect none{};
     const bool sel = fs && fs->scratch;
-    if (sel)
-        hipLaunchKernelGGL(k_xf_front<true>, dim3(nb_nrm + nb_nn + nb_cloud + fs->nblk + kFsBlocks), dim3(kFrontBlock), 0, ctx->stream,
-                           d_pat_in, d_pat, d_off, m, d_nrm, nb_nrm, g, d_ctbp_in, d_ctbp, nq, d_idx, d_d2, nb_nn, d_cloud_in, d_cloud, n,
-                           nb_cloud, d_state, d_ns, d_bbox_part, d_slot, *fs, kFsBlocks, init ? *init : FrontInit{}, d_guard);
-    else
-        hipLaunchKernelGGL(k_xf_front<false>, dim3(nb_nrm + nb_nn + nb_cloud), dim3(kFrontBlock), 0, ctx->stream,
-                           d_pat_in, d_pat, d_off, m, d_nrm, nb_nrm, g, d_ctbp_in, d_ctbp, nq, d_idx, d_d2, nb_nn, d_cloud_in, d_cloud, n,
-                           nb_cloud, d_state, d_ns, d_bbox_part, d_slot, none, kFsBlocks, init ? *init : FrontInit{}, d_guard);
+    const FrontInit fi = init ? *init : FrontInit{};
+#define PW_XF_FRONT(SEL_, QG_, NSEL_, FS_)                                                                                          \
+    hipLaunchKernelGGL((k_xf_front<SEL_, QG_>), dim3(nb_nrm + nb_nn + nb_cloud + (NSEL_)), dim3(kFrontBlock), 0, ctx->stream, d_pat_in,    \
+                       d_pat, d_off, m, d_nrm, nb_nrm, g, d_ctbp_in, d_ctbp, nq, d_idx, d_d2, nb_nn, d_cloud_in, d_cloud, n, nb_cloud,    \
+                       d_state, d_ns, d_bbox_part, d_slot, FS_, kFsBlocks, fi, d_guard)
+    if (sel) { if (qg == 4) PW_XF_FRONT(true, 4, fs->nblk + kFsBlocks, *fs); else PW_XF_FRONT(true, 8, fs->nblk + kFsBlocks, *fs); }
+    else { if (qg == 4) PW_XF_FRONT(false, 4, 0, none); else PW_XF_FRONT(false, 8, 0, none); }
+#undef PW_XF_FRONT
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
 }
