@@ -217,16 +217,23 @@ int pw_grid_build(pwicp_context* ctx, const float4* d_pts, int n, float cell_edg
 // exact 1-NN of d_q[0..nq) ; d_idx may be null; d_examined (optional) accumulates #points examined
 int pw_nn_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_q, int nq, int* d_idx, float* d_d2,
                  unsigned long long* d_examined);
+// buffers of the far-query hand-over of a dense launch (grid.hip: k_nn_dense_far); far_bufs != nullptr selects it
+struct DenseFarBuffers {
+    DevBuf<float4> q;
+    DevBuf<int> slot;
+    DevBuf<unsigned> count;
+};
 // dense NN of patch points: query i = patch point qorder[i] (skipped, sentinel written, unless stable[pt_patch[.]])
 // d_qpatch (optional with `dense`): d_pt_patch[d_qorder[i]] precomputed; dense != nullptr selects the disc-pruned kernel
 int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pat, const int* d_qorder,
                            const int* d_pt_patch, const int* d_stable, int nq, float* d_d2,
                            unsigned long long* d_examined, const GridLevel* dense = nullptr, const int* d_qpatch = nullptr,
-                           const struct FusedSelect* fs = nullptr);
+                           const struct FusedSelect* fs = nullptr, struct DenseFarBuffers* far_bufs = nullptr);
 // passes 1 / 2 of the fused percentile selection (select_dev.h) as launches of their own
 int pw_fs_pass_launch(pwicp_context* ctx, int pass, const struct FusedSelect& fs);
 int pw_grid_add_dense(pwicp_context* ctx, const float4* d_pts, int n, float cell_edge, Grid* g);
-int pw_dense_level_for(pwicp_context* ctx, const Grid& g, const float4* d_q, int nq, const GridLevel** out);
+// far_frac (optional): share of the probed queries that leave the small-cell search at their initial position
+int pw_dense_level_for(pwicp_context* ctx, const Grid& g, const float4* d_q, int nq, const GridLevel** out, double* far_frac = nullptr);
 // out[i] = src[order[i]]
 int pw_gather_int_launch(pwicp_context* ctx, const int* d_src, const int* d_order, int n, int* d_out);
 int pw_morton_order(pwicp_context* ctx, const GridDesc& g, const float4* d_pts, int n, DevBuf<int>* order);

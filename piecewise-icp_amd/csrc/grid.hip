@@ -311,6 +311,13 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_direct(GridDesc gd, const f
     add_examined(examined, cnt);
 }
 
+// far queries of a dense launch, handed over to k_nn_dense_far: (x, y, z, candidate d2) | slot in d2out | count | readers
+struct DenseFarList {
+    float4* q = nullptr;
+    int* slot = nullptr;
+    unsigned* count = nullptr;      // [0] entries, [1] blocks of k_nn_dense_far that have read it (the last one re-arms both)
+};
+
 // ---- dense 1-NN, distance only, disc-pruned (the default dense kernel) --------------------------------------------------
 // One lane per query (queries in Morton order of their target cell, XCD-aware tile order as above).  `dl` is a level of
 // SMALL cells (edge ~1.5 point spacings) over the target cloud: phase A takes a candidate from the query's own row
@@ -320,6 +327,7 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_direct(GridDesc gd, const f
 // general block / shell expansion).  Same float arithmetic per candidate as every other search: the result is the exact
 // minimum d2 (bit-identical to k_nn_dense_direct and the oracle).
 constexpr float kMaxRhoCells = 2.75f;
+constexpr float kFirstBallCells = 1.1f;     // first ball of a far query without a usable candidate (k_nn_dense_far)
 
 __device__ __forceinline__ float dense_far_path(const GridDesc& far, float4 q, float best, unsigned& cnt) {
     if (best < INFINITY) {
@@ -344,12 +352,15 @@ __device__ __forceinline__ float dense_far_path(const GridDesc& far, float4 q, f
 
 // PERM = dl.perm: the level's axis roles (the query is put into the level's order for everything that concerns `dl`;
 // the far path works on the levels of `far`, which are always in (x, y, z))
-template <int PERM>
+// FARG: the far queries of the block are searched by eight lanes each (more registers: 5 instead of 7 waves per SIMD, so only
+// launches that expect many far queries use this instantiation - the first search of a pair whose probe found them)
+template <int PERM, bool FARG>
 __global__ void __launch_bounds__(kBlock) k_nn_dense_disc(GridLevel dl, GridDesc far, const float4* __restrict__ pat,
                                                           const int* __restrict__ qorder, const int* __restrict__ qpatch,
                                                           const int* __restrict__ stable, int nq,
                                                           float* __restrict__ d2out,
-                                                          unsigned long long* __restrict__ examined, int chunk, FusedSelect fs) {
+                                                          unsigned long long* __restrict__ examined, int chunk, FusedSelect fs,
+                                                          DenseFarList fl) {
     __shared__ unsigned s_hist[kFsBins];    // pass 0 of the percentile selection (select_dev.h), fs.scratch != nullptr only
     __shared__ float4 s_q[kBlock];          // .w carries the candidate d2 of an unresolved query
     __shared__ int s_slot[kBlock];
@@ -409,7 +420,20 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_disc(GridLevel dl, GridDesc
         s_slot[base + before] = i;
     }
     __syncthreads();
-    if (tid < total) {
+    if (FARG) {
+        // ... and handed to the launch behind this one (k_nn_dense_far), which puts EIGHT lanes on each: a far query scans ~40
+        // rows and ~200 candidates (the first iteration of a real pair: half the queries), and a launch of 10^5 queries is a
+        // wave or two per SIMD - one lane per far query makes this launch as long as its slowest lane's chain of round trips
+        // (217 us on the reference's Epoch_002 -> Epoch_001, 140 k points), eight lanes on 32 queries of the block at a time
+        // cost five such chains one after the other.
+        __shared__ unsigned s_base;
+        if (tid == 0 && total > 0) s_base = atomicAdd(fl.count, (unsigned)total);
+        __syncthreads();
+        if (tid < total) {
+            fl.q[s_base + tid] = s_q[tid];
+            fl.slot[s_base + tid] = s_slot[tid];
+        }
+    } else if (tid < total) {
         const float4 u = s_q[tid];
         const float d = dense_far_path(far, u, u.w, cnt);
         d2out[s_slot[tid]] = d;
@@ -417,6 +441,67 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_disc(GridLevel dl, GridDesc
     }
     add_examined(examined, cnt);
     if (fs.scratch) fs_pass0_epilogue(s_hist, fs);
+}
+
+// The far queries of the dense launch before it, eight lanes each (group-cooperative forms of dense_far_path's steps: the
+// ball of the candidate on the larger cells of `far`, else the general search); their share of the selection's pass 0.
+__global__ void __launch_bounds__(kBlock) k_nn_dense_far(GridDesc far, DenseFarList fl, float* __restrict__ d2out, FusedSelect fs) {
+    __shared__ unsigned s_hist[kFsBins];
+    __shared__ unsigned s_n, s_last;
+    const int tid = threadIdx.x;
+    if (fs.scratch)
+        for (int t = tid; t < kFsBins; t += kBlock) s_hist[t] = 0u;
+    if (tid == 0) s_n = __hip_atomic_load(&fl.count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int n = (int)s_n;
+    const int sub = tid % kGroup;
+    for (int qi = (int)blockIdx.x * (kBlock / kGroup) + tid / kGroup; qi < n; qi += (int)gridDim.x * (kBlock / kGroup)) {
+        const float4 u = fl.q[qi];
+        float d = u.w;                              // the candidate of the query's own row segment, if any
+        // Level by level (the larger cells of `far`: fine, then coarse): with a candidate whose ball fits kMaxRhoCells cells,
+        // that ball; otherwise the widest ball that fits - whatever it finds within its guaranteed radius (the ball minus the
+        // rounding slack of the cell boundaries) is the exact minimum, and most queries of a misaligned first iteration have
+        // no candidate at all in their own three cells.  Only a query with nothing within 2.75 coarse cells takes the general
+        // search.
+        bool done = false;
+#pragma unroll
+        for (int lv = 0; lv < 2 && !done; ++lv) {
+            const GridLevel& L = lv == 0 ? far.fine : far.coarse;
+            const float lim = kMaxRhoCells * L.h, sl2 = 2.0f * L.slack;
+            const float sq = d < INFINITY ? fast_sqrt_up(d) : INFINITY;
+            if (sq + sl2 <= lim) {
+                scan_disc_group<kGroup>(L, u.x, u.y, u.z, sq + sl2, sub, d);
+                done = true;
+            } else {
+                // (a small ball first: three quarters of a real pair's far queries are within a cell of the surface)
+                const float r1 = kFirstBallCells * L.h;
+                scan_disc_group<kGroup>(L, u.x, u.y, u.z, r1, sub, d);
+                done = d < INFINITY && fast_sqrt_up(d) + sl2 <= r1;
+                if (!done) {
+                    const float sq2 = d < INFINITY ? fast_sqrt_up(d) + sl2 : INFINITY;
+                    const float r2 = fminf(sq2, lim);                  // the candidate's ball if it fits, else the widest
+                    scan_disc_group<kGroup>(L, u.x, u.y, u.z, r2, sub, d);
+                    done = sq2 <= lim || (d < INFINITY && fast_sqrt_up(d) + sl2 <= lim);
+                }
+            }
+        }
+        if (!done) {                                // nothing within 2.75 coarse cells: the general search
+            const NNBest b = nn_query_group<kGroup>(far, u.x, u.y, u.z, sub);
+            d = fminf(d, b.d2());
+        }
+        if (sub == 0) {
+            d2out[fl.slot[qi]] = d;
+            if (fs.scratch) atomicAdd(&s_hist[__float_as_uint(d) >> 21], 1u);
+        }
+    }
+    if (fs.scratch) fs_pass0_epilogue(s_hist, fs);
+    // the block that reads the count last re-arms the list for the next launch
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned prev = atomicAdd(&fl.count[1], 1u);
+        s_last = (prev == gridDim.x - 1u) ? 1u : 0u;
+        if (s_last) { fl.count[0] = 0u; fl.count[1] = 0u; }
+    }
 }
 
 // passes 1 / 2 of the fused selection as launches of their own (only when no transform / front launch follows the dense
@@ -998,16 +1083,18 @@ __global__ void k_query_occupancy(GridLevel g, const float4* __restrict__ q, int
 // The small-cell level the dense search of a pair should use: the target's layout, or — when that is cells and a level of
 // columns exists — columns if the queries' stencils hold at most kColsTolerance times as many points there (rows are what
 // the disc search pays for: 36 cell rows against 6 column rows per ball).  Synchronises the stream (one-off, at pair creation).
-int pw_dense_level_for(pwicp_context* ctx, const Grid& g, const float4* d_q, int nq, const GridLevel** out) {
+int pw_dense_level_for(pwicp_context* ctx, const Grid& g, const float4* d_q, int nq, const GridLevel** out, double* far_frac) {
     *out = g.has_dense ? &g.dense : nullptr;
-    if (!g.has_dense || !g.has_dense_alt || nq <= 0) return PWICP_OK;
+    if (far_frac) *far_frac = 0.0;
+    if (!g.has_dense || nq <= 0) return PWICP_OK;
     // candidates: the target's own layout (cells), the columns beside it, the levels with other axis roles.  Cost of a level =
     // candidates + kRowCost * rows + kFarCost * queries that leave the disc search, probed on ~16 k of the pair's queries.
     constexpr double kRowCost = 8.0, kFarCost = 40.0;   // (measured on the steep scene of tools/scene_shapes.py: a far query ~ 40-50 candidates)
     const GridLevel* cand[5] = {&g.dense, &g.dense_alt, nullptr, nullptr, nullptr};
-    int nc = 2;
-    for (const auto& x : g.extra)
-        if (x.has) cand[nc++] = &x.lv;
+    int nc = g.has_dense_alt ? 2 : 1;           // (a single level: the probe still tells how many queries start far)
+    if (g.has_dense_alt)
+        for (const auto& x : g.extra)
+            if (x.has) cand[nc++] = &x.lv;
     DevBuf<unsigned long long> acc;
     HIPCHK(ctx, acc.reserve(15));
     HIPCHK(ctx, hipMemsetAsync(acc.p, 0, 15 * sizeof(unsigned long long), ctx->stream));
@@ -1029,7 +1116,10 @@ int pw_dense_level_for(pwicp_context* ctx, const Grid& g, const float4* d_q, int
         if (trace)
             fprintf(stderr, "[pwicp dense level] candidate %d (perm %d, %s): %llu candidates, %llu rows, %llu far -> cost %.3g\n", c, cand[c]->perm,
                     (cand[c]->inv_hy == 0.0f || cand[c]->inv_hz == 0.0f) ? "columns" : "cells", h[3 * c], h[3 * c + 1], h[3 * c + 2], cost);
-        if (c == 0 || cost < best_cost) { best_cost = cost; *out = cand[c]; }
+        if (c == 0 || cost < best_cost) {
+            best_cost = cost; *out = cand[c];
+            if (far_frac) *far_frac = (double)h[3 * c + 2] / (double)std::max(div_up(nq, stride), 1);
+        }
     }
     return PWICP_OK;
 }
@@ -1049,21 +1139,33 @@ int pw_gather_int_launch(pwicp_context* ctx, const int* d_src, const int* d_orde
 
 int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pat, const int* d_qorder,
                            const int* d_pt_patch, const int* d_stable, int nq, float* d_d2,
-                           unsigned long long* d_examined, const GridLevel* dense, const int* d_qpatch, const FusedSelect* fs) {
+                           unsigned long long* d_examined, const GridLevel* dense, const int* d_qpatch, const FusedSelect* fs,
+                           DenseFarBuffers* far_bufs) {
     if (nq <= 0) return PWICP_OK;
+    const bool far_group = far_bufs != nullptr;
+    DenseFarList fl{};
+    if (far_group) {
+        HIPCHK(ctx, far_bufs->q.reserve((size_t)nq));
+        HIPCHK(ctx, far_bufs->slot.reserve((size_t)nq));
+        if (!far_bufs->count.p) {
+            HIPCHK(ctx, far_bufs->count.reserve(2));
+            HIPCHK(ctx, hipMemsetAsync(far_bufs->count.p, 0, 2 * sizeof(unsigned), ctx->stream));
+        }
+        fl.q = far_bufs->q.p; fl.slot = far_bufs->slot.p; fl.count = far_bufs->count.p;
+    }
     if (dense && d_qpatch && d_qorder) {
         const int tiles = div_up(nq, kBlock);
         const int chunk = div_up(tiles, kXcds);
         FusedSelect none{};
-        if (dense->perm == 0)
-            hipLaunchKernelGGL(k_nn_dense_disc<0>, dim3(chunk * kXcds), dim3(kBlock), 0, ctx->stream, *dense, g, d_pat, d_qorder, d_qpatch,
-                               d_stable, nq, d_d2, d_examined, chunk, fs ? *fs : none);
-        else if (dense->perm == 1)
-            hipLaunchKernelGGL(k_nn_dense_disc<1>, dim3(chunk * kXcds), dim3(kBlock), 0, ctx->stream, *dense, g, d_pat, d_qorder, d_qpatch,
-                               d_stable, nq, d_d2, d_examined, chunk, fs ? *fs : none);
-        else
-            hipLaunchKernelGGL(k_nn_dense_disc<2>, dim3(chunk * kXcds), dim3(kBlock), 0, ctx->stream, *dense, g, d_pat, d_qorder, d_qpatch,
-                               d_stable, nq, d_d2, d_examined, chunk, fs ? *fs : none);
+#define PW_DENSE(PERM_, FARG_)                                                                                              \
+    hipLaunchKernelGGL((k_nn_dense_disc<PERM_, FARG_>), dim3(chunk * kXcds), dim3(kBlock), 0, ctx->stream, *dense, g, d_pat, d_qorder, \
+                       d_qpatch, d_stable, nq, d_d2, d_examined, chunk, fs ? *fs : none, fl)
+        if (far_group) { if (dense->perm == 0) PW_DENSE(0, true); else if (dense->perm == 1) PW_DENSE(1, true); else PW_DENSE(2, true); }
+        else { if (dense->perm == 0) PW_DENSE(0, false); else if (dense->perm == 1) PW_DENSE(1, false); else PW_DENSE(2, false); }
+#undef PW_DENSE
+        if (far_group)
+            hipLaunchKernelGGL(k_nn_dense_far, dim3((unsigned)std::min(div_up((long long)nq * kGroup, kBlock), ctx->n_cu * 8)), dim3(kBlock), 0,
+                               ctx->stream, g, fl, d_d2, fs ? *fs : none);
         HIPCHK(ctx, hipGetLastError());
         return PWICP_OK;
     }

@@ -222,6 +222,8 @@ struct pwicp_pair {
     DevBuf<int> qorder;      // source patch points in Morton order of their initial target-grid cell
     DevBuf<int> qpatch;      // pt_patch2[qorder[i]]
     const GridLevel* dense_lv = nullptr;   // small-cell level of the target this pair's dense search uses (pw_dense_level_for)
+    double dense_far0 = 0.0;               // share of this pair's queries that start far from the target (same probe)
+    DenseFarBuffers dense_far;             // hand-over of the far queries of a dense launch to the launch that puts 8 lanes on each
     DevBuf<int> all_stable;  // all-ones flags (bench replay over every patch)
     // per-iteration work
     DevBuf<int> mCTBP, stable;   // matches of the 7*m2 centroid+boundary queries
@@ -294,7 +296,7 @@ int finish_create(pwicp_pair* pr) {
     HIPCHK(ctx, pr->pt_patch2.reserve((size_t)std::max(pr->P2.tot, 1)));
     PWCHK(pw_point_patch_ids_launch(ctx, pr->P2.off.p, m2, pr->pt_patch2.p));
     PWCHK(pw_morton_order(ctx, pr->tgt->g_c1.d, pr->P2.pat.p, pr->P2.tot, &pr->qorder));
-    PWCHK(pw_dense_level_for(ctx, pr->tgt->g_c1, pr->P2.pat.p, pr->P2.tot, &pr->dense_lv));
+    PWCHK(pw_dense_level_for(ctx, pr->tgt->g_c1, pr->P2.pat.p, pr->P2.tot, &pr->dense_lv, &pr->dense_far0));
     HIPCHK(ctx, pr->qpatch.reserve((size_t)std::max(pr->P2.tot, 1)));
     PWCHK(pw_gather_int_launch(ctx, pr->pt_patch2.p, pr->qorder.p, pr->P2.tot, pr->qpatch.p));
     // pristine source copies; centroids and boundary points live in ONE buffer so that a single NN launch and a
@@ -703,6 +705,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     // the device never idles during a round trip: the transform update (8) reads T from the ICP state, and the
     // "front" of the next iteration (NN of centroids/boundary points + source patch normals) needs no threshold.
     bool front_ready = false;                 // front of iteration k already enqueued by iteration k-1
+    double last_d75 = -1.0;                   // percentile of the run's previous dense search
     float prev_lod = NAN;
     // src_now: the front of the CURRENT iteration's state (pristine arrays on a lazily reset pair until the first transform);
     // false: the front of the NEXT iteration, enqueued behind a transform, reads the working arrays that transform writes
@@ -763,6 +766,12 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
             HIPCHK(ctx, hipEventRecord(pr->event(n_ev), ctx->stream));
         }
         const bool fused = pr->dense_lv && !pr->no_fused_select;
+        // the run's first search of a pair most of whose queries start far from the target (the probe at pair creation: 56 % on
+        // the reference's scans, where the first transformation is centimetres; 16 % on the synthetic pair, whose far queries the
+        // search handles faster inside its own blocks): their far queries go to a launch that puts eight lanes on each (grid.hip).
+        // A later search of the run: when the percentile of the one before was still more than 1.5 cells of the small-cell level.
+        static const int far_group_env = getenv("PWICP_DENSE_FAR_GROUP") ? atoi(getenv("PWICP_DENSE_FAR_GROUP")) : -1;
+        const bool far_group_now = far_group_env >= 0 ? far_group_env != 0 : (res->n_dense_nn_launches == 0 ? pr->dense_far0 > 0.3 : (pr->dense_lv && last_d75 > 1.5 * (double)pr->dense_lv->h));
         FusedSelect fs{};
         if (fused) {
             int kk = (int)((float)nsp * 0.75f);         // C.cpp:177
@@ -774,7 +783,8 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
             fs.mail.dst = pr->mail_d + kSelMailPayload; fs.mail.seq_ptr = pr->mail_d + kSelMailSeq; fs.mail.seq = sel_seq;
         }
         PWCHK(pw_nn_dense_launch(ctx, pr->tgt->g_c1.d, pr->src_pat(), pr->qorder.p, pr->pt_patch2.p, pr->stable.p, pr->P2.tot,
-                                 pr->d2dense.p, pr->examined.p, pr->dense_lv, pr->qpatch.p, fused ? &fs : nullptr));
+                                 pr->d2dense.p, pr->examined.p, pr->dense_lv, pr->qpatch.p, fused ? &fs : nullptr,
+                                 far_group_now ? &pr->dense_far : nullptr));
         if (ev) {
             HIPCHK(ctx, hipEventRecord(pr->event(n_ev + 1), ctx->stream));
             n_ev += 2;
@@ -970,6 +980,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
             ht("percentile mail arrived");
             res->n_corr += nsp; res->n_corr_dense += nsp; res->n_dense_nn_launches++;
             res->d75[k] = Dist75;
+            last_d75 = Dist75;
             if ((double)currDT > Dist75) currDT = (float)Dist75; else stage2 = true;
             if (currDT <= LoDet_min) currDT = LoDet_min;
             BB2 = BB1; BB1 = maxBB;

@@ -477,6 +477,52 @@ __device__ __forceinline__ unsigned scan_disc_lean(const GridLevel& g, float qx,
     return cnt;
 }
 
+// scan_disc_lean shared by a group of G lanes (one query): the rows of the ball are dealt to the lanes round-robin and every lane
+// walks ITS rows as the per-lane search does (four rows' begin / end words in flight, then their points four at a time) - a wide
+// ball (40 rows, 200 candidates) is 1/G of the rows and candidates per lane, i.e. a chain of ~10 round trips instead of ~90.
+// Same pruning, same float expression per candidate: after the group minimum, the same exact d2.
+template <int G>
+__device__ __forceinline__ void scan_disc_group(const GridLevel& g, float qx, float qy, float qz, float rho, int sub, float& best) {
+    const bool gy = g.inv_hy != 0.0f, gz = g.inv_hz != 0.0f;
+    const int y0 = gy ? max(icell(qy - rho, g.oy, g.inv_hy), 0) : 0, y1 = gy ? min(icell(qy + rho, g.oy, g.inv_hy), g.ny - 1) : 0;
+    const int z0 = gz ? max(icell(qz - rho, g.oz, g.inv_hz), 0) : 0, z1 = gz ? min(icell(qz + rho, g.oz, g.inv_hz), g.nz - 1) : 0;
+    const float rho2 = rho * rho, slack2 = 2.0f * g.slack;
+    const int wy = y1 - y0 + 1;
+    const int nrows = (y1 >= y0 && z1 >= z0) ? wy * (z1 - z0 + 1) : 0;
+    for (int t0 = sub; t0 < nrows; t0 += 4 * G) {
+        int lo[4], hi[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            lo[k] = hi[k] = 0;
+            const int t = t0 + k * G;
+            if (t >= nrows) continue;
+            const int y = y0 + t % wy, z = z0 + t / wy;
+            float rem = rho2;
+            if (gz) {
+                const float l = g.oz + (float)z * g.h;
+                const float ez = fmaxf(fmaxf(l - qz, qz - (l + g.h)) - slack2, 0.0f);
+                rem -= ez * ez;
+            }
+            if (gy) {
+                const float l = g.oy + (float)y * g.h;
+                const float ey = fmaxf(fmaxf(l - qy, qy - (l + g.h)) - slack2, 0.0f);
+                rem -= ey * ey;
+            }
+            if (!(rem > 0.0f)) continue;
+            const float rx = fast_sqrt_up(rem) + slack2;
+            const int x0 = max(icell(qx - rx, g.ox, g.inv_h), 0), x1 = min(icell(qx + rx, g.ox, g.inv_h), g.nx - 1);
+            if (x0 > x1) continue;
+            const int row = (z * g.ny + y) * g.nx;
+            lo[k] = g.cell_start[row + x0];
+            hi[k] = g.cell_start[row + x1 + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) scan_d2x4<0>(g.pts, lo[k], hi[k], qx, qy, qz, best);
+    }
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) best = fminf(best, __shfl_xor(best, o));
+}
+
 // diagnostic: points examined.  `ctr` is an array of 256 counters, 128 bytes apart (one per cache line), indexed
 // by block: same-line atomics from every wave would serialise (~5 ns each) and dominate a fast kernel.
 __device__ __forceinline__ void add_examined(unsigned long long* ctr, unsigned cnt) {
