@@ -72,7 +72,7 @@ def segment(cloud, sv, ctx):
     return ctx.frontend_segment(cloud, sv, 45, R_SPACING)
 
 
-def cpu_baseline(tgt, l1, n1, src, l2, n2, passes=10):
+def cpu_baseline(tgt, l1, n1, src, l2, n2, passes=25, passes_mt=10):
     """The CPU oracle (single-threaded C restatement of the reference path, KD-trees rebuilt and patch normals
     recomputed at the reference's call sites) timed on this host, same inputs."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -91,7 +91,7 @@ def cpu_baseline(tgt, l1, n1, src, l2, n2, passes=10):
     mt, cores = None, min(O.max_threads(), 64)
     if cores > 1:
         O.set_num_threads(cores)
-        for _ in range(passes):
+        for _ in range(passes_mt):
             io = O.run_loop(tgt, src, P1, P2, r, r, 10 * r, 10 * r, 10 * r, 0.8 * r, faithful=True)
             if mt is None or io.t_loop_s < mt.t_loop_s:
                 mt = io
@@ -535,7 +535,7 @@ def main():
             same = (io.n_outer == res.n_outer and
                     np.abs(np.array(io.T16, dtype=np.float64) - np.array(res.T16, dtype=np.float64)).max() < 1e-5)
             out["cpu_baseline"] = {"value": round(cpu_val, 1), "unit": "correspondences/s", "cores": 1, "kind": "port",
-                                   "sample": "the full %d-pt pair loop, best of 10 passes, %.2f s per pass; single-threaded "
+                                   "sample": "the full %d-pt pair loop, best of 25 passes (~12 s of CPU work), %.2f s per pass; single-threaded "
                                              "C oracle with KD-trees rebuilt at the reference's call sites" %
                                              (args.points, io.t_loop_s),
                                    "host_cores_available": os.cpu_count(),
