@@ -708,7 +708,9 @@ __global__ void __launch_bounds__(kClsThreads) k_classify_icp0(ClassifyArgs a, i
     KT_MAX(2);
     if (f) {
         const float4 c = a.ct2[i];
-        float4 n = a.nrm2[i];
+        // (a.nrm2 == nullptr: PWICP_SOURCE_NORMALS=0, loop.hip: source_normals() - the source normals have no consumer, PCL's
+        // point-to-plane estimate reads the target's; the working arrays still get a unit vector to rotate)
+        float4 n = a.nrm2 ? a.nrm2[i] : make_float4(0.f, 0.f, 1.f, 0.f);
         if (!(np > 6 && n.w != 0.0f)) n = make_float4(0.f, 0.f, 1.f, 0.f);
         n.w = 0.f;
         const int pos = base + wave_off + in - 1;

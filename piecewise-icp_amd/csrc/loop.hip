@@ -261,6 +261,22 @@ struct pwicp_pair {
 
 namespace {
 
+// The source patch normals of an outer iteration (generateCentroidCloudWithPatchNormals for CTcloud2_withNorm, R.cpp:823-824).
+// In the reference they are DEAD values: the only reader of stableCT2's normal fields is pcl::IterativeClosestPointWithNormals,
+// whose estimator (TransformationEstimationPointToPlaneLLS, PCL 1.8.1 transformation_estimation_point_to_plane_lls.hpp) forms
+// its rows from the source POINT and the TARGET normal; the source normals are rotated along with the points
+// (transformPointCloudWithNormals) and dropped with the aligned cloud.  Nothing of them reaches T, the VCM, a count, a
+// threshold or a record.  They are computed all the same, in every iteration, as the reference does (row a5 of the path).
+// PWICP_SOURCE_NORMALS=0 leaves them out (the front launches then only move the patch points; the working normals hold the
+// (0,0,1) the reference uses for a failed fit): every result is bit-identical (tests/test_gpu_parity.py: scheduling switches)
+// and a registration of the 1 M-point pair is 2 % shorter (k_front 16.8 -> 13.2 us, k_xf_front 22.0 -> 20.2 us) - the
+// launches are bound by their slowest centroid queries and by the cloud's transform, not by the normals.
+bool source_normals() {
+    static const bool on = !(getenv("PWICP_SOURCE_NORMALS") && atoi(getenv("PWICP_SOURCE_NORMALS")) == 0);
+    return on;
+}
+
+
 // static target side once its cloud and patches are on the device: patch normals, centroid normals, grids
 int finish_target(pwicp_target* t) {
     pwicp_context* ctx = t->ctx;
@@ -716,7 +732,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         FrontInit in;
         in.slot = slot_k;
         if (run_start) { in.zero = pr->examined.p; in.n_zero = n_zero; }
-        return pw_front_launch(ctx, src_now ? pr->src_pat() : pr->P2.pat.p, pr->P2.off.p, m2, pr->nrm2.p, pr->tgt->g_ct1.d,
+        return pw_front_launch(ctx, src_now ? pr->src_pat() : pr->P2.pat.p, pr->P2.off.p, m2, source_normals() ? pr->nrm2.p : nullptr, pr->tgt->g_ct1.d,
                                src_now ? pr->src_ctbp() : pr->ctbp2.p, 7 * m2, pr->mCTBP.p, pr->dCTBP.p, fs, &in);
     };
     auto enqueue_transform = [&](unsigned* slot, const FusedSelect* fs = nullptr) {
@@ -734,9 +750,9 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     auto enqueue_xf_front = [&](unsigned* slot, const FusedSelect* fs = nullptr, const unsigned* guard = nullptr) -> int {
         FrontInit in;
         in.slot = slot + kSlot;                 // the front is the next iteration's
-        return pw_xf_front_launch(ctx, pr->src_pat(), pr->P2.pat.p, pr->P2.off.p, m2, pr->nrm2.p, pr->tgt->g_ct1.d, pr->src_ctbp(),
+        return pw_xf_front_launch(ctx, pr->src_pat(), pr->P2.pat.p, pr->P2.off.p, m2, source_normals() ? pr->nrm2.p : nullptr, pr->tgt->g_ct1.d, pr->src_ctbp(),
                                   pr->ctbp2.p, 7 * m2, pr->mCTBP.p, pr->dCTBP.p, pr->src_cloud(), pr->cloud2.p, pr->n2,
-                                  (const IcpState*)pr->icp.state.p, (const unsigned*)(slot + 2), pr->bbox_part.p, slot, fs, &in, guard);
+                                  (const IcpState*)pr->icp.state.p, (const unsigned*)(slot + 2), pr->bbox_part.p, slot, fs, &in, guard, pr->P2.tot);
     };
     // the run's LAST update and the VCM (9) in one launch (icp.hip: k_xf_vcm).  guess: enqueued before the host has seen the
     // iteration's result; the VCM part then only runs if the iteration reaches Stage 3 (currDT == LoDet_min, R.cpp:896)
@@ -826,7 +842,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         ClassifyArgs cls;
         cls.m2 = m2; cls.mCT = pr->mCTBP.p; cls.dCT = pr->dCTBP.p; cls.mBP = pr->mCTBP.p + m2; cls.dBP = pr->dCTBP.p + m2;
         cls.ctstd1 = pr->tgt->P1.ctstd.p; cls.bpstd2 = pr->P2.bpstd.p; cls.nrm1 = pr->tgt->nrm1.p; cls.ct1 = pr->tgt->P1.ct.p;
-        cls.ct1n = pr->tgt->ct1n.p; cls.ct2 = ct2; cls.bp2 = bp2; cls.nrm2 = pr->nrm2.p; cls.off2 = pr->P2.off.p;
+        cls.ct1n = pr->tgt->ct1n.p; cls.ct2 = ct2; cls.bp2 = bp2; cls.nrm2 = source_normals() ? pr->nrm2.p : nullptr; cls.off2 = pr->P2.off.p;
         cls.currDT = currDT; cls.DTmin = DTmin; cls.DTctct = DTctct;
         // (5) R.cpp:875-877: inner ICP enqueued right behind, its point count read from the slot on the device;
         // ONE host round trip returns the counts, LoD_min and the ICP state together.  Once Stage 2 is reached the
@@ -1105,14 +1121,14 @@ int pwicp_pair_step(pwicp_pair* pr, pwicp_step* sp) {
     unsigned* const slot = pr->scal.p;
     hipLaunchKernelGGL(k_scal_init, dim3(1), dim3(64), 0, ctx->stream, pr->scal.p, 1, (unsigned long long*)nullptr, 0);
     // (1) R.cpp:737-747 + source patch normals (R.cpp:824)
-    PWCHK(pw_front_launch(ctx, pr->P2.pat.p, pr->P2.off.p, m2, pr->nrm2.p, pr->tgt->g_ct1.d, pr->ctbp2.p, 7 * m2, pr->mCTBP.p,
+    PWCHK(pw_front_launch(ctx, pr->P2.pat.p, pr->P2.off.p, m2, source_normals() ? pr->nrm2.p : nullptr, pr->tgt->g_ct1.d, pr->ctbp2.p, 7 * m2, pr->mCTBP.p,
                           pr->dCTBP.p));
     // (2)-(4) R.cpp:750-871
     const float DTctct = currDT_in + 1 * (prm.SVRes1 + prm.SVRes2);
     ClassifyArgs cls;
     cls.m2 = m2; cls.mCT = pr->mCTBP.p; cls.dCT = pr->dCTBP.p; cls.mBP = pr->mCTBP.p + m2; cls.dBP = pr->dCTBP.p + m2;
     cls.ctstd1 = pr->tgt->P1.ctstd.p; cls.bpstd2 = pr->P2.bpstd.p; cls.nrm1 = pr->tgt->nrm1.p; cls.ct1 = pr->tgt->P1.ct.p;
-    cls.ct1n = pr->tgt->ct1n.p; cls.ct2 = ct2; cls.bp2 = bp2; cls.nrm2 = pr->nrm2.p; cls.off2 = pr->P2.off.p;
+    cls.ct1n = pr->tgt->ct1n.p; cls.ct2 = ct2; cls.bp2 = bp2; cls.nrm2 = source_normals() ? pr->nrm2.p : nullptr; cls.off2 = pr->P2.off.p;
     cls.currDT = currDT_in; cls.DTmin = DTmin; cls.DTctct = DTctct;
     // the same fused launch as pwicp_pair_run (classification, compaction, inner iteration 0): identical sums, identical T
     PWCHK(pw_classify_icp0_launch(ctx, cls, pr->stable.p, pr->stCT.p, pr->stN.p, &pr->icp, slot, 1e-6, nullptr));

@@ -33,7 +33,8 @@ int pw_xf_front_launch(pwicp_context* ctx, const float4* d_pat_in, float4* d_pat
                        const GridDesc& g, const float4* d_ctbp_in, float4* d_ctbp, int nq, int* d_idx, float* d_d2,
                        const float4* d_cloud_in, float4* d_cloud, int n, const IcpState* d_state, const unsigned* d_ns,
                        unsigned* d_bbox_part, unsigned* d_slot, const struct FusedSelect* fs = nullptr,
-                       const FrontInit* init = nullptr, const unsigned* d_guard = nullptr);
+                       const FrontInit* init = nullptr, const unsigned* d_guard = nullptr, int npat = 0);
+// d_nrm == nullptr (both front launches): no normals, the patch points (npat of them) are only moved
 // d_guard (optional): the launch only runs if *d_guard == 1 (the stage guard's flag, stage_dev.h)
 int pw_patch_stats_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, int m, float4* ct, float4* bp,
                           float* bpstd, float* ctstd);

@@ -329,6 +329,20 @@ __global__ void __launch_bounds__(kFrontBlock) k_front(const float4* __restrict_
     }
 }
 
+// pcl::transformPointCloud of a point array on `nb` blocks (4 coalesced requests in flight per lane)
+__device__ __forceinline__ void xf_points_block(const Mat4& T, const float4* in, float4* out, int n, int bid, int nb) {
+    const int stride = nb * kFrontBlock;
+    for (int i = bid * kFrontBlock + (int)threadIdx.x; i < n; i += 4 * stride) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * stride < n) v[u] = in[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * stride < n) out[i + u * stride] = xform_point(T.m, v[u]);
+    }
+}
+
 // Transform update (R.cpp:943-954) AND the front of the next outer iteration (R.cpp:737-747, 824) in ONE launch.  Every role
 // only needs T (read from the ICP state on the device, guarded like k_transform_all), so nothing waits for anything:
 //   normal blocks   move the points of their patches (pat_in -> pat) on the way into the covariance sums;
@@ -346,7 +360,7 @@ __global__ void __launch_bounds__(kFrontBlock) k_xf_front(const float4* pat_in, 
                                                           const float4* cloud_in, float4* cloud, int n, int nb_cloud,
                                                           const IcpState* __restrict__ st, const unsigned* __restrict__ ns_dev,
                                                           unsigned* __restrict__ bbox_part, unsigned* __restrict__ slot, FusedSelect fs,
-                                                          int nblk2, FrontInit init, const unsigned* __restrict__ guard) {
+                                                          int nblk2, FrontInit init, const unsigned* __restrict__ guard, int npat) {
     __shared__ float4 tiles[(kFrontBlock / kGroup) * kTileStride];
     front_init(init);
     static_assert(kFrontBlock == kXfBlock, "xf_cloud_block is written for this block size");
@@ -374,6 +388,11 @@ __global__ void __launch_bounds__(kFrontBlock) k_xf_front(const float4* pat_in, 
     int bid = (int)blockIdx.x - nsel - nsel2;
     if (bid < nb_nrm) {
         FT_ROLE_BEGIN(0);
+        if (!nrm_out) {                 // no consumer for the source patch normals (loop.hip: source_normals()): the points only
+            xf_points_block(T, pat_in, pat, npat, bid, nb_nrm);
+            FT_ROLE_END(0);
+            return;
+        }
         const int t = bid * kFrontBlock + threadIdx.x;
         const int i = t / kGroup;
         if (i < m) patch_normal_group<true>(pat, off, i, t % kGroup, nrm_out, tiles + (threadIdx.x / kGroup) * kTileStride, pat_in, T.m, pat);
@@ -561,10 +580,10 @@ int pw_front_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, i
     if (split < 0) { const char* e = getenv("PWICP_FRONT_SPLIT"); split = e ? atoi(e) : 0; }
     if (split) {
         if (fs && fs->scratch) PWCHK(pw_fs_pass_launch(ctx, 2, *fs));
-        PWCHK(pw_patch_normals_launch(ctx, d_pat, d_off, m, d_nrm));
+        if (d_nrm) PWCHK(pw_patch_normals_launch(ctx, d_pat, d_off, m, d_nrm));
         return pw_nn_launch(ctx, g, d_q, nq, d_idx, d_d2, nullptr);
     }
-    const int nb_nrm = div_up((long long)m * kGroup, kFrontBlock);
+    const int nb_nrm = d_nrm ? div_up((long long)m * kGroup, kFrontBlock) : 0;      // nullptr: the queries only
     const int qg = front_query_lanes(false);
     const int nb_nn = div_up((long long)nq * qg, kFrontBlock);
     FusedSelect none{};
@@ -583,8 +602,10 @@ int pw_front_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, i
 int pw_xf_front_launch(pwicp_context* ctx, const float4* d_pat_in, float4* d_pat, const int* d_off, int m, float4* d_nrm,
                        const GridDesc& g, const float4* d_ctbp_in, float4* d_ctbp, int nq, int* d_idx, float* d_d2,
                        const float4* d_cloud_in, float4* d_cloud, int n, const IcpState* d_state, const unsigned* d_ns,
-                       unsigned* d_bbox_part, unsigned* d_slot, const FusedSelect* fs, const FrontInit* init, const unsigned* d_guard) {
-    const int nb_nrm = div_up((long long)m * kGroup, kFrontBlock);
+                       unsigned* d_bbox_part, unsigned* d_slot, const FusedSelect* fs, const FrontInit* init, const unsigned* d_guard,
+                       int npat) {
+    // d_nrm == nullptr: the patch points are only moved (npat of them), on as many blocks as the cloud's share per point
+    const int nb_nrm = d_nrm ? div_up((long long)m * kGroup, kFrontBlock) : std::max(1, std::min(div_up(npat, kFrontBlock), ctx->n_cu * 4));
     const int qg = front_query_lanes(true);
     const int nb_nn = div_up((long long)nq * qg, kFrontBlock);
     const int nb_cloud = std::min(div_up(n, kFrontBlock), ctx->n_cu * 8);
@@ -594,7 +615,7 @@ int pw_xf_front_launch(pwicp_context* ctx, const float4* d_pat_in, float4* d_pat
 #define PW_XF_FRONT(SEL_, QG_, NSEL_, FS_)                                                                                          \
     hipLaunchKernelGGL((k_xf_front<SEL_, QG_>), dim3(nb_nrm + nb_nn + nb_cloud + (NSEL_)), dim3(kFrontBlock), 0, ctx->stream, d_pat_in,    \
                        d_pat, d_off, m, d_nrm, nb_nrm, g, d_ctbp_in, d_ctbp, nq, d_idx, d_d2, nb_nn, d_cloud_in, d_cloud, n, nb_cloud,    \
-                       d_state, d_ns, d_bbox_part, d_slot, FS_, kFsBlocks, fi, d_guard)
+                       d_state, d_ns, d_bbox_part, d_slot, FS_, kFsBlocks, fi, d_guard, npat)
     if (sel) { if (qg == 4) PW_XF_FRONT(true, 4, fs->nblk + kFsBlocks, *fs); else PW_XF_FRONT(true, 8, fs->nblk + kFsBlocks, *fs); }
     else { if (qg == 4) PW_XF_FRONT(false, 4, 0, none); else PW_XF_FRONT(false, 8, 0, none); }
 #undef PW_XF_FRONT

@@ -404,7 +404,9 @@ print("FINGERPRINT", h.hexdigest())
 def test_scheduling_switches_do_not_change_a_bit(tmp_path):
     """Stage guard (the Stage-1 -> Stage-2 decision on the device), speculative first dense search, fused percentile selection,
     the closing stream synchronisation, the allocation pool, the form of the dense search's far path and the lanes per front
-    query only change WHEN things are launched, by how many lanes, and where buffers come from: T, VCM, every per-iteration series and the moved source cloud are bit-identical with each of them switched off."""
+    query only change WHEN things are launched, by how many lanes, and where buffers come from: T, VCM, every per-iteration series and the moved source cloud are bit-identical with each of them switched off.
+    So they are without the per-iteration SOURCE patch normals (R.cpp:823-824): PCL's point-to-plane estimate reads the target's
+    normals only, the source's are dead values in the reference (loop.hip: source_normals())."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -416,10 +418,11 @@ def test_scheduling_switches_do_not_change_a_bit(tmp_path):
                         ("no pool, closing synchronisation", {"PWICP_POOL_MB": "0", "PWICP_RUN_SYNC": "1"}),
                         ("far queries of every dense search on their own launch", {"PWICP_DENSE_FAR_GROUP": "1"}),
                         ("far queries inside the search's blocks, 8 lanes per front query", {"PWICP_DENSE_FAR_GROUP": "0", "PWICP_FRONT_QUERY_LANES": "8"}),
-                        ("4 lanes per front query", {"PWICP_FRONT_QUERY_LANES": "4"})):
+                        ("4 lanes per front query", {"PWICP_FRONT_QUERY_LANES": "4"}),
+                        ("source patch normals left out", {"PWICP_SOURCE_NORMALS": "0"})):
         env = dict(os.environ)
         for k in ("PWICP_STAGE_GUARD", "PWICP_SPECULATE_DENSE", "PWICP_FUSED_SELECT", "PWICP_POOL_MB", "PWICP_RUN_SYNC",
-                  "PWICP_DENSE_FAR_GROUP", "PWICP_FRONT_QUERY_LANES"):
+                  "PWICP_DENSE_FAR_GROUP", "PWICP_FRONT_QUERY_LANES", "PWICP_SOURCE_NORMALS"):
             env.pop(k, None)
         env.update(extra)
         out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
