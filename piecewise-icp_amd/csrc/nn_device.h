@@ -276,7 +276,9 @@ __device__ __forceinline__ unsigned scan_points4(const float4* __restrict__ pts,
 // rows (y in [y0,y1], z in [z0,z1]) x [x0,x1], shared by the group: the lanes fetch the begin/end words of eight rows
 // at once (one row each), hand them round with shuffles, and then walk every row TOGETHER, points interleaved over the
 // lanes, four loads in flight each.  The chain is 1 + sum_rows ceil(n_row / 32) round trips, whatever the shape of
-// the box (the coarse boxes of stage 2 have few, long rows).
+// the box (the coarse boxes of stage 2 have few, long rows).  (Every lane walking its OWN row when the rows are short - the
+// boxes of stage 2 behind a stencil candidate are ~4 rows of ~5 points, tools/qstat_front.py - shortens the chain on paper and
+// lengthens the front launches by 2-3 us: four times the distinct lines per load instruction.)
 template <int G = kGroup>
 __device__ __forceinline__ unsigned scan_box_group(const GridLevel& g, int x0, int x1, int y0, int y1, int z0, int z1, int sub,
                                                    float qx, float qy, float qz, NNBest& b) {
@@ -300,6 +302,12 @@ __device__ __forceinline__ unsigned scan_box_group(const GridLevel& g, int x0, i
 // G: lanes per query (a power of two <= 8; sub = lane % G).  8 for the launches with ~10^4 queries (ICP, VCM: the chain of
 // round trips is everything), 4 where 10^5 queries share the chip with other work (the front launches: half the waves and
 // about 0.6x the instructions per query, the chain as long - a lane's two or three rows are requested together).
+#ifdef PWICP_QSTAT
+static __device__ unsigned long long pw_qstat[32];
+#define QS_ADD(i_, v_) do { if (sub == 0) atomicAdd(&pw_qstat[i_], (unsigned long long)(v_)); } while (0)
+#else
+#define QS_ADD(i_, v_) do { } while (0)
+#endif
 template <int G = kGroup>
 __device__ __forceinline__ NNBest nn_query_group(const GridDesc& gd, float qx, float qy, float qz, int sub) {
     NNBest b;
@@ -320,7 +328,7 @@ __device__ __forceinline__ NNBest nn_query_group(const GridDesc& gd, float qx, f
 #pragma unroll
         for (int i = 0; i < R; ++i) scan_points4(g.pts, lo[i], hi[i], 1, qx, qy, qz, b);
         group_min<G>(b);
-        if (nn_resolved(g, 1, b)) return b;
+        if (nn_resolved(g, 1, b)) { QS_ADD(0, 1); return b; }
     }
     const GridLevel& c = gd.coarse;
     // stage 2: candidate known -> coarse cells touching the cube [q - rho, q + rho]
@@ -330,8 +338,11 @@ __device__ __forceinline__ NNBest nn_query_group(const GridDesc& gd, float qx, f
         const int y0 = max(cell_of(qy - rho, c.oy, c.inv_hy), 0), y1 = min(cell_of(qy + rho, c.oy, c.inv_hy), c.ny - 1);
         const int z0 = max(cell_of(qz - rho, c.oz, c.inv_hz), 0), z1 = min(cell_of(qz + rho, c.oz, c.inv_hz), c.nz - 1);
         if ((y1 - y0 + 1) * (z1 - z0 + 1) <= 64) {
-            if (x0 <= x1 && y0 <= y1 && z0 <= z1) scan_box_group<G>(c, x0, x1, y0, y1, z0, z1, sub, qx, qy, qz, b);
+            unsigned qs_n = 0;
+            if (x0 <= x1 && y0 <= y1 && z0 <= z1) qs_n = scan_box_group<G>(c, x0, x1, y0, y1, z0, z1, sub, qx, qy, qz, b);
             group_min<G>(b);
+            (void)qs_n;
+            QS_ADD(1, 1); QS_ADD(8, (y1 - y0 + 1) * (z1 - z0 + 1)); QS_ADD(9, qs_n);
             return b;
         }
     }
@@ -364,6 +375,7 @@ __device__ __forceinline__ NNBest nn_query_group(const GridDesc& gd, float qx, f
             group_min<G>(b);
         }
     }
+    QS_ADD(2, 1);
     return b;
 }
 

@@ -40,6 +40,16 @@ extern "C" __attribute__((visibility("default"))) int pwicp_debug_ftrace(unsigne
     }
     return 0;
 }
+#ifdef PWICP_QSTAT
+extern "C" __attribute__((visibility("default"))) int pwicp_debug_qstat(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(pw_qstat), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long z[32];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pw_qstat), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 #else
 #define FT_ROLE_BEGIN(r_) do { } while (0)
 #define FT_ROLE_END(r_) do { } while (0)
