@@ -209,6 +209,40 @@ def series_workload(args, ctx, P, rank, world):
     ctx.close()
 
 
+def concurrent_pairs(args, P, local_rank, data, prm, expect_T16, in_flight=4):
+    """A SECOND figure beside `value`, never mixed into it: the same registration as the timed steps, `in_flight` of them side by
+    side on as many contexts (= HIP streams) from as many host threads - independent pairs of a 4D series (R.cpp:89-150) need
+    not wait for each other, and one registration is a chain of ~14 short launches that leaves most of the chip idle."""
+    import threading
+    tgt, l1, n1, src, l2, n2 = data
+    reps = max(3 * args.steps, 30)
+    ctxs = [P.Context(local_rank) for _ in range(in_flight)]
+    pairs = [P.Pair(c, tgt, l1, n1, src, l2, n2, prm) for c in ctxs]
+    last = [None] * in_flight
+
+    def loop(i, n):
+        for _ in range(n):
+            pairs[i].reset()
+            last[i] = pairs[i].run()
+
+    def side_by_side(n):
+        th = [threading.Thread(target=loop, args=(i, n)) for i in range(in_flight)]
+        t0 = time.perf_counter()
+        for t in th: t.start()
+        for t in th: t.join()
+        return time.perf_counter() - t0
+    side_by_side(5)                                  # warm-up
+    dt = side_by_side(reps)
+    same = all(list(r.T16) == list(expect_T16) for r in last)
+    corr = float(sum(r.n_corr for r in last)) * reps
+    for pr in pairs: pr.close()
+    for c in ctxs: c.close()
+    return {"in_flight": in_flight, "registrations": reps * in_flight, "ms_per_registration": round(1e3 * dt / (reps * in_flight), 4),
+            "value": round(corr / dt, 1), "unit": "correspondences/s", "results_identical_to_the_timed_steps": bool(same),
+            "note": "throughput of independent pairs on ONE GPU (one context, stream and host thread per pair in flight); `value` and "
+                    "ms_per_step above are one pair at a time"}
+
+
 def series_end_to_end(args, P, rank, world, local_rank, dist, dev, barrier):
     """BASELINE configs[3] end to end, beside the loop-only figure: ONE Direct2Ref series of `--series-epochs` source epochs of
     `--points` points (PCD files written by rank 0), its pairs dealt p -> rank p mod world, every rank going from the files through
@@ -345,6 +379,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--series-epochs", type=int, default=8,
                     help="source epochs of the end-to-end series measured beside the loop-only figure (BASELINE configs[3]); 0: skip")
+    ap.add_argument("--pairs-in-flight", type=int, default=4,
+                    help="a second, separate figure at N=1: this many registrations side by side on as many contexts; <= 1: skip")
     ap.add_argument("--no-inner-timing", action="store_true",
                     help="skip the two extra untimed steps that time the inner ICP with HIP events (kernel-trace runs: the last "
                          "step of the process is then a step as timed)")
@@ -445,6 +481,9 @@ def main():
         corr_total = float(c.item())
 
     res = results[-1]
+    side_by_side = None
+    if world == 1 and args.pairs_in_flight > 1:
+        side_by_side = concurrent_pairs(args, P, local_rank, (tgt, l1, n1, src, l2, n2), prm, res.T16, args.pairs_in_flight)
     series_line = None
     if args.series_epochs > 0:
         series_line = series_end_to_end(args, P, rank, world, local_rank, dist, dev, barrier)
@@ -528,6 +567,7 @@ def main():
             "frontend_s": round(FRONTEND_S, 3), "setup_s": round(t_setup, 3),
             "roofline": roofline,
             "series_end_to_end": series_line,
+            "pairs_side_by_side": side_by_side,
         }
         if world == 1 and not args.no_cpu_baseline:
             io, io_mt, mt_cores = cpu_baseline(tgt, l1, n1, src, l2, n2)

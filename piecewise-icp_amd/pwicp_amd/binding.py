@@ -1,7 +1,9 @@
 """ctypes binding of include/pwicp.h.  Names mirror the reference's own functions where one
 exists (calPercentileDistBetween2PC, P2PICPwithPatchNormal, calTransParaVCM, Piecewise_ICP ...)."""
+import atexit
 import ctypes as C
 import os
+import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -9,6 +11,26 @@ PWICP_MAX_OUTER = 256
 
 STATUS = {0: "OK", -1: "NO_DEVICE", -2: "INVALID", -3: "TOO_FEW_PATCHES", -4: "TOO_FEW_STABLE",
           -5: "NOMEM", -6: "INTERNAL", -7: "NOT_CONVERGED"}
+
+
+# Handles still open when the interpreter exits are closed here, dependants first (pairs, targets, series, then contexts), while
+# the HIP runtime is still up: a handle collected during interpreter shutdown - or never - would otherwise meet a runtime that
+# is already tearing down (seen as a std::bad_variant_access abort at exit with 8 contexts left open).
+_LIVE = {k: weakref.WeakSet() for k in ("pair", "target", "series", "context")}
+
+
+def _track(kind, obj):
+    _LIVE[kind].add(obj)
+
+
+@atexit.register
+def _close_all():
+    for kind in ("pair", "target", "series", "context"):
+        for obj in list(_LIVE[kind]):
+            try:
+                obj.close()
+            except Exception:
+                pass
 
 
 class PwicpError(RuntimeError):
@@ -229,6 +251,7 @@ class Series:
         if rc != 0:
             raise PwicpError(rc, "pwicp_series_open")
         self._h = h
+        _track("series", self)
         self._start = int(startEpoch)
         self.pair_mode = int(pairMode)
 
@@ -351,6 +374,7 @@ class Context:
         if rc != 0:
             raise PwicpError(rc, "pwicp_create(device %d): no usable HIP device" % device_id)
         self._h = h
+        _track("context", self)
         self.device = int(self._L.pwicp_context_device(h)) if hasattr(self._L, "pwicp_context_device") else int(device_id)
 
     def close(self):
@@ -492,6 +516,7 @@ class Target:
         ctx._chk(self._L.pwicp_target_create(ctx._h, _p(c1), len(c1), _p(l1, ip), int(nsv1), float(Res1), float(SVRes1),
                                              C.byref(h)))
         self._h = h
+        _track("target", self)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -521,6 +546,7 @@ class Pair:
             ctx._chk(self._L.pwicp_pair_create_with_target_on(ctx._h, target._h, _p(c2), len(c2), _p(l2, ip), int(nsv2),
                                                               C.byref(params), C.byref(h)))
             self._h = h
+            _track("pair", self)
             return
         c1, c2 = f4(cloud1), f4(cloud2)
         if patches is None:
@@ -537,6 +563,7 @@ class Pair:
                                                             len(off1) - 1, _p(c2), len(c2), _p(pat2), _p(off2, ip),
                                                             len(off2) - 1, C.byref(params), C.byref(h)))
         self._h = h
+        _track("pair", self)
 
     def set_profiling(self, flags):
         """PROF_DENSE = 1 (default), PROF_INNER = 2, PROF_REPLAY = 4 (include/pwicp.h)."""

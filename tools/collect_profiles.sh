@@ -7,13 +7,13 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-inner-timing --series-epochs 0"
+ARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-inner-timing --series-epochs 0 --pairs-in-flight 0"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $R/bench.py $ARGS > $OUT/bench_trace.log 2>&1
 python $R/tools/trace_last_step.py $OUT/trace > $OUT/last_step_timeline.txt 2>&1
 for G in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" \
          "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES"; do
   N=$(echo $G | cut -d' ' -f1)
-  timeout 600 rocprofv3 --pmc $G --output-format csv -d $OUT/pmc -o $N -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-inner-timing --series-epochs 0 > $OUT/pmc_$N.log 2>&1
+  timeout 600 rocprofv3 --pmc $G --output-format csv -d $OUT/pmc -o $N -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-inner-timing --series-epochs 0 --pairs-in-flight 0 > $OUT/pmc_$N.log 2>&1
 done
 # calibration of FETCH_SIZE / WRITE_SIZE on a kernel with a known byte count (k_transform_all through pwicp_pair_step)
 for N in FETCH_SIZE WRITE_SIZE; do
