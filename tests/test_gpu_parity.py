@@ -187,6 +187,51 @@ def test_pairs_of_one_target_on_two_contexts(ctx):
     ctx2.close()
 
 
+def test_four_registrations_side_by_side(ctx):
+    """Independent pairs of a series on four contexts (= streams, mailboxes, pools) of one GPU, re-registered from four host threads
+    at once (bench.py: pairs_side_by_side, tools/loop_concurrency.py): every repetition of every pair gives bit for bit what the
+    pair gives alone - T, VCM, the DT series, the per-iteration counts."""
+    import threading
+    import pwicp_amd as P
+    prm = _data.params()
+    K, REP = 4, 25
+    tgt = _data.pair(200000, epoch=1)[0]
+    lt, nt = _labels(tgt, "grid")
+    T = P.Target(ctx, tgt, lt, nt, prm.Res1, prm.SVRes1)
+    ctxs = [ctx] + [P.Context(0) for _ in range(K - 1)]
+    pairs, alone = [], []
+    for e in range(K):
+        s = _data.pair(200000, epoch=e + 1)[1]
+        l, n = _labels(s, "grid")
+        pairs.append(P.Pair(ctxs[e], None, None, 0, s, l, n, prm, target=T))
+    for pr in pairs:
+        alone.append(pr.run())
+
+    def key(r):
+        no = r.n_outer
+        return (r.status, no, list(r.T16), list(r.VCM), list(r.DTseries[:no + 1]), list(r.n_inner[:no]), list(r.n_stable[:no]))
+    bad = []
+
+    def work(i):
+        want = key(alone[i])
+        for rep in range(REP):
+            pairs[i].reset()
+            if key(pairs[i].run()) != want:
+                bad.append((i, rep))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(K)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not bad, bad
+    assert all(a.status == 0 for a in alone)
+    for pr in pairs:
+        pr.close()
+    T.close()
+    for c in ctxs[1:]:
+        c.close()
+
+
 def _loop_both(ctx, oracle, tgt, src, l1, n1, l2, n2, manual=True):
     import pwicp_amd as P
     R = _data.R
