@@ -177,25 +177,34 @@ __global__ void __launch_bounds__(kAccBlock) k_icp_iter(GridDesc g, const float4
         return;
     }
     const int bx = (int)blockIdx.x - nsel;
-    if (st->done) {                 // converged in an earlier launch of the batch: only the message is left to do
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = threadIdx.x % kGroup;
+    const int i = bx * kAccPts + threadIdx.x / kGroup;
+    // Everything the launch reads before its search is requested at once - the state's flags, the count, the previous estimate
+    // and the lane's point (ns_host bounds the arrays whether or not the count lives on the device) - instead of one
+    // dependent round trip after the other (done -> count -> point and estimate: ~1.5 us before the first cell is looked at).
+    const int done_in = st->done, iters_in = st->iters;
+    const unsigned ns_in = ns_dev ? *ns_dev : (unsigned)ns_host;
+    float Tp[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Tp[e] = st->T[e];
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), nrm = p;
+    if (i < ns_host) { p = src[i]; nrm = srcn[i]; }
+    if (done_in) {                  // converged in an earlier launch of the batch: only the message is left to do
         if (mail.dst && bx == 0) icp_send_mail(mail, st);
         return;
     }
-    const int ns = ns_dev ? (int)*ns_dev : ns_host;          // the count may live on the device (no host sync)
+    const int ns = (int)ns_in;                                // the count may live on the device (no host sync)
     if (ns <= 0) {
         if (mail.dst && bx == 0) icp_send_mail(mail, st);
         return;
     }
     if ((int)(bx * kAccPts) >= ns) return;
     if (bx == 0 && threadIdx.x == 0) KT_STAMP(16);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = threadIdx.x % kGroup;
-    const int i = bx * kAccPts + threadIdx.x / kGroup;
     double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
     if (i < ns) {
-        float4 p = src[i], nrm = srcn[i];
-        if (st->iters > 0) {       // transformPointCloudWithNormals with the previous estimate
-            p = xform_point(st->T, p);
-            nrm = xform_normal(st->T, nrm);
+        if (iters_in > 0) {        // transformPointCloudWithNormals with the previous estimate
+            p = xform_point(Tp, p);
+            nrm = xform_normal(Tp, nrm);
             if (sub == 0) { src[i] = p; srcn[i] = nrm; }
         }
         const NNBest b = nn_query_group(g, p.x, p.y, p.z, sub);
@@ -601,7 +610,9 @@ __global__ void __launch_bounds__(kClsThreads) k_classify_icp0(ClassifyArgs a, i
             for (int e = 0; e < 8; ++e) s_row[ptid][e] = row[e];
         }
     }
+    KT_MAX(14);
     __syncthreads();
+    KT_MAX(11);
     // thread (k, seg): sum k of the 28 (21 upper-triangle products row by row, 6 row * d, sum of d2 - the order of k_icp_iter)
     // over the patches of segment seg, in patch order; then the segments in order: a fixed summation order
     if (tid < kNSums * kClsSegs) {
@@ -615,21 +626,33 @@ __global__ void __launch_bounds__(kClsThreads) k_classify_icp0(ClassifyArgs a, i
         else { p_ = 7; q_ = -1; }
         double acc = 0.0;
         const int lo = seg * kClsSegLen, hi = min(lo + kClsSegLen, kClsBlock);
-        for (int r = lo; r < hi; ++r) {
-            const float u = s_row[r][p_];
-            double v;
-            if (q_ < 0) v = (double)u;                                   // d2
-            else {
-                const float w = s_row[r][q_];
+        // all LDS reads of the segment first (in flight together), then the sum in row order: the loop with a read, a product and
+        // an add per trip paid the LDS latency 29 times
+        float u_[kClsSegLen], w_[kClsSegLen];
+        const int qq = max(q_, 0);
+#pragma unroll
+        for (int j = 0; j < kClsSegLen; ++j) {
+            const int r = min(lo + j, kClsBlock - 1);
+            u_[j] = s_row[r][p_];
+            w_[j] = s_row[r][qq];
+        }
+#pragma unroll
+        for (int j = 0; j < kClsSegLen; ++j) {
+            if (lo + j < hi) {
+                const float u = u_[j], w = w_[j];
+                double v;
+                if (q_ < 0) v = (double)u;                                   // d2
                 // PCL's ATA / ATb: products among the normal's components are float products (widened afterwards), everything
                 // that involves a, b, c or d is a double product of the widened float values
-                v = (k < 21 && p_ >= 3) ? (double)(u * w) : (double)u * (double)w;
+                else v = (k < 21 && p_ >= 3) ? (double)(u * w) : (double)u * (double)w;
+                acc += v;
             }
-            acc += v;
         }
         s_part[seg][k] = acc;
     }
+    KT_MAX(12);
     __syncthreads();
+    KT_MAX(13);
     if (tid < kNSums) {
         double acc = s_part[0][tid];
 #pragma unroll

@@ -24,6 +24,9 @@ for rep in range(4):
     L.pwicp_debug_ktrace(buf, 0)
     t0 = buf[0]
     print("run %d: " % rep + " | ".join("%s +%.2f us" % (names[i], (buf[i] - t0) / 100.0) for i in range(1, 11)))
+    if buf[11]:
+        print("   classify, between `classified` and `partials stored`: rows formed +%.2f | rows in LDS (barrier) +%.2f | segment sums +%.2f | barrier +%.2f us" %
+              tuple((buf[i] - t0) / 100.0 for i in (14, 11, 12, 13)))
     # the last REAL k_icp_iter launch of the run (launches after convergence do not stamp)
     inames = {17: "NN done (last block)", 18: "partials stored (last)", 19: "last block identified", 22: "tail: partials summed",
               23: "tail: 6x6 inverted", 24: "tail: T formed", 25: "tail done"}
