@@ -24,18 +24,29 @@ struct ClassifyRow { float4 q, t, tn; float dct; };
 
 // returns the stable flag; *lod = the patch's level of detection; *row (optional): the operands of the patch's LLS row
 __device__ __forceinline__ int classify_patch(const ClassifyArgs& a, int i, float* lod, ClassifyRow* row = nullptr) {
+    // All loads that only need the patch index first (the seven matches, the patch's own points and sigma), then everything
+    // that hangs on a match (the matched patches' sigma, normals, centroids): two memory round trips, whatever order the
+    // arithmetic below consumes them in.
+    const int j = max(a.mCT[i], 0);                  // (-1 = empty target: rejected on the host before the launch)
+    int jb[6];
+    float4 b[6], nn[6], tt[6];
+    float db[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { jb[k] = max(a.mBP[6 * i + k], 0); b[k] = a.bp2[6 * i + k]; db[k] = a.dBP[6 * i + k]; }
+    const float s2 = a.bpstd2[i];
+    const float4 q = a.ct2[i];
+    const float dct = a.dCT[i];
+    const float s1 = a.ctstd1[j];
+    const float4 n = a.nrm1[j], t = a.ct1[j];
+    if (row) { row->q = q; row->t = t; row->tn = a.ct1n[j]; row->dct = dct; }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { nn[k] = a.nrm1[jb[k]]; tt[k] = a.ct1[jb[k]]; }
     // (2) level of detection, R.cpp:756-766
     const float maxLoD = a.DTmin * 2.0f, minLoD = a.DTmin;
-    const int j = max(a.mCT[i], 0);                  // (-1 = empty target: rejected on the host before the launch)
-    const float s1 = a.ctstd1[j], s2 = a.bpstd2[i];
     float LoD = (float)(1.96 * (double)sqrtf(s1 * s1 + s2 * s2));
     if (LoD > maxLoD) LoD = maxLoD; else if (LoD < minLoD) LoD = minLoD;
     *lod = LoD;
     // (3) point-to-plane distances with the matched TARGET patch normal, R.cpp:781-812
-    const float4 q = a.ct2[i];
-    const float4 n = a.nrm1[j], t = a.ct1[j];
-    const float dct = a.dCT[i];
-    if (row) { row->q = q; row->t = t; row->tn = a.ct1n[j]; row->dct = dct; }
     float resCT;
     if (n.w != 0.0f) {
         const float dx = t.x - q.x, dy = t.y - q.y, dz = t.z - q.z;
@@ -45,15 +56,6 @@ __device__ __forceinline__ int classify_patch(const ClassifyArgs& a, int i, floa
     // (4) R.cpp:826-862; `thr < dist` fails, exactly the reference's comparisons
     const float thr = (a.currDT <= LoD) ? LoD : a.currDT;
     bool pass = !(thr < resCT);
-    // the six boundary points: all index loads, then all gathers, in flight together (a chain of dependent round trips,
-    // not throughput)
-    int jb[6];
-    float4 b[6], nn[6], tt[6];
-    float db[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { jb[k] = max(a.mBP[6 * i + k], 0); b[k] = a.bp2[6 * i + k]; db[k] = a.dBP[6 * i + k]; }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { nn[k] = a.nrm1[jb[k]]; tt[k] = a.ct1[jb[k]]; }
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         float res;
