@@ -945,19 +945,22 @@ __global__ void __launch_bounds__(kVcmBlock) k_xf_vcm(GridDesc g, const float4* 
                                                       int n_pat, const IcpState* __restrict__ st, const unsigned* __restrict__ slot_ro,
                                                       unsigned* __restrict__ bbox_part, unsigned* __restrict__ slot, int nb_rest) {
     __shared__ float shb[kVcmBlock / 64][6];
-    if (!st->done || slot_ro[2] < 4u) return;
+    const int done_in = st->done;               // (flag, count, stage word and T requested together)
+    const unsigned ns_in = slot_ro[2];
     int bid = (int)blockIdx.x;
+    const unsigned stage_in = (bid < nb_vcm && stage3_bits) ? coh_load(&slot_ro[0]) : 0u;
+    Mat4 T;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) T.m[i] = st->Tfinal[i];
+    if (!done_in || ns_in < 4u) return;
     if (bid < nb_vcm) {
-        if (stage3_bits && coh_load(&slot_ro[0]) != stage3_bits) return;
+        if (stage3_bits && stage_in != stage3_bits) return;
         VT_BEGIN(0);
-        vcm_block(g, tgt, tgt_n, stct, (int)slot_ro[2], match, partials, counter, vcm, mail, bid, true);
+        vcm_block(g, tgt, tgt_n, stct, (int)ns_in, match, partials, counter, vcm, mail, bid, true);
         VT_END();
         return;
     }
     bid -= nb_vcm;
-    Mat4 T;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) T.m[i] = st->Tfinal[i];
     if (bid < nb_rest) { VT_BEGIN(1); xf_rest_block<kVcmBlock>(T, ctbp_in, ctbp, n_ctbp, pat_in, pat, n_pat, bid, nb_rest); VT_END(); return; }
     VT_BEGIN(2);
     xf_cloud_block<kVcmBlock>(T, cloud_in, cloud, n, bid - nb_rest, nb_cloud, bbox_part, slot, shb);

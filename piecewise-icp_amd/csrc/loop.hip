@@ -71,10 +71,12 @@ __global__ void __launch_bounds__(kBlock) k_transform_all(const float4* cloud_in
         return;
     }
     const int bid = (int)blockIdx.x - nsel;
-    if (!st->done || *ns_dev < 4u) return;
+    const int done_in = st->done;               // (flag, count and T requested together)
+    const unsigned ns_in = *ns_dev;
     Mat4 T;
 #pragma unroll
     for (int i = 0; i < 16; ++i) T.m[i] = st->Tfinal[i];
+    if (!done_in || ns_in < 4u) return;
     if (bid >= nb_cloud) {
         xf_rest_block(T, ctbp_in, ctbp, n_ctbp, pat_in, pat, n_pat, bid - nb_cloud, nb_work - nb_cloud);
         return;

@@ -390,11 +390,14 @@ __global__ void __launch_bounds__(kFrontBlock) k_xf_front(const float4* pat_in, 
         fs_pass_embedded<2>((unsigned*)tiles, f2, (int)blockIdx.x - nsel, fs.mail.seq);
         return;
     }
-    if (!st->done || *ns_dev < 4u) return;
-    if (guard && *guard != 1u) return;          // enqueued on the guess that this iteration ends Stage 1: the ICP tail says otherwise
+    // (flags, count, guard word and T are requested together: one round trip before the roles start instead of up to four)
+    const int done_in = st->done;
+    const unsigned ns_in = *ns_dev, guard_in = guard ? *guard : 1u;
     Mat4 T;
 #pragma unroll
     for (int i = 0; i < 16; ++i) T.m[i] = st->Tfinal[i];
+    if (!done_in || ns_in < 4u) return;
+    if (guard_in != 1u) return;                 // enqueued on the guess that this iteration ends Stage 1: the ICP tail says otherwise
     int bid = (int)blockIdx.x - nsel - nsel2;
     if (bid < nb_nrm) {
         FT_ROLE_BEGIN(0);
