@@ -228,7 +228,10 @@ struct DenseFarBuffers {
 int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pat, const int* d_qorder,
                            const int* d_pt_patch, const int* d_stable, int nq, float* d_d2,
                            unsigned long long* d_examined, const GridLevel* dense = nullptr, const int* d_qpatch = nullptr,
-                           const struct FusedSelect* fs = nullptr, struct DenseFarBuffers* far_bufs = nullptr);
+                           const struct FusedSelect* fs = nullptr, struct DenseFarBuffers* far_bufs = nullptr,
+                           const float4* d_patq = nullptr);
+// d_patq (optional, disc-pruned kernel): d_pat[d_qorder[i]] precomputed - the queries themselves in launch order
+int pw_gather_f4_launch(pwicp_context* ctx, const float4* d_src, const int* d_order, int n, float4* d_out);
 // passes 1 / 2 of the fused percentile selection (select_dev.h) as launches of their own
 int pw_fs_pass_launch(pwicp_context* ctx, int pass, const struct FusedSelect& fs);
 int pw_grid_add_dense(pwicp_context* ctx, const float4* d_pts, int n, float cell_edge, Grid* g);

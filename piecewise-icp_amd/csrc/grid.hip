@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_disc(GridLevel dl, GridDesc
                                                           const int* __restrict__ stable, int nq,
                                                           float* __restrict__ d2out,
                                                           unsigned long long* __restrict__ examined, int chunk, FusedSelect fs,
-                                                          DenseFarList fl) {
+                                                          DenseFarList fl, const float4* __restrict__ patq) {
     __shared__ unsigned s_hist[kFsBins];    // pass 0 of the percentile selection (select_dev.h), fs.scratch != nullptr only
     __shared__ float4 s_q[kBlock];          // .w carries the candidate d2 of an unresolved query
     __shared__ int s_slot[kBlock];
@@ -377,16 +377,30 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_disc(GridLevel dl, GridDesc
         __syncthreads();
     }
     if (i < nq) {
-        const int p = qorder[i], pa = qpatch[i];  // (p < 0: padding slot of a tile-ordered query list)
-        const int st = p >= 0 ? stable[pa] : 0;
-        q = pat[max(p, 0)];                       // (both gathers in flight together)
-        if (st) {
-            const float ux = PERM == 0 ? q.x : (PERM == 1 ? q.y : q.z);       // the query in the level's axis order
-            const float uy = PERM == 0 ? q.y : (PERM == 1 ? q.z : q.x);
-            const float uz = PERM == 0 ? q.z : (PERM == 1 ? q.x : q.y);
-            const int cx = cell_of(ux, dl.ox, dl.inv_h), cy = cell_of(uy, dl.oy, dl.inv_hy), cz = cell_of(uz, dl.oz, dl.inv_hz);
-            int loA, hiA;
+        // patq (the run's first search, on a source that has not moved yet): the queries lie in launch order, so the point comes
+        // with the first round trip, and the stable flag of its patch shares the second one with the words of the query's own
+        // row - one round trip less in a chain of about eight
+        const int p = patq ? 0 : qorder[i], pa = qpatch[i];  // (p < 0: padding slot of a tile-ordered query list)
+        int st = 0, loA = 0, hiA = 0, cx = 0, cy = 0, cz = 0;
+        float ux = 0.f, uy = 0.f, uz = 0.f;
+        if (patq) {
+            q = patq[i];
+            ux = PERM == 0 ? q.x : (PERM == 1 ? q.y : q.z); uy = PERM == 0 ? q.y : (PERM == 1 ? q.z : q.x); uz = PERM == 0 ? q.z : (PERM == 1 ? q.x : q.y);
+            cx = cell_of(ux, dl.ox, dl.inv_h); cy = cell_of(uy, dl.oy, dl.inv_hy); cz = cell_of(uz, dl.oz, dl.inv_hz);
             row_range(dl, cy, cz, cx - 1, cx + 1, loA, hiA);
+            st = stable[pa];
+        } else {
+            st = p >= 0 ? stable[pa] : 0;
+            q = pat[max(p, 0)];                   // (both gathers in flight together)
+        }
+        if (st) {
+            if (!patq) {
+                ux = PERM == 0 ? q.x : (PERM == 1 ? q.y : q.z);       // the query in the level's axis order
+                uy = PERM == 0 ? q.y : (PERM == 1 ? q.z : q.x);
+                uz = PERM == 0 ? q.z : (PERM == 1 ? q.x : q.y);
+                cx = cell_of(ux, dl.ox, dl.inv_h); cy = cell_of(uy, dl.oy, dl.inv_hy); cz = cell_of(uz, dl.oz, dl.inv_hz);
+                row_range(dl, cy, cz, cx - 1, cx + 1, loA, hiA);
+            }
             scan_d2x4<PERM>(dl.pts, loA, hiA, ux, uy, uz, best);
             cnt += (unsigned)(hiA - loA);
             const float rho = fast_sqrt_up(best) + 2.0f * dl.slack;
@@ -516,6 +530,12 @@ __global__ void __launch_bounds__(kBlock) k_fs_pass(FusedSelect fs) {
 __global__ void k_gather_int(const int* __restrict__ src, const int* __restrict__ order, int n, int* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = src[order[i]];
+}
+
+// the queries of the dense search themselves in launch order (static while the source has not moved)
+__global__ void k_gather_f4(const float4* __restrict__ src, const int* __restrict__ order, int n, float4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[max(order[i], 0)];
 }
 
 // Morton code (10 bits per axis) of the fine cell of each point, for the one-off query ordering
@@ -1131,6 +1151,12 @@ int pw_fs_pass_launch(pwicp_context* ctx, int pass, const FusedSelect& fs) {
     return PWICP_OK;
 }
 
+int pw_gather_f4_launch(pwicp_context* ctx, const float4* d_src, const int* d_order, int n, float4* d_out) {
+    if (n > 0) hipLaunchKernelGGL(k_gather_f4, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_src, d_order, n, d_out);
+    HIPCHK(ctx, hipGetLastError());
+    return PWICP_OK;
+}
+
 int pw_gather_int_launch(pwicp_context* ctx, const int* d_src, const int* d_order, int n, int* d_out) {
     if (n > 0) hipLaunchKernelGGL(k_gather_int, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_src, d_order, n, d_out);
     HIPCHK(ctx, hipGetLastError());
@@ -1140,7 +1166,7 @@ int pw_gather_int_launch(pwicp_context* ctx, const int* d_src, const int* d_orde
 int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pat, const int* d_qorder,
                            const int* d_pt_patch, const int* d_stable, int nq, float* d_d2,
                            unsigned long long* d_examined, const GridLevel* dense, const int* d_qpatch, const FusedSelect* fs,
-                           DenseFarBuffers* far_bufs) {
+                           DenseFarBuffers* far_bufs, const float4* d_patq) {
     if (nq <= 0) return PWICP_OK;
     const bool far_group = far_bufs != nullptr;
     DenseFarList fl{};
@@ -1159,7 +1185,7 @@ int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pa
         FusedSelect none{};
 #define PW_DENSE(PERM_, FARG_)                                                                                              \
     hipLaunchKernelGGL((k_nn_dense_disc<PERM_, FARG_>), dim3(chunk * kXcds), dim3(kBlock), 0, ctx->stream, *dense, g, d_pat, d_qorder, \
-                       d_qpatch, d_stable, nq, d_d2, d_examined, chunk, fs ? *fs : none, fl)
+                       d_qpatch, d_stable, nq, d_d2, d_examined, chunk, fs ? *fs : none, fl, d_patq)
         if (far_group) { if (dense->perm == 0) PW_DENSE(0, true); else if (dense->perm == 1) PW_DENSE(1, true); else PW_DENSE(2, true); }
         else { if (dense->perm == 0) PW_DENSE(0, false); else if (dense->perm == 1) PW_DENSE(1, false); else PW_DENSE(2, false); }
 #undef PW_DENSE

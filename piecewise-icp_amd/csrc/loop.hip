@@ -223,6 +223,7 @@ struct pwicp_pair {
     DevBuf<int> pt_patch2;   // patch id of every source patch point
     DevBuf<int> qorder;      // source patch points in Morton order of their initial target-grid cell
     DevBuf<int> qpatch;      // pt_patch2[qorder[i]]
+    DevBuf<float4> patq0;    // pat2_0[qorder[i]]: the queries of a dense search on the source as uploaded, in launch order
     const GridLevel* dense_lv = nullptr;   // small-cell level of the target this pair's dense search uses (pw_dense_level_for)
     double dense_far0 = 0.0;               // share of this pair's queries that start far from the target (same probe)
     DenseFarBuffers dense_far;             // hand-over of the far queries of a dense launch to the launch that puts 8 lanes on each
@@ -325,6 +326,8 @@ int finish_create(pwicp_pair* pr) {
     HIPCHK(ctx, pr->ctbp2_0.reserve((size_t)std::max(m2, 1) * 7));
     HIPCHK(ctx, hipMemcpyAsync(pr->cloud2_0.p, pr->cloud2.p, (size_t)pr->n2 * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(pr->pat2_0.p, pr->P2.pat.p, (size_t)pr->P2.tot * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, pr->patq0.reserve((size_t)std::max(pr->P2.tot, 1)));
+    PWCHK(pw_gather_f4_launch(ctx, pr->P2.pat.p, pr->qorder.p, pr->P2.tot, pr->patq0.p));
     HIPCHK(ctx, hipMemcpyAsync(pr->ctbp2_0.p, pr->P2.ct.p, (size_t)m2 * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(pr->ctbp2_0.p + m2, pr->P2.bp.p, (size_t)m2 * 6 * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(pr->ctbp2.p, pr->ctbp2_0.p, (size_t)m2 * 7 * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
@@ -800,9 +803,12 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
             sel_seq = ++pr->sel_mail_seq;
             fs.mail.dst = pr->mail_d + kSelMailPayload; fs.mail.seq_ptr = pr->mail_d + kSelMailSeq; fs.mail.seq = sel_seq;
         }
+        // (the source as uploaded - a reset pending, or nothing has moved it yet: the queries are at hand in launch order)
+        static const bool patq_on = !(getenv("PWICP_DENSE_QUERY_COPY") && atoi(getenv("PWICP_DENSE_QUERY_COPY")) == 0);
+        const bool unmoved = pr->lazy || !pr->dirty;
         PWCHK(pw_nn_dense_launch(ctx, pr->tgt->g_c1.d, pr->src_pat(), pr->qorder.p, pr->pt_patch2.p, pr->stable.p, pr->P2.tot,
                                  pr->d2dense.p, pr->examined.p, pr->dense_lv, pr->qpatch.p, fused ? &fs : nullptr,
-                                 far_group_now ? &pr->dense_far : nullptr));
+                                 far_group_now ? &pr->dense_far : nullptr, (patq_on && unmoved) ? pr->patq0.p : nullptr));
         if (ev) {
             HIPCHK(ctx, hipEventRecord(pr->event(n_ev + 1), ctx->stream));
             n_ev += 2;

@@ -464,10 +464,11 @@ def test_scheduling_switches_do_not_change_a_bit(tmp_path):
                         ("far queries of every dense search on their own launch", {"PWICP_DENSE_FAR_GROUP": "1"}),
                         ("far queries inside the search's blocks, 8 lanes per front query", {"PWICP_DENSE_FAR_GROUP": "0", "PWICP_FRONT_QUERY_LANES": "8"}),
                         ("4 lanes per front query", {"PWICP_FRONT_QUERY_LANES": "4"}),
-                        ("source patch normals left out", {"PWICP_SOURCE_NORMALS": "0"})):
+                        ("source patch normals left out", {"PWICP_SOURCE_NORMALS": "0"}),
+                        ("dense search gathers its queries through the order array", {"PWICP_DENSE_QUERY_COPY": "0"})):
         env = dict(os.environ)
         for k in ("PWICP_STAGE_GUARD", "PWICP_SPECULATE_DENSE", "PWICP_FUSED_SELECT", "PWICP_POOL_MB", "PWICP_RUN_SYNC",
-                  "PWICP_DENSE_FAR_GROUP", "PWICP_FRONT_QUERY_LANES", "PWICP_SOURCE_NORMALS"):
+                  "PWICP_DENSE_FAR_GROUP", "PWICP_FRONT_QUERY_LANES", "PWICP_SOURCE_NORMALS", "PWICP_DENSE_QUERY_COPY"):
             env.pop(k, None)
         env.update(extra)
         out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
