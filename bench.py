@@ -539,7 +539,7 @@ def main():
                     "valu_issue_frac": (round(valu * 4.0 / (1024 * 2.4e9 * dur_s), 3) if valu else None),
                     "note": "achieved/frac = PHYSICAL HBM bytes per launch / HIP-event time / 8 TB/s; model_gbs = SURVEY 8d's algorithmic "
                             "stream (cache hits included) for reference.  The kernel is bound by vector-ALU issue and load latency, not "
-                            "by HBM: its traffic is ~1.35x the compulsory bytes (DESIGN.md 4.1)"}
+                            "by HBM: its traffic is ~1.3x the compulsory bytes (DESIGN.md 4.1)"}
         if stale:
             roofline["stale_profile"] = stale
 

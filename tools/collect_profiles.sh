@@ -22,10 +22,10 @@ done
 # the segmentation front end (row f1): kernel statistics of one warm-up + 3 timed clouds of 1 M points
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_frontend -o fe -- python $R/bench.py --workload frontend --steps 3 > $OUT/bench_frontend_trace.log 2>&1
 cd $R
-python tools/summarize_pmc.py $OUT > $OUT/summary.log 2>&1
-cp $OUT/traffic.json profiles/traffic_latest.json      # (on the box's copy: the bench lines below then carry the traffic of THESE sources)
-timeout 600 python bench.py > $OUT/bench_plain.log 2>/dev/null
+timeout 600 python bench.py --no-cpu-baseline --series-epochs 0 --pairs-in-flight 0 > $OUT/bench_plain.log 2>/dev/null     # (its in-run duration of the dense launch goes into the summary)
 timeout 600 python bench.py --workload frontend --steps 5 > $OUT/bench_frontend.log 2>&1
 timeout 600 python bench.py --workload series --epochs 4 --points 5000000 > $OUT/bench_series.log 2>&1
 python tools/summarize_pmc.py $OUT > $OUT/summary.log 2>&1
+cp $OUT/traffic.json profiles/traffic_latest.json      # (on the box's copy: the line below then carries the traffic of THESE sources)
+timeout 600 python bench.py > $OUT/bench_final.log 2>/dev/null
 tail -5 $OUT/summary.log
