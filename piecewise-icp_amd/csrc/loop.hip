@@ -255,7 +255,8 @@ struct pwicp_pair {
     hipEvent_t event(size_t i) {
         while (ev.size() <= i) {
             hipEvent_t e;
-            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            // (timing only: no system-scope fence when the event completes)
+            if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) return nullptr;
             ev.push_back(e);
         }
         return ev[i];
