@@ -82,12 +82,18 @@ __global__ void k_ref_seed_keys(const int* __restrict__ nb, int k, int n, const 
     const int* row = nb + (size_t)i * k;
     const int li = lab[i];
     bool any = false;
-    for (int e = 0; e < k; ++e) {
-        const int j = row[e];
-        if (lab[j] != li) {
-            any = true;
-            atomicMin(&key[j], 65ull * (unsigned long long)i + (unsigned long long)(e + 1));
-        }
+    for (int e0 = 0; e0 < k; e0 += 8) {                  // (neighbours and their labels eight at a time)
+        int j[8], lj[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) j[u] = (e0 + u < k) ? row[e0 + u] : i;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) lj[u] = lab[j[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e0 + u < k && lj[u] != li) {
+                any = true;
+                atomicMin(&key[j[u]], 65ull * (unsigned long long)i + (unsigned long long)(e0 + u + 1));
+            }
     }
     if (any) atomicMin(&key[i], 65ull * (unsigned long long)i);
 }
@@ -106,11 +112,19 @@ __global__ void k_ref_seed_emit(const int* __restrict__ nb, int k, int n, const 
         if (SCATTER) out[base] = i;
         ++c;
     }
-    for (int e = 0; e < k; ++e) {
-        const int j = row[e];
-        if (lab[j] != li && key[j] == 65ull * (unsigned long long)i + (unsigned long long)(e + 1)) {
-            if (SCATTER) out[base + c] = j;
-            ++c;
+    for (int e0 = 0; e0 < k; e0 += 8) {                  // (neighbours and their labels eight at a time)
+        int j[8], lj[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) j[u] = (e0 + u < k) ? row[e0 + u] : i;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) lj[u] = lab[j[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u;
+            if (e < k && lj[u] != li && key[j[u]] == 65ull * (unsigned long long)i + (unsigned long long)(e + 1)) {
+                if (SCATTER) out[base + c] = j[u];
+                ++c;
+            }
         }
     }
     if (!SCATTER) cnt[i] = c;
@@ -853,10 +867,22 @@ __global__ void k_fus_reverse(const int* __restrict__ cen, int nc, const int* __
     if (t >= nc) return;
     const int c = cen[t];
     const int* a = arena0 + off0[c];
-    for (int e = 0, m = len0[c]; e < m; ++e) {
-        const int x0 = root0[a[e]];
-        const int at = atomicAdd(&cnt_or_cursor[x0], 1);
-        if (MODE == 1) revown[at] = c;
+    // (eight entries at a time - entries, their roots, the counters: three round trips per eight entries instead of per entry;
+    // the order inside a root's range is the atomics' order of arrival either way)
+    const int m = len0[c];
+    for (int e0 = 0; e0 < m; e0 += 8) {
+        int y[8], x0[8], at[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) y[u] = (e0 + u < m) ? a[e0 + u] : 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x0[u] = root0[y[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) at[u] = (e0 + u < m) ? atomicAdd(&cnt_or_cursor[x0[u]], 1) : 0;
+        if (MODE == 1) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + u < m) revown[at[u]] = c;
+        }
     }
 }
 __global__ void k_fus_total_absorbed(const int* __restrict__ cen, int nc, const int* __restrict__ rec_absn, int* __restrict__ per_centre,
