@@ -193,18 +193,26 @@ __global__ void k_ref_push(const int* __restrict__ L, int m, const int* __restri
         const int* row = nb + (size_t)i * k;
         const int mine = nl[p];
         const int base = MODE == 2 ? cnt[p] : 0;
-        for (int e = 0; e < k; ++e) {
-            const int j = row[e];
-            if (j == i) continue;
-            const int pj = pos[j];
-            const int b = pj < p ? nl[pj] : lab[j];
-            if (b == mine) continue;
-            if (pj != kNone && pj > p) continue;
-            const unsigned long long kk = 64ull * (unsigned long long)p + (unsigned long long)e;
-            if (MODE == 0) atomicMin(&key[j], kk);
-            else if (key[j] == kk) {
-                if (MODE == 2) out[base + c] = j;
-                ++c;
+        for (int e0 = 0; e0 < k; e0 += 8) {              // (indices, positions and labels of eight neighbours at a time)
+            int j8[8], pj8[8], b8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) j8[u] = (e0 + u < k) ? row[e0 + u] : i;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pj8[u] = pos[j8[u]];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) b8[u] = pj8[u] < p ? nl[pj8[u]] : lab[j8[u]];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u, j = j8[u], pj = pj8[u];
+                if (e >= k || j == i) continue;
+                if (b8[u] == mine) continue;
+                if (pj != kNone && pj > p) continue;
+                const unsigned long long kk = 64ull * (unsigned long long)p + (unsigned long long)e;
+                if (MODE == 0) atomicMin(&key[j], kk);
+                else if (key[j] == kk) {
+                    if (MODE == 2) out[base + c] = j;
+                    ++c;
+                }
             }
         }
     }
@@ -840,9 +848,16 @@ __global__ void k_fus_min_metric(const FePt* __restrict__ P, const int* __restri
     const int* row = nb + (size_t)i * k;
     const FePt me = P[i];
     double d = DBL_MAX;
-    for (int e = 0; e < k; ++e) {
-        const int j = row[e];
-        if (j != i) d = fmin(d, sv_metric(me, P[j], res));
+    for (int e0 = 0; e0 < k; e0 += 8) {                  // (eight neighbours in flight)
+        int j[8];
+        FePt pj[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) j[u] = (e0 + u < k) ? row[e0 + u] : i;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pj[u] = P[j[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (j[u] != i) d = fmin(d, sv_metric(me, pj[u], res));
     }
     out[i] = d;
 }
@@ -979,20 +994,34 @@ __global__ void k_fe_scatter(const float4* __restrict__ cloud, const int* __rest
     if (i >= n) return;
     const int* row = nb + (size_t)i * k;
     double m0 = 0, m1 = 0, m2 = 0, count = 0;
-    for (int e = 0; e < k; ++e) {
-        const float4 v = cloud[row[e]];
-        m0 += (double)v.x; m1 += (double)v.y; m2 += (double)v.z;
-        count += 1.0;
+    for (int e0 = 0; e0 < k; e0 += 8) {                  // (eight neighbours in flight; the sums in neighbour order)
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e0 + u < k) v[u] = cloud[row[e0 + u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e0 + u < k) {
+                m0 += (double)v[u].x; m1 += (double)v[u].y; m2 += (double)v[u].z;
+                count += 1.0;
+            }
     }
     const double to_mean = 1.0 / count;
     m0 *= to_mean; m1 *= to_mean; m2 *= to_mean;
     double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0, weight = 0;
-    for (int e = 0; e < k; ++e) {
-        const float4 v = cloud[row[e]];
-        const double d0 = (double)v.x - m0, d1 = (double)v.y - m1, d2 = (double)v.z - m2;
-        xx += d0 * d0; xy += d0 * d1; xz += d0 * d2;
-        yy += d1 * d1; yz += d1 * d2; zz += d2 * d2;
-        weight += 1.0;
+    for (int e0 = 0; e0 < k; e0 += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e0 + u < k) v[u] = cloud[row[e0 + u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e0 + u < k) {
+                const double d0 = (double)v[u].x - m0, d1 = (double)v[u].y - m1, d2 = (double)v[u].z - m2;
+                xx += d0 * d0; xy += d0 * d1; xz += d0 * d2;
+                yy += d1 * d1; yz += d1 * d2; zz += d2 * d2;
+                weight += 1.0;
+            }
     }
     const double scale = 1.0 / weight;
     double* o = S6 + (size_t)i * 6;
