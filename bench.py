@@ -310,7 +310,7 @@ def series_end_to_end(args, P, rank, world, local_rank, dist, dev, barrier):
                "rank0_scan_bytes_to_gpu": stages["scan_bytes"],
                "note": "stages of rank 0 (its share of the pairs + the shared target): reading scans, GPU preparation (voxel grid incl. the "
                        "host-side std::sort order, SOR, reduction), what is left of the front ends after that, registrations; the "
-                       "front end of a cloud (~100 ms per 1 M points of device time) is what a pair costs, the loop is 0.28 ms of it"}
+                       "front end of a cloud (~85 ms per 1 M points of device time) is what a pair costs, the loop is 0.27 ms of it"}
         shutil.rmtree(d, ignore_errors=True)
     return out
 
