@@ -8,12 +8,23 @@ import pwicp_amd as P
 import _data
 L = P.load_library()
 L.pwicp_debug_ktrace.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 ctx = P.Context(0)
-tgt, src, _ = _data.pair(n)
-l1, n1 = ctx.frontend_segment(tgt, 10 * _data.R, 45, _data.R)
-l2, n2 = ctx.frontend_segment(src, 10 * _data.R, 45, _data.R)
-pair = P.Pair(ctx, tgt, l1, n1, src, l2, n2, _data.params())
+if len(sys.argv) > 1 and sys.argv[1] == "real":          # python tools/ktrace.py real [epoch]: one of the reference's own pairs (fixtures)
+    from pwicp_amd.pcd import read_pcd
+    g = os.path.join(ROOT, "tests", "golden", "inputs")
+    e = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    tgt = ctx.preprocess(read_pcd(os.path.join(g, "Epoch_001.pcd")), 0.005, 14, 5.0)
+    src = ctx.preprocess(read_pcd(os.path.join(g, "Epoch_%03d.pcd" % e)), 0.005, 14, 5.0)
+    cen = tgt[:, :3].mean(0); tgt[:, :3] -= cen; src[:, :3] -= cen
+    l1, n1 = ctx.frontend_segment(tgt, 0.05, 45, 0.005)
+    l2, n2 = ctx.frontend_segment(src, 0.05, 45, 0.005)
+    pair = P.Pair(ctx, tgt, l1, n1, src, l2, n2, P.Params(0.005, 0.005, 0.05, 0.05, 1, 0.05, 0.004))
+else:
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+    tgt, src, _ = _data.pair(n)
+    l1, n1 = ctx.frontend_segment(tgt, 10 * _data.R, 45, _data.R)
+    l2, n2 = ctx.frontend_segment(src, 10 * _data.R, 45, _data.R)
+    pair = P.Pair(ctx, tgt, l1, n1, src, l2, n2, _data.params())
 names = ["first block starts", "classified (last block to get there)", "base known (last)", "partials stored (last)", "last block identified",
          "totals done, tail starts", "tail: partials summed", "tail: 6x6 inverted", "tail: T formed", "tail done", "mail sent"]
 for rep in range(4):
