@@ -483,7 +483,10 @@ def main():
     res = results[-1]
     side_by_side = None
     if world == 1 and args.pairs_in_flight > 1:
-        side_by_side = concurrent_pairs(args, P, local_rank, (tgt, l1, n1, src, l2, n2), prm, res.T16, args.pairs_in_flight)
+        try:
+            side_by_side = concurrent_pairs(args, P, local_rank, (tgt, l1, n1, src, l2, n2), prm, res.T16, args.pairs_in_flight)
+        except Exception as e:                 # a secondary figure must not take the metric line with it
+            side_by_side = {"error": "%s: %s" % (type(e).__name__, e)}
     series_line = None
     if args.series_epochs > 0:
         series_line = series_end_to_end(args, P, rank, world, local_rank, dist, dev, barrier)
