@@ -489,7 +489,13 @@ def main():
             side_by_side = {"error": "%s: %s" % (type(e).__name__, e)}
     series_line = None
     if args.series_epochs > 0:
-        series_line = series_end_to_end(args, P, rank, world, local_rank, dist, dev, barrier)
+        if world == 1:
+            try:
+                series_line = series_end_to_end(args, P, rank, world, local_rank, dist, dev, barrier)
+            except Exception as e:             # (a secondary figure: the metric line survives it; with several ranks a failure
+                series_line = {"error": "%s: %s" % (type(e).__name__, e)}      # must stay loud - the others would wait for this one)
+        else:
+            series_line = series_end_to_end(args, P, rank, world, local_rank, dist, dev, barrier)
     # inner-iteration timing needs two more HIP events per ICP call (a ~6 us stream bubble each): measured on two
     # extra, untimed steps so that the timed region carries only the dense-NN events of the roofline figure
     pair.set_profiling(1 | 2)
