@@ -577,10 +577,12 @@ int pw_patch_normals_launch(pwicp_context* ctx, const float4* d_pat, const int* 
 // Lanes per query of the front launches' searches (nn_device.h: nn_query_group<G>).  Measured on the 1 M-point pair: k_front
 // (queries + normals: the chain of round trips decides) 17.0 us with 8 lanes, 18.0 with 4; k_xf_front (the cloud's transform
 // shares the chip: resident blocks decide) 23.2 us with 8, 21.7 with 4, 25.6 with 2.  PWICP_FRONT_QUERY_LANES = 4 / 8 forces one for both.
-static int front_query_lanes(bool with_cloud) {
+// Few queries (the reference's own scans: 1.8 k patches, 14 k queries) leave the chip to the chains whatever else runs: 8 there
+// too (their loop on Epoch_012: 0.80 -> 0.78 ms).
+static int front_query_lanes(bool with_cloud, int nq) {
     static int v = -1;
     if (v < 0) { const char* e = getenv("PWICP_FRONT_QUERY_LANES"); v = e ? ((atoi(e) == 4 || atoi(e) == 8) ? atoi(e) : 0) : 0; }
-    return v ? v : (with_cloud ? 4 : 8);
+    return v ? v : ((with_cloud && nq >= 50000) ? 4 : 8);
 }
 
 int pw_front_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, int m, float4* d_nrm, const GridDesc& g,
@@ -597,7 +599,7 @@ int pw_front_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, i
         return pw_nn_launch(ctx, g, d_q, nq, d_idx, d_d2, nullptr);
     }
     const int nb_nrm = d_nrm ? div_up((long long)m * kGroup, kFrontBlock) : 0;      // nullptr: the queries only
-    const int qg = front_query_lanes(false);
+    const int qg = front_query_lanes(false, nq);
     const int nb_nn = div_up((long long)nq * qg, kFrontBlock);
     FusedSelect none{};
     const bool sel = fs && fs->scratch;
@@ -619,7 +621,7 @@ int pw_xf_front_launch(pwicp_context* ctx, const float4* d_pat_in, float4* d_pat
                        int npat) {
     // d_nrm == nullptr: the patch points are only moved (npat of them), on as many blocks as the cloud's share per point
     const int nb_nrm = d_nrm ? div_up((long long)m * kGroup, kFrontBlock) : std::max(1, std::min(div_up(npat, kFrontBlock), ctx->n_cu * 4));
-    const int qg = front_query_lanes(true);
+    const int qg = front_query_lanes(true, nq);
     const int nb_nn = div_up((long long)nq * qg, kFrontBlock);
     const int nb_cloud = std::min(div_up(n, kFrontBlock), ctx->n_cu * 8);
     FusedSelect none{};
