@@ -1190,8 +1190,15 @@ int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pa
         else { if (dense->perm == 0) PW_DENSE(0, false); else if (dense->perm == 1) PW_DENSE(1, false); else PW_DENSE(2, false); }
 #undef PW_DENSE
         if (far_group)
-            hipLaunchKernelGGL(k_nn_dense_far, dim3((unsigned)std::min(div_up((long long)nq * kGroup, kBlock), ctx->n_cu * 8)), dim3(kBlock), 0,
+        {
+            // blocks per CU: four, each walking its share of the list (measured on the reference's scans, 120 k far queries: loop
+            // 0.465 / 0.437 / 0.434 / 0.438 / 0.443 / 0.462 / 0.533 ms with 1 / 2 / 3 / 4 / 6 / 8 / 16 - a block's epilogue, the
+            // flush of its selection bins, costs more than a second and third pass over the list; PWICP_FAR_BLOCKS_PER_CU)
+            static int per_cu = -1;
+            if (per_cu < 0) { const char* e = getenv("PWICP_FAR_BLOCKS_PER_CU"); per_cu = e ? std::max(atoi(e), 1) : 4; }
+            hipLaunchKernelGGL(k_nn_dense_far, dim3((unsigned)std::min(div_up((long long)nq * kGroup, kBlock), ctx->n_cu * per_cu)), dim3(kBlock), 0,
                                ctx->stream, g, fl, d_d2, fs ? *fs : none);
+        }
         HIPCHK(ctx, hipGetLastError());
         return PWICP_OK;
     }
