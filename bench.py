@@ -3,7 +3,8 @@
 correspondences/s and ms per ICP iteration on a synthetic 1 M-point pair).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU; every rank registers its own source epoch of a
+  (N > 1: one rank per GPU under torch.distributed.run — the driver's launch, or, when no launcher environment is set,
+   bench.py starts the N ranks itself; a world size other than N is an error; every rank registers its own source epoch of a
    synthetic 4D series against the shared reference epoch — independent pairs, weak scaling — and the 384-byte
    result records of all steps are all-gathered over RCCL once, inside the timed region: the series' one exchange.)
 
@@ -282,9 +283,8 @@ def series_end_to_end(args, P, rank, world, local_rank, dist, dev, barrier):
         barrier()
         t0 = time.perf_counter()
         recs = series.run_pairs(mine) if mine else np.zeros(0, fourd.RECORD)
-        if dist is not None:
-            table = fourd.gather_records([recs[k:k + 1] for k in range(len(recs))], E, world, dist=dist, device=dev)
-            assert len(table) == E, "record gather incomplete"
+        table = fourd.gather_records([recs[k:k + 1] for k in range(len(recs))], E, world, dist=dist, device=dev)
+        assert len(table) == E, "record gather incomplete"
         barrier()
         wall = time.perf_counter() - t0
         stages = series.stage_times()
@@ -312,6 +312,13 @@ def series_end_to_end(args, P, rank, world, local_rank, dist, dev, barrier):
                        "host-side std::sort order, SOR, reduction), what is left of the front ends after that, registrations; the "
                        "front end of a cloud (~85 ms per 1 M points of device time) is what a pair costs, the loop is 0.27 ms of it"}
         shutil.rmtree(d, ignore_errors=True)
+        if args.dump_records:
+            # the gathered table of the series, pair order (tests compare N ranks against one rank: tests/test_gpu_configs.py);
+            # the two timing fields are not results
+            tab = np.concatenate([table[p].reshape(1) for p in range(E)])
+            tab["t_loop_ms"] = 0
+            tab["t_pair_ms"] = 0
+            np.save(args.dump_records, tab)
     return out
 
 
@@ -370,6 +377,24 @@ def frontend_workload(args, ctx, P, rank, world):
     ctx.close()
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` started by hand (no launcher environment): start the N ranks the way the driver does —
+    torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1 and a free port — and pass their exit code on."""
+    import socket
+    import subprocess
+    import uuid
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("PWICP_JOB_ID", uuid.uuid4().hex)          # the token of the library's own RCCL rendezvous (host/comm.cpp)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -391,18 +416,29 @@ def main():
                          "through one GPU (shared device-side target, one source epoch after the other: upload, patch selection, grids, "
                          "loop), per-pair wall time and the host->device rate; never mixed into the pair line's `value`")
     ap.add_argument("--epochs", type=int, default=4, help="source epochs of --workload series (BASELINE configs[4]: 4 per GPU at 5 M points)")
+    ap.add_argument("--dump-records", default=None, metavar="FILE.npy",
+                    help="rank 0 saves the gathered 384-byte records of the end-to-end series (pair order) for comparison across N")
     ap.add_argument("--single-device", action="store_true",
                     help="debug: every rank uses GPU 0 (functional check of the N>1 path on a 1-GPU box; needs --backend gloo)")
     args = ap.parse_args()
     global LABELS
     LABELS = args.labels
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        # never print an n_gpus other than the one asked for
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or let bench.py --gpus N launch the ranks itself)"
+                 % (args.gpus, world, args.gpus))
     import torch
     import pwicp_amd as P
     from pwicp_amd import fourd
+    if world > 1 and not args.single_device and torch.cuda.device_count() < world:
+        sys.exit("bench.py: --gpus %d but only %d device(s) visible (--single-device --backend gloo shares one GPU for a functional check)"
+                 % (world, torch.cuda.device_count()))
 
     dist = None
     if world > 1:

@@ -199,3 +199,15 @@ def test_series_driver_failure_on_one_rank_ends_every_rank(tmp_path):
                              capture_output=True, text=True, timeout=240, cwd=str(tmp_path))
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
         assert "RANK0_RETURNED_False" in res.stdout and "RANK1_RETURNED_False" in res.stdout
+
+
+def test_bench_refuses_a_launcher_world_other_than_gpus():
+    """bench.py --gpus N must never report fewer ranks than asked: with a launcher environment of another
+    size it exits non-zero before touching a device."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode != 0 and "--gpus 8" in p.stderr and not p.stdout.strip()

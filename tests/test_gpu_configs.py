@@ -300,3 +300,73 @@ def test_loop_parity_on_cliff_like_scenes(ctx, oracle, shape):
     io = _oracle_loop(oracle, tgt, l1, n1, src, l2, n2)
     _assert_loop_parity(res, io)
     pair.close()
+
+
+# ---- the reference's SECOND input set: data/data_synthetic/syntheticPC_no_transformations -----------------------------------
+_NT = json.load(open(os.path.join(G.GOLD, "no_transformations_expected.json")))["pairs"]
+NT_INPUTS = os.path.join(G.GOLD, "inputs_no_transformations")
+# the reference's own accuracy on the transformed set (largest entries of its TransPara_AbsError.txt: 57.1 mgon, 1.14 mm)
+NT_ANG, NT_TR = 58.0 * np.pi / 200000.0, 1.2e-3
+# pairs on which the METHOD (oracle == product) does not come back to the identity that closely: its result slides along y
+# (e2, e6, e7: 4.6 / 4.7 / 35 mm) or rests on a few hundred stable patches (e11, e16, e19) - recorded, not hidden
+NT_DRIFT = {2, 6, 7, 11, 16, 19}
+
+
+@pytest.mark.parametrize("epoch", list(range(2, 21)))
+def test_no_transformations_pairs_through_gpu(ctx, oracle, epoch):
+    """The 19 Direct2Ref pairs of the reference's untransformed series (main.cpp:27-28's call on the other folder of
+    data/data_synthetic): GPU == oracle on every discrete quantity, GPU == the committed oracle results
+    (tests/golden/no_transformations_expected.json), and the identity property: |angles|, |t| within the reference's own
+    accuracy level wherever the oracle's are."""
+    if not oracle.ref_frontend_available():
+        pytest.skip("oracle/_ref not built")
+    import pwicp_amd as P
+    from pwicp_amd.pcd import read_pcd
+    p1 = G.preprocess_4d(oracle, read_pcd(os.path.join(NT_INPUTS, "Epoch_001.pcd")))
+    p2 = G.preprocess_4d(oracle, read_pcd(os.path.join(NT_INPUTS, "Epoch_%03d.pcd" % epoch)))
+    r1, r2, shift = G.reduce_pair(p1, p2)
+    l1, n1 = oracle.ref_frontend(r1, 0.05)
+    l2, n2 = oracle.ref_frontend(r2, 0.05)
+    pair = P.Pair(ctx, r1, l1, n1, r2, l2, n2, P.Params(0.005, 0.005, 0.05, 0.05, 1, 0.05, 0.004))
+    res = pair.run(check=False)
+    io = _oracle_loop(oracle, r1, l1, n1, r2, l2, n2, r=0.005, sv=0.05, dtinit=0.05, dtmin=0.004)
+    _assert_loop_parity(res, io)
+    pair.close()
+    exp = _NT[str(epoch)]
+    k = res.n_outer
+    assert k == exp["n_outer"] and list(res.n_inner[:k]) == exp["n_inner"] and list(res.n_stable[:k]) == exp["n_stable"]
+    assert [float(v) for v in res.DTseries[:k + 1]] == exp["DTseries"]
+    Tf = G.final_matrix(res.T16, shift)
+    Te = np.array(exp["T_final"]).reshape(4, 4)
+    assert np.abs(G.euler(Tf) - G.euler(Te)).max() < 1e-5 and np.abs(Tf[:3, 3] - Te[:3, 3]).max() < 1e-4
+    if epoch not in NT_DRIFT:
+        assert np.abs(G.euler(Tf)).max() < NT_ANG and np.abs(Tf[:3, 3]).max() < NT_TR
+
+
+def test_no_transformations_series_through_the_exported_entry_point(tmp_path, ctx):
+    """PiecewiseICP_4D_call(cfg, 0, 20, 0, 0.75) on the untransformed folder, everything by the product (preprocessing, device
+    front end, loop, files): every <e>_Direct2Ref_TransMatrix.txt within 1e-5 rad / 1e-4 m of the oracle's result."""
+    import pwicp_amd as P
+    out = str(tmp_path) + "/"
+    cfg = tmp_path / "cfg.txt"
+    with open(cfg, "w") as f:
+        f.write("string FolderFilePath1: %s\nstring FolderFilePath2: %s\nbool isSetResSVsize (yes-1, no-0): 1\n"
+                "float PCres1 (m): 0.005\nfloat PCres2 (m): 0.005\nfloat SVsize1 (m): 0.05\nfloat SVsize2 (m): 0.05\n"
+                "bool isSetDTinit (yes-1, no-0): 1\nfloat DTinit (m): 0.05\nfloat DTmin (m): 0.004\nbool isVisual (yes-1, no-0): 0"
+                % (NT_INPUTS, out))
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        assert P.PiecewiseICP_4D_call(str(cfg), 0, 20, 0, 0.75) is True
+    finally:
+        os.chdir(cwd)
+    bad, near_identity = {}, 0
+    for e in range(2, 21):
+        T, _, _ = G.parse_transmatrix_file(out + "%d_Direct2Ref_TransMatrix.txt" % e)
+        Te = np.array(_NT[str(e)]["T_final"]).reshape(4, 4)
+        da, dt = float(np.abs(G.euler(T) - G.euler(Te)).max()), float(np.abs(T[:3, 3] - Te[:3, 3]).max())
+        if not (da < 1e-5 and dt < 1e-4):
+            bad[e] = (da, dt)
+        near_identity += int(np.abs(G.euler(T)).max() < NT_ANG and np.abs(T[:3, 3]).max() < NT_TR)
+    assert not bad, bad
+    assert near_identity == 19 - len(NT_DRIFT)
