@@ -1246,12 +1246,47 @@ static void msvc_sort(vg_entry* first, vg_entry* last, ptrdiff_t ideal)
     if (32 < count) msvc_heap_sort(first, last);
     else if (2 <= count) msvc_insertion_sort(first, last);
 }
+/* the library's heap sort (std::make_heap + std::sort_heap; _Pop_heap_hole_by_index: the hole sinks to the bottom along the
+ * larger child, then the value is pushed back up).  Not reached by any fixture - see piecewise-icp_amd/host/msvc_sort.h. */
+static void msvc_heap_hole(vg_entry* first, ptrdiff_t hole, ptrdiff_t bottom, vg_entry val)
+{
+    const ptrdiff_t top = hole;
+    ptrdiff_t idx = hole;
+    const ptrdiff_t max_non_leaf = (bottom - 1) / 2;
+    while (idx < max_non_leaf) {
+        idx = 2 * idx + 2;
+        if (VG_LT(first[idx], first[idx - 1])) --idx;
+        first[hole] = first[idx];
+        hole = idx;
+    }
+    if (idx == max_non_leaf && bottom % 2 == 0) {
+        first[hole] = first[bottom - 1];
+        hole = bottom - 1;
+    }
+    for (ptrdiff_t i = (hole - 1) / 2; top < hole && VG_LT(first[i], val); i = (hole - 1) / 2) {
+        first[hole] = first[i];
+        hole = i;
+    }
+    first[hole] = val;
+}
 static int g_msvc_heap_used = 0;
 static void msvc_heap_sort(vg_entry* first, vg_entry* last)
 {
-    g_msvc_heap_used = 1;                                        /* order of equal keys after a heap sort not restated */
-    qsort(first, (size_t)(last - first), sizeof(vg_entry), vg_cmp);
+    g_msvc_heap_used = 1;
+    const ptrdiff_t bottom = last - first;
+    for (ptrdiff_t hole = bottom / 2; 0 < hole;) {
+        --hole;
+        msvc_heap_hole(first, hole, bottom, first[hole]);
+    }
+    for (; 2 <= last - first; --last) {
+        vg_entry val = *(last - 1);
+        *(last - 1) = *first;
+        msvc_heap_hole(first, 0, last - 1 - first, val);
+    }
 }
+static ptrdiff_t g_msvc_budget = -1;          /* tests: initial depth budget instead of n (orc_set_msvc_sort_budget) */
+void orc_set_msvc_sort_budget(long long b) { g_msvc_budget = (ptrdiff_t)b; }
+int orc_msvc_heap_used(void) { return g_msvc_heap_used; }
 
 /* PCL: filters/impl/voxel_grid.hpp applyFilter() (downsample_all_data_, no field filter,
  * min_points_per_voxel_ = 0): ijk = floor(p * inverse_leaf) - min_b; linear index
@@ -1293,7 +1328,7 @@ int orc_voxel_grid(const float* in4, int n, float leaf, float* out4)
         e[i].pt = i;
     }
     if (g_dbg_variant & 8u) qsort(e, (size_t)n, sizeof(vg_entry), vg_cmp);      /* diagnosis: input order inside a voxel */
-    else msvc_sort(e, e + n, (ptrdiff_t)n);
+    else msvc_sort(e, e + n, g_msvc_budget >= 0 ? g_msvc_budget : (ptrdiff_t)n);
     int m = 0, i = 0;
     while (i < n) {
         int j = i;

@@ -29,6 +29,8 @@ int pwicp_create(pwicp_context** out, int device_id) {
     pwicp_context* ctx = new (std::nothrow) pwicp_context();
     if (!ctx) return PWICP_E_NOMEM;
     ctx->device = device_id;
+    ctx->pool->device = device_id;
+    PwPoolRegistry::get().add(ctx->pool);
     if (hipSetDevice(device_id) != hipSuccess) { delete ctx; return PWICP_E_NO_DEVICE; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
@@ -42,7 +44,7 @@ void pwicp_destroy(pwicp_context* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->scratch.reset();
-    if (pw_tls_ctx == ctx) pw_tls_ctx = nullptr;
+    if (pw_tls_pool.get() == ctx->pool.get()) pw_tls_pool.reset();
     if (ctx->pool) ctx->pool->trim();           // (the pool itself lives as long as a buffer of this context does)
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -25,10 +25,29 @@
 // is only ever handed out again under that context - i.e. to work on the same stream, which runs after whatever still uses
 // it.  Blocks come in size classes (<= 12.5 % above the request); the cache is capped (PWICP_POOL_MB, default 8192 per
 // context), beyond that - and when the device runs out of memory - blocks are really freed.  PWICP_POOL_MB=0: no caching.
+// Several contexts share a device (the auxiliary front-end contexts of a series worker, a streaming second context, pairs side
+// by side): every pool is listed per device (PwPoolRegistry), and an allocation that still fails after its own pool was
+// trimmed gives the cached blocks of ALL pools of that device back before it reports PWICP_E_NOMEM - memory idle in a sibling's
+// cache must not fail a request.
+struct PwPool;
+struct PwPoolRegistry {
+    std::mutex mu;
+    std::vector<std::weak_ptr<PwPool>> pools;
+    static PwPoolRegistry& get() { static PwPoolRegistry r; return r; }
+    void add(const std::shared_ptr<PwPool>& p) {
+        std::lock_guard<std::mutex> g(mu);
+        size_t k = 0;
+        for (auto& w : pools) if (!w.expired()) pools[k++] = w;      // (dead entries go as new ones come)
+        pools.resize(k);
+        pools.push_back(p);
+    }
+    inline void trim_device(int device);
+};
 struct PwPool {
     std::mutex mu;
     std::multimap<size_t, void*> free_blocks;       // capacity -> block
     size_t cached = 0, cap = 0;
+    int device = -1;                                // set when the pool's context is created (pwicp_create)
     PwPool() {
         const char* e = getenv("PWICP_POOL_MB");
         cap = (size_t)(e ? std::max(atol(e), 0L) : 8192L) << 20;
@@ -65,6 +84,11 @@ struct PwPool {
             (void)hipGetLastError();
             trim();
             e = hipMalloc(out, c);
+            if (e == hipErrorOutOfMemory) {         // ... then what the other contexts of this device keep cached
+                (void)hipGetLastError();
+                PwPoolRegistry::get().trim_device(device);
+                e = hipMalloc(out, c);
+            }
         }
         *cap_out = c;
         return e;
@@ -77,6 +101,16 @@ struct PwPool {
         (void)hipFree(p);
     }
 };
+
+inline void PwPoolRegistry::trim_device(int device) {
+    std::vector<std::shared_ptr<PwPool>> live;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto& w : pools)
+            if (auto p = w.lock()) if (p->device == device || device < 0) live.push_back(p);
+    }
+    for (auto& p : live) p->trim();                 // (a cached block is not in use by definition; hipFree waits for the device)
+}
 
 struct pwicp_context {
     int device = 0;
@@ -97,12 +131,16 @@ struct pwicp_context {
 
 #define PW_STR2(x) #x
 #define PW_STR(x) PW_STR2(x)
-// (the context a thread is working under: DevBuf::reserve takes its pool from it.  Every entry point passes through HIPCHK
-// with its context before it allocates.)
-inline thread_local pwicp_context* pw_tls_ctx = nullptr;
+// (the allocation pool a thread is working under: DevBuf::reserve takes blocks from it.  Every entry point passes through
+// HIPCHK with its context before it allocates.  The thread holds the POOL, shared, not the context: a context that another
+// thread destroys leaves nothing dangling here - its pool lives until the last holder lets go.)
+inline thread_local std::shared_ptr<PwPool> pw_tls_pool;
+inline void pw_tls_enter(pwicp_context* ctx) {
+    if (pw_tls_pool.get() != ctx->pool.get()) pw_tls_pool = ctx->pool;
+}
 #define HIPCHK(ctx, expr)                                                   \
     do {                                                                    \
-        pw_tls_ctx = (ctx);                                                 \
+        pw_tls_enter(ctx);                                                  \
         hipError_t e__ = (expr);                                            \
         if (e__ != hipSuccess) {                                            \
             (ctx)->set_err(__FILE__ ":" PW_STR(__LINE__) " " #expr, e__);   \
@@ -148,8 +186,8 @@ struct DevBuf {
         release();
         if (count == 0) count = 1;
         hipError_t e;
-        if (pw_tls_ctx && pw_tls_ctx->pool && pw_tls_ctx->pool->cap > 0) {
-            pool = pw_tls_ctx->pool;
+        if (pw_tls_pool && pw_tls_pool->cap > 0) {
+            pool = pw_tls_pool;
             e = pool->take(count * sizeof(T), (void**)&p, &cap_bytes);
             if (e != hipSuccess) { p = nullptr; pool.reset(); cap_bytes = 0; }
         } else {

@@ -860,14 +860,23 @@ __device__ __forceinline__ void vcm_block(const GridDesc& g, const float4* __res
         }
         wave_sync();
         if (t == 0) {
-            // v^T v with v = A x - L, x = Qxx A^T L:  v^T v = L^T L - x^T (A^T L)  (normal equations) - no second pass over the
-            // points.  The two terms cancel when the fit explains nearly all of L; then (and only then: never at the end of a
-            // registration, where x ~ 0) the residuals are formed point by point below, as the reference does (R.cpp:1331-1333).
-            double xtl = 0.0;
+            // v^T v with v = A x - L from the sums of the first pass - no second pass over the points:
+            //     v^T v = L^T L - 2 x^T (A^T L) + x^T (A^T A) x.
+            // The quadratic form, not its simplification L^T L - x^T A^T L (valid at the exact solution only): its gradient in x
+            // vanishes at the least-squares solution, so an error of x - which grows with cond(A^T A) - enters in SECOND order and
+            // what is left is the rounding of the sums, ~1e-16 L^T L.  The terms cancel when the fit explains nearly all of L;
+            // below 1e-3 L^T L (relative error of v^T v <= ~1e-13 above it; never at the end of a registration, where x ~ 0) the
+            // residuals are formed point by point below, as the reference does (R.cpp:1331-1333).
+            double xtl = 0.0, xax = 0.0;
             for (int c = 0; c < 6; ++c) xtl += xs[c] * sums[21 + c];
-            const double vv_id = sums[27] - xtl;
+            for (int r = 0; r < 6; ++r) {
+                double row = 0.0;
+                for (int c = 0; c < 6; ++c) row += A[r][c] * xs[c];
+                xax += xs[r] * row;
+            }
+            const double vv_id = (sums[27] - 2.0 * xtl) + xax;
             s_vv = vv_id;
-            s_explicit = (vv_id > 1e-4 * sums[27]) ? 0 : 1;
+            s_explicit = (vv_id > 1e-3 * sums[27]) ? 0 : 1;
 #ifdef PWICP_KTRACE
             pw_ktrace[20] = (unsigned long long)s_explicit; pw_ktrace[21] = (unsigned long long)__double_as_longlong(vv_id / sums[27]);
 #endif

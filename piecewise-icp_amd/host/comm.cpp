@@ -63,11 +63,10 @@ Rccl g_rccl;
 // what every rank of one launch shares and no other launch does
 uint64_t job_token() {
     std::string t;
+    // launcher-agnostic: nothing of the process tree goes in (ranks started through per-rank wrappers, `mpirun bash -c`, a
+    // container exec have different parents); $PWICP_JOB_ID tells two launches apart that share address, port and world size
     if (const char* e = std::getenv("PWICP_JOB_ID")) t = e;
-    else {
-        if (const char* r = std::getenv("TORCHELASTIC_RUN_ID")) t = r;
-        t += "/ppid=" + std::to_string((long)getppid());
-    }
+    else if (const char* r = std::getenv("TORCHELASTIC_RUN_ID")) t = r;
     for (const char* k : {"MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE"})
         if (const char* e = std::getenv(k)) { t += "/"; t += e; }
     uint64_t h = 1469598103934665603ull;                 // FNV-1a
@@ -105,6 +104,15 @@ int read_id_file(const std::string& path, ncclUniqueId* id) {
     IdFile f;
     const bool ok = read(fd, &f, sizeof(f)) == (ssize_t)sizeof(f);
     close(fd);
+    if (ok && f.magic == kIdMagic && f.token != job_token()) {
+        static bool told = false;
+        if (!told) {
+            told = true;
+            std::cerr << "pwicp: " << path << " holds the id of another launch (job token differs) - waiting for this launch's; if "
+                         "the ranks of ONE launch see different $PWICP_JOB_ID / $TORCHELASTIC_RUN_ID / MASTER_ADDR / MASTER_PORT / "
+                         "WORLD_SIZE, export one PWICP_JOB_ID for all of them\n";
+        }
+    }
     if (!ok || f.magic != kIdMagic || f.token != job_token()) return 0;                 // another job's, or a torn write
     if ((int64_t)std::time(nullptr) - f.written_at > kIdMaxAgeSeconds) return 0;        // left behind by an earlier run
     *id = f.id;
@@ -253,11 +261,13 @@ PWICP_API bool pwicp_series_run_distributed(const char* confile, int startEpoch,
             if (const char* e = getenv("PWICP_ADAPTIVE_WINDOW")) W = std::max(1, atoi(e));
             std::vector<float> mine_tab((size_t)nf * nf, NAN);
             {
-                std::vector<int32_t> ij;
-                int p = 0;
+                // dealt in CONTIGUOUS blocks of the (source, target) order: a rank reads the scans of its block of sources plus
+                // the W before it, and its scan cache (bounded, registration.cpp: series_overlap) walks along with it
+                std::vector<int32_t> all_ij, ij;
                 for (int j = startEpoch + 1; j < nf; ++j)
-                    for (int i = std::max(startEpoch, j - W); i < j; ++i, ++p)
-                        if (p % world == rank) { ij.push_back(i); ij.push_back(j); }
+                    for (int i = std::max(startEpoch, j - W); i < j; ++i) { all_ij.push_back(i); all_ij.push_back(j); }
+                const long long nc = (long long)(all_ij.size() / 2);
+                for (long long p = nc * rank / world; p < nc * (rank + 1) / world; ++p) { ij.push_back(all_ij[2 * p]); ij.push_back(all_ij[2 * p + 1]); }
                 std::vector<float> r(ij.size() / 2 + 1);
                 ok = pwicp_series_overlap_ratios(s, ij.data(), (int)(ij.size() / 2), r.data()) == PWICP_OK;
                 for (size_t k = 0; ok && k < ij.size() / 2; ++k) mine_tab[(size_t)ij[2 * k] * nf + ij[2 * k + 1]] = r[k];

@@ -11,7 +11,11 @@
 //
 // The algorithm restated here is the published structure of that library's std::sort: introsort with a depth budget that
 // shrinks by 3/4 per level, a "fat" three-way partition around a median-of-three (ninther above 40 elements) pivot guess that
-// gathers the pivot's equals in the middle, recursion into the smaller side, insertion sort at <= 32 elements.
+// gathers the pivot's equals in the middle, recursion into the smaller side, insertion sort at <= 32 elements; a sub-range
+// whose depth budget runs out is heap-sorted (make_heap bottom-up through "hole to the bottom along the larger child, then push
+// the value back up", then pop after pop) - restated below from the same library's published <algorithm>; unlike the
+// introsort part, which the reference's 57 result files vouch for, no fixture reaches it (it takes an adversarial key
+// sequence), so product and oracle are only held to EACH OTHER there (tests/test_host_stages.py, budget forced small).
 // Entries are sorted in place; `less` must be a strict weak order.
 #ifndef PWICP_HOST_MSVC_SORT_H
 #define PWICP_HOST_MSVC_SORT_H
@@ -103,6 +107,45 @@ void insertion_sort(T* first, T* last, Less& less) {
     }
 }
 
+// _Pop_heap_hole_by_index: the hole sinks to the bottom along the larger child, then `val` is pushed up from there
+template <typename T, typename Less>
+void heap_hole(T* first, std::ptrdiff_t hole, std::ptrdiff_t bottom, T val, Less& less) {
+    const std::ptrdiff_t top = hole;
+    std::ptrdiff_t idx = hole;
+    const std::ptrdiff_t max_non_leaf = (bottom - 1) / 2;
+    while (idx < max_non_leaf) {
+        idx = 2 * idx + 2;
+        if (less(first[idx], first[idx - 1])) --idx;
+        first[hole] = first[idx];
+        hole = idx;
+    }
+    if (idx == max_non_leaf && bottom % 2 == 0) {          // only child at the bottom
+        first[hole] = first[bottom - 1];
+        hole = bottom - 1;
+    }
+    for (std::ptrdiff_t i = (hole - 1) / 2; top < hole && less(first[i], val); i = (hole - 1) / 2) {
+        first[hole] = first[i];
+        hole = i;
+    }
+    first[hole] = val;
+}
+
+// std::make_heap + std::sort_heap of that library (the fall-back of its std::sort)
+template <typename T, typename Less>
+void heap_sort(T* first, T* last, Less& less) {
+    const std::ptrdiff_t bottom = last - first;
+    for (std::ptrdiff_t hole = bottom / 2; 0 < hole;) {
+        --hole;
+        T val = first[hole];
+        heap_hole(first, hole, bottom, val, less);
+    }
+    for (; 2 <= last - first; --last) {
+        T val = *(last - 1);
+        *(last - 1) = *first;
+        heap_hole(first, (std::ptrdiff_t)0, last - 1 - first, val, less);
+    }
+}
+
 // Task pool for the independent sides of a partition (the order of the result does not depend on the schedule: every
 // sub-range is sorted by the same sequential procedure, whoever runs it).
 template <typename T, typename Less>
@@ -110,16 +153,17 @@ class Sorter {
   public:
     Sorter(Less less, int threads) : less_(less), nthreads_(std::max(threads, 1)) {}
 
-    // returns false if the depth budget ran out somewhere (the library falls back to a heap sort there, whose order of equal
-    // keys is not restated: the caller then has to take its documented fall-back)
-    bool sort(T* first, T* last) {
+    // budget: the library's initial depth budget is the element count; a smaller one (tests) makes sub-ranges take the
+    // heap-sort fall-back.  Always returns true (kept for the callers' documented fall-back, which nothing reaches any more).
+    bool sort(T* first, T* last, std::ptrdiff_t budget = -1) {
         ok_.store(true);
+        if (budget < 0) budget = last - first;
         if (nthreads_ == 1 || last - first < kParallelMin) {
-            run(first, last, last - first, false);
+            run(first, last, budget, false);
             return ok_.load();
         }
         pending_.store(1);
-        push(Task{first, last, last - first});
+        push(Task{first, last, budget});
         std::vector<std::thread> th;
         for (int t = 0; t < nthreads_; ++t) th.emplace_back([this] { worker(); });
         for (auto& t : th) t.join();
@@ -166,7 +210,7 @@ class Sorter {
                 run(of, ol, ideal, spawn);
             }
         }
-        if (kInsertionMax < count) ok_.store(false);
+        if (kInsertionMax < count) heap_sort(first, last, less_);
         else if (2 <= count) insertion_sort(first, last, less_);
     }
 
@@ -180,9 +224,9 @@ class Sorter {
 };
 
 template <typename T, typename Less>
-bool sort(T* first, T* last, Less less, int threads = 1) {
+bool sort(T* first, T* last, Less less, int threads = 1, std::ptrdiff_t budget = -1) {
     Sorter<T, Less> s(less, threads);
-    return s.sort(first, last);
+    return s.sort(first, last, budget);
 }
 
 }  // namespace msvc_order

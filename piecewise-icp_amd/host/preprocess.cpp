@@ -33,7 +33,10 @@ bool voxel_order_is_msvc() {
 // (voxel index, point) entries -> the order pcl::VoxelGrid's std::sort leaves them in.  false: the sort's depth budget ran
 // out (adversarial input); `e` then holds a permutation in an unspecified state and the caller sorts it stably instead.
 bool voxel_sort_msvc(VoxelEntry* e, size_t n) {
-    return msvc_order::sort(e, e + n, [](const VoxelEntry& a, const VoxelEntry& b) { return a.idx < b.idx; }, host_threads());
+    // $PWICP_MSVC_SORT_BUDGET (tests only): initial depth budget of the introsort instead of n, so that the heap-sort fall-back runs
+    std::ptrdiff_t budget = -1;
+    if (const char* b = std::getenv("PWICP_MSVC_SORT_BUDGET")) budget = (std::ptrdiff_t)std::atoll(b);
+    return msvc_order::sort(e, e + n, [](const VoxelEntry& a, const VoxelEntry& b) { return a.idx < b.idx; }, host_threads(), budget);
 }
 
 // returns the number of output points; out must hold n points

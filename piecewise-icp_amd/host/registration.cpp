@@ -9,6 +9,7 @@
 // calTransToReferenceEpoch Registration.cpp:977-1153, calAbsErrorOfTransPara Registration.cpp:1157-1251.
 // Pipeline per pair: load PCD -> VoxelGrid + SOR -> subtract the target centroid -> supervoxel labels (host front
 // end) -> pwicp_pair_create / pwicp_pair_run (the fine-registration loop on the GPU) -> T_final = S^-1 T S -> files.
+#include <algorithm>
 #include <chrono>
 #include <climits>
 #include <cmath>
@@ -550,7 +551,8 @@ struct pwicp_series {
     std::mutex stage_mu;
     double stage_ms[4] = {0, 0, 0, 0};    // wall time spent so far: reading scans | GPU preparation | front ends (rest) | registrations
     long long stage_bytes = 0;            // bytes of raw scans handed to the GPU
-    std::vector<std::vector<float>> scan_cache;   // raw scans read for the overlap ratios, dropped once the map is known
+    std::vector<std::vector<float>> scan_cache;   // raw scans read for the overlap ratios: at most scan_cache_cap() at a time,
+    std::vector<int> scan_lru;                    // least recently used first; all dropped once the map is known
     std::vector<std::unique_ptr<SeriesWorker>> workers;      // [0] = `device`; more after pwicp_series_set_devices
 
     SeriesWorker* w0() {
@@ -573,9 +575,28 @@ bool series_overlap(pwicp_series* s, int i, int j, float* ratio) {
     if (!s->w0()->need_ctx()) return false;
     const int fileCount = (int)s->files.size();
     if (i < 0 || j < 0 || i >= fileCount || j >= fileCount) return false;
-    if ((int)s->scan_cache.size() != fileCount) s->scan_cache.assign((size_t)fileCount, {});
-    auto cloud = [&](int f) -> std::vector<float>& { if (s->scan_cache[(size_t)f].empty()) load_pcd(s->files[(size_t)f], &s->scan_cache[(size_t)f]); return s->scan_cache[(size_t)f]; };
-    std::vector<float>&a = cloud(i), &b = cloud(j);
+    if ((int)s->scan_cache.size() != fileCount) { s->scan_cache.assign((size_t)fileCount, {}); s->scan_lru.clear(); }
+    // The candidates of a source j are the W targets before it (R.cpp:593-614) and callers walk the sources in order (a rank of a
+    // sharded run walks ITS contiguous block of them, host/comm.cpp): W + 2 scans cover the working set, whatever the series'
+    // length - a few hundred 5 M-point epochs must not end up resident in every rank ($PWICP_SCAN_CACHE: scans kept, >= 2).
+    static const int cap = [] { const char* e = getenv("PWICP_SCAN_CACHE"); return std::max(2, e ? atoi(e) : 8); }();
+    auto cloud = [&](int f, int keep) -> std::vector<float>& {
+        auto it = std::find(s->scan_lru.begin(), s->scan_lru.end(), f);
+        if (it != s->scan_lru.end()) s->scan_lru.erase(it);
+        else {
+            while ((int)s->scan_lru.size() >= cap) {
+                auto victim = s->scan_lru.begin();
+                if (*victim == keep) ++victim;
+                std::vector<float>().swap(s->scan_cache[(size_t)*victim]);
+                s->scan_lru.erase(victim);
+            }
+            load_pcd(s->files[(size_t)f], &s->scan_cache[(size_t)f]);
+        }
+        s->scan_lru.push_back(f);
+        return s->scan_cache[(size_t)f];
+    };
+    std::vector<float>& a = cloud(i, j);
+    std::vector<float>& b = cloud(j, i);
     return pwicp_overlap_ratio(s->w0()->ctx, a.data(), (int)(a.size() / 4), b.data(), (int)(b.size() / 4), s->cfg.DTinit, ratio) == PWICP_OK;
 }
 
@@ -596,9 +617,9 @@ bool adaptive_pair_sequence(pwicp_series* s, float overlapThd, const std::string
         }
         s->regPairs[j - startEpoch] = idxTarget - startEpoch;
         std::cout << "Pair: " << idxTarget - startEpoch << " - " << j - startEpoch << ";  Overlap ratio = " << 100 * ratio << "% \n";
-        if (idxTarget > startEpoch && !s->scan_cache.empty()) std::vector<float>().swap(s->scan_cache[(size_t)idxTarget - 1]);   // never read again
     }
     std::vector<std::vector<float>>().swap(s->scan_cache);
+    s->scan_lru.clear();
     if (!pairFile.empty()) {
         std::ofstream pf(pairFile);
         if (!pf) { std::cerr << "Error: Cannot open adaptivePairFile!\n"; return false; }

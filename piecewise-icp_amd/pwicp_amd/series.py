@@ -70,7 +70,8 @@ def run_series(confile, start_epoch, epoch_num, pair_mode, overlap_thd=0.75, bac
                 nf = series.num_scans
                 W = max(1, int(os.environ.get("PWICP_ADAPTIVE_WINDOW", "6")))
                 cand = [(i, j) for j in range(start_epoch + 1, nf) for i in range(max(start_epoch, j - W), j)]
-                mine_ij = [c for p, c in enumerate(cand) if p % world == rank]
+                # contiguous blocks of the (source, target) order: a rank reads its block of sources + the W scans before it
+                mine_ij = cand[len(cand) * rank // world: len(cand) * (rank + 1) // world]
                 table = np.full((nf, nf), np.nan, np.float32)
                 if mine_ij:
                     r = series.overlap_ratios(mine_ij)

@@ -148,6 +148,38 @@ def test_vcm_when_the_fit_explains_nearly_everything(ctx, oracle):
     assert np.allclose(Vg.reshape(36), Vo, rtol=1e-8, atol=1e-22)
 
 
+def test_vcm_on_an_ill_conditioned_patch_layout(ctx, oracle):
+    """v^T v from the sums must not lose digits when A^T A is ill-conditioned.  Target centroids on a strip 5 m long
+    and 2 cm wide with nearly parallel normals (the rotation about the strip's axis and two translations are barely
+    constrained: cond(A^T A) ~ 1e9 and more), sources = targets + noise (v^T v / L^T L ~ 1: the branch that uses the sums) and
+    sources = targets + a tiny rigid motion (ratio ~ 0: the point-by-point branch).  Both against the oracle's explicit residuals
+    (R.cpp:1331-1333) at the tolerance of the well-conditioned test."""
+    rng = np.random.default_rng(7)
+    m = 3000
+    ct = np.zeros((m, 4), np.float32)
+    ct[:, 0] = rng.uniform(0, 5, m)
+    ct[:, 1] = rng.uniform(0, 0.02, m)
+    ct[:, 2] = 0.05 * np.sin(ct[:, 0])
+    ct[:, 3] = 1.0
+    nrm = np.zeros((m, 4), np.float32)
+    nrm[:, 0] = -0.05 * np.cos(ct[:, 0]) + rng.normal(0, 1e-3, m)
+    nrm[:, 1] = rng.normal(0, 1e-3, m)
+    nrm[:, 2] = 1.0
+    nrm[:, :3] /= np.linalg.norm(nrm[:, :3], axis=1)[:, None]
+    for moved in ((ct[:, :3] + rng.normal(0, 2e-3, (m, 3))).astype(np.float32),
+                  (ct[:, :3] + np.array([1e-5, 0, 2e-5])).astype(np.float32)):
+        Vg = ctx.calTransParaVCM(ct, nrm, moved)
+        Vo = np.zeros(36)
+        oracle.lib().orc_cal_trans_para_vcm(oracle._p(oracle.f4(ct)), oracle._p(oracle.f4(nrm)), m,
+                                            oracle._p(oracle.f4(moved)), len(moved), oracle._p(Vo, oracle.dp))
+        assert np.isfinite(Vg).all() and np.isfinite(Vo).all()
+        # sigma0^2 scales the whole matrix: compare it through the diagonal, to 1e-8 relative whatever the conditioning ...
+        d_g, d_o = np.diag(Vg.reshape(6, 6)), np.diag(Vo.reshape(6, 6))
+        assert np.allclose(d_g, d_o, rtol=1e-8, atol=0)
+        # ... and the ratio of any two entries is Qxx's, which both sides invert with the same LU
+        assert np.allclose(Vg.reshape(36) / d_g[0], Vo / d_o[0], rtol=1e-7, atol=1e-12 * np.abs(Vo / d_o[0]).max())
+
+
 def test_pairs_of_one_target_on_two_contexts(ctx):
     """pwicp_pair_create_with_target_on: the pairs of a shared target may live on other contexts (= streams) of its device; a pair
     created and run on a second context while another one runs on the first gives bit for bit what it gives alone."""

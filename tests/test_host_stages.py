@@ -23,6 +23,38 @@ def test_preprocess_matches_oracle(oracle):
         assert len(a) < len(cloud)
 
 
+def test_voxel_grid_heap_sort_fallback_of_the_std_sort_order(oracle, monkeypatch):
+    """pcl::VoxelGrid sums the points of a voxel in the order MSVC's std::sort leaves them in (host/msvc_sort.h).  Where that
+    sort's depth budget runs out it heap-sorts the sub-range: unreachable with the fixtures, so the budget is forced small here
+    (product: $PWICP_MSVC_SORT_BUDGET, oracle: orc_set_msvc_sort_budget).  Product == oracle bit for bit on every budget, the
+    heap sort really ran, and the centroids then DIFFER in last bits from the full-budget ones (the order matters: that is why
+    the fall-back is restated instead of replaced by input order)."""
+    import ctypes as C
+    import pwicp_amd as P
+    tgt, _, _ = _data.pair(60000, reduce=False)
+    rng = np.random.default_rng(3)
+    cloud = np.vstack([tgt, tgt + rng.normal(0, 0.002, tgt.shape).astype(np.float32)])       # several points per voxel
+    L = oracle.lib()
+    L.orc_set_msvc_sort_budget.argtypes = [C.c_longlong]
+    L.orc_set_msvc_sort_budget.restype = None
+    L.orc_msvc_heap_used.restype = C.c_int
+    full = oracle.voxel_grid(cloud, 0.02)
+    outs = []
+    try:
+        for budget in (0, 1, 8, 200):
+            L.orc_set_msvc_sort_budget(budget)
+            monkeypatch.setenv("PWICP_MSVC_SORT_BUDGET", str(budget))
+            b = oracle.voxel_grid(cloud, 0.02)
+            a = P.preprocess(cloud, 0.02, 14, 1.0e9)            # (a multiplier no point exceeds: SOR keeps everything)
+            assert L.orc_msvc_heap_used() == 1
+            assert a.shape == b.shape == full.shape and np.array_equal(a, b), budget
+            assert np.allclose(a, full, rtol=0, atol=1e-5)
+            outs.append(a)
+    finally:
+        L.orc_set_msvc_sort_budget(-1)
+    assert any(not np.array_equal(o, full) for o in outs)
+
+
 def test_preprocess_voxel_index_overflow_passes_the_cloud_through(oracle):
     """pcl::VoxelGrid (PCL 1.8.1): a leaf whose voxel indices would overflow int32 -> warning, output = input; the
     reference then runs SOR on the full cloud (C.cpp:423-439).  Same here, and SORfilter alone
