@@ -218,6 +218,7 @@ struct GridLevel {
                              // Only the small-cell levels of the dense search use 1 / 2 (pw_grid_add_dense).
     const int* cell_start;   // nx*ny*nz + 1 entries
     const float4* pts;       // sorted by cell; w = __int_as_float(original index)
+    const float* pts3;       // the same points packed x, y, z (12 B each): levels of the dense search only, else nullptr
 };
 
 // Two levels over the same points: `fine` serves the common 27-cell stencil, `coarse` (2x the edge) resolves
@@ -236,17 +237,20 @@ struct Grid {
     bool has_dense = false;
     DevBuf<int> dcell_start;
     DevBuf<float4> dpts;
+    DevBuf<float> dpts3;
     // when `fine` is a grid of cells: the same small cells as columns, for pairs whose queries lie on gentle parts
     GridLevel dense_alt{};
     bool has_dense_alt = false;
     DevBuf<int> acell_start;
     DevBuf<float4> apts;
+    DevBuf<float> apts3;
     // ... and with other axis roles (rows along y or z, columns along x): a face that no layout on (x, y, z) fits
     struct Extra {
         GridLevel lv{};
         bool has = false;
         DevBuf<int> cell_start;
         DevBuf<float4> pts;
+        DevBuf<float> pts3;
     } extra[3];
 };
 
@@ -277,7 +281,7 @@ int pw_grid_add_dense(pwicp_context* ctx, const float4* d_pts, int n, float cell
 int pw_dense_level_for(pwicp_context* ctx, const Grid& g, const float4* d_q, int nq, const GridLevel** out, double* far_frac = nullptr);
 // out[i] = src[order[i]]
 int pw_gather_int_launch(pwicp_context* ctx, const int* d_src, const int* d_order, int n, int* d_out);
-int pw_morton_order(pwicp_context* ctx, const GridDesc& g, const float4* d_pts, int n, DevBuf<int>* order);
+int pw_morton_order(pwicp_context* ctx, const GridDesc& g, const float4* d_pts, int n, DevBuf<int>* order, const GridLevel* strip_lv = nullptr);
 int pw_bbox(pwicp_context* ctx, const float4* d_pts, int n, float mn[3], float mx[3]);
 int pw_check_finite(pwicp_context* ctx, const float4* d_pts, int n);
 int pw_knn_launch(pwicp_context* ctx, const GridDesc& g, int k, int* d_nb);

@@ -360,12 +360,16 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_disc(GridLevel dl, GridDesc
                                                           const int* __restrict__ stable, int nq,
                                                           float* __restrict__ d2out,
                                                           unsigned long long* __restrict__ examined, int chunk, FusedSelect fs,
-                                                          DenseFarList fl, const float4* __restrict__ patq) {
+                                                          DenseFarList fl, const float4* __restrict__ patq, int sub) {
     __shared__ unsigned s_hist[kFsBins];    // pass 0 of the percentile selection (select_dev.h), fs.scratch != nullptr only
     __shared__ float4 s_q[kBlock];          // .w carries the candidate d2 of an unresolved query
     __shared__ int s_slot[kBlock];
     __shared__ int s_wcnt[kBlock / 64];
-    const int tile = chunk > 0 ? (int)(blockIdx.x % kXcds) * chunk + (int)(blockIdx.x / kXcds) : (int)blockIdx.x;
+    // block b runs on XCD b % 8: the XCDs take the ordered tiles in runs of `sub`.  One contiguous eighth of the list per XCD
+    // (round 3) left the kernel waiting for the XCD whose eighth happened to be the expensive one (TA_BUSY max / mean 1.7 over
+    // the CUs): 47.2 us -> 41.1 us with runs of four tiles; L2 locality does not show (runs of 1: 41.6, of 64: 44.7).
+    const int xr = (int)(blockIdx.x / kXcds);
+    const int tile = chunk > 0 ? (xr / sub) * (kXcds * sub) + (int)(blockIdx.x % kXcds) * sub + xr % sub : (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = tile * kBlock + tid;
     unsigned cnt = 0;
@@ -401,14 +405,14 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_disc(GridLevel dl, GridDesc
                 cx = cell_of(ux, dl.ox, dl.inv_h); cy = cell_of(uy, dl.oy, dl.inv_hy); cz = cell_of(uz, dl.oz, dl.inv_hz);
                 row_range(dl, cy, cz, cx - 1, cx + 1, loA, hiA);
             }
-            scan_d2x4<PERM>(dl.pts, loA, hiA, ux, uy, uz, best);
+            scan_d2_level<PERM>(dl, loA, hiA, ux, uy, uz, best);
             cnt += (unsigned)(hiA - loA);
             const float rho = fast_sqrt_up(best) + 2.0f * dl.slack;
             if (best < INFINITY && rho <= kMaxRhoCells * dl.h) {
                 // (a row outside the grid / an empty clipped segment: nothing of the ball has been scanned yet)
                 const bool in = cy >= 0 && cy < dl.ny && cz >= 0 && cz < dl.nz && max(cx - 1, 0) <= min(cx + 1, dl.nx - 1);
-                cnt += scan_disc_lean<PERM>(dl, ux, uy, uz, rho, in ? cy : INT_MIN, in ? cz : INT_MIN, max(cx - 1, 0), min(cx + 1, dl.nx - 1),
-                                 loA, hiA, best);
+                cnt += scan_disc_lean<PERM, false, true>(dl, ux, uy, uz, rho, in ? cy : INT_MIN, in ? cz : INT_MIN, max(cx - 1, 0),
+                                                         min(cx + 1, dl.nx - 1), loA, hiA, best);
                 d2out[i] = best;
                 if (fs.scratch) atomicAdd(&s_hist[__float_as_uint(best) >> 21], 1u);
             } else {
@@ -556,6 +560,24 @@ __global__ void k_morton_keys(GridLevel g, const float4* __restrict__ p, int n, 
     const unsigned cy = (unsigned)min(max(cell_of(v.y, g.oy, g.inv_hy), 0), g.ny - 1) >> shift;
     const unsigned cz = (unsigned)min(max(cell_of(v.z, g.oz, g.inv_hz), 0), g.nz - 1) >> shift;
     keys[i] = part1by2(cx) | (part1by2(cy) << 1) | (part1by2(cz) << 2);
+    vals[i] = i;
+}
+
+// keys of the STRIP order: the cells of level g (axis roles g.perm) in blocks of xb cells along the row direction by rb rows;
+// blocks row-major, rows inside a block one after the other, cells of a row segment left to right.  64 consecutive queries
+// then lie along one row: their candidate ranges tile one contiguous span of the row's points.
+__global__ void k_strip_keys(GridLevel g, const float4* __restrict__ p, int n, int xb, int rb, unsigned* __restrict__ keys,
+                             int* __restrict__ vals) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 v = p[i];
+    const float ux = g.perm == 0 ? v.x : (g.perm == 1 ? v.y : v.z), uy = g.perm == 0 ? v.y : (g.perm == 1 ? v.z : v.x),
+                uz = g.perm == 0 ? v.z : (g.perm == 1 ? v.x : v.y);
+    const unsigned cx = (unsigned)min(max(cell_of(ux, g.ox, g.inv_h), 0), g.nx - 1);
+    const unsigned cy = (unsigned)min(max(cell_of(uy, g.oy, g.inv_hy), 0), g.ny - 1);
+    const unsigned cz = (unsigned)min(max(cell_of(uz, g.oz, g.inv_hz), 0), g.nz - 1);
+    const unsigned row = cz * (unsigned)g.ny + cy, nxb = ((unsigned)g.nx + xb - 1) / xb;
+    keys[i] = ((row / rb) * nxb + cx / xb) * (unsigned)(rb * xb) + (row % rb) * xb + cx % xb;
     vals[i] = i;
 }
 
@@ -825,6 +847,7 @@ int build_level(pwicp_context* ctx, const float4* d_pts, int n, float h, const f
     HIPCHK(ctx, rank.reserve((size_t)n));
     d->cell_start = cell_start->p;
     d->pts = pts->p;
+    d->pts3 = nullptr;
     hipLaunchKernelGGL(k_cell_count, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_pts, n, *d,
                        cell_start->p, cell_id.p, rank.p);
     PWCHK(pw_exclusive_scan(ctx, cell_start->p, ncell + 1, &tmp));
@@ -989,6 +1012,19 @@ int pw_count_below_launch(pwicp_context* ctx, const float* d_d2, int n, float th
 // third level of small cells over the same points, same layout (cells / columns) as g->d.fine
 namespace {
 // (x, y, z) -> the axis order of a permuted level; w (the original index) is kept
+// the points of a small-cell level once more, packed x, y, z (GridLevel::pts3)
+__global__ void k_pack_xyz3(const float4* __restrict__ in, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = in[i];
+    out[3 * (size_t)i] = p.x; out[3 * (size_t)i + 1] = p.y; out[3 * (size_t)i + 2] = p.z;
+}
+int pack_level(pwicp_context* ctx, GridLevel* lv, DevBuf<float>* buf) {
+    HIPCHK(ctx, buf->reserve((size_t)lv->n * 3 + 4));
+    hipLaunchKernelGGL(k_pack_xyz3, dim3(div_up(lv->n, kBlock)), dim3(kBlock), 0, ctx->stream, lv->pts, lv->n, buf->p);
+    lv->pts3 = buf->p;
+    return PWICP_OK;
+}
 __global__ void k_permute_axes(const float4* __restrict__ in, int n, int perm, float4* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1006,6 +1042,7 @@ int pw_grid_add_dense(pwicp_context* ctx, const float4* d_pts, int n, float cell
     const int axis = g->d.fine.ny == 1 && g->d.fine.inv_hy == 0.0f ? 1 : (g->d.fine.nz == 1 && g->d.fine.inv_hz == 0.0f ? 2 : 0);
     PWCHK(build_level(ctx, d_pts, n, cell_edge, mn, mx, &g->dense, &g->dcell_start, &g->dpts, axis));
     g->has_dense = true;
+    PWCHK(pack_level(ctx, &g->dense, &g->dpts3));
     static int want_alt = -1;              // PWICP_DENSE_ALT=0: no level of columns beside a level of cells (A/B measurements)
     if (want_alt < 0) { const char* e = getenv("PWICP_DENSE_ALT"); want_alt = e ? atoi(e) : 1; }
     if (axis == 0 && want_alt) {
@@ -1015,6 +1052,7 @@ int pw_grid_add_dense(pwicp_context* ctx, const float4* d_pts, int n, float cell
         const int alt = (mx[1] - mn[1]) < (mx[2] - mn[2]) ? 1 : 2;
         PWCHK(build_level(ctx, d_pts, n, cell_edge, mn, mx, &g->dense_alt, &g->acell_start, &g->apts, alt));
         g->has_dense_alt = true;
+        PWCHK(pack_level(ctx, &g->dense_alt, &g->apts3));
         // ... and levels with other axis roles: columns along x (no layout on (x, y, z) has them: a face in the y-z plane), cells
         // with their rows along y / along z (a sheet tilted about that axis is contiguous along it).  Built on a copy of the
         // points in the permuted order; which one a pair uses is decided by a cost probe on its queries (pw_dense_level_for).
@@ -1032,6 +1070,7 @@ int pw_grid_add_dense(pwicp_context* ctx, const float4* d_pts, int n, float cell
                 PWCHK(build_level(ctx, tmp.p, n, cell_edge, pmn, pmx, &g->extra[e].lv, &g->extra[e].cell_start, &g->extra[e].pts, flat_of[e]));
                 g->extra[e].lv.perm = perm;
                 g->extra[e].has = true;
+                PWCHK(pack_level(ctx, &g->extra[e].lv, &g->extra[e].pts3));
             }
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // (tmp goes out of scope)
         }
@@ -1055,13 +1094,13 @@ __global__ void k_dense_probe(GridLevel dl, const float4* __restrict__ q4, int n
         int loA, hiA;
         row_range(dl, cy, cz, cx - 1, cx + 1, loA, hiA);
         float best = INFINITY;
-        scan_d2x4<PERM>(dl.pts, loA, hiA, ux, uy, uz, best);
+        scan_d2_level<PERM>(dl, loA, hiA, ux, uy, uz, best);
         cand += (unsigned long long)(hiA - loA);
         rows += 1;
         const float rho = fast_sqrt_up(best) + 2.0f * dl.slack;
         if (best < INFINITY && rho <= kMaxRhoCells * dl.h) {
             const bool in = cy >= 0 && cy < dl.ny && cz >= 0 && cz < dl.nz && max(cx - 1, 0) <= min(cx + 1, dl.nx - 1);
-            const unsigned c = scan_disc_lean<PERM, true>(dl, ux, uy, uz, rho, in ? cy : INT_MIN, in ? cz : INT_MIN, max(cx - 1, 0),
+            const unsigned c = scan_disc_lean<PERM, true, true>(dl, ux, uy, uz, rho, in ? cy : INT_MIN, in ? cz : INT_MIN, max(cx - 1, 0),
                                                           min(cx + 1, dl.nx - 1), loA, hiA, best);
             cand += c & 0xfffffu;
             rows += c >> 20;
@@ -1181,11 +1220,15 @@ int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pa
     }
     if (dense && d_qpatch && d_qorder) {
         const int tiles = div_up(nq, kBlock);
-        const int chunk = div_up(tiles, kXcds);
+        static int sub_env = -1;            // PWICP_DENSE_XCD_SUB: tiles per run dealt to an XCD (0: one contiguous eighth each)
+        if (sub_env < 0) { const char* e = getenv("PWICP_DENSE_XCD_SUB"); sub_env = e ? std::max(atoi(e), 0) : 4; }
+        int chunk = div_up(tiles, kXcds);
+        const int sub = sub_env > 0 ? std::min(sub_env, chunk) : chunk;
+        chunk = div_up(chunk, sub) * sub;
         FusedSelect none{};
 #define PW_DENSE(PERM_, FARG_)                                                                                              \
     hipLaunchKernelGGL((k_nn_dense_disc<PERM_, FARG_>), dim3(chunk * kXcds), dim3(kBlock), 0, ctx->stream, *dense, g, d_pat, d_qorder, \
-                       d_qpatch, d_stable, nq, d_d2, d_examined, chunk, fs ? *fs : none, fl, d_patq)
+                       d_qpatch, d_stable, nq, d_d2, d_examined, chunk, fs ? *fs : none, fl, d_patq, sub)
         if (far_group) { if (dense->perm == 0) PW_DENSE(0, true); else if (dense->perm == 1) PW_DENSE(1, true); else PW_DENSE(2, true); }
         else { if (dense->perm == 0) PW_DENSE(0, false); else if (dense->perm == 1) PW_DENSE(1, false); else PW_DENSE(2, false); }
 #undef PW_DENSE
@@ -1216,9 +1259,34 @@ int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pa
 }
 
 // permutation of 0..n-1 that lists the points in Morton order of their fine cell in grid g
-int pw_morton_order(pwicp_context* ctx, const GridDesc& g, const float4* d_pts, int n, DevBuf<int>* order) {
+int pw_morton_order(pwicp_context* ctx, const GridDesc& g, const float4* d_pts, int n, DevBuf<int>* order, const GridLevel* strip_lv) {
     HIPCHK(ctx, order->reserve((size_t)std::max(n, 1)));
     if (n <= 0) return PWICP_OK;
+    // The queries of the dense search in STRIP order on the level the pair searches (k_strip_keys): blocks of 32 cells x 8 rows.
+    // In Morton order (round 3) the 64 queries of a wave sit in ~4 x 4 cells of four rows and every gather of the wave touches
+    // ~20 cache lines (TCP_TOTAL_CACHE_ACCESSES / SQ_INSTS_VMEM_RD); along a row their windows tile one span of the row's
+    // points.  41.3 -> 39.1 us.  PWICP_QUERY_ORDER="xb,rb" (0: Morton order of the fine cells).
+    static int xb = -1, rb = 8;
+    if (xb < 0) {
+        xb = 32;
+        if (const char* e = getenv("PWICP_QUERY_ORDER")) { xb = std::max(atoi(e), 0); if (const char* c = strchr(e, ',')) rb = std::max(atoi(c + 1), 1); }
+    }
+    if (xb > 0 && strip_lv && (double)strip_lv->nx * strip_lv->ny * strip_lv->nz * 1.1 + (double)xb * rb * 2 < 4.0e9) {
+        DevBuf<unsigned> keys, keys_out;
+        DevBuf<int> vals;
+        HIPCHK(ctx, keys.reserve((size_t)n));
+        HIPCHK(ctx, keys_out.reserve((size_t)n));
+        HIPCHK(ctx, vals.reserve((size_t)n));
+        hipLaunchKernelGGL(k_strip_keys, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, *strip_lv, d_pts, n, xb, rb, keys.p, vals.p);
+        size_t tbytes = 0;
+        HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tbytes, keys.p, keys_out.p, vals.p, order->p, n, 0, 32, ctx->stream));
+        DevBuf<unsigned char> tmp;
+        HIPCHK(ctx, tmp.reserve(tbytes));
+        HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tbytes, keys.p, keys_out.p, vals.p, order->p, n, 0, 32, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipGetLastError());
+        return PWICP_OK;
+    }
     int shift = 0;
     while (((std::max(g.fine.nx, std::max(g.fine.ny, g.fine.nz)) - 1) >> shift) > 1023) ++shift;
     DevBuf<unsigned> keys, keys_out;

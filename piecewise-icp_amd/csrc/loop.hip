@@ -315,8 +315,8 @@ int finish_create(pwicp_pair* pr) {
     // dense-query order (one-off): Morton order of the source patch points in the target grid
     HIPCHK(ctx, pr->pt_patch2.reserve((size_t)std::max(pr->P2.tot, 1)));
     PWCHK(pw_point_patch_ids_launch(ctx, pr->P2.off.p, m2, pr->pt_patch2.p));
-    PWCHK(pw_morton_order(ctx, pr->tgt->g_c1.d, pr->P2.pat.p, pr->P2.tot, &pr->qorder));
     PWCHK(pw_dense_level_for(ctx, pr->tgt->g_c1, pr->P2.pat.p, pr->P2.tot, &pr->dense_lv, &pr->dense_far0));
+    PWCHK(pw_morton_order(ctx, pr->tgt->g_c1.d, pr->P2.pat.p, pr->P2.tot, &pr->qorder, pr->dense_lv));
     HIPCHK(ctx, pr->qpatch.reserve((size_t)std::max(pr->P2.tot, 1)));
     PWCHK(pw_gather_int_launch(ctx, pr->pt_patch2.p, pr->qorder.p, pr->P2.tot, pr->qpatch.p));
     // pristine source copies; centroids and boundary points live in ONE buffer so that a single NN launch and a

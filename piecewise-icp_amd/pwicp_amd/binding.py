@@ -66,7 +66,8 @@ class Step(C.Structure):
 
 
 def lib_path():
-    return os.path.join(os.path.dirname(_HERE), "libpwicp.so")
+    # $PWICP_LIB: another build of the same library (A/B of compile-time variants, tools/build_variant.sh); never a fallback
+    return os.environ.get("PWICP_LIB") or os.path.join(os.path.dirname(_HERE), "libpwicp.so")
 
 
 _lib = None

@@ -1,0 +1,9 @@
+#!/bin/bash
+# dense search: tiles dealt to the XCDs in runs of S (0 = one contiguous eighth per XCD)
+for c in 0 1 4 16 64 256; do
+  echo "== sub=$c"
+  PWICP_DENSE_XCD_SUB=$c python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-inner-timing --series-epochs 0 --pairs-in-flight 0 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print('ms_per_step',d['ms_per_step'],'dense_us',r['avg_launch_us'],'kbar',r['kbar'], 'outer', d['config']['outer_iterations'], 'corr', d['config']['correspondences_per_step'])"
+done
