@@ -354,30 +354,34 @@ __device__ __forceinline__ float dense_far_path(const GridDesc& far, float4 q, f
 // the far path works on the levels of `far`, which are always in (x, y, z))
 // FARG: the far queries of the block are searched by eight lanes each (more registers: 5 instead of 7 waves per SIMD, so only
 // launches that expect many far queries use this instantiation - the first search of a pair whose probe found them)
+#ifndef PW_DENSE_BLOCK
+#define PW_DENSE_BLOCK 256
+#endif
+constexpr int kDenseBlock = PW_DENSE_BLOCK;     // threads per block of the dense search (a multiple of 64)
 template <int PERM, bool FARG>
-__global__ void __launch_bounds__(kBlock) k_nn_dense_disc(GridLevel dl, GridDesc far, const float4* __restrict__ pat,
+__global__ void __launch_bounds__(kDenseBlock) k_nn_dense_disc(GridLevel dl, GridDesc far, const float4* __restrict__ pat,
                                                           const int* __restrict__ qorder, const int* __restrict__ qpatch,
                                                           const int* __restrict__ stable, int nq,
                                                           float* __restrict__ d2out,
                                                           unsigned long long* __restrict__ examined, int chunk, FusedSelect fs,
                                                           DenseFarList fl, const float4* __restrict__ patq, int sub) {
     __shared__ unsigned s_hist[kFsBins];    // pass 0 of the percentile selection (select_dev.h), fs.scratch != nullptr only
-    __shared__ float4 s_q[kBlock];          // .w carries the candidate d2 of an unresolved query
-    __shared__ int s_slot[kBlock];
-    __shared__ int s_wcnt[kBlock / 64];
+    __shared__ float4 s_q[kDenseBlock];          // .w carries the candidate d2 of an unresolved query
+    __shared__ int s_slot[kDenseBlock];
+    __shared__ int s_wcnt[kDenseBlock / 64];
     // block b runs on XCD b % 8: the XCDs take the ordered tiles in runs of `sub`.  One contiguous eighth of the list per XCD
     // (round 3) left the kernel waiting for the XCD whose eighth happened to be the expensive one (TA_BUSY max / mean 1.7 over
     // the CUs): 47.2 us -> 41.1 us with runs of four tiles; L2 locality does not show (runs of 1: 41.6, of 64: 44.7).
     const int xr = (int)(blockIdx.x / kXcds);
     const int tile = chunk > 0 ? (xr / sub) * (kXcds * sub) + (int)(blockIdx.x % kXcds) * sub + xr % sub : (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = tile * kBlock + tid;
+    const int i = tile * kDenseBlock + tid;
     unsigned cnt = 0;
     bool unresolved = false;
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     float best = INFINITY;
     if (fs.scratch) {
-        for (int t = tid; t < kFsBins; t += kBlock) s_hist[t] = 0u;
+        for (int t = tid; t < kFsBins; t += kDenseBlock) s_hist[t] = 0u;
         __syncthreads();
     }
     if (i < nq) {
@@ -429,7 +433,7 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_disc(GridLevel dl, GridDesc
     __syncthreads();
     int base = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w) {
+    for (int w = 0; w < kDenseBlock / 64; ++w) {
         if (w < wave) base += s_wcnt[w];
         total += s_wcnt[w];
     }
@@ -1219,7 +1223,7 @@ int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pa
         fl.q = far_bufs->q.p; fl.slot = far_bufs->slot.p; fl.count = far_bufs->count.p;
     }
     if (dense && d_qpatch && d_qorder) {
-        const int tiles = div_up(nq, kBlock);
+        const int tiles = div_up(nq, kDenseBlock);
         static int sub_env = -1;            // PWICP_DENSE_XCD_SUB: tiles per run dealt to an XCD (0: one contiguous eighth each)
         if (sub_env < 0) { const char* e = getenv("PWICP_DENSE_XCD_SUB"); sub_env = e ? std::max(atoi(e), 0) : 4; }
         int chunk = div_up(tiles, kXcds);
@@ -1227,7 +1231,7 @@ int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pa
         chunk = div_up(chunk, sub) * sub;
         FusedSelect none{};
 #define PW_DENSE(PERM_, FARG_)                                                                                              \
-    hipLaunchKernelGGL((k_nn_dense_disc<PERM_, FARG_>), dim3(chunk * kXcds), dim3(kBlock), 0, ctx->stream, *dense, g, d_pat, d_qorder, \
+    hipLaunchKernelGGL((k_nn_dense_disc<PERM_, FARG_>), dim3(chunk * kXcds), dim3(kDenseBlock), 0, ctx->stream, *dense, g, d_pat, d_qorder, \
                        d_qpatch, d_stable, nq, d_d2, d_examined, chunk, fs ? *fs : none, fl, d_patq, sub)
         if (far_group) { if (dense->perm == 0) PW_DENSE(0, true); else if (dense->perm == 1) PW_DENSE(1, true); else PW_DENSE(2, true); }
         else { if (dense->perm == 0) PW_DENSE(0, false); else if (dense->perm == 1) PW_DENSE(1, false); else PW_DENSE(2, false); }
