@@ -1,8 +1,7 @@
-# A/B of an environment switch on the loop of two of the reference's own pairs (tools/real_pair_loop.py): bash tools/ab_real.sh VAR v1 v2 ...
-cd $GRAFT_REPO_ROOT
-VAR=$1; shift
+#!/bin/bash
+# the loop on the reference's Epoch_002 / Epoch_012 -> Epoch_001 under run-time switches: each argument one "ENV=VAL ..." setting ("-": defaults)
 for v in "$@"; do
-  echo "== $VAR=$v"
-  env $VAR=$v python tools/real_pair_loop.py 2 20 | tail -2
-  env $VAR=$v python tools/real_pair_loop.py 12 20 | tail -2
+  [ "$v" == "-" ] && v="PWICP_NOP=1"
+  echo "== $v"
+  for E in 2 12; do env $v python tools/real_pair_loop.py $E 30 | tail -1; done
 done
