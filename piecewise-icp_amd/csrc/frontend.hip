@@ -321,7 +321,10 @@ constexpr int kFusArenas = 256;
 // previous sweep - Gauss-Seidel inside the chunk, Jacobi between chunks.  Neighbouring centres are neighbours in the visiting
 // order, which is where most dependencies are: the worst round needs ~3x fewer sweeps.  Any mixture of old and new guesses
 // converges to the same fixed point; a sweep without changes still certifies it.
-constexpr int kFusChunk = 16, kFusFresh = 128;
+#ifndef PW_FUS_CHUNK
+#define PW_FUS_CHUNK 16
+#endif
+constexpr int kFusChunk = PW_FUS_CHUNK, kFusFresh = 8 * PW_FUS_CHUNK;
 
 struct FusWave {           // per-wavefront scratch (LDS)
     int* keys; int* vals; int* queue;
@@ -347,7 +350,7 @@ __device__ __forceinline__ int fus_absorber(const FusState& s, const FusWave& w,
     if (w.ndone) {
         if (c != kNone && fus_chunk_index(w, c) >= 0) c = kNone;
         if (w.nfresh) {
-            int sl = (int)(((unsigned)x * 2654435761u) >> 24) & (kFusFresh - 1);
+            int sl = (int)(((unsigned)x * 2654435761u) >> (32 - __builtin_ctz(kFusFresh)));
             for (;;) {
                 const int key = w.fkey[sl];
                 if (key == -1) break;
@@ -571,7 +574,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_fus_run(FusState s, int nW, int 
                     const int idx = base + lane;
                     if (idx <= total && w.queue[idx] < 0) {
                         const int node = w.queue[idx] & 0x7fffffff;
-                        int sl = (int)(((unsigned)node * 2654435761u) >> 24) & (kFusFresh - 1);
+                        int sl = (int)(((unsigned)node * 2654435761u) >> (32 - __builtin_ctz(kFusFresh)));
                         for (;;) {
                             const int prev = atomicCAS(&w.fkey[sl], -1, node);
                             if (prev == -1) { w.fval[sl] = i; break; }

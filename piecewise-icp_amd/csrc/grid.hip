@@ -465,19 +465,127 @@ __global__ void __launch_bounds__(kDenseBlock) k_nn_dense_disc(GridLevel dl, Gri
     if (fs.scratch) fs_pass0_epilogue(s_hist, fs);
 }
 
+#ifndef PW_FAR_RUN
+#define PW_FAR_RUN 4
+#endif
 // The far queries of the dense launch before it, eight lanes each (group-cooperative forms of dense_far_path's steps: the
 // ball of the candidate on the larger cells of `far`, else the general search); their share of the selection's pass 0.
+#ifdef PW_FAR_STATS
+// -DPW_FAR_STATS (tools/far_stats.py): where the far queries end - [0] queries, [1] candidate's ball on the fine level, [2] small ball
+// fine, [3] wide ball fine, [4] candidate's ball coarse, [5] small ball coarse, [6] wide ball coarse, [7] general search, [8+l] launches
+__device__ unsigned long long pw_far_stats[16];
+extern "C" __attribute__((visibility("default"))) int pwicp_debug_far_stats(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pw_far_stats), sizeof(pw_far_stats)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(pw_far_stats), z, sizeof(z)); }
+    return 0;
+}
+#define FAR_STAT(k) do { if (sub == 0) atomicAdd(&pw_far_stats[k], 1ull); } while (0)
+#else
+#define FAR_STAT(k) do {} while (0)
+#endif
+// The general search of ONE query by a whole block (distance only, level c in (x, y, z) order): the Chebyshev block of radius r
+// around the query's cell, then shell after shell, until every point outside the scanned block is provably farther than the best
+// one (the bound of nn_resolved) or the grid is exhausted - the stage 3 of nn_query_group, but with the row segments of a block /
+// shell dealt to the threads, a prefix over their lengths in LDS, and the candidates taken thread by thread from that line.
+// A query with nothing within 2.75 coarse cells (source points outside the target's coverage: a handful per launch on the
+// reference's Epoch_012) walks ~10 shells; on eight lanes that is ~50 us and the launch waits for it - 107 -> 63 us, 55 -> 36 us
+// for the two far launches of that pair.  Same float expression per candidate, same stopping rule: the same exact minimum.
+// Called by ALL threads of the block with block-uniform arguments; s_lo / s_pre: kBlock (+ 1) ints, s_red: kBlock / 64 floats.
+__device__ float nn_block_shells_d2(const GridLevel& c, float qx, float qy, float qz, float best_in, int* s_lo, int* s_pre, float* s_red) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cx = cell_of(qx, c.ox, c.inv_h), cy = cell_of(qy, c.oy, c.inv_hy), cz = cell_of(qz, c.oz, c.inv_hz);
+    const int ex = max(0, max(-cx, cx - (c.nx - 1))), ey = max(0, max(-cy, cy - (c.ny - 1))), ez = max(0, max(-cz, cz - (c.nz - 1)));
+    int r = max(max(ex, ey), max(ez, 1));
+    const int rcover = max(max(max(cx, c.nx - 1 - cx), max(cy, c.ny - 1 - cy)), max(cz, c.nz - 1 - cz));
+    float best = best_in;
+    for (bool first = true;; first = false) {
+        // (only the rows that exist: a level of columns has ONE layer of them, whatever r)
+        const int dy0 = max(-r, -cy), dy1 = min(r, c.ny - 1 - cy), dz0 = max(-r, -cz), dz1 = min(r, c.nz - 1 - cz);
+        const int wy = max(dy1 - dy0 + 1, 0), wz = max(dz1 - dz0 + 1, 0);
+        const long long nseg = (first ? 1ll : 2ll) * wy * wz;
+        float local = INFINITY;
+        for (long long sb = 0; sb < nseg; sb += kBlock) {
+            const long long sg = sb + tid;
+            int lo = 0, hi = 0;
+            if (sg < nseg) {
+                const int t = (int)(first ? sg : sg >> 1), part = first ? 0 : (int)(sg & 1);
+                const int dz = dz0 + t / wy, dy = dy0 + t % wy;
+                if (first || dz == -r || dz == r || dy == -r || dy == r) {
+                    if (part == 0) row_range(c, cy + dy, cz + dz, cx - r, cx + r, lo, hi);
+                } else {
+                    row_range(c, cy + dy, cz + dz, part ? cx + r : cx - r, part ? cx + r : cx - r, lo, hi);
+                }
+            }
+            const int len = hi - lo;
+            int incl = len;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int u = __shfl_up(incl, o);
+                if (lane >= o) incl += u;
+            }
+            if (lane == 63) s_pre[kBlock - 1 - wave] = incl;         // (parked at the far end until the sums are known)
+            __syncthreads();
+            int basew = 0, T = 0;
+#pragma unroll
+            for (int k = 0; k < kBlock / 64; ++k) {
+                const int v = s_pre[kBlock - 1 - k];
+                if (k < wave) basew += v;
+                T += v;
+            }
+            __syncthreads();
+            s_lo[tid] = lo;
+            s_pre[tid] = basew + incl - len;
+            __syncthreads();
+            for (int cnd = tid; cnd < T; cnd += kBlock) {
+                int a = 0, b = kBlock - 1;                           // last j with s_pre[j] <= cnd
+                while (a < b) {
+                    const int m = (a + b + 1) >> 1;
+                    if (s_pre[m] <= cnd) a = m; else b = m - 1;
+                }
+                nn_consider_d2<0>(c.pts[s_lo[a] + (cnd - s_pre[a])], qx, qy, qz, local);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) local = fminf(local, __shfl_xor(local, o));
+        if (lane == 0) s_red[wave] = local;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kBlock / 64; ++k) best = fminf(best, s_red[k]);
+        __syncthreads();
+#ifdef PW_FAR_STATS
+        if (tid == 0) { atomicAdd(&pw_far_stats[10], 1ull); atomicMax(&pw_far_stats[11], (unsigned long long)r); }
+#endif
+        const float bound = (float)r * c.h - 2.0f * c.slack;
+        if (best < INFINITY && bound > 0.0f && best < bound * bound * 0.99999f) break;
+        if (r >= rcover) break;
+        ++r;
+    }
+    return best;
+}
+
 __global__ void __launch_bounds__(kBlock) k_nn_dense_far(GridDesc far, DenseFarList fl, float* __restrict__ d2out, FusedSelect fs) {
     __shared__ unsigned s_hist[kFsBins];
     __shared__ unsigned s_n, s_last;
+    constexpr int kSlowCap = 32;            // queries of this block that need the general search: the whole block takes them at the end
+    __shared__ int s_slow[kSlowCap];
+    __shared__ float s_slow_d[kSlowCap];
+    __shared__ unsigned s_nslow;
+    __shared__ int s_blo[kBlock], s_bpre[kBlock];
+    __shared__ float s_bred[kBlock / 64];
     const int tid = threadIdx.x;
     if (fs.scratch)
         for (int t = tid; t < kFsBins; t += kBlock) s_hist[t] = 0u;
-    if (tid == 0) s_n = __hip_atomic_load(&fl.count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) { s_n = __hip_atomic_load(&fl.count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_nslow = 0u; }
     __syncthreads();
     const int n = (int)s_n;
     const int sub = tid % kGroup;
-    for (int qi = (int)blockIdx.x * (kBlock / kGroup) + tid / kGroup; qi < n; qi += (int)gridDim.x * (kBlock / kGroup)) {
+    // (entry qi to block qi % #blocks: neighbours on the list are neighbours in space, and the few queries that need the general
+    // search come in clusters - dealt out like this they end up on different blocks instead of queueing on one)
+    // PW_FAR_RUN consecutive entries stay together (their balls share cache lines), the runs of a block are #blocks runs apart
+    constexpr int kRun = PW_FAR_RUN;
+    for (int qi = (((tid / kGroup) / kRun) * (int)gridDim.x + (int)blockIdx.x) * kRun + (tid / kGroup) % kRun; qi < n;
+         qi += (int)gridDim.x * (kBlock / kGroup)) {
         const float4 u = fl.q[qi];
         float d = u.w;                              // the candidate of the query's own row segment, if any
         // Level by level (the larger cells of `far`: fine, then coarse): with a candidate whose ball fits kMaxRhoCells cells,
@@ -494,24 +602,46 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_far(GridDesc far, DenseFarL
             if (sq + sl2 <= lim) {
                 scan_disc_group<kGroup>(L, u.x, u.y, u.z, sq + sl2, sub, d);
                 done = true;
+                FAR_STAT(1 + 3 * lv);
             } else {
                 // (a small ball first: three quarters of a real pair's far queries are within a cell of the surface)
                 const float r1 = kFirstBallCells * L.h;
                 scan_disc_group<kGroup>(L, u.x, u.y, u.z, r1, sub, d);
                 done = d < INFINITY && fast_sqrt_up(d) + sl2 <= r1;
+                if (done) FAR_STAT(2 + 3 * lv);
                 if (!done) {
                     const float sq2 = d < INFINITY ? fast_sqrt_up(d) + sl2 : INFINITY;
                     const float r2 = fminf(sq2, lim);                  // the candidate's ball if it fits, else the widest
                     scan_disc_group<kGroup>(L, u.x, u.y, u.z, r2, sub, d);
                     done = sq2 <= lim || (d < INFINITY && fast_sqrt_up(d) + sl2 <= lim);
+                    if (done) FAR_STAT(3 + 3 * lv);
                 }
             }
         }
-        if (!done) {                                // nothing within 2.75 coarse cells: the general search
-            const NNBest b = nn_query_group<kGroup>(far, u.x, u.y, u.z, sub);
+        FAR_STAT(0);
+        if (!done) {                                // nothing within 2.75 coarse cells: the general search, by the whole block below
+            FAR_STAT(7);
+            unsigned at = 0u;
+            if (sub == 0) at = atomicAdd(&s_nslow, 1u);
+            at = (unsigned)__shfl((int)at, 0, kGroup);
+            if (at < (unsigned)kSlowCap) {
+                if (sub == 0) { s_slow[at] = qi; s_slow_d[at] = d; }
+                continue;
+            }
+            const NNBest b = nn_query_group<kGroup>(far, u.x, u.y, u.z, sub);      // (more than the block keeps: on the group's lanes)
             d = fminf(d, b.d2());
         }
         if (sub == 0) {
+            d2out[fl.slot[qi]] = d;
+            if (fs.scratch) atomicAdd(&s_hist[__float_as_uint(d) >> 21], 1u);
+        }
+    }
+    __syncthreads();
+    for (int k = 0, nk = (int)min(s_nslow, (unsigned)kSlowCap); k < nk; ++k) {
+        const int qi = s_slow[k];
+        const float4 u = fl.q[qi];
+        const float d = nn_block_shells_d2(far.coarse, u.x, u.y, u.z, s_slow_d[k], s_blo, s_bpre, s_bred);
+        if (tid == 0) {
             d2out[fl.slot[qi]] = d;
             if (fs.scratch) atomicAdd(&s_hist[__float_as_uint(d) >> 21], 1u);
         }

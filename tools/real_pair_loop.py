@@ -24,4 +24,5 @@ for _ in range(runs):
 no = r.n_outer
 print("epoch %d: %d / %d points, patches %s, outer %d, inner %s, stable %s" % (e, len(p1), len(p2), pair.num_patches(), no, list(r.n_inner[:no]), list(r.n_stable[:no])))
 print("dense: kbar %.1f, queries %d, launches %d, d75 %s, DT %s" % (r.dense_kbar, r.n_corr_dense, r.n_dense_nn_launches, [round(float(x), 5) for x in r.d75[:no]], [round(float(x), 5) for x in r.DTseries[:no + 1]]))
+print("maxBB %s  (DTmin 0.004)" % [round(float(x), 5) for x in r.maxBB[:no]])
 print("loop wall: median %.3f ms, min %.3f ms (t_loop_ms %.3f)" % (1e3 * sorted(ts)[len(ts) // 2], 1e3 * min(ts), r.t_loop_ms))
