@@ -11,9 +11,12 @@ ARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-inner-timing --series-epochs 
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $R/bench.py $ARGS > $OUT/bench_trace.log 2>&1
 python $R/tools/trace_last_step.py $OUT/trace > $OUT/last_step_timeline.txt 2>&1
 for G in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" \
-         "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES"; do
+         "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" \
+         "TA_TA_BUSY_sum TA_BUSY_avr TA_BUSY_max" "TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TA_TCP_STATE_READ_sum" \
+         "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_READ_sum" "TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum" \
+         "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TOTAL_ACCESSES_sum" "GRBM_GUI_ACTIVE"; do
   N=$(echo $G | cut -d' ' -f1)
-  timeout 600 rocprofv3 --pmc $G --output-format csv -d $OUT/pmc -o $N -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-inner-timing --series-epochs 0 --pairs-in-flight 0 > $OUT/pmc_$N.log 2>&1
+  timeout 240 rocprofv3 --pmc $G --output-format csv -d $OUT/pmc -o $N -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-inner-timing --series-epochs 0 --pairs-in-flight 0 > $OUT/pmc_$N.log 2>&1
 done
 # calibration of FETCH_SIZE / WRITE_SIZE on a kernel with a known byte count (k_transform_all through pwicp_pair_step)
 for N in FETCH_SIZE WRITE_SIZE; do
@@ -25,6 +28,10 @@ cd $R
 timeout 600 python bench.py --no-cpu-baseline --series-epochs 0 --pairs-in-flight 0 > $OUT/bench_plain.log 2>/dev/null     # (its in-run duration of the dense launch goes into the summary)
 timeout 600 python bench.py --workload frontend --steps 5 > $OUT/bench_frontend.log 2>&1
 timeout 600 python bench.py --workload series --epochs 4 --points 5000000 > $OUT/bench_series.log 2>&1
+# the loop on two of the reference's own pairs, with the kernel timeline of their last run
+bash tools/real_pair_trace.sh > $OUT/real_pair_timeline.txt 2>&1
+# N = 2 rehearsal on this box's one GPU (bench.py starts the ranks itself)
+timeout 600 python bench.py --gpus 2 --single-device --backend gloo --steps 5 --warmup 1 --no-cpu-baseline --no-inner-timing --series-epochs 4 --pairs-in-flight 0 > $OUT/bench_gpus2.log 2>/dev/null
 python tools/summarize_pmc.py $OUT > $OUT/summary.log 2>&1
 cp $OUT/traffic.json profiles/traffic_latest.json      # (on the box's copy: the line below then carries the traffic of THESE sources)
 timeout 600 python bench.py > $OUT/bench_final.log 2>/dev/null
