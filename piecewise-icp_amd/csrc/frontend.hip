@@ -25,6 +25,7 @@
 // All decisions use the reference's double arithmetic (no contraction: the library is built with -ffp-contract=off;
 // sqrt and the division are IEEE on gfx950), so labels are identical to the host pipeline's, which the tests assert.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -845,6 +846,19 @@ __global__ void __launch_bounds__(1024) k_fus_advance(FusState s, int* __restric
 
 // ---- set-up and hand-over between rounds ----------------------------------------------------------------------------
 // smallest metric to a neighbour (:91-102); lambda0 = its median
+// key of a centre's spatial tile (two axes a, b of the cloud's box, tiles of edge 1 / inv): the full sweeps of a round take the
+// centres tile by tile - a wavefront's chunk of consecutive slots is then a PATCH of the surface (its centres still in ascending
+// order: the sort is stable), and what a centre has just decided reaches its neighbours across the scan lines in the same sweep
+__global__ void k_fus_tile_keys(const FePt* __restrict__ P, const int* __restrict__ cen, int nc, int a, int b, double mna, double mnb,
+                                double inv, unsigned ntx, unsigned* __restrict__ keys) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nc) return;
+    const FePt& p = P[cen[t]];
+    const double ua = a == 0 ? p.x : (a == 1 ? p.y : p.z), ub = b == 0 ? p.x : (b == 1 ? p.y : p.z);
+    const unsigned tx = (unsigned)fmin(fmax((ua - mna) * inv, 0.0), (double)(ntx - 1));
+    const unsigned ty = (unsigned)fmax((ub - mnb) * inv, 0.0);
+    keys[t] = ty * ntx + tx;
+}
 __global__ void k_fus_min_metric(const FePt* __restrict__ P, const int* __restrict__ nb, int k, int n, double res, double* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1082,6 +1096,11 @@ struct FeWorkspace {
         dflag, cflag, dtmin, Wa, Wb, dq, dq2, ovf, o_sz, o_ran, o_absn, o_adjn, o_dirty, o_oldabsn, alive, newlen, cut, arenaA, arenaB, sa, ctr;
     DevBuf<long long> offA, offB, rec_ptr, o_ptr, o_oldptr;
     DevBuf<unsigned long long> big;     // [0] absorbed in the round, [16 * (1 + r)] bump pointer of arena region r
+    DevBuf<int> cen_t;                  // the centres of a round in TILE order (fusion_device: full sweeps)
+    DevBuf<unsigned> tkey, tkey2;
+    DevBuf<unsigned char> tsort;
+    double bb_mn[3] = {0, 0, 0}, bb_mx[3] = {0, 0, 0};      // bounding box of the cloud (set by the driver of the pipeline)
+    bool bb_set = false;
     int sa_factor = 3;                  // list arena = sa_factor * n * k entries (doubled, once, when a round overflows it)
     bool sa_overflow = false;           // set by fusion_device when it gave up because of the arena
     FeWorkspace() = default;
@@ -1403,6 +1422,8 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     const int batch_cap = getenv("PWICP_FUSION_BATCH_CAP") ? std::max(atoi(getenv("PWICP_FUSION_BATCH_CAP")), 64) : 1024;
     s.nW_dev = nullptr; s.stop = nullptr;
     const int wake_all_div = getenv("PWICP_FUSION_WAKE_DIV") ? std::max(atoi(getenv("PWICP_FUSION_WAKE_DIV")), 1) : 32;
+    const int chunk_div = getenv("PWICP_FUSION_CHUNK_DIV") ? std::max(atoi(getenv("PWICP_FUSION_CHUNK_DIV")), 1) : 2048;   // chunks wanted per sweep (8192: 53.4 ms of fusion at 1 M points, 2048: 51.4, 512: 51.4)
+    const int tile_pop = getenv("PWICP_FUSION_TILE") ? std::max(atoi(getenv("PWICP_FUSION_TILE")), 0) : 16;     // centres per tile; 0: index order
     for (;; lambda *= 2.0, ++round) {
         if (nc <= 1) {                                  // (:106) nothing left to fuse
             HIPCHK(ctx, hipMemcpyAsync(d_lab, ws.root0.p, sizeof(int) * N, hipMemcpyDeviceToDevice, st));
@@ -1427,8 +1448,33 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
         HIPCHK(ctx, hipMemsetAsync(ws.big.p, 0, sizeof(unsigned long long) * 16 * (kFusArenas + 1), st));
         s.wake_all_above = std::max(nc / wake_all_div, 64);
         s.lambda = lambda; s.len0 = len0; s.off0 = off0; s.arena0 = arena0; s.revown = ws.revown.p;
+        // full sweeps take the centres in tile order (k_fus_tile_keys); the certificate keeps the plain order
+        const int* cen_full = cen;
+        if (tile_pop > 0 && ws.bb_set && nc >= 4096) {
+            int ax[3] = {0, 1, 2};
+            double ext[3] = {ws.bb_mx[0] - ws.bb_mn[0], ws.bb_mx[1] - ws.bb_mn[1], ws.bb_mx[2] - ws.bb_mn[2]};
+            std::sort(ax, ax + 3, [&](int u, int v) { return ext[u] > ext[v]; });
+            const int a = ax[0], b = ax[1];
+            const double area = std::max(ext[a], 1e-30) * std::max(ext[b], 1e-30);
+            const double edge = std::sqrt((double)tile_pop * area / (double)nc);
+            const double ntx_d = std::floor(ext[a] / edge) + 1.0, nty_d = std::floor(ext[b] / edge) + 1.0;
+            if (edge > 0.0 && ntx_d * nty_d < 4.0e9) {
+                HIPCHK(ctx, ws.cen_t.reserve(N));
+                HIPCHK(ctx, ws.tkey.reserve(N));
+                HIPCHK(ctx, ws.tkey2.reserve(N));
+                hipLaunchKernelGGL(k_fus_tile_keys, grid1(nc), dim3(256), 0, st, dP, cen, nc, a, b, ws.bb_mn[a], ws.bb_mn[b], 1.0 / edge,
+                                   (unsigned)ntx_d, ws.tkey.p);
+                int end_bit = 1;
+                while (end_bit < 32 && (double)(1ull << end_bit) < ntx_d * nty_d) ++end_bit;
+                size_t tb = 0;
+                HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, ws.tkey.p, ws.tkey2.p, cen, ws.cen_t.p, nc, 0, end_bit, st));
+                HIPCHK(ctx, ws.tsort.reserve(tb));
+                HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(ws.tsort.p, tb, ws.tkey.p, ws.tkey2.p, cen, ws.cen_t.p, nc, 0, end_bit, st));
+                cen_full = ws.cen_t.p;
+            }
+        }
         int* W = ws.Wa.p; int* Wn = ws.Wb.p;
-        HIPCHK(ctx, hipMemcpyAsync(W, cen, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(W, cen_full, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
         int nW = nc, sweeps = 0;
         long long runs = 0;
         // The round ends with a CERTIFICATE: one sweep over all centres, every one reading the standing state only, that
@@ -1481,7 +1527,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
                 }
                 if (!h_ctr[5]) { nW = h_ctr[4]; continue; }              // the batch ran through (W holds the next list, possibly empty)
                 if (h_ctr[3] || h_ctr[10] || h_ctr[11]) {                // everybody runs again ([3]: a search outgrew the small queue)
-                    HIPCHK(ctx, hipMemcpyAsync(W, cen, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
+                    HIPCHK(ctx, hipMemcpyAsync(W, cen_full, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
                     nW = nc;
                 } else {                                                 // the next list outgrew the batch: back to single sweeps
                     std::swap(W, Wn);
@@ -1492,7 +1538,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
             runs += nW;
             if (trace && getenv("PWICP_TRACE_SWEEPS")) fprintf(stderr, "      sweep %d: %d\n", sweeps, nW);
             HIPCHK(ctx, hipMemsetAsync(ws.ctr.p, 0, sizeof(int) * 16, st));
-            const int chunk = certify ? 1 : std::max(1, std::min(std::min(nW / 8192, kFusChunk), gs_chunk));
+            const int chunk = certify ? 1 : std::max(1, std::min(std::min(nW / chunk_div, kFusChunk), gs_chunk));
             hipLaunchKernelGGL((k_fus_run<kFusQueueS, kFusHashS, 4>), dim3((unsigned)std::min(div_up(div_up(nW, chunk), 4), 8192)), dim3(256), 0, st,
                                s, nW, chunk, (const int*)nullptr, (const int*)nullptr, ws.ovf.p, ws.ctr.p + 3);
             hipLaunchKernelGGL((k_fus_run<kFusQueue, kFusHash, 1>), dim3(256), dim3(64), 0, st, s, 0, 1, (const int*)ws.ovf.p,
@@ -1514,7 +1560,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
             if (certify && h_ctr[1] == 0) { certified = true; break; }       // nothing changed against the rebuilt absorbers
             certify = false;
             if (h_ctr[10] || h_ctr[11]) {               // closure deeper than the levels / too many changes: everybody runs again (always sound)
-                HIPCHK(ctx, hipMemcpyAsync(W, cen, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
+                HIPCHK(ctx, hipMemcpyAsync(W, cen_full, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
                 nW = nc;
             } else {
                 std::swap(W, Wn);
@@ -1766,5 +1812,7 @@ int pw_frontend_segment_device(pwicp_context* ctx, const float* cloud_xyz4, int 
         }
     }
     tr.lap("occupied cells");
+    for (int d = 0; d < 3; ++d) { ws.bb_mn[d] = mn[d]; ws.bb_mx[d] = mx[d]; }
+    ws.bb_set = true;
     return segment_from_device_graph(ctx, tr, cloud_xyz4, dP.p, d_nb.p, k, n, res, n_sv, labels, n_supervoxels);
 }
