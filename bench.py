@@ -468,6 +468,7 @@ def main():
     t0 = time.time()
     pair = P.Pair(ctx, tgt, l1, n1, src, l2, n2, prm)
     t_setup = time.time() - t0
+    pair.set_profiling(1)        # HIP events around the dense 1-NN launch in EVERY step (the roofline figure; ~9 us of every step)
 
     def barrier():
         if dist is not None:

@@ -383,10 +383,10 @@ PWICP_API bool pwicp_series_run_distributed(const char* confile, int startEpoch,
                                             int rank, int world, int device, const char* id_file);
 
 /* ---- measurement hooks ------------------------------------------------------------------------------------
- * HIP events on the pair's stream feed pwicp_result.t_dense_nn_ms / t_inner_ms.  An event record costs a ~6 us
- * bubble on the stream, so only the dense-NN pair is on by default. */
+ * HIP events on the pair's stream feed pwicp_result.t_dense_nn_ms / t_inner_ms.  An event record costs a ~5 us
+ * bubble on the stream: none is recorded unless asked for (bench.py asks for PWICP_PROF_DENSE in every timed step). */
 enum {
-    PWICP_PROF_DENSE = 1,    /* events around every dense 1-NN launch   -> t_dense_nn_ms (default) */
+    PWICP_PROF_DENSE = 1,    /* events around every dense 1-NN launch   -> t_dense_nn_ms */
     PWICP_PROF_INNER = 2,    /* events around every inner-ICP batch     -> t_inner_ms */
     PWICP_PROF_REPLAY = 4    /* keep the stable flags of the first dense launch for pwicp_pair_bench_dense_nn */
 };

@@ -241,7 +241,7 @@ struct pwicp_pair {
     // stable flags of the first Stage-1 dense NN launch of the last run (replayed by bench_dense_nn)
     DevBuf<int> stable0;
     int ns0 = 0, nsp0 = 0;
-    int profiling = PWICP_PROF_DENSE;     // pwicp_pair_set_profiling
+    int profiling = 0;                    // pwicp_pair_set_profiling (no events unless asked for: a record is a ~5 us bubble on the stream)
     std::vector<hipEvent_t> ev;
     // mailbox in pinned coherent host memory: [0] sequence word, [16..] payload
     unsigned* mail_h = nullptr;
