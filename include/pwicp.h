@@ -399,6 +399,13 @@ PWICP_API int pwicp_pair_set_profiling(pwicp_pair* pair, int flags);
 PWICP_API int pwicp_pair_bench_dense_nn(pwicp_pair* pair, int n_launches, double* ms_per_launch,
                                         long long* n_queries, double* kbar, double* cell_edge);
 
+/* The dense 1-NN search of calPercentileDistBetween2PC (CommonFunc.cpp:266-281) by itself: the squared distance of EVERY source
+ * patch point (pwicp_pair_num_patch_points: tot2 of them, in the order of the source patch arrays, current positions) to its nearest
+ * point of cloud1 - the search the loop runs on the points of its stable patches, here with every patch taken as stable.
+ * far_group: 0 / 1 = the far queries inside the search's own launch / on the launch that puts eight lanes on each; -1 = as the loop
+ * would choose for a first search.  d2_out: tot2 floats.  (Parity tests compare it with a brute-force search.) */
+PWICP_API int pwicp_pair_dense_distances(pwicp_pair* pair, int far_group, float* d2_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1282,4 +1282,30 @@ int pwicp_pair_bench_dense_nn(pwicp_pair* pr, int n_launches, double* ms_per_lau
     return PWICP_OK;
 }
 
+int pwicp_pair_dense_distances(pwicp_pair* pr, int far_group, float* d2_out) {
+    if (!pr || !d2_out) return PWICP_E_INVALID;
+    pwicp_context* ctx = pr->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int m2 = pr->P2.m, tot = pr->P2.tot;
+    if (m2 <= 0 || tot <= 0) { ctx->set_err("pwicp_pair_dense_distances: no source patches"); return PWICP_E_INVALID; }
+    PWCHK(materialize(pr));
+    HIPCHK(ctx, pr->all_stable.reserve((size_t)m2));
+    {
+        std::vector<int> ones((size_t)m2, 1);
+        HIPCHK(ctx, hipMemcpyAsync(pr->all_stable.p, ones.data(), (size_t)m2 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    const bool far = far_group < 0 ? pr->dense_far0 > 0.3 : far_group != 0;
+    PWCHK(pw_nn_dense_launch(ctx, pr->tgt->g_c1.d, pr->P2.pat.p, pr->qorder.p, pr->pt_patch2.p, pr->all_stable.p, tot, pr->d2dense.p, nullptr,
+                             pr->dense_lv, pr->qpatch.p, nullptr, far ? &pr->dense_far : nullptr, nullptr));
+    std::vector<float> d2((size_t)tot);
+    std::vector<int> order((size_t)tot);
+    HIPCHK(ctx, hipMemcpyAsync(d2.data(), pr->d2dense.p, (size_t)tot * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(order.data(), pr->qorder.p, (size_t)tot * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < tot; ++i) d2_out[order[(size_t)i]] = d2[(size_t)i];      // launch order -> order of the patch arrays
+    HIPCHK(ctx, hipGetLastError());
+    return PWICP_OK;
+}
+
 }  // extern "C"

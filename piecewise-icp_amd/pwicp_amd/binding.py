@@ -113,6 +113,9 @@ def load_library():
         ("pwicp_pair_step", [vp, C.POINTER(Step)]),
         ("pwicp_pair_auto_dtinit", [vp, fp]),
         ("pwicp_pair_bench_dense_nn", [vp, C.c_int, dp, C.POINTER(C.c_longlong), dp, dp]),
+        ("pwicp_pair_dense_distances", [vp, C.c_int, fp]),
+        ("pwicp_pair_num_patch_points", [vp, ip, ip]),
+        ("pwicp_pair_download_state", [vp, fp, fp, fp, fp]),
         ("pwicp_pair_set_profiling", [vp, C.c_int]),
         ("pwicp_target_create", [vp, fp, C.c_int, ip, C.c_int, C.c_float, C.c_float, C.POINTER(vp)]),
         ("pwicp_target_destroy", [vp]),
@@ -610,6 +613,25 @@ class Pair:
     def download_source(self):
         out = np.zeros((self.n2, 4), np.float32)
         self._ctx._chk(self._L.pwicp_pair_download_source(self._h, _p(out)))
+        return out
+
+    def num_patch_points(self):
+        a, b = C.c_int32(), C.c_int32()
+        self._ctx._chk(self._L.pwicp_pair_num_patch_points(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def source_patch_points(self):
+        """The points of the selected source patches (current positions), float32 (tot2, 4), in the order of the patch arrays."""
+        out = np.empty((self.num_patch_points()[1], 4), np.float32)
+        self._ctx._chk(self._L.pwicp_pair_download_state(self._h, None, None, None, _p(out)))
+        return out
+
+    def dense_distances(self, far_group=-1):
+        """Squared distance of every source patch point (order of the source patch arrays) to its nearest target point: the
+        dense search of calPercentileDistBetween2PC with every patch taken as stable."""
+        tot = self.num_patch_points()[1]
+        out = np.empty(tot, np.float32)
+        self._ctx._chk(self._L.pwicp_pair_dense_distances(self._h, int(far_group), _p(out)))
         return out
 
     def bench_dense_nn(self, n_launches=10):

@@ -650,3 +650,32 @@ def test_single_iteration_steps_equal_the_whole_loop(ctx, oracle, manual):
     assert np.array_equal(T.reshape(16), np.array(res.T16, np.float32))
     assert list(st.VCM) == list(res.VCM)
     pair.close()
+
+
+@pytest.mark.parametrize("far_group", [0, 1])
+@pytest.mark.parametrize("scene", ["aligned", "offset", "beyond_coverage"])
+def test_dense_search_against_brute_force(ctx, oracle, scene, far_group):
+    """The dense 1-NN search of calPercentileDistBetween2PC (C.cpp:266-281) by itself (pwicp_pair_dense_distances: every
+    source patch point, both forms of its far path) against the oracle's exhaustive search: the float d2 of every query,
+    bit for bit.  `offset`: the clouds 3 cm apart (every ball wide, most queries far: the levels of larger cells);
+    `beyond_coverage`: a third of the source lies 0.2 - 0.6 m outside the target's extent (nothing within 2.75 coarse cells:
+    the general search, taken by whole blocks - more such queries per block than a block keeps, too)."""
+    import pwicp_amd as P
+    tgt, src, _ = _data.pair(60000, epoch=2)
+    src = src.copy()
+    if scene == "offset":
+        src[:, 0] += np.float32(0.03); src[:, 2] += np.float32(0.012)
+    elif scene == "beyond_coverage":
+        far = src[:, 0] > np.quantile(src[:, 0], 0.67)
+        src[far, 0] += np.float32(0.2) + (src[far, 0] - src[far, 0].min()) * np.float32(1.5)
+    l1, n1 = _labels(tgt, "grid")
+    l2, n2 = _labels(src, "grid")
+    pair = P.Pair(ctx, tgt, l1, n1, src, l2, n2, _data.params())
+    q = pair.source_patch_points()
+    d2 = pair.dense_distances(far_group)
+    _, ref = oracle.nn1(tgt, q[:, :3])
+    assert len(q) > 10000
+    assert d2.tobytes() == np.asarray(ref, np.float32).tobytes()
+    if scene == "beyond_coverage":
+        assert (np.sqrt(d2) > 0.1).sum() > 2000
+    pair.close()
