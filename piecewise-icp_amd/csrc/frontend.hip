@@ -1536,7 +1536,10 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
                 continue;
             }
             runs += nW;
-            if (trace && getenv("PWICP_TRACE_SWEEPS")) fprintf(stderr, "      sweep %d: %d\n", sweeps, nW);
+            static const bool trace_sweeps = getenv("PWICP_TRACE_SWEEPS") != nullptr;
+            const auto t_sweep = std::chrono::steady_clock::now();
+            const int nW_sweep = nW;
+            const bool cert_sweep = certify;
             HIPCHK(ctx, hipMemsetAsync(ws.ctr.p, 0, sizeof(int) * 16, st));
             const int chunk = certify ? 1 : std::max(1, std::min(std::min(nW / chunk_div, kFusChunk), gs_chunk));
             hipLaunchKernelGGL((k_fus_run<kFusQueueS, kFusHashS, 4>), dim3((unsigned)std::min(div_up(div_up(nW, chunk), 4), 8192)), dim3(256), 0, st,
@@ -1551,6 +1554,9 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
             hipLaunchKernelGGL(k_fus_sweep_end, dim3((unsigned)std::min(256, std::max(8, nW / 256))), dim3(256), 0, st, s, ws.dq.p, ndq, ws.dq2.p,
                                ndq + 1);
             PWCHK(fe_read_words(ctx, ws, ws.ctr.p, 16, h_ctr));
+            if (trace && trace_sweeps)
+                fprintf(stderr, "      sweep %d: %d centres%s, %d changed nodes, %.3f ms\n", sweeps, nW_sweep, cert_sweep ? " (certificate)" : "", h_ctr[1],
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_sweep).count());
             if (h_ctr[8] || h_ctr[9]) {
                 if (trace) fprintf(stderr, "[pwicp front end/dev]   fusion gives up in round %d (%s overflow)\n", round, h_ctr[8] ? "queue" : "arena");
                 ws.sa_overflow = !h_ctr[8] && h_ctr[9];
