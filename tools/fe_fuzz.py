@@ -35,6 +35,10 @@ for c in range(cases):
         knobs["PWICP_FUSION_QUEUE"] = str(int(rng.choice([40, 100, 300])))
     if rng.random() < 0.4:
         knobs["PWICP_FUSION_BATCH"] = str(int(rng.choice([1, 2, 16])))
+    if rng.random() < 0.5:
+        knobs["PWICP_FUSION_TILE"] = str(int(rng.choice([0, 3, 16, 100])))
+    if rng.random() < 0.3:
+        knobs["PWICP_FUSION_CHUNK_DIV"] = str(int(rng.choice([16, 256, 8192])))
     out = {}
     for mode in ("host", "device"):
         os.environ["PWICP_FRONTEND"] = mode
