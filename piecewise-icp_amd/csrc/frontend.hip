@@ -295,6 +295,7 @@ struct FusState {
     const int* nW_dev;
     int* stop;
     int queue_limit;           // <= kFusQueue ($PWICP_FUSION_QUEUE: smaller, to exercise the fallback)
+    int slot0;                 // first slot of the part of the work list this launch takes (a sweep in two colours: fusion_device)
 };
 
 // search queue / visited hash of a wavefront: the common case in LDS small enough for 5 blocks of 4 wavefronts per CU (the kernel
@@ -434,7 +435,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_fus_run(FusState s, int nW, int 
       }
       const int slot_end = min(nW, (ci + 1) * chunk);
       for (int sl_i = ci * chunk; sl_i < slot_end; ++sl_i) {
-        const int slot = list ? list[sl_i] : sl_i;
+        const int slot = list ? list[sl_i] : s.slot0 + sl_i;
         const int i = s.W[slot];
         if (lane == 0) { s.slot_of[i] = slot; s.wake[i] = 0; }
         const int old_ran = s.rec_ran[i], old_sz = s.rec_sz[i], old_absn = s.rec_absn[i], old_adjn = s.rec_adjn[i];
@@ -596,8 +597,8 @@ __global__ void __launch_bounds__(64 * WAVES) k_fus_run(FusState s, int nW, int 
 // the claims of the outcomes that changed: first all old ones are withdrawn, then the new ones are made (two launches)
 __global__ void k_fus_retract(FusState s, int nW) {
     FUS_BATCHED_NW(s, nW);
-    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= nW || s.o_dirty[slot] != 1) return;
+    const int slot = s.slot0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= s.slot0 + nW || s.o_dirty[slot] != 1) return;
     const int c = s.W[slot];
     const long long p = s.o_oldptr[slot];
     for (int e = 0, m = s.o_oldabsn[slot]; e < m; ++e) {
@@ -607,8 +608,8 @@ __global__ void k_fus_retract(FusState s, int nW) {
 }
 __global__ void k_fus_claim(FusState s, int nW) {
     FUS_BATCHED_NW(s, nW);
-    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= nW || s.o_dirty[slot] == 2) return;
+    const int slot = s.slot0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= s.slot0 + nW || s.o_dirty[slot] == 2) return;
     const int c = s.W[slot];
     if (s.o_dirty[slot] == 1) {
         s.rec_sz[c] = s.o_sz[slot]; s.rec_ran[c] = s.o_ran[slot]; s.rec_absn[c] = s.o_absn[slot]; s.rec_adjn[c] = s.o_adjn[slot];
@@ -850,14 +851,21 @@ __global__ void __launch_bounds__(1024) k_fus_advance(FusState s, int* __restric
 // centres tile by tile - a wavefront's chunk of consecutive slots is then a PATCH of the surface (its centres still in ascending
 // order: the sort is stable), and what a centre has just decided reaches its neighbours across the scan lines in the same sweep
 __global__ void k_fus_tile_keys(const FePt* __restrict__ P, const int* __restrict__ cen, int nc, int a, int b, double mna, double mnb,
-                                double inv, unsigned ntx, unsigned* __restrict__ keys) {
+                                double inv, unsigned ntx, unsigned ntiles, int ncol, unsigned* __restrict__ keys) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nc) return;
     const FePt& p = P[cen[t]];
     const double ua = a == 0 ? p.x : (a == 1 ? p.y : p.z), ub = b == 0 ? p.x : (b == 1 ? p.y : p.z);
     const unsigned tx = (unsigned)fmin(fmax((ua - mna) * inv, 0.0), (double)(ntx - 1));
     const unsigned ty = (unsigned)fmax((ub - mnb) * inv, 0.0);
-    keys[t] = ty * ntx + tx;
+    // (colours: ncol = 2 the tiles of a checkerboard, 4 the 2 x 2 pattern - all tiles of colour 0 first, then colour 1, ...)
+    const unsigned colour = ncol == 4 ? (tx & 1u) + 2u * (ty & 1u) : (ncol == 2 ? (tx + ty) & 1u : 0u);
+    keys[t] = colour * ntiles + ty * ntx + tx;
+}
+// number of keys below `limit` in a sorted array (= the centres of the first colour)
+__global__ void k_fus_count_below(const unsigned* __restrict__ keys, int n, unsigned limit, int* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n && keys[t] < limit && (t + 1 == n || keys[t + 1] >= limit)) *out = t + 1;
 }
 __global__ void k_fus_min_metric(const FePt* __restrict__ P, const int* __restrict__ nb, int k, int n, double res, double* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1423,6 +1431,8 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     s.nW_dev = nullptr; s.stop = nullptr;
     const int wake_all_div = getenv("PWICP_FUSION_WAKE_DIV") ? std::max(atoi(getenv("PWICP_FUSION_WAKE_DIV")), 1) : 32;
     const int chunk_div = getenv("PWICP_FUSION_CHUNK_DIV") ? std::max(atoi(getenv("PWICP_FUSION_CHUNK_DIV")), 1) : 2048;   // chunks wanted per sweep (8192: 53.4 ms of fusion at 1 M points, 2048: 51.4, 512: 51.4)
+    // sweeps over all centres: the tiles of one colour after the other (1: all at once, 2: checkerboard, 4: 2 x 2 pattern)
+    const int n_colours = getenv("PWICP_FUSION_COLOURS") ? (atoi(getenv("PWICP_FUSION_COLOURS")) >= 4 ? 4 : (atoi(getenv("PWICP_FUSION_COLOURS")) >= 2 ? 2 : 1)) : 2;
     const int tile_pop = getenv("PWICP_FUSION_TILE") ? std::max(atoi(getenv("PWICP_FUSION_TILE")), 0) : 16;     // centres per tile; 0: index order
     for (;; lambda *= 2.0, ++round) {
         if (nc <= 1) {                                  // (:106) nothing left to fuse
@@ -1450,6 +1460,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
         s.lambda = lambda; s.len0 = len0; s.off0 = off0; s.arena0 = arena0; s.revown = ws.revown.p;
         // full sweeps take the centres in tile order (k_fus_tile_keys); the certificate keeps the plain order
         const int* cen_full = cen;
+        int n_parts = 1, part_begin[4] = {0, 0, 0, 0}, part_end[4] = {nc, 0, 0, 0};      // colours: cen_full[part_begin[c] .. part_end[c])
         if (tile_pop > 0 && ws.bb_set && nc >= 4096) {
             int ax[3] = {0, 1, 2};
             double ext[3] = {ws.bb_mx[0] - ws.bb_mn[0], ws.bb_mx[1] - ws.bb_mn[1], ws.bb_mx[2] - ws.bb_mn[2]};
@@ -1458,23 +1469,40 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
             const double area = std::max(ext[a], 1e-30) * std::max(ext[b], 1e-30);
             const double edge = std::sqrt((double)tile_pop * area / (double)nc);
             const double ntx_d = std::floor(ext[a] / edge) + 1.0, nty_d = std::floor(ext[b] / edge) + 1.0;
-            if (edge > 0.0 && ntx_d * nty_d < 4.0e9) {
+            if (edge > 0.0 && ntx_d * nty_d < 2.0e9) {
                 HIPCHK(ctx, ws.cen_t.reserve(N));
                 HIPCHK(ctx, ws.tkey.reserve(N));
                 HIPCHK(ctx, ws.tkey2.reserve(N));
+                const unsigned ntiles = (unsigned)(ntx_d * nty_d);
+                const int ncol = ntx_d * nty_d * n_colours < 4.0e9 ? n_colours : 1;
                 hipLaunchKernelGGL(k_fus_tile_keys, grid1(nc), dim3(256), 0, st, dP, cen, nc, a, b, ws.bb_mn[a], ws.bb_mn[b], 1.0 / edge,
-                                   (unsigned)ntx_d, ws.tkey.p);
+                                   (unsigned)ntx_d, ntiles, ncol, ws.tkey.p);
                 int end_bit = 1;
-                while (end_bit < 32 && (double)(1ull << end_bit) < ntx_d * nty_d) ++end_bit;
+                while (end_bit < 32 && (double)(1ull << end_bit) < ntx_d * nty_d * ncol) ++end_bit;
                 size_t tb = 0;
                 HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, ws.tkey.p, ws.tkey2.p, cen, ws.cen_t.p, nc, 0, end_bit, st));
                 HIPCHK(ctx, ws.tsort.reserve(tb));
                 HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(ws.tsort.p, tb, ws.tkey.p, ws.tkey2.p, cen, ws.cen_t.p, nc, 0, end_bit, st));
                 cen_full = ws.cen_t.p;
+                if (ncol > 1) {
+                    HIPCHK(ctx, hipMemsetAsync(ws.ctr.p + 12, 0, 3 * sizeof(int), st));
+                    for (int c = 1; c < ncol; ++c)
+                        hipLaunchKernelGGL(k_fus_count_below, grid1(nc), dim3(256), 0, st, (const unsigned*)ws.tkey2.p, nc, (unsigned)c * ntiles,
+                                           ws.ctr.p + 11 + c);
+                    int below[3] = {0, 0, 0};
+                    PWCHK(fe_read_words(ctx, ws, ws.ctr.p + 12, 3, below));
+                    n_parts = 0;
+                    int prev = 0;
+                    for (int c = 1; c <= ncol; ++c) {                      // (empty colours drop out)
+                        const int upto = c < ncol ? std::max(below[c - 1], prev) : nc;
+                        if (upto > prev) { part_begin[n_parts] = prev; part_end[n_parts] = upto; ++n_parts; prev = upto; }
+                    }
+                }
             }
         }
         int* W = ws.Wa.p; int* Wn = ws.Wb.p;
         HIPCHK(ctx, hipMemcpyAsync(W, cen_full, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
+        bool w_is_full = true;            // W holds cen_full (all centres, tile order, first colour first)
         int nW = nc, sweeps = 0;
         long long runs = 0;
         // The round ends with a CERTIFICATE: one sweep over all centres, every one reading the standing state only, that
@@ -1485,6 +1513,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
             if (nW == 0) {
                 HIPCHK(ctx, hipMemcpyAsync(W, cen, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
                 nW = nc;
+                w_is_full = false;
                 certify = true;
                 // absorbers from scratch: the smallest centre whose standing outcome absorbs the node
                 hipLaunchKernelGGL(k_fill<int>, grid1(n), dim3(256), 0, st, ws.ab.p, (long long)n, kNone);
@@ -1525,13 +1554,15 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
                     *gave_up = true;
                     return PWICP_OK;
                 }
-                if (!h_ctr[5]) { nW = h_ctr[4]; continue; }              // the batch ran through (W holds the next list, possibly empty)
+                if (!h_ctr[5]) { nW = h_ctr[4]; w_is_full = false; continue; }      // the batch ran through (W holds the next list, possibly empty)
                 if (h_ctr[3] || h_ctr[10] || h_ctr[11]) {                // everybody runs again ([3]: a search outgrew the small queue)
                     HIPCHK(ctx, hipMemcpyAsync(W, cen_full, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
                     nW = nc;
+                    w_is_full = true;
                 } else {                                                 // the next list outgrew the batch: back to single sweeps
                     std::swap(W, Wn);
                     nW = h_ctr[0];
+                    w_is_full = false;
                 }
                 continue;
             }
@@ -1542,12 +1573,22 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
             const bool cert_sweep = certify;
             HIPCHK(ctx, hipMemsetAsync(ws.ctr.p, 0, sizeof(int) * 16, st));
             const int chunk = certify ? 1 : std::max(1, std::min(std::min(nW / chunk_div, kFusChunk), gs_chunk));
-            hipLaunchKernelGGL((k_fus_run<kFusQueueS, kFusHashS, 4>), dim3((unsigned)std::min(div_up(div_up(nW, chunk), 4), 8192)), dim3(256), 0, st,
-                               s, nW, chunk, (const int*)nullptr, (const int*)nullptr, ws.ovf.p, ws.ctr.p + 3);
-            hipLaunchKernelGGL((k_fus_run<kFusQueue, kFusHash, 1>), dim3(256), dim3(64), 0, st, s, 0, 1, (const int*)ws.ovf.p,
-                               (const int*)(ws.ctr.p + 3), (int*)nullptr, (int*)nullptr);
-            hipLaunchKernelGGL(k_fus_retract, grid1(nW), dim3(256), 0, st, s, nW);
-            hipLaunchKernelGGL(k_fus_claim, grid1(nW), dim3(256), 0, st, s, nW);
+            // A sweep over ALL centres in tile order runs colour by colour: the tiles of one colour (no two of them neighbours), their
+            // outcomes and claims made standing, then the next colour - which sees what its neighbours of the colours before have just
+            // decided (Gauss-Seidel between tiles as it is inside one).  Any mixture of old and new outcomes is a valid guess; the round's certificate is untouched.
+            const bool halves = !certify && w_is_full && n_parts > 1 && nW == nc;
+            for (int half = 0; half < (halves ? n_parts : 1); ++half) {
+                const int h0 = halves ? part_begin[half] : 0, hn = halves ? part_end[half] - part_begin[half] : nW;
+                s.slot0 = h0;
+                if (half > 0) HIPCHK(ctx, hipMemsetAsync(ws.ctr.p + 3, 0, sizeof(int), st));
+                hipLaunchKernelGGL((k_fus_run<kFusQueueS, kFusHashS, 4>), dim3((unsigned)std::min(div_up(div_up(hn, chunk), 4), 8192)), dim3(256), 0, st,
+                                   s, hn, chunk, (const int*)nullptr, (const int*)nullptr, ws.ovf.p, ws.ctr.p + 3);
+                hipLaunchKernelGGL((k_fus_run<kFusQueue, kFusHash, 1>), dim3(256), dim3(64), 0, st, s, 0, 1, (const int*)ws.ovf.p,
+                                   (const int*)(ws.ctr.p + 3), (int*)nullptr, (int*)nullptr);
+                hipLaunchKernelGGL(k_fus_retract, grid1(hn), dim3(256), 0, st, s, hn);
+                hipLaunchKernelGGL(k_fus_claim, grid1(hn), dim3(256), 0, st, s, hn);
+            }
+            s.slot0 = 0;
             hipLaunchKernelGGL(k_fus_dirty0, grid1(nW), dim3(256), 0, st, s, nW, ws.dq.p, ndq);
             // (grids for the changed nodes: at most a few per slot)
             hipLaunchKernelGGL(k_fus_wake, dim3((unsigned)std::min(1024, std::max(32, nW / 64))), dim3(256), 0, st, s, ws.dq.p, ndq, ws.dq2.p, ndq + 1);
@@ -1568,9 +1609,11 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
             if (h_ctr[10] || h_ctr[11]) {               // closure deeper than the levels / too many changes: everybody runs again (always sound)
                 HIPCHK(ctx, hipMemcpyAsync(W, cen_full, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
                 nW = nc;
+                w_is_full = true;
             } else {
                 std::swap(W, Wn);
                 nW = h_ctr[0];
+                w_is_full = false;
             }
         }
         // absorbed in this round, per centre

@@ -128,11 +128,13 @@ def test_search_queue_overflow_falls_back_to_the_serial_pass(ctx, capfd):
                                    {"PWICP_FUSION_CHUNK": "16", "PWICP_FUSION_WAKE_DIV": "1"},
                                    {"PWICP_FUSION_CHUNK": "3", "PWICP_FUSION_WAKE_DIV": "100000"},
                                    {"PWICP_FUSION_TILE": "0"}, {"PWICP_FUSION_TILE": "4", "PWICP_FUSION_CHUNK_DIV": "64"},
-                                   {"PWICP_FUSION_TILE": "300", "PWICP_FUSION_CHUNK": "5"}])
+                                   {"PWICP_FUSION_TILE": "300", "PWICP_FUSION_CHUNK": "5"},
+                                   {"PWICP_FUSION_COLOURS": "1"}, {"PWICP_FUSION_COLOURS": "4", "PWICP_FUSION_TILE": "7"}])
 def test_labels_do_not_depend_on_the_sweep_schedule(ctx, knobs):
     """The fixed point is the serial result whatever the schedule: chunks of 1 (Jacobi) ... 16 centres per wavefront
     (Gauss-Seidel inside a chunk), work lists from the first sweep on (WAKE_DIV 1) or hardly ever (100000), the full sweeps in
-    index order (TILE 0) or tile by tile with tiles of 4 / 300 centres, 64 instead of 2048 chunks wanted per sweep."""
+    index order (TILE 0) or tile by tile with tiles of 4 / 300 centres, 64 instead of 2048 chunks wanted per sweep, the tiles of a
+    sweep all at once, in two colours (the default) or in four."""
     tgt, _, _ = _data.pair(400000)
     os.environ.update(knobs)
     try:

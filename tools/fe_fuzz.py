@@ -37,6 +37,8 @@ for c in range(cases):
         knobs["PWICP_FUSION_BATCH"] = str(int(rng.choice([1, 2, 16])))
     if rng.random() < 0.5:
         knobs["PWICP_FUSION_TILE"] = str(int(rng.choice([0, 3, 16, 100])))
+    if rng.random() < 0.4:
+        knobs["PWICP_FUSION_COLOURS"] = str(int(rng.choice([1, 2, 4])))
     if rng.random() < 0.3:
         knobs["PWICP_FUSION_CHUNK_DIV"] = str(int(rng.choice([16, 256, 8192])))
     out = {}
