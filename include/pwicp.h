@@ -382,6 +382,11 @@ PWICP_API int  pwicp_comm_broadcast(pwicp_comm* comm, void* buf, size_t bytes, i
 PWICP_API bool pwicp_series_run_distributed(const char* confile, int startEpoch, int epochNum, int pairMode, float overlapThd,
                                             int rank, int world, int device, const char* id_file);
 
+/* A series that is closed leaves its device contexts and front-end work spaces PARKED (one set per device) for the next series of
+ * the process on that device: setting them up costs 0.15 - 0.25 s, a third of an 8 x 1 M-point series ($PWICP_SERIES_KEEP=0: off).
+ * This frees them (also done at process exit). */
+PWICP_API void pwicp_series_release_parked(void);
+
 /* ---- measurement hooks ------------------------------------------------------------------------------------
  * HIP events on the pair's stream feed pwicp_result.t_dense_nn_ms / t_inner_ms.  An event record costs a ~5 us
  * bubble on the stream: none is recorded unless asked for (bench.py asks for PWICP_PROF_DENSE in every timed step). */

@@ -519,6 +519,27 @@ PWICP_API int pwicp_write_trans_matrix_file(const char* path, const float* T16, 
 // One GPU of a series: its context and the target clouds prepared on it.  A series owns one worker per device it was
 // opened on; the pairs handed to pwicp_series_run_pairs are dealt to the workers (pair k of the call -> worker k mod G),
 // each worker runs on a host thread of its own (the pairs are independent, R.cpp:89-187).
+// What a series worker needs of a device - its context and the auxiliary contexts of the front ends with their work spaces
+// (~2 GB each at 1 M points, pinned staging buffers, loaded kernels) - costs 0.15 - 0.25 s to set up from nothing: more than a
+// third of an 8 x 1 M-point series.  A worker that closes PARKS them per device and the next series of the process on that device
+// takes them over warm: the second PiecewiseICP_4D_call of a process costs what its clouds cost.  One set per device is kept
+// ($PWICP_SERIES_KEEP=0: none) until pwicp_series_release_parked() or the end of the process.
+struct ParkedWorker { pwicp_context* ctx = nullptr; std::unique_ptr<AuxContexts> aux; };
+struct WorkerParking {
+    std::mutex mu;
+    std::map<int, ParkedWorker> by_device;
+    bool exit_hook = false;
+    static WorkerParking& get() { static WorkerParking* p = new WorkerParking; return *p; }       // (the object itself is never deleted)
+    // destroys what is parked (pwicp_series_release_parked, and once at exit: registered when the first set is parked, i.e. after
+    // the HIP runtime has registered its own exit work, so it runs before the runtime goes away)
+    void release_all() {
+        std::map<int, ParkedWorker> take;
+        { std::lock_guard<std::mutex> g(mu); take.swap(by_device); }
+        for (auto& kv : take) { kv.second.aux.reset(); if (kv.second.ctx) pwicp_destroy(kv.second.ctx); }
+    }
+    static bool enabled() { static const bool on = !(std::getenv("PWICP_SERIES_KEEP") && atoi(std::getenv("PWICP_SERIES_KEEP")) == 0); return on; }
+};
+
 struct SeriesWorker {
     int device = 0;
     pwicp_context* ctx = nullptr;         // created by the first call that needs the GPU
@@ -527,14 +548,30 @@ struct SeriesWorker {
     std::map<int, std::shared_ptr<Prepared>> targets;
     std::unique_ptr<AuxContexts> aux;     // streams for the front ends of the clouds of a window
     bool need_ctx() {
+        if (!ctx && !aux && WorkerParking::enabled()) {           // a warm set parked by an earlier series of this process?
+            WorkerParking& pk = WorkerParking::get();
+            std::lock_guard<std::mutex> g(pk.mu);
+            auto it = pk.by_device.find(device);
+            if (it != pk.by_device.end()) { ctx = it->second.ctx; aux = std::move(it->second.aux); pk.by_device.erase(it); }
+        }
         if (!aux) aux.reset(new AuxContexts(device));
         if (ctx) return true;
         if (pwicp_create(&ctx, device) != PWICP_OK) { std::cerr << "Error: no usable HIP device (pwicp has no CPU fallback).\n"; ctx = nullptr; return false; }
         return true;
     }
     void close() {
-        aux.reset();
         targets.clear();                  // device-side targets go before their context
+        if (ctx && aux && WorkerParking::enabled()) {
+            WorkerParking& pk = WorkerParking::get();
+            std::lock_guard<std::mutex> g(pk.mu);
+            if (!pk.by_device.count(device)) {
+                ParkedWorker& slot = pk.by_device[device];
+                slot.ctx = ctx; slot.aux = std::move(aux);
+                ctx = nullptr;
+                if (!pk.exit_hook) { pk.exit_hook = true; std::atexit([] { WorkerParking::get().release_all(); }); }
+            }
+        }
+        aux.reset();
         if (ctx) pwicp_destroy(ctx);
         ctx = nullptr;
     }
@@ -659,6 +696,9 @@ PWICP_API int pwicp_series_open(const char* confile, int startEpoch, int epochNu
     *out = s.release();
     return PWICP_OK;
 }
+
+// frees what closed series have left parked per device (contexts, front-end work spaces): for hosts that are done with series
+PWICP_API void pwicp_series_release_parked(void) { WorkerParking::get().release_all(); }
 
 PWICP_API void pwicp_series_close(pwicp_series* s) {
     if (!s) return;

@@ -237,6 +237,13 @@ def PiecewiseICP_4D_call(confile, startEpoch, epochNum, pairMode, overlapThd=0.7
                                                     float(overlapThd)))
 
 
+def series_release_parked():
+    """Frees the device contexts / front-end work spaces closed series have left parked for the next one (pwicp.h)."""
+    L = load_library()
+    L.pwicp_series_release_parked.restype = None
+    L.pwicp_series_release_parked()
+
+
 class Series:
     """A 4D series (PiecewiseICP_4D_call, R.cpp:17-215) as a handle whose pairs can be run one by one, on any GPU.
     Records are rows of pwicp_amd.fourd.RECORD (= pwicp_pair_record, 384 bytes)."""

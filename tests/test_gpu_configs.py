@@ -370,3 +370,35 @@ def test_no_transformations_series_through_the_exported_entry_point(tmp_path, ct
         near_identity += int(np.abs(G.euler(T)).max() < NT_ANG and np.abs(T[:3, 3]).max() < NT_TR)
     assert not bad, bad
     assert near_identity == 19 - len(NT_DRIFT)
+
+
+def test_a_second_series_takes_over_the_parked_contexts_of_the_first(tmp_path, ctx):
+    """A closed series parks its device contexts and front-end work spaces for the next one of the process
+    (pwicp_series_release_parked frees them): the same series run three times - cold, on parked resources, after a release -
+    gives byte-identical records."""
+    import pwicp_amd as P
+    from pwicp_amd import synth
+    from pwicp_amd.pcd import write_pcd_binary
+    inp = tmp_path / "scans"
+    inp.mkdir()
+    t, _ = synth.make_tile(60000, R)
+    write_pcd_binary(str(inp / "Epoch_001.pcd"), t.astype(np.float32))
+    for e in (1, 2):
+        s, _ = synth.make_source(60000, R, epoch=e)
+        write_pcd_binary(str(inp / ("Epoch_%03d.pcd" % (e + 1))), s.astype(np.float32))
+    cfg = tmp_path / "cfg.txt"
+    _write_series_config(str(cfg), str(inp), str(tmp_path / "out_"))
+    runs = []
+    for k in range(3):
+        if k == 2:
+            P.series_release_parked()
+        series = P.Series(str(cfg), 0, 3, 0, 0.75, 0)
+        recs = series.run_pairs([0, 1])
+        series.close()
+        assert np.all(recs["status"] == 0)
+        rec = recs.copy()
+        rec["t_loop_ms"] = 0
+        rec["t_pair_ms"] = 0
+        runs.append(rec.tobytes())
+    assert runs[0] == runs[1] == runs[2]
+    P.series_release_parked()
