@@ -296,6 +296,8 @@ struct FusState {
     int* stop;
     int queue_limit;           // <= kFusQueue ($PWICP_FUSION_QUEUE: smaller, to exercise the fallback)
     int slot0;                 // first slot of the part of the work list this launch takes (a sweep in two colours: fusion_device)
+    int* changed;              // [16 x 32] centres whose outcome changed in the running sweep, spread over 16 lines (k_fus_run adds,
+                               // k_fus_dirty0 reads); nullptr: not counted (batched sweeps)
 };
 
 // search queue / visited hash of a wavefront: the common case in LDS small enough for 5 blocks of 4 wavefronts per CU (the kernel
@@ -426,6 +428,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_fus_run(FusState s, int nW, int 
     FUS_BATCHED_NW(s, nW);
     if (list) { nW = *n_list; chunk = 1; }
     const int n_chunks = (nW + chunk - 1) / chunk;
+    int n_changed = 0;                                  // (wave-uniform)
     for (int ci = blockIdx.x * WAVES + wave; ci < n_chunks; ci += gridDim.x * WAVES) {
       w.ndone = 0; w.nfresh = 0;
       bool chunk_live = chunk > 1;
@@ -556,6 +559,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_fus_run(FusState s, int nW, int 
             s.o_dirty[slot] = same ? 0 : 1;
             s.o_oldptr[slot] = old_ptr; s.o_oldabsn[slot] = old_absn;
         }
+        n_changed += same ? 0 : 1;
         // what the later centres of the chunk see of this one
         if (chunk_live && sl_i + 1 < slot_end && w.ndone < kFusChunk) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // its lists are in memory before they are read back
@@ -592,6 +596,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_fus_run(FusState s, int nW, int 
         }
       }
     }
+    if (s.changed && lane == 0 && n_changed) atomicAdd(&s.changed[(blockIdx.x & 15) * 32], n_changed);
 }
 
 // the claims of the outcomes that changed: first all old ones are withdrawn, then the new ones are made (two launches)
@@ -660,6 +665,18 @@ __device__ __forceinline__ void fus_mark_dirty(const FusState& s, bool on, int x
 // level 0 of the dirty list: centres whose outcome changed, nodes whose absorber changed
 __global__ void k_fus_dirty0(FusState s, int nW, int* dq, int* ndq) {
     FUS_BATCHED_NW(s, nW);
+    // More centres changed their outcome in this sweep than the wake-up looks at changed nodes (every such centre is one): the
+    // list would be thrown away - k_fus_wake asks for everybody to run again - so it is not made.  The count is final (k_fus_run
+    // has ended); the host then takes the sweep's absorbers as the previous ones wholesale.
+    if (s.changed) {
+        int nch = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nch += s.changed[r * 32];
+        if (nch > s.wake_all_above) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) *ndq = nch;
+            return;
+        }
+    }
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = slot < nW && s.o_dirty[slot] != 2;
     const bool on = live && s.o_dirty[slot] == 1;
@@ -768,6 +785,12 @@ __global__ void __launch_bounds__(256) k_fus_wake(FusState s, const int* dq, con
 
 __global__ void k_fus_sweep_end(FusState s, const int* dq, const int* ndq, const int* dq2, const int* ndq2) {
     if (s.nW_dev && *s.stop) return;
+    if (s.changed) {                                   // (k_fus_dirty0 made no list: nothing was flagged, *ndq is only a count)
+        int nch = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nch += s.changed[r * 32];
+        if (nch > s.wake_all_above) return;
+    }
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < *ndq; t += gridDim.x * blockDim.x) {
         const int x = dq[t];
         s.dflag[x] = 0;
@@ -1104,6 +1127,7 @@ struct FeWorkspace {
         dflag, cflag, dtmin, Wa, Wb, dq, dq2, ovf, o_sz, o_ran, o_absn, o_adjn, o_dirty, o_oldabsn, alive, newlen, cut, arenaA, arenaB, sa, ctr;
     DevBuf<long long> offA, offB, rec_ptr, o_ptr, o_oldptr;
     DevBuf<unsigned long long> big;     // [0] absorbed in the round, [16 * (1 + r)] bump pointer of arena region r
+    DevBuf<int> chg;                    // FusState::changed
     DevBuf<int> cen_t;                  // the centres of a round in TILE order (fusion_device: full sweeps)
     DevBuf<unsigned> tkey, tkey2;
     DevBuf<unsigned char> tsort;
@@ -1395,6 +1419,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     for (DevBuf<int>* b : {&ws.revoff, &ws.alive, &ws.newlen}) HIPCHK(ctx, b->reserve(N + 1));
     for (DevBuf<long long>* b : {&ws.offA, &ws.offB, &ws.rec_ptr, &ws.o_ptr, &ws.o_oldptr}) HIPCHK(ctx, b->reserve(N));
     HIPCHK(ctx, ws.ctr.reserve(16));
+    HIPCHK(ctx, ws.chg.reserve(16 * 32));
     HIPCHK(ctx, ws.big.reserve(16 * (kFusArenas + 1)));
     // lists of changed outcomes are appended, nothing is freed inside a round: 2.2 n k entries at most on the clouds measured
     // (the round after the first one).  3 n k = 0.54 GB per 1 M points; a round that overflows it is retried once with 6 n k
@@ -1536,6 +1561,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
                 const int init[16] = {0, 0, 0, 0, nW, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 HIPCHK(ctx, hipMemcpyAsync(ws.ctr.p, init, sizeof(init), hipMemcpyHostToDevice, st));
                 s.nW_dev = ws.ctr.p + 4; s.stop = ws.ctr.p + 5;
+                s.changed = nullptr;
                 for (int b = 0; b < batch_sweeps; ++b) {
                     hipLaunchKernelGGL((k_fus_run<kFusQueueS, kFusHashS, 4>), dim3((unsigned)div_up(batch_cap, 4)), dim3(256), 0, st, s, 0, 1,
                                        (const int*)nullptr, (const int*)nullptr, ws.ovf.p, ws.ctr.p + 3);
@@ -1572,6 +1598,8 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
             const int nW_sweep = nW;
             const bool cert_sweep = certify;
             HIPCHK(ctx, hipMemsetAsync(ws.ctr.p, 0, sizeof(int) * 16, st));
+            HIPCHK(ctx, hipMemsetAsync(ws.chg.p, 0, sizeof(int) * 16 * 32, st));
+            s.changed = certify ? nullptr : ws.chg.p;
             const int chunk = certify ? 1 : std::max(1, std::min(std::min(nW / chunk_div, kFusChunk), gs_chunk));
             // A sweep over ALL centres in tile order runs colour by colour: the tiles of one colour (no two of them neighbours), their
             // outcomes and claims made standing, then the next colour - which sees what its neighbours of the colours before have just
@@ -1607,6 +1635,9 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
             if (certify && h_ctr[1] == 0) { certified = true; break; }       // nothing changed against the rebuilt absorbers
             certify = false;
             if (h_ctr[10] || h_ctr[11]) {               // closure deeper than the levels / too many changes: everybody runs again (always sound)
+                // (the changed nodes may not have been listed at all - k_fus_dirty0 - so their absorbers of this sweep become the
+                // previous ones here, all of them at once, and no flag of a listed node is left standing: none was set)
+                if (h_ctr[11]) HIPCHK(ctx, hipMemcpyAsync(ws.ab_prev.p, ws.ab.p, sizeof(int) * N, hipMemcpyDeviceToDevice, st));
                 HIPCHK(ctx, hipMemcpyAsync(W, cen_full, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
                 nW = nc;
                 w_is_full = true;
