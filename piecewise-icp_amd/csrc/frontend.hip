@@ -260,7 +260,8 @@ struct FusState {
     // static in a round
     const FePt* P;
     double res, lambda;
-    const int* root0;          // [n] root of a point at the start of the round
+    const int* root0;          // [n] root of a point at the start of the round (the entries of the base lists ARE roots at the start
+                               // of the round - k_fus_next_lists resolves them on the way into the arena - so no search reads it)
     const int* s0;             // [n] size of a root
     const int* len0;           // [n] length of its adjacency list (0: absorbed in an earlier round / isolated)
     const long long* off0;     // [n] offset of the list in arena0
@@ -329,6 +330,15 @@ constexpr int kFusArenas = 256;
 #define PW_FUS_CHUNK 16
 #endif
 constexpr int kFusChunk = PW_FUS_CHUNK, kFusFresh = 8 * PW_FUS_CHUNK;
+// wavefronts per block of the sweeps' launch (the wavefronts of a block share nothing: a block only holds its slots until its
+// slowest wavefront is done) and the most blocks of one launch (beyond that a wavefront takes several chunks)
+#ifndef PW_FUS_WAVES
+#define PW_FUS_WAVES 4
+#endif
+#ifndef PW_FUS_GRID_CAP
+#define PW_FUS_GRID_CAP 8192
+#endif
+constexpr int kFusWaves = PW_FUS_WAVES, kFusGridCap = PW_FUS_GRID_CAP;
 
 struct FusWave {           // per-wavefront scratch (LDS)
     int* keys; int* vals; int* queue;
@@ -367,7 +377,7 @@ __device__ __forceinline__ int fus_absorber(const FusState& s, const FusWave& w,
 }
 
 __device__ __forceinline__ int fus_root_at(const FusState& s, const FusWave& w, int y, int t) {
-    int x = s.root0[y], g = -1;
+    int x = y, g = -1;                 // (y is a root of the round's start: base lists are resolved, outcome lists hold roots)
     for (;;) {
         const int c = fus_absorber(s, w, x);
         if (c >= t || c <= g) break;
@@ -934,11 +944,9 @@ __global__ void k_fus_reverse(const int* __restrict__ cen, int nc, const int* __
     // the order inside a root's range is the atomics' order of arrival either way)
     const int m = len0[c];
     for (int e0 = 0; e0 < m; e0 += 8) {
-        int y[8], x0[8], at[8];
+        int x0[8], at[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) y[u] = (e0 + u < m) ? a[e0 + u] : 0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) x0[u] = root0[y[u]];
+        for (int u = 0; u < 8; ++u) x0[u] = (e0 + u < m) ? a[e0 + u] : 0;     // (entries are roots: k_fus_next_lists)
 #pragma unroll
         for (int u = 0; u < 8; ++u) at[u] = (e0 + u < m) ? atomicAdd(&cnt_or_cursor[x0[u]], 1) : 0;
         if (MODE == 1) {
@@ -984,7 +992,8 @@ __global__ void k_fus_next_lists(const int* __restrict__ cen, int nc, const int*
                                  const int* __restrict__ rec_absn, const int* __restrict__ rec_adjn, const long long* __restrict__ rec_ptr,
                                  const int* __restrict__ sa, const int* __restrict__ arena_old, const long long* __restrict__ off_old,
                                  const int* __restrict__ len_old, int* __restrict__ arena_new, long long* __restrict__ off_new,
-                                 int* __restrict__ len_new, int* __restrict__ s0, int* __restrict__ cen_new) {
+                                 int* __restrict__ len_new, int* __restrict__ s0, int* __restrict__ cen_new,
+                                 const int* __restrict__ root_new) {
     const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (t >= nc) return;
     const int c = cen[t];
@@ -995,7 +1004,9 @@ __global__ void k_fus_next_lists(const int* __restrict__ cen, int nc, const int*
     const int m = len_scan[t + 1] - len_scan[t];
     const int* src = rec_ran[c] ? sa + rec_ptr[c] + rec_absn[c] : arena_old + off_old[c];
     int* dst = arena_new + len_scan[t];
-    for (int e = lane; e < m; e += 64) dst[e] = src[e];
+    // every entry as the root it has at the start of the next round (k_fus_new_roots has run): the searches and the reverse index
+    // of that round then read the list and nothing else - one dependent gather less per entry, in every run of every sweep
+    for (int e = lane; e < m; e += 64) dst[e] = root_new[src[e]];
     if (lane == 0) {
         len_new[c] = m; off_new[c] = len_scan[t];
         s0[c] = rec_sz[c];
@@ -1563,7 +1574,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
                 s.nW_dev = ws.ctr.p + 4; s.stop = ws.ctr.p + 5;
                 s.changed = nullptr;
                 for (int b = 0; b < batch_sweeps; ++b) {
-                    hipLaunchKernelGGL((k_fus_run<kFusQueueS, kFusHashS, 4>), dim3((unsigned)div_up(batch_cap, 4)), dim3(256), 0, st, s, 0, 1,
+                    hipLaunchKernelGGL((k_fus_run<kFusQueueS, kFusHashS, kFusWaves>), dim3((unsigned)div_up(batch_cap, kFusWaves)), dim3(64 * kFusWaves), 0, st, s, 0, 1,
                                        (const int*)nullptr, (const int*)nullptr, ws.ovf.p, ws.ctr.p + 3);
                     hipLaunchKernelGGL(k_fus_post, dim3(1), dim3(1024), 0, st, s, ws.dq.p, ndq);
                     hipLaunchKernelGGL(k_fus_wake, dim3(64), dim3(256), 0, st, s, ws.dq.p, ndq, ws.dq2.p, ndq + 1);
@@ -1609,7 +1620,8 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
                 const int h0 = halves ? part_begin[half] : 0, hn = halves ? part_end[half] - part_begin[half] : nW;
                 s.slot0 = h0;
                 if (half > 0) HIPCHK(ctx, hipMemsetAsync(ws.ctr.p + 3, 0, sizeof(int), st));
-                hipLaunchKernelGGL((k_fus_run<kFusQueueS, kFusHashS, 4>), dim3((unsigned)std::min(div_up(div_up(hn, chunk), 4), 8192)), dim3(256), 0, st,
+                hipLaunchKernelGGL((k_fus_run<kFusQueueS, kFusHashS, kFusWaves>), dim3((unsigned)std::min(div_up(div_up(hn, chunk), kFusWaves), kFusGridCap)),
+                                   dim3(64 * kFusWaves), 0, st,
                                    s, hn, chunk, (const int*)nullptr, (const int*)nullptr, ws.ovf.p, ws.ctr.p + 3);
                 hipLaunchKernelGGL((k_fus_run<kFusQueue, kFusHash, 1>), dim3(256), dim3(64), 0, st, s, 0, 1, (const int*)ws.ovf.p,
                                    (const int*)(ws.ctr.p + 3), (int*)nullptr, (int*)nullptr);
@@ -1707,7 +1719,8 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
         HIPCHK(ctx, hipStreamSynchronize(st));
         HIPCHK(ctx, arena_next->reserve((size_t)std::max(n_list, 1)));
         hipLaunchKernelGGL(k_fus_next_lists, grid1((long long)nc * 64), dim3(256), 0, st, cen, nc, ws.alive.p, ws.newlen.p, ws.ab.p, ws.rec_ran.p, ws.rec_sz.p,
-                           ws.rec_absn.p, ws.rec_adjn.p, ws.rec_ptr.p, ws.sa.p, arena0, off0, len0, arena_next->p, off1, len1, ws.s0.p, cen1);
+                           ws.rec_absn.p, ws.rec_adjn.p, ws.rec_ptr.p, ws.sa.p, arena0, off0, len0, arena_next->p, off1, len1, ws.s0.p, cen1,
+                           (const int*)ws.root0.p);
         arena0 = arena_next->p;
         std::swap(arena_next, arena_cur);
         std::swap(len0, len1); std::swap(off0, off1); std::swap(cen, cen1);
