@@ -813,10 +813,11 @@ static int run_pairs_on(pwicp_series* s, SeriesWorker* w, const int32_t* pairs, 
         // ---- GPU parts one after the other; the host part of a cloud starts on its own thread as soon as its k-NN graph
         //      is down, so the serial host passes of earlier clouds run while the GPU prepares the later ones -------------
         std::vector<char> ok((size_t)nw, 1);
-        std::vector<std::thread> th;
+        std::vector<std::thread> th;                                   // front ends of the targets prepared in this window
+        std::vector<std::thread> th_src((size_t)nw);                   // front end of source k (not joinable: none was started)
         std::vector<char> okt(raw1.size(), 1);
         std::vector<Prepared> src((size_t)nw);
-        th.reserve(raw1.size() + (size_t)nw);
+        th.reserve(raw1.size());
         {
             size_t ti = 0;
             for (auto& kv : raw1) {
@@ -845,24 +846,30 @@ static int run_pairs_on(pwicp_series* s, SeriesWorker* w, const int32_t* pairs, 
             const float SVRes2 = cfg.isSetResSVsize ? cfg.SVsize2 : Res2 * 10;
             if (good) good = prepare_gpu(w->ctx, raw2[(size_t)k], Res2, SVRes2, sor_mult, it->second->shift, &src[(size_t)k]);
             ok[(size_t)k] = good ? 1 : 0;
-            if (good) th.emplace_back([&ok, &src, k, w] { ok[(size_t)k] = prepare_labels(&src[(size_t)k], w->aux.get()) ? 1 : 0; });
+            if (good) th_src[(size_t)k] = std::thread([&ok, &src, k, w] { ok[(size_t)k] = prepare_labels(&src[(size_t)k], w->aux.get()) ? 1 : 0; });
             std::vector<float>().swap(raw2[(size_t)k]);
         }
         tm.lap("voxel grid + SOR, k-NN graphs (GPU)");
         stage(1);
-        for (auto& t : th) t.join();
+        for (auto& t : th) t.join();                                   // (the targets' front ends were started first)
         {
             size_t ti = 0;
             for (auto& kv : raw1) { if (!okt[ti]) w->targets.erase(kv.first); ++ti; }
         }
-        tm.lap("normals + supervoxels (host threads, rest)");
-        stage(2);
-        // ---- registrations ---------------------------------------------------------------------------------------------
-        const double t_setup_each = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / nw;
+        // ---- registrations: pair k as soon as ITS source is segmented, on the worker's own stream, beside the front ends of the
+        //      later sources (the front ends finish roughly in the order they were started; records and printed lines keep the
+        //      order of the pairs) ----------------------------------------------------------------------------------------
+        double reg_ms = 0.0;
+        std::vector<float> reg_each((size_t)nw, 0.f);
         for (int k = 0; k < nw; ++k) {
+            if (th_src[(size_t)k].joinable()) th_src[(size_t)k].join();
             pwicp_pair_record* rec = &recs[w0 + k];
             const int pair = pairs[w0 + k], step = pair + 1, i = s->startEpoch + pair;
             const auto tp = std::chrono::steady_clock::now();
+            struct RegTime {                       // (time of this registration, whichever way the iteration is left)
+                double* sum; float* mine; std::chrono::steady_clock::time_point t;
+                ~RegTime() { const double d = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); *sum += d; *mine = (float)d; }
+            } reg_time{&reg_ms, &reg_each[(size_t)k], tp};
             std::cout << "\n//////////////////////  Process Pair_" << step << ":  Epoch-" << s->times[(size_t)refIdx[(size_t)k]] << " and Epoch-"
                       << s->times[(size_t)i + 1] << "   //////////////////////////////////////////// \n\n";
             auto it = w->targets.find(refIdx[(size_t)k]);
@@ -880,11 +887,23 @@ static int run_pairs_on(pwicp_series* s, SeriesWorker* w, const int32_t* pairs, 
             std::memcpy(rec->VCM, out.VCM, sizeof(rec->VCM));
             rec->n_corr = out.res.n_corr;
             rec->t_loop_ms = (float)out.res.t_loop_ms;
-            rec->t_pair_ms = (float)(t_setup_each + std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp).count());
             std::vector<float>().swap(src[(size_t)k].p);                                                     // release early
         }
-        tm.lap("registrations (GPU)");
-        stage(3);
+        tm.lap("normals + supervoxels (host threads, rest) with the registrations beside them");
+        {
+            // wall time of this stretch: the registrations' own time under [3], what is left (front ends) under [2]
+            const auto now = std::chrono::steady_clock::now();
+            const double all = std::chrono::duration<double, std::milli>(now - t_stage).count();
+            std::lock_guard<std::mutex> g(s->stage_mu);
+            s->stage_ms[3] += std::min(reg_ms, all);
+            s->stage_ms[2] += std::max(all - reg_ms, 0.0);
+            t_stage = now;
+        }
+        {
+            const double setup_each = std::max(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - reg_ms, 0.0) / nw;
+            for (int k = 0; k < nw; ++k)
+                if (recs[w0 + k].status == PWICP_OK) recs[w0 + k].t_pair_ms = (float)(setup_each + reg_each[(size_t)k]);
+        }
         // keep the reference epoch and the targets of this window, drop older ones
         for (auto it = w->targets.begin(); it != w->targets.end();) {
             bool used = it->first == s->startEpoch;
