@@ -303,7 +303,7 @@ def series_end_to_end(args, P, rank, world, local_rank, dist, dev, barrier):
         # first series of the process: device contexts, ~2 GB of front-end work space per stream, pinned staging buffers and kernel
         # code are set up on the way (reported as cold_wall_s) - the warm-up of this figure; the timed one finds them parked
         wall_cold = one_series()[0]
-        wall, recs, table, stages = one_series()
+        warm = [one_series() for _ in range(3)]  # three warm series: the figure is their median (one alone scatters by +-5 %)
     finally:
         import ctypes
         ctypes.CDLL(None).fflush(None)           # what the library has buffered for stdout goes to /dev/null too
@@ -311,23 +311,27 @@ def series_end_to_end(args, P, rank, world, local_rank, dist, dev, barrier):
         os.close(saved)
         os.close(devnull)
     import torch
-    tmax, tcold = wall, wall_cold
+    walls, tcold = [w[0] for w in warm], wall_cold
     if dist is not None:
-        t = torch.tensor([wall, wall_cold], dtype=torch.float64, device=dev)
+        t = torch.tensor(walls + [wall_cold], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        tmax, tcold = float(t[0].item()), float(t[1].item())
-    ok = bool(np.all(recs["status"] == 0)) if len(recs) else True
+        walls, tcold = [float(x) for x in t[:-1].tolist()], float(t[-1].item())
+    mid = sorted(range(len(walls)), key=lambda i: walls[i])[len(walls) // 2]      # (the same series on every rank: reduced walls)
+    tmax = walls[mid]
+    _, recs, table, stages = warm[mid]
+    ok = all(bool(np.all(w[1]["status"] == 0)) if len(w[1]) else True for w in warm)
     if rank == 0:
         out = {"metric": "pairs/sec, PCD files -> transforms (Direct2Ref series of %d source epochs x %d pts, pairs dealt over the GPUs)" % (E, n),
                "value": round(E / tmax, 3), "unit": "pairs/s", "scaling": "strong", "n_gpus": world, "pairs": E, "wall_s": round(tmax, 3),
-               "cold_wall_s": round(tcold, 3), "all_pairs_ok": ok,
+               "cold_wall_s": round(tcold, 3), "warm_walls_s": [round(x, 3) for x in walls], "all_pairs_ok": ok,
                "rank0_stage_wall_ms": {k: round(v, 1) for k, v in stages.items() if k.endswith("_ms")},
                "rank0_scan_bytes_to_gpu": stages["scan_bytes"],
                "note": "stages of rank 0 (its share of the pairs + the shared target): reading scans, GPU preparation (voxel grid incl. the "
                        "host-side std::sort order, SOR, reduction), what is left of the front ends after that, registrations; the "
-                       "front end of a cloud (~70 ms per 1 M points alone, ~50 ms with several side by side) is what a pair costs, the "
-                       "loop is 0.26 ms of it.  wall_s: the second series of the process (fresh Series object, nothing prepared; the "
-                       "device contexts and work spaces of the first one are reused); cold_wall_s: the first one"}
+                       "front end of a cloud (~65 ms per 1 M points alone, ~45 ms with several side by side) is what a pair costs, the "
+                       "loop is 0.25 ms of it; a pair is registered as soon as its source is segmented, beside the later front ends.  "
+                       "wall_s: the median of three warm series of the process (warm_walls_s; each through a fresh Series object, "
+                       "nothing prepared - the device contexts and work spaces of the first one are reused); cold_wall_s: the first one"}
         shutil.rmtree(d, ignore_errors=True)
         if args.dump_records:
             # the gathered table of the series, pair order (tests compare N ranks against one rank: tests/test_gpu_configs.py);

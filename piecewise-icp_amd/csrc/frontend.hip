@@ -346,14 +346,17 @@ struct FusWave {           // per-wavefront scratch (LDS)
     bool overflow;
     // centres this wavefront has already run in this sweep (chunk), and the nodes they absorbed
     int* cid; int* csz; int* cran; int* cabsn; int* cadjn; long long* cptr;
+    int cidv;              // lane t: the t-th centre of the chunk that has run (the copy fus_chunk_index scans: a v_readlane per
+                           // entry instead of an LDS read and its wait - the scan runs three or four times per centre)
     int* fkey; int* fval;
     int ndone, nfresh;
 };
 
 __device__ __forceinline__ int fus_chunk_index(const FusWave& w, int c) {
     int q = -1;
-    for (int t = 0; t < w.ndone; ++t)
-        if (w.cid[t] == c) q = t;
+    const int nd = __builtin_amdgcn_readfirstlane(w.ndone);
+    for (int t = 0; t < nd; ++t)
+        if (__builtin_amdgcn_readlane(w.cidv, t) == c) q = t;
     return q;
 }
 
@@ -422,8 +425,8 @@ __device__ __forceinline__ void fus_expand(const FusState& s, FusWave& w, const 
 template <int QCAP, int HCAP, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES) k_fus_run(FusState s, int nW, int chunk, const int* __restrict__ list,
                                                          const int* __restrict__ n_list, int* __restrict__ ovf, int* __restrict__ n_ovf) {
-    __shared__ int s_keys[WAVES][HCAP];
-    __shared__ int s_vals[WAVES][HCAP];
+    __shared__ __attribute__((aligned(16))) int s_keys[WAVES][HCAP];
+    __shared__ __attribute__((aligned(16))) int s_vals[WAVES][HCAP];
     __shared__ int s_queue[WAVES][QCAP];
     __shared__ int s_chunk[WAVES][5][kFusChunk];
     __shared__ long long s_cptr[WAVES][kFusChunk];
@@ -440,8 +443,12 @@ __global__ void __launch_bounds__(64 * WAVES) k_fus_run(FusState s, int nW, int 
     const int n_chunks = (nW + chunk - 1) / chunk;
     int n_changed = 0;                                  // (wave-uniform)
     for (int ci = blockIdx.x * WAVES + wave; ci < n_chunks; ci += gridDim.x * WAVES) {
-      w.ndone = 0; w.nfresh = 0;
+      w.ndone = 0; w.nfresh = 0; w.cidv = -1;
+#ifdef PW_FUS_JACOBI_CHUNK          // (diagnostic build: the chunk's centres do not see each other - what the fresh view costs per run)
+      bool chunk_live = false;
+#else
       bool chunk_live = chunk > 1;
+#endif
       if (chunk > 1) {
           for (int t = lane; t < kFusFresh; t += 64) w.fkey[t] = -1;
           WSYNC();
@@ -457,7 +464,11 @@ __global__ void __launch_bounds__(64 * WAVES) k_fus_run(FusState s, int nW, int 
         w.qn = 1; w.gcount = 0; w.overflow = false;
         if (s.len0[i] != 0 && !(fus_absorber(s, w, i) < i)) {
             ran = 1;
-            for (int t = lane; t < HCAP; t += 64) { w.keys[t] = -1; w.vals[t] = INT_MAX; }
+            {   // (four entries per store)
+                int4* k4 = reinterpret_cast<int4*>(w.keys);
+                int4* v4 = reinterpret_cast<int4*>(w.vals);
+                for (int t = lane; t < HCAP / 4; t += 64) { k4[t] = make_int4(-1, -1, -1, -1); v4[t] = make_int4(INT_MAX, INT_MAX, INT_MAX, INT_MAX); }
+            }
             WSYNC();
             if (lane == 0) {
                 const int sl = (int)(((unsigned)i * 2654435761u) >> (32 - __builtin_ctz(HCAP)));
@@ -572,11 +583,12 @@ __global__ void __launch_bounds__(64 * WAVES) k_fus_run(FusState s, int nW, int 
         n_changed += same ? 0 : 1;
         // what the later centres of the chunk see of this one
         if (chunk_live && sl_i + 1 < slot_end && w.ndone < kFusChunk) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // its lists are in memory before they are read back
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // its lists are in memory before they are read back (measured: free)
             if (lane == 0) {
                 const int q = w.ndone;
                 w.cid[q] = i; w.csz[q] = size_i; w.cran[q] = ran; w.cabsn[q] = nabs; w.cadjn[q] = nadj; w.cptr[q] = new_ptr;
             }
+            if (lane == w.ndone) w.cidv = i;
             if (nabs > 0 && w.nfresh + nabs > kFusFresh / 2) {
                 // no room for its claims: the rest of the chunk reads the standing state only (a view that is neither the old
                 // nor the new state would not be flagged as a change)
