@@ -5,10 +5,26 @@
 
 #include <chrono>
 #include <cstdio>
+#include <map>
+#include <mutex>
+#include <vector>
 
 #include "common.h"
 #include "icp.h"
 #include "patch.h"
+
+namespace {
+// Streams of destroyed contexts, per device, for the next pwicp_create.  The runtime gives every NEW stream the next hardware
+// queue (up to $GPU_MAX_HW_QUEUES) and keeps the queue of a destroyed stream allocated: after four contexts had come and gone, the
+// streams of a series sat on queues 4 - 7 with queues 0 - 3 idle but alive, and every launch of the front ends (thousands of small
+// dependent ones) was slower - 8 x 1 M points 0.41 -> 0.45 s (tools/series_repeat.py, SERIES_REPEAT_PRE=ctx).  A context that
+// takes over a parked stream sits on the queue the old one had.  (Idle streams are never destroyed: a few hundred bytes each.)
+struct StreamPool {
+    std::mutex mu;
+    std::map<int, std::vector<hipStream_t>> idle;
+    static StreamPool& get() { static StreamPool* p = new StreamPool; return *p; }     // (never destructed: no HIP call at exit)
+};
+}  // namespace
 
 extern "C" {
 
@@ -34,7 +50,13 @@ int pwicp_create(pwicp_context** out, int device_id) {
     if (hipSetDevice(device_id) != hipSuccess) { delete ctx; return PWICP_E_NO_DEVICE; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PWICP_E_NO_DEVICE; }
+    {
+        StreamPool& sp = StreamPool::get();
+        std::lock_guard<std::mutex> g(sp.mu);
+        auto& v = sp.idle[device_id];
+        if (!v.empty()) { ctx->stream = v.back(); v.pop_back(); }
+    }
+    if (!ctx->stream && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PWICP_E_NO_DEVICE; }
     *out = ctx;
     return PWICP_OK;
 }
@@ -46,7 +68,12 @@ void pwicp_destroy(pwicp_context* ctx) {
     ctx->scratch.reset();
     if (pw_tls_pool.get() == ctx->pool.get()) pw_tls_pool.reset();
     if (ctx->pool) ctx->pool->trim();           // (the pool itself lives as long as a buffer of this context does)
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream) {                           // (synchronised above: nothing of this context is left on it)
+        StreamPool& sp = StreamPool::get();
+        std::lock_guard<std::mutex> g(sp.mu);
+        sp.idle[ctx->device].push_back(ctx->stream);
+        ctx->stream = nullptr;
+    }
     delete ctx;
 }
 

@@ -20,7 +20,12 @@ for s, e, n in ev:
     bins[b][2][n] += e - s
     us = max(s, cur_end)
     if e > us:
-        bins[b][0] += e - us
+        a = us                                  # (a union interval is split over the bins it crosses)
+        while a < e:
+            bb = (a - t0) // BIN
+            z = min(e, t0 + (bb + 1) * BIN)
+            bins[bb][0] += z - a
+            a = z
         cur_end = e
 for b in sorted(bins):
     u, sm, c = bins[b]

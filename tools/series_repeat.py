@@ -24,6 +24,26 @@ open(cfg, "w").write("string FolderFilePath1: %s\nstring FolderFilePath2: %s\nbo
                      "float PCres1 (m): %g\nfloat PCres2 (m): %g\nfloat SVsize1 (m): %g\nfloat SVsize2 (m): %g\n"
                      "bool isSetDTinit (yes-1, no-0): 1\nfloat DTinit (m): %g\nfloat DTmin (m): %g\nbool isVisual (yes-1, no-0): 0"
                      % (inp, os.path.join(d, "out_"), r, r, 10 * r, 10 * r, 10 * r, 0.8 * r))
+pre = os.environ.get("SERIES_REPEAT_PRE", "")       # what the process did before: "ctx" - four contexts created and closed;
+if pre:                                             # "pairs" - a registration on each of them, side by side (bench.py's pairs_side_by_side)
+    import threading
+    ctxs = [P.Context(0) for _ in range(4)]
+    if pre == "pairs":
+        m = 200000
+        tg, _ = synth.make_tile(m, r); sr, _ = synth.make_source(m, r, epoch=1)
+        c0 = tg.mean(axis=0); tg = (tg - c0).astype(np.float32); sr = (sr - c0).astype(np.float32)
+        l1, n1 = synth.grid_labels(tg, 10 * r); l2, n2 = synth.grid_labels(sr, 10 * r)
+        prm = P.Params(r, r, 10 * r, 10 * r, 1, 10 * r, 0.8 * r)
+        prs = [P.Pair(c, tg, l1, n1, sr, l2, n2, prm) for c in ctxs]
+        def loop(i):
+            for _ in range(20):
+                prs[i].reset(); prs[i].run()
+        th = [threading.Thread(target=loop, args=(i,)) for i in range(4)]
+        for t_ in th: t_.start()
+        for t_ in th: t_.join()
+        for pr in prs: pr.close()
+    if pre != "ctx_keep":
+        for c in ctxs: c.close()
 devnull = os.open(os.devnull, os.O_WRONLY); saved = os.dup(1); os.dup2(devnull, 1)
 ts, ok = [], True
 for rep in range(reps):
