@@ -32,6 +32,28 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MI
 R_SPACING = 0.005
 
 
+def cpu_budget():
+    """CPUs this process may really use: the affinity mask, cut by the cgroup's CPU quota (v2 cpu.max / v1 cfs_quota_us).  A box
+    that shows 256 hardware threads under a 16-CPU quota freezes the whole cgroup once its threads overrun the quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(q) // int(per)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def kernel_source_hash():
     """sha256 over the HIP sources of libpwicp.so: ties profiles/traffic_latest.json (PMC passes, collected with
     tools/collect_profiles.sh) to the kernels that are being timed."""
@@ -93,7 +115,7 @@ def cpu_baseline(tgt, l1, n1, src, l2, n2, passes=25, passes_mt=10):
             best = io
     # SURVEY 8d's second CPU figure: the same path with its nearest-neighbour queries spread over all host cores
     # (OpenMP; tree builds and reductions stay serial, results identical)
-    mt, cores = None, min(O.max_threads(), 64)
+    mt, cores = None, min(O.max_threads(), 64, cpu_budget())
     if cores > 1:
         O.set_num_threads(cores)
         for _ in range(passes_mt):
@@ -410,7 +432,7 @@ def launch_ranks(n):
     env = dict(os.environ)
     env.setdefault("PWICP_JOB_ID", uuid.uuid4().hex)          # the token of the library's own RCCL rendezvous (host/comm.cpp)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, cpu_budget() // n)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.exit(subprocess.call(cmd, env=env))
@@ -647,7 +669,7 @@ def main():
                                    "sample": "the full %d-pt pair loop, best of 25 passes (~12 s of CPU work), %.2f s per pass; single-threaded "
                                              "C oracle with KD-trees rebuilt at the reference's call sites" %
                                              (args.points, io.t_loop_s),
-                                   "host_cores_available": os.cpu_count(),
+                                   "host_cores_available": os.cpu_count(), "host_cpus_usable": cpu_budget(),
                                    "gpu_matches_cpu_transform": bool(same)}
             out["speedup_vs_cpu"] = round(value / cpu_val, 1)
             if io_mt is not None:

@@ -183,6 +183,7 @@ struct DevBuf {
     // grows only; contents are NOT preserved
     hipError_t reserve(size_t count) {
         if (count <= n && p) return hipSuccess;
+        if (p && count * sizeof(T) <= cap_bytes) { n = count; return hipSuccess; }     // (the block's size class already holds it)
         release();
         if (count == 0) count = 1;
         hipError_t e;

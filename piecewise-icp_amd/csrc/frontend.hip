@@ -1180,6 +1180,9 @@ struct FeWorkspace {
             if (e != hipSuccess) return e;
         }
         if (n <= h_n) return hipSuccess;
+        // (with headroom: the clouds of a series differ by a few thousand points after the outlier removal, and a pinned
+        // re-allocation of 72 bytes per point is 10 - 25 ms on the stream's host thread - it hit every other cloud of a series)
+        n = (n + n / 8 + 65535) & ~(size_t)65535;
         if (hS) (void)hipHostFree(hS);
         if (hN) (void)hipHostFree(hN);
         hS = hN = nullptr;
@@ -1852,6 +1855,7 @@ int pw_frontend_segment_device(pwicp_context* ctx, const float* cloud_xyz4, int 
     DevBuf<double>&dS = ws.dS, &dN = ws.dN;
     DevBuf<FePt>& dP = ws.dP;
     HIPCHK(ctx, ws.host_reserve((size_t)n));
+    if (getenv("PWICP_TRACE_NORMALS")) tr.lap("  normals: pinned staging");
     HIPCHK(ctx, dS.reserve((size_t)n * 6));
     HIPCHK(ctx, dN.reserve((size_t)n * 3));
     HIPCHK(ctx, dP.reserve((size_t)n));
@@ -1867,7 +1871,9 @@ int pw_frontend_segment_device(pwicp_context* ctx, const float* cloud_xyz4, int 
             mn[d] = std::min(mn[d], c); mx[d] = std::max(mx[d], c);
         }
     HIPCHK(ctx, hipStreamSynchronize(st));
+    if (getenv("PWICP_TRACE_NORMALS")) tr.lap("  normals: buffers, scatter, sums down, box");
     pwhost::fe_normals_from_scatter(S6, n, N3);
+    if (getenv("PWICP_TRACE_NORMALS")) tr.lap("  normals: eigen step (host)");
     if (getenv("PWICP_NORMALS") && std::string(getenv("PWICP_NORMALS")) == "device") {
         // experiment: eigen step on the device; report how many normals differ from the host's in any bit
         hipLaunchKernelGGL(k_fe_eigen_device, grid1(n), dim3(256), 0, st, dS.p, n, dN.p);

@@ -772,7 +772,7 @@ static int run_pairs_on(pwicp_series* s, SeriesWorker* w, const int32_t* pairs, 
     if (!w->need_ctx()) { for (int k = 0; k < n_pairs; ++k) recs[k].status = PWICP_E_NO_DEVICE; return PWICP_E_NO_DEVICE; }
     const ConfigPara& cfg = s->cfg;
     const double sor_mult = 5.0;                                           // R.cpp:415-416
-    int window = std::max(1, std::min(host_threads() - 1, 16));
+    int window = 16;         // (clouds whose setup stages overlap; what runs side by side inside it: $PWICP_FRONTEND_STREAMS, the CPU budget)
     if (const char* e = std::getenv("PWICP_SERIES_WINDOW")) window = std::max(1, atoi(e));
     for (int w0 = 0; w0 < n_pairs; w0 += window) {
         const int w1 = std::min(n_pairs, w0 + window), nw = w1 - w0;
