@@ -116,11 +116,21 @@ bool prepare_gpu(pwicp_context* ctx, const std::vector<float>& raw, float Res, f
 // and host thread (a front end is hundreds of small dependent launches: one alone leaves most of the GPU idle).
 struct AuxContexts {
     int device = 0, limit = 3, made = 0;
+    bool limit_from_env = false;
     std::mutex m;
     std::condition_variable cv;
     std::vector<pwicp_context*> idle;
     explicit AuxContexts(int dev) : device(dev) {
-        if (const char* e = std::getenv("PWICP_FRONTEND_STREAMS")) limit = std::max(1, std::min(atoi(e), 16));
+        if (const char* e = std::getenv("PWICP_FRONTEND_STREAMS")) { limit = std::max(1, std::min(atoi(e), 16)); limit_from_env = true; }
+    }
+    // Streams by the size of the clouds they will segment: the front end of a 1 M-point cloud fills the device for most of its
+    // time and three of them side by side saturate it (3 / 4 / 6 streams: 0.41 / 0.40 / 0.41 s for 8 pairs); that of a 140 k-point
+    // scan is a chain of small launches - the reference's 19 pairs: 0.28 - 0.32 s with three streams, 0.23 - 0.25 s with six
+    // ($PWICP_FRONTEND_STREAMS decides when it is set).
+    void size_for(long long points_per_cloud) {
+        if (limit_from_env) return;
+        std::lock_guard<std::mutex> lk(m);
+        limit = std::max(limit, points_per_cloud < 400000 ? 6 : 3);
     }
     AuxContexts(const AuxContexts&) = delete;
     AuxContexts& operator=(const AuxContexts&) = delete;
@@ -772,7 +782,7 @@ static int run_pairs_on(pwicp_series* s, SeriesWorker* w, const int32_t* pairs, 
     if (!w->need_ctx()) { for (int k = 0; k < n_pairs; ++k) recs[k].status = PWICP_E_NO_DEVICE; return PWICP_E_NO_DEVICE; }
     const ConfigPara& cfg = s->cfg;
     const double sor_mult = 5.0;                                           // R.cpp:415-416
-    int window = 16;         // (clouds whose setup stages overlap; what runs side by side inside it: $PWICP_FRONTEND_STREAMS, the CPU budget)
+    int window = 32;         // (clouds whose setup stages overlap; what runs side by side inside it: $PWICP_FRONTEND_STREAMS, the CPU budget)
     if (const char* e = std::getenv("PWICP_SERIES_WINDOW")) window = std::max(1, atoi(e));
     for (int w0 = 0; w0 < n_pairs; w0 += window) {
         const int w1 = std::min(n_pairs, w0 + window), nw = w1 - w0;
@@ -809,6 +819,11 @@ static int run_pairs_on(pwicp_series* s, SeriesWorker* w, const int32_t* pairs, 
             for (auto& kv : raw1) b += (long long)kv.second.size() * 4;
             std::lock_guard<std::mutex> g(s->stage_mu);
             s->stage_bytes += b;
+        }
+        {
+            long long pts = 0, cnt = 0;
+            for (auto& v : raw2) if (!v.empty()) { pts += (long long)v.size() / 4; ++cnt; }
+            if (cnt) w->aux->size_for(pts / cnt);
         }
         // ---- GPU parts one after the other; the host part of a cloud starts on its own thread as soon as its k-NN graph
         //      is down, so the serial host passes of earlier clouds run while the GPU prepares the later ones -------------
