@@ -25,6 +25,7 @@
 #include <sstream>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <vector>
 
 #include "frontend.h"
@@ -75,17 +76,45 @@ bool frontend_on_device() {
 
 // GPU part.  shift_in == nullptr: the cloud is a target and is reduced by its own centroid (R.cpp:419-436:
 // pcl::compute3DCentroid float sums, float shift); otherwise the target's shift is applied.
+// VoxelGrid + SOR of a raw scan do not depend on the role the scan plays in a pair (only the shift that follows does): in the
+// adaptive and the fixed-interval mode every scan of a window is a source AND a target, and is preprocessed once (keyed by scan,
+// leaf size and SOR multiplier; the reference's own run in those modes: the one-after-the-other GPU stage 230 -> 120 ms).
+struct PreCache {
+    struct Key {
+        int scan; float res; double sor;
+        bool operator<(const Key& o) const { return std::tie(scan, res, sor) < std::tie(o.scan, o.res, o.sor); }
+    };
+    struct Out { std::vector<float> p; int m = 0; };
+    std::map<Key, std::shared_ptr<const Out>> done;
+    std::map<int, float> resolution;         // calPCresolution of a raw scan (when the configuration does not give it)
+};
+
 bool prepare_gpu(pwicp_context* ctx, const std::vector<float>& raw, float Res, float SVRes, double sor_mult, const float* shift_in,
-                 Prepared* c) {
+                 Prepared* c, PreCache* cache = nullptr, int scan = -1) {
     const int n = (int)(raw.size() / 4);
     c->Res = Res; c->SVRes = SVRes; c->sor_mult = sor_mult;
-    c->p.resize((size_t)std::max(n, 1) * 4);
-    if (pwicp_preprocess_dev(ctx, raw.data(), n, Res, 14, sor_mult, c->p.data(), &c->m) != PWICP_OK) {      // R.cpp:412-416
-        std::cerr << "Error: preprocessing failed: " << pwicp_last_error(ctx) << "\n";
-        return false;
+    std::shared_ptr<const PreCache::Out> hit;
+    if (cache && scan >= 0) {
+        auto it = cache->done.find(PreCache::Key{scan, Res, sor_mult});
+        if (it != cache->done.end()) hit = it->second;
+    }
+    if (hit) {
+        c->p = hit->p;
+        c->m = hit->m;
+    } else {
+        c->p.resize((size_t)std::max(n, 1) * 4);
+        if (pwicp_preprocess_dev(ctx, raw.data(), n, Res, 14, sor_mult, c->p.data(), &c->m) != PWICP_OK) {      // R.cpp:412-416
+            std::cerr << "Error: preprocessing failed: " << pwicp_last_error(ctx) << "\n";
+            return false;
+        }
+        c->p.resize((size_t)std::max(c->m, 1) * 4);
+        if (cache && scan >= 0) {
+            auto o = std::make_shared<PreCache::Out>();
+            o->p = c->p; o->m = c->m;
+            cache->done[PreCache::Key{scan, Res, sor_mult}] = o;
+        }
     }
     const int m = c->m;
-    c->p.resize((size_t)std::max(m, 1) * 4);
     if (m < kNN + 1) { std::cerr << "Error: too few points after preprocessing.\n"; return false; }
     if (shift_in) {
         for (int d = 0; d < 3; ++d) c->shift[d] = shift_in[d];
@@ -827,6 +856,21 @@ static int run_pairs_on(pwicp_series* s, SeriesWorker* w, const int32_t* pairs, 
         }
         // ---- GPU parts one after the other; the host part of a cloud starts on its own thread as soon as its k-NN graph
         //      is down, so the serial host passes of earlier clouds run while the GPU prepares the later ones -------------
+        PreCache pre;                                                  // (of this window: a scan that is a source and a target)
+        bool share_pre = false;                                        // (no scan plays two roles: no copies are kept)
+        {
+            std::map<int, int> uses;
+            for (int k = 0; k < nw; ++k) ++uses[s->startEpoch + pairs[w0 + k] + 1];
+            for (auto& kv : raw1) ++uses[kv.first];
+            for (auto& kv : uses) share_pre = share_pre || kv.second > 1;
+        }
+        auto resolution_of = [&](int scan, const std::vector<float>& raw, float* out) {
+            auto it = pre.resolution.find(scan);
+            if (it != pre.resolution.end()) { *out = it->second; return true; }
+            if (pwicp_pc_resolution_dev(w->ctx, raw.data(), (int)(raw.size() / 4), out) != PWICP_OK) return false;
+            pre.resolution[scan] = *out;
+            return true;
+        };
         std::vector<char> ok((size_t)nw, 1);
         std::vector<std::thread> th;                                   // front ends of the targets prepared in this window
         std::vector<std::thread> th_src((size_t)nw);                   // front end of source k (not joinable: none was started)
@@ -839,9 +883,9 @@ static int run_pairs_on(pwicp_series* s, SeriesWorker* w, const int32_t* pairs, 
                 auto t = std::make_shared<Prepared>();
                 float Res1 = cfg.PCres1;
                 bool good = !kv.second.empty();
-                if (good && !cfg.isSetResSVsize && pwicp_pc_resolution_dev(w->ctx, kv.second.data(), (int)(kv.second.size() / 4), &Res1) != PWICP_OK) good = false;
+                if (good && !cfg.isSetResSVsize && !resolution_of(kv.first, kv.second, &Res1)) good = false;
                 const float SVRes1 = cfg.isSetResSVsize ? cfg.SVsize1 : Res1 * 10;                       // R.cpp:635-640
-                if (good) good = prepare_gpu(w->ctx, kv.second, Res1, SVRes1, sor_mult, nullptr, t.get());
+                if (good) good = prepare_gpu(w->ctx, kv.second, Res1, SVRes1, sor_mult, nullptr, t.get(), share_pre ? &pre : nullptr, kv.first);
                 if (good) {
                     w->targets[kv.first] = t;
                     Prepared* p = t.get();
@@ -857,9 +901,10 @@ static int run_pairs_on(pwicp_series* s, SeriesWorker* w, const int32_t* pairs, 
             auto it = w->targets.find(refIdx[(size_t)k]);
             float Res2 = cfg.PCres2;
             bool good = it != w->targets.end() && !raw2[(size_t)k].empty();
-            if (good && !cfg.isSetResSVsize && pwicp_pc_resolution_dev(w->ctx, raw2[(size_t)k].data(), (int)(raw2[(size_t)k].size() / 4), &Res2) != PWICP_OK) good = false;
+            const int scan2 = s->startEpoch + pairs[w0 + k] + 1;
+            if (good && !cfg.isSetResSVsize && !resolution_of(scan2, raw2[(size_t)k], &Res2)) good = false;
             const float SVRes2 = cfg.isSetResSVsize ? cfg.SVsize2 : Res2 * 10;
-            if (good) good = prepare_gpu(w->ctx, raw2[(size_t)k], Res2, SVRes2, sor_mult, it->second->shift, &src[(size_t)k]);
+            if (good) good = prepare_gpu(w->ctx, raw2[(size_t)k], Res2, SVRes2, sor_mult, it->second->shift, &src[(size_t)k], share_pre ? &pre : nullptr, scan2);
             ok[(size_t)k] = good ? 1 : 0;
             if (good) th_src[(size_t)k] = std::thread([&ok, &src, k, w] { ok[(size_t)k] = prepare_labels(&src[(size_t)k], w->aux.get()) ? 1 : 0; });
             std::vector<float>().swap(raw2[(size_t)k]);
