@@ -184,7 +184,9 @@ bool save_pcd_binary(const std::string& path, const float* xyz4, int n) {
     if (!out) return false;
     out << "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\n"
         << "WIDTH " << n << "\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS " << n << "\nDATA binary\n";
-    for (int i = 0; i < n; ++i) out.write(reinterpret_cast<const char*>(xyz4 + 4 * (size_t)i), 12);
+    std::vector<float> packed((size_t)n * 3);
+    for (int i = 0; i < n; ++i) std::memcpy(&packed[3 * (size_t)i], xyz4 + 4 * (size_t)i, 12);
+    out.write(reinterpret_cast<const char*>(packed.data()), (std::streamsize)(packed.size() * sizeof(float)));
     return (bool)out;
 }
 

@@ -419,6 +419,11 @@ std::vector<int32_t> env_devices() {
 
 }  // namespace
 
+// the context of the pair entry point (with the front-end streams and work spaces that hang on it) is parked between calls
+// like a series worker's (WorkerParking, below): a process that calls PiecewiseICP_pair_call in a loop sets them up once
+pwicp_context* pair_context_take(int device);
+void pair_context_park(pwicp_context* ctx);
+
 extern "C" {
 
 PWICP_API bool PiecewiseICP_pair_call(const char* confile, const char* outfile) {
@@ -428,8 +433,8 @@ PWICP_API bool PiecewiseICP_pair_call(const char* confile, const char* outfile) 
     if (!read_config(confile, &cfg)) { std::cerr << "Error: Cannot open configuration file! Aborting.\n\n"; return false; }
     std::vector<float> c1, c2;
     if (!load_pcd(cfg.FolderFilePath1, &c1) || !load_pcd(cfg.FolderFilePath2, &c2) || c1.empty() || c2.empty()) return false;   // R.cpp:252-256
-    pwicp_context* ctx = nullptr;
-    if (pwicp_create(&ctx, env_device()) != PWICP_OK) { std::cerr << "Error: no usable HIP device (pwicp has no CPU fallback).\n"; return false; }
+    pwicp_context* ctx = pair_context_take(env_device());
+    if (!ctx) { std::cerr << "Error: no usable HIP device (pwicp has no CPU fallback).\n"; return false; }
     float Res1 = cfg.PCres1, Res2 = cfg.PCres2;
     if (!cfg.isSetResSVsize &&
         (pwicp_pc_resolution_dev(ctx, c1.data(), (int)(c1.size() / 4), &Res1) != PWICP_OK ||
@@ -440,7 +445,7 @@ PWICP_API bool PiecewiseICP_pair_call(const char* confile, const char* outfile) 
     }
     PairOutput out;
     const bool ok = register_pair(ctx, c1, c2, cfg, Res1, Res2, 2.7, &out);          // SOR multiplier 2.7 (R.cpp:272-273)
-    pwicp_destroy(ctx);
+    if (ok) pair_context_park(ctx); else pwicp_destroy(ctx);
     if (!ok) return false;
     if (!write_transmatrix_file(std::string(outfile) + "TransMatrix.txt", out.T, out.VCM)) return false;
     std::cout << "--->>> Transformation results saved.\n";
@@ -567,17 +572,43 @@ struct ParkedWorker { pwicp_context* ctx = nullptr; std::unique_ptr<AuxContexts>
 struct WorkerParking {
     std::mutex mu;
     std::map<int, ParkedWorker> by_device;
+    std::map<int, pwicp_context*> pair_by_device;      // the context of PiecewiseICP_pair_call (its front-end streams hang on it)
     bool exit_hook = false;
     static WorkerParking& get() { static WorkerParking* p = new WorkerParking; return *p; }       // (the object itself is never deleted)
     // destroys what is parked (pwicp_series_release_parked, and once at exit: registered when the first set is parked, i.e. after
     // the HIP runtime has registered its own exit work, so it runs before the runtime goes away)
     void release_all() {
         std::map<int, ParkedWorker> take;
-        { std::lock_guard<std::mutex> g(mu); take.swap(by_device); }
+        std::map<int, pwicp_context*> take_pair;
+        { std::lock_guard<std::mutex> g(mu); take.swap(by_device); take_pair.swap(pair_by_device); }
         for (auto& kv : take) { kv.second.aux.reset(); if (kv.second.ctx) pwicp_destroy(kv.second.ctx); }
+        for (auto& kv : take_pair) if (kv.second) pwicp_destroy(kv.second);
+    }
+    void hook_exit() {          // (call with mu held)
+        if (!exit_hook) { exit_hook = true; std::atexit([] { WorkerParking::get().release_all(); }); }
     }
     static bool enabled() { static const bool on = !(std::getenv("PWICP_SERIES_KEEP") && atoi(std::getenv("PWICP_SERIES_KEEP")) == 0); return on; }
 };
+
+pwicp_context* pair_context_take(int device) {
+    if (WorkerParking::enabled()) {
+        WorkerParking& pk = WorkerParking::get();
+        std::lock_guard<std::mutex> g(pk.mu);
+        auto it = pk.pair_by_device.find(device);
+        if (it != pk.pair_by_device.end()) { pwicp_context* c = it->second; pk.pair_by_device.erase(it); return c; }
+    }
+    pwicp_context* c = nullptr;
+    return pwicp_create(&c, device) == PWICP_OK ? c : nullptr;
+}
+void pair_context_park(pwicp_context* ctx) {
+    if (WorkerParking::enabled()) {
+        WorkerParking& pk = WorkerParking::get();
+        std::lock_guard<std::mutex> g(pk.mu);
+        const int device = pwicp_context_device(ctx);
+        if (!pk.pair_by_device.count(device)) { pk.pair_by_device[device] = ctx; pk.hook_exit(); return; }
+    }
+    pwicp_destroy(ctx);
+}
 
 struct SeriesWorker {
     int device = 0;
@@ -607,7 +638,7 @@ struct SeriesWorker {
                 ParkedWorker& slot = pk.by_device[device];
                 slot.ctx = ctx; slot.aux = std::move(aux);
                 ctx = nullptr;
-                if (!pk.exit_hook) { pk.exit_hook = true; std::atexit([] { WorkerParking::get().release_all(); }); }
+                pk.hook_exit();
             }
         }
         aux.reset();

@@ -17,7 +17,7 @@ open(cfg, "w").write("string FolderFilePath1: %s\nstring FolderFilePath2: %s\nbo
                      "float PCres1 (m): %g\nfloat PCres2 (m): %g\nfloat SVsize1 (m): %g\nfloat SVsize2 (m): %g\n"
                      "bool isSetDTinit (yes-1, no-0): 1\nfloat DTinit (m): %g\nfloat DTmin (m): %g\nbool isVisual (yes-1, no-0): 0"
                      % (os.path.join(d, "t.pcd"), os.path.join(d, "s.pcd"), r, r, 10 * r, 10 * r, 10 * r, 0.8 * r))
-for k in range(2):
+for k in range(4):
     t0 = time.perf_counter()
     ok = P.PiecewiseICP_pair_call(cfg, os.path.join(d, "out%d_" % k))
     print("PiecewiseICP_pair_call #%d: %s, %.2f s wall" % (k, ok, time.perf_counter() - t0), file=sys.stderr)
