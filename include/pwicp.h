@@ -384,7 +384,7 @@ PWICP_API bool pwicp_series_run_distributed(const char* confile, int startEpoch,
 
 /* A series that is closed leaves its device contexts and front-end work spaces PARKED (one set per device) for the next series of
  * the process on that device: setting them up costs 0.15 - 0.25 s, a third of an 8 x 1 M-point series ($PWICP_SERIES_KEEP=0: off).
- * This frees them (also done at process exit). */
+ * PiecewiseICP_pair_call parks its context the same way.  This frees both (also done at process exit). */
 PWICP_API void pwicp_series_release_parked(void);
 
 /* ---- measurement hooks ------------------------------------------------------------------------------------
