@@ -74,6 +74,17 @@ bool frontend_on_device() {
     return !(e && std::string(e) == "host");
 }
 
+// $PWICP_TRACE_TIMELINE=1: wall-clock stamps (ms since the first one) of the series' events on stderr
+void timeline(const char* what, int k = -1) {
+    static const bool on = std::getenv("PWICP_TRACE_TIMELINE") != nullptr;
+    if (!on) return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    static std::mutex mu;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    std::lock_guard<std::mutex> g(mu);
+    std::fprintf(stderr, "[pwicp timeline] %9.2f ms  %s %d\n", ms, what, k);
+}
+
 // GPU part.  shift_in == nullptr: the cloud is a target and is reduced by its own centroid (R.cpp:419-436:
 // pcl::compute3DCentroid float sums, float shift); otherwise the target's shift is applied.
 // VoxelGrid + SOR of a raw scan do not depend on the role the scan plays in a pair (only the shift that follows does): in the
@@ -187,7 +198,9 @@ struct AuxContexts {
 bool prepare_labels(Prepared* c, AuxContexts* aux) {
     if (c->segmented) return true;
     if (frontend_on_device()) {
+        timeline("front end: waiting for a stream");
         pwicp_context* ctx = aux->acquire();
+        timeline("front end: stream acquired");
         if (!ctx) { std::cerr << "Error: no usable HIP device (pwicp has no CPU fallback).\n"; return false; }
         c->lab.resize((size_t)c->m);
         // the device pipeline indexes its lists with 32 bits (n * k < 2^31) and wants ~1 KB of work space per point; a cloud
@@ -207,6 +220,7 @@ bool prepare_labels(Prepared* c, AuxContexts* aux) {
         }
         if (rc != PWICP_OK) std::cerr << "Error: supervoxel segmentation failed: " << pwicp_last_error(ctx) << "\n";
         aux->release(ctx);
+        timeline("front end: done");
         c->segmented = rc == PWICP_OK;
         return c->segmented;
     }
@@ -839,7 +853,9 @@ static int run_pairs_on(pwicp_series* s, SeriesWorker* w, const int32_t* pairs, 
     }
     if (n_pairs == 0) return PWICP_OK;
     if (s->adaptive_deferred) { std::cerr << "Error: the adaptive pair map of this series has not been determined yet.\n"; return PWICP_E_INVALID; }
+    timeline("run_pairs: begins");
     if (!w->need_ctx()) { for (int k = 0; k < n_pairs; ++k) recs[k].status = PWICP_E_NO_DEVICE; return PWICP_E_NO_DEVICE; }
+    timeline("run_pairs: worker context ready");
     const ConfigPara& cfg = s->cfg;
     const double sor_mult = 5.0;                                           // R.cpp:415-416
     int window = 32;         // (clouds whose setup stages overlap; what runs side by side inside it: $PWICP_FRONTEND_STREAMS, the CPU budget)
@@ -872,6 +888,7 @@ static int run_pairs_on(pwicp_series* s, SeriesWorker* w, const int32_t* pairs, 
             for (auto& t : th) t.join();
         }
         tm.lap("read scans (host threads)");
+        timeline("scans read");
         stage(0);
         {
             long long b = 0;
@@ -935,7 +952,9 @@ static int run_pairs_on(pwicp_series* s, SeriesWorker* w, const int32_t* pairs, 
             const int scan2 = s->startEpoch + pairs[w0 + k] + 1;
             if (good && !cfg.isSetResSVsize && !resolution_of(scan2, raw2[(size_t)k], &Res2)) good = false;
             const float SVRes2 = cfg.isSetResSVsize ? cfg.SVsize2 : Res2 * 10;
+            timeline("prep of source begins", k);
             if (good) good = prepare_gpu(w->ctx, raw2[(size_t)k], Res2, SVRes2, sor_mult, it->second->shift, &src[(size_t)k], share_pre ? &pre : nullptr, scan2);
+            timeline("prep of source done", k);
             ok[(size_t)k] = good ? 1 : 0;
             if (good) th_src[(size_t)k] = std::thread([&ok, &src, k, w] { ok[(size_t)k] = prepare_labels(&src[(size_t)k], w->aux.get()) ? 1 : 0; });
             std::vector<float>().swap(raw2[(size_t)k]);
@@ -954,6 +973,7 @@ static int run_pairs_on(pwicp_series* s, SeriesWorker* w, const int32_t* pairs, 
         std::vector<float> reg_each((size_t)nw, 0.f);
         for (int k = 0; k < nw; ++k) {
             if (th_src[(size_t)k].joinable()) th_src[(size_t)k].join();
+            timeline("registration begins", k);
             pwicp_pair_record* rec = &recs[w0 + k];
             const int pair = pairs[w0 + k], step = pair + 1, i = s->startEpoch + pair;
             const auto tp = std::chrono::steady_clock::now();
