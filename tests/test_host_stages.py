@@ -219,6 +219,30 @@ def test_pair_entry_point(tmp_path, ctx, oracle):
 
 
 @pytest.mark.gpu
+def test_pair_entry_point_again_with_parked_and_recycled_contexts(tmp_path):
+    """The entry point parks its context (front-end streams and work spaces) between calls and contexts that are destroyed leave
+    their streams to the next ones: the files of a second and third call - after contexts have come and gone, and after the parked
+    set was released - are byte-identical to the first call's."""
+    import pwicp_amd as P
+    cfg = tmp_path / "cfg_pair.txt"
+    _write_config(cfg, os.path.join(G.GOLD, "inputs", "Epoch_001.pcd"), os.path.join(G.GOLD, "inputs", "Epoch_002.pcd"))
+    outs = [str(tmp_path / ("run%d_" % k)) for k in range(3)]
+    assert P.PiecewiseICP_pair_call(str(cfg), outs[0]) is True
+    for _ in range(3):                                   # contexts come and go (their streams are recycled)
+        cs = [P.Context(0) for _ in range(3)]
+        for c in cs:
+            c.close()
+    assert P.PiecewiseICP_pair_call(str(cfg), outs[1]) is True          # on the parked context
+    P.series_release_parked()
+    assert P.PiecewiseICP_pair_call(str(cfg), outs[2]) is True          # on a new one
+    ref_t = open(outs[0] + "TransMatrix.txt", "rb").read()
+    ref_c = open(outs[0] + "RegisteredSourceCloud.pcd", "rb").read()
+    for o in outs[1:]:
+        assert open(o + "TransMatrix.txt", "rb").read() == ref_t
+        assert open(o + "RegisteredSourceCloud.pcd", "rb").read() == ref_c
+
+
+@pytest.mark.gpu
 def test_gpu_knn_and_frontend_match_host(ctx, oracle):
     """k-NN graph on the GPU == host KD-tree lists (order included); labels == host front end == reference front end."""
     import pwicp_amd as P
