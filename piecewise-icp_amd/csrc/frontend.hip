@@ -304,7 +304,13 @@ struct FusState {
 // search queue / visited hash of a wavefront: the common case in LDS small enough for 5 blocks of 4 wavefronts per CU (the kernel
 // is bound by the latency of dependent gathers: occupancy is throughput); a centre whose search outgrows it runs again in
 // the same sweep on a wavefront with the large configuration
-constexpr int kFusQueueS = 256, kFusHashS = 512, kFusQueue = 2048, kFusHash = 4096;
+#ifndef PW_FUS_QUEUE_S
+#define PW_FUS_QUEUE_S 256
+#endif
+#ifndef PW_FUS_MIN_WAVES
+#define PW_FUS_MIN_WAVES 1            // wavefronts per SIMD asked of the compiler for the sweeps' kernel (build parameter, measured)
+#endif
+constexpr int kFusQueueS = PW_FUS_QUEUE_S, kFusHashS = 2 * PW_FUS_QUEUE_S, kFusQueue = 2048, kFusHash = 4096;
 constexpr int kFusArenas = 256;
 
 // batched sweeps (FusState::nW_dev): the number of slots lives on the device, a raised stop flag ends the batch
@@ -423,7 +429,7 @@ __device__ __forceinline__ void fus_expand(const FusState& s, FusWave& w, const 
 // QCAP / HCAP: capacity of the search queue / visited hash; WAVES wavefronts per block.  list == nullptr: the work list W in
 // chunks; else the slots on `list` (the centres whose search outgrew the small configuration), one at a time.
 template <int QCAP, int HCAP, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES) k_fus_run(FusState s, int nW, int chunk, const int* __restrict__ list,
+__global__ void __launch_bounds__(64 * WAVES, PW_FUS_MIN_WAVES) k_fus_run(FusState s, int nW, int chunk, const int* __restrict__ list,
                                                          const int* __restrict__ n_list, int* __restrict__ ovf, int* __restrict__ n_ovf) {
     __shared__ __attribute__((aligned(16))) int s_keys[WAVES][HCAP];
     __shared__ __attribute__((aligned(16))) int s_vals[WAVES][HCAP];
