@@ -11,7 +11,7 @@ import pwicp_amd as P
 from pwicp_amd import synth
 from pwicp_amd.pcd import write_pcd_binary
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-n, E, r = 1000000, 8, 0.005
+n, E, r = int(os.environ.get("SERIES_N", 1000000)), int(os.environ.get("SERIES_E", 8)), 0.005
 d = tempfile.mkdtemp(dir="/dev/shm")
 inp = os.path.join(d, "scans"); os.mkdir(inp)
 t, _ = synth.make_tile(n, r)
