@@ -259,6 +259,8 @@ __global__ void k_relabel(int* __restrict__ lab, int n, const int* __restrict__ 
 struct FusState {
     // static in a round
     const FePt* P;
+    const float4* Pf;          // [2 n] the same points in single precision, 32 B each: (x, y, z, nx) (ny, nz, -, -) - fus_loss_decides
+    float inv_res_f;           // (float)(1 / res)
     double res, lambda;
     const int* root0;          // [n] root of a point at the start of the round (the entries of the base lists ARE roots at the start
                                // of the round - k_fus_next_lists resolves them on the way into the arena - so no search reads it)
@@ -426,6 +428,28 @@ __device__ __forceinline__ void fus_expand(const FusState& s, FusWave& w, const 
     }
 }
 
+// Does centre `me` absorb a root j of size sj?  The reference's test is lambda - sj * metric(i, j) > 0 in double (:120-123), and the
+// double metric - a square root, a division - is ~90 of the ~410 vector instructions of a run.  The same expression in single
+// precision (v_sqrt_f32, a multiplication by 1 / res) is within kFusEps * (1 + distance term) of it: Pf holds the double
+// coordinates (exact: they were floats) and normals (relative 2^-24) rounded once; the dot product of two (near-)unit normals
+// is then off by < 6 * 2^-24, the distance term by < 9 * 2^-24 relative, the two sums by 2 * 2^-24 each - under 11 * 2^-24 *
+// (1 + term) = 6.6e-7 * (1 + term) in all; kFusEps is six times that.  Whenever lambda is farther from the single-precision loss
+// than that bound the sign of the double expression is known; the (rare: ~1e-5 of the candidates) others take the double path.
+// So the decision is the reference's, bit for bit, and the double points are only gathered for the ambiguous candidates.
+constexpr float kFusEps = 4.0e-6f;
+__device__ __forceinline__ bool fus_loss_decides(const FusState& s, const float4 m0, const float4 m1, int j, int sj, bool& absorb) {
+    const float4 a0 = s.Pf[2 * (size_t)j], a1 = s.Pf[2 * (size_t)j + 1];
+    const float dotf = m0.w * a0.w + m1.x * a1.x + m1.y * a1.y;
+    const float t1 = m0.x - a0.x, t2 = m0.y - a0.y, t3 = m0.z - a0.z;
+    const float term = __builtin_amdgcn_sqrtf(t1 * t1 + t2 * t2 + t3 * t3) * s.inv_res_f * 0.4f;
+    const float mf = 1.0f - fabsf(dotf) + term;
+    const double lossf = (double)sj * (double)mf;
+    const double bound = (double)sj * (double)(kFusEps * (1.0f + term));
+    const double imp = s.lambda - lossf;
+    absorb = imp > 0.0;
+    return fabs(imp) > bound;
+}
+
 // QCAP / HCAP: capacity of the search queue / visited hash; WAVES wavefronts per block.  list == nullptr: the work list W in
 // chunks; else the slots on `list` (the centres whose search outgrew the small configuration), one at a time.
 template <int QCAP, int HCAP, int WAVES>
@@ -483,7 +507,7 @@ __global__ void __launch_bounds__(64 * WAVES, PW_FUS_MIN_WAVES) k_fus_run(FusSta
             }
             WSYNC();
             fus_expand<HCAP>(s, w, s.arena0 + s.off0[i], s.len0[i], i, lane);
-            const FePt me = s.P[i];
+            const float4 me0 = s.Pf[2 * (size_t)i], me1 = s.Pf[2 * (size_t)i + 1];
             int front = 1;
             while (front < w.qn && !w.overflow) {
                 const int stop = w.qn;
@@ -492,7 +516,7 @@ __global__ void __launch_bounds__(64 * WAVES, PW_FUS_MIN_WAVES) k_fus_run(FusSta
                     const bool valid = idx < stop;
                     const int j = valid ? w.queue[idx] : 0;
                     int sj = 0;
-                    bool absorb = false;
+                    bool absorb = false, sure = true;
                     if (valid) {
                         if (j < i) {
                             const int q = fus_chunk_index(w, j);
@@ -500,10 +524,22 @@ __global__ void __launch_bounds__(64 * WAVES, PW_FUS_MIN_WAVES) k_fus_run(FusSta
                         } else {
                             sj = s.s0[j];
                         }
-                        const double loss = (double)sj * sv_metric(me, s.P[j], s.res);
+#ifdef PW_FUS_DOUBLE_ONLY          // (the reference's expression for every candidate: A/B and cross-check build)
+                        const double loss = (double)sj * sv_metric(s.P[i], s.P[j], s.res);
                         absorb = s.lambda - loss > 0.0;
-                        if (absorb) w.queue[idx] = j | (int)0x80000000;
+#else
+                        sure = fus_loss_decides(s, me0, me1, j, sj, absorb);
+#endif
                     }
+#ifndef PW_FUS_DOUBLE_ONLY
+                    if (__ballot(valid && !sure)) {                     // (wave-uniform, rare)
+                        if (valid && !sure) {
+                            const double loss = (double)sj * sv_metric(s.P[i], s.P[j], s.res);
+                            absorb = s.lambda - loss > 0.0;
+                        }
+                    }
+#endif
+                    if (valid && absorb) w.queue[idx] = j | (int)0x80000000;
                     unsigned long long A = __ballot(absorb);
                     while (A && !w.overflow) {
                         const int l = __builtin_ctzll(A);
@@ -937,6 +973,14 @@ __global__ void k_fus_min_metric(const FePt* __restrict__ P, const int* __restri
     }
     out[i] = d;
 }
+// the points once more in single precision (fus_loss_decides)
+__global__ void k_fus_pack_single(const FePt* __restrict__ P, int n, float4* __restrict__ Pf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const FePt p = P[i];
+    Pf[2 * (size_t)i] = make_float4((float)p.x, (float)p.y, (float)p.z, (float)p.nx);
+    Pf[2 * (size_t)i + 1] = make_float4((float)p.ny, (float)p.nz, 0.f, 0.f);
+}
 __global__ void k_fus_first_round(int n, int k, int* root0, int* s0, int* len0, long long* off0, int* cen) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1136,6 +1180,7 @@ struct FeWorkspace {
     DevBuf<int> d_nb, d_lab, lab0, d_roots, d_map, cell_cnt;
     DevBuf<double> dS, dN;
     DevBuf<FePt> dP;
+    DevBuf<float4> Pf;                  // the points in single precision (fusion_device)
     DevBuf<unsigned long long> table;
     double* hS = nullptr;               // pinned: scatter down, normals up
     double* hN = nullptr;
@@ -1468,8 +1513,11 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     DevBuf<int>* arena_cur = &ws.arenaB;       // (the one arena0 points into from the second round on)
     int nc = n, round = 0;
     long long count = n;
+    HIPCHK(ctx, ws.Pf.reserve(2 * N));
+    hipLaunchKernelGGL(k_fus_pack_single, grid1(n), dim3(256), 0, st, dP, n, ws.Pf.p);
     FusState s{};
     s.P = dP; s.res = res;
+    s.Pf = ws.Pf.p; s.inv_res_f = (float)(1.0 / res);
     s.root0 = ws.root0.p; s.s0 = ws.s0.p;
     s.revoff = ws.revoff.p;
     s.ab = ws.ab.p; s.ab_prev = ws.ab_prev.p; s.rec_sz = ws.rec_sz.p; s.rec_ran = ws.rec_ran.p; s.rec_absn = ws.rec_absn.p; s.rec_adjn = ws.rec_adjn.p;
