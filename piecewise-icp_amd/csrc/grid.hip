@@ -1467,8 +1467,7 @@ __global__ void __launch_bounds__(64) k_knn_lds(GridLevel g, int k, int* __restr
     Real worst = (Real)0;
     int worst_i = 0;
     // one candidate into the sorted list (by (d2, id); the current k-th entry is kept in registers)
-    auto consider = [&](int j) {
-        const float4 p = g.pts[j];
+    auto consider = [&](const float4 p) {
         const Real dx = qx - (Real)p.x, dy2 = qy - (Real)p.y, dz2 = qz - (Real)p.z;
         Real d2 = dx * dx;
         d2 = d2 + dy2 * dy2;
@@ -1476,6 +1475,27 @@ __global__ void __launch_bounds__(64) k_knn_lds(GridLevel g, int k, int* __restr
         const int id = __float_as_int(p.w);
         if (cnt == k && !(d2 < worst || (d2 == worst && id < worst_i))) return;
         int pos = cnt < k ? cnt : k - 1;
+#ifndef PW_KNN_SHIFT1
+        // four entries per step: their eight LDS reads are in flight together, then the (up to) four moves - one entry per step
+        // is a read -> compare -> write chain that pays the LDS latency ~10 times per candidate at one wavefront per SIMD.
+        // (The list ascends, so "the candidate comes before entry e" holds for a prefix of the four.)
+        while (pos >= 4) {
+            const Real p1 = nd[(pos - 1) * 64], p2 = nd[(pos - 2) * 64], p3 = nd[(pos - 3) * 64], p4 = nd[(pos - 4) * 64];
+            const int i1 = ni[(pos - 1) * 64], i2 = ni[(pos - 2) * 64], i3 = ni[(pos - 3) * 64], i4 = ni[(pos - 4) * 64];
+            const bool c1 = d2 < p1 || (d2 == p1 && id < i1);
+            if (!c1) break;
+            const bool c2 = d2 < p2 || (d2 == p2 && id < i2);
+            const bool c3 = c2 && (d2 < p3 || (d2 == p3 && id < i3));
+            const bool c4 = c3 && (d2 < p4 || (d2 == p4 && id < i4));
+            nd[pos * 64] = p1; ni[pos * 64] = i1;
+            if (c2) { nd[(pos - 1) * 64] = p2; ni[(pos - 1) * 64] = i2; }
+            if (c3) { nd[(pos - 2) * 64] = p3; ni[(pos - 2) * 64] = i3; }
+            if (c4) { nd[(pos - 3) * 64] = p4; ni[(pos - 3) * 64] = i4; }
+            const int moved = 1 + (c2 ? 1 : 0) + (c3 ? 1 : 0) + (c4 ? 1 : 0);
+            pos -= moved;
+            if (moved < 4) goto placed;
+        }
+#endif
         while (pos > 0) {
             const Real pd = nd[(pos - 1) * 64];
             const int pi = ni[(pos - 1) * 64];
@@ -1484,10 +1504,24 @@ __global__ void __launch_bounds__(64) k_knn_lds(GridLevel g, int k, int* __restr
             ni[pos * 64] = pi;
             --pos;
         }
+#ifndef PW_KNN_SHIFT1
+    placed:
+#endif
         nd[pos * 64] = d2;
         ni[pos * 64] = id;
         if (cnt < k) ++cnt;
         if (cnt == k) { worst = nd[(k - 1) * 64]; worst_i = ni[(k - 1) * 64]; }
+    };
+    // the points of a row segment, four loads in flight (one wavefront per SIMD: a load per candidate was a round trip per candidate)
+    auto scan = [&](int lo, int hi) {
+        int j = lo;
+#ifndef PW_KNN_SHIFT1
+        for (; j + 4 <= hi; j += 4) {
+            const float4 a = g.pts[j], b = g.pts[j + 1], c = g.pts[j + 2], d = g.pts[j + 3];
+            consider(a); consider(b); consider(c); consider(d);
+        }
+#endif
+        for (; j < hi; ++j) consider(g.pts[j]);
     };
     // The block of cells grows shell by shell and the list is kept: every cell is scanned once (the search with its list in
     // global memory restarts at every radius: the slowest lane of a wavefront - a corner of the cloud, a hole: radius 6 to 12
@@ -1499,12 +1533,12 @@ __global__ void __launch_bounds__(64) k_knn_lds(GridLevel g, int k, int* __restr
                 int lo, hi;
                 if (max(abs(dy), abs(dz)) == r) {             // a row that no smaller block had: its whole x-range
                     row_range(g, cy + dy, cz + dz, cx - r, cx + r, lo, hi);
-                    for (int j = lo; j < hi; ++j) consider(j);
+                    scan(lo, hi);
                 } else {                                        // a row of the previous block: its two new end cells
                     row_range(g, cy + dy, cz + dz, cx - r, cx - r, lo, hi);
-                    for (int j = lo; j < hi; ++j) consider(j);
+                    scan(lo, hi);
                     row_range(g, cy + dy, cz + dz, cx + r, cx + r, lo, hi);
-                    for (int j = lo; j < hi; ++j) consider(j);
+                    scan(lo, hi);
                 }
             }
         if (r >= rcover) break;
@@ -1550,6 +1584,14 @@ int pw_knn_mean_dist_launch(pwicp_context* ctx, const GridDesc& g, int mean_k, f
     if (n <= 0) return PWICP_OK;
     const int k = mean_k + 1;
     static const bool lds_off = getenv("PWICP_KNN_LDS") && atoi(getenv("PWICP_KNN_LDS")) == 0;
+    if (k <= 16 && !lds_off) {
+        // (the outlier removal's 14 + 1 neighbours: a 16-entry list is 8 KB of LDS per wavefront instead of 24.6 - five times the
+        // wavefronts per CU for a search that is a chain of LDS round trips)
+        hipLaunchKernelGGL((k_knn_lds<float, 16>), dim3(div_up(n, 64)), dim3(64), 0, ctx->stream, g.fine, k, (int*)nullptr, d_mean);
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipGetLastError());
+        return PWICP_OK;
+    }
     if (k <= kKnnLdsMax && !lds_off) {
         hipLaunchKernelGGL((k_knn_lds<float, kKnnLdsMax>), dim3(div_up(n, 64)), dim3(64), 0, ctx->stream, g.fine, k, (int*)nullptr, d_mean);
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
