@@ -492,6 +492,9 @@ __global__ void __launch_bounds__(64 * WAVES, PW_FUS_MIN_WAVES) k_fus_run(FusSta
         const long long old_ptr = s.rec_ptr[i];
         int ran = 0, size_i = s.s0[i], nabs = 0;
         w.qn = 1; w.gcount = 0; w.overflow = false;
+#if defined(PW_FUS_KO) && PW_FUS_KO == 1      // (knock-out profiling, tools/fus_knockout.sh: the run ends after its prologue)
+        if (old_ran + old_sz + old_absn + old_adjn + (int)old_ptr != -12345) { if (lane == 0) { s.o_sz[slot] = old_sz; s.o_ran[slot] = old_ran; s.o_absn[slot] = old_absn; s.o_adjn[slot] = old_adjn; s.o_ptr[slot] = old_ptr; s.o_dirty[slot] = 0; s.o_oldptr[slot] = old_ptr; s.o_oldabsn[slot] = old_absn; } continue; }
+#endif
         if (s.len0[i] != 0 && !(fus_absorber(s, w, i) < i)) {
             ran = 1;
             {   // (four entries per store)
@@ -509,6 +512,9 @@ __global__ void __launch_bounds__(64 * WAVES, PW_FUS_MIN_WAVES) k_fus_run(FusSta
             fus_expand<HCAP>(s, w, s.arena0 + s.off0[i], s.len0[i], i, lane);
             const float4 me0 = s.Pf[2 * (size_t)i], me1 = s.Pf[2 * (size_t)i + 1];
             int front = 1;
+#if defined(PW_FUS_KO) && PW_FUS_KO == 2      // (... after the search has taken in the centre's own list)
+            front = w.qn;
+#endif
             while (front < w.qn && !w.overflow) {
                 const int stop = w.qn;
                 for (int base = front; base < stop && !w.overflow; base += 64) {
@@ -568,6 +574,10 @@ __global__ void __launch_bounds__(64 * WAVES, PW_FUS_MIN_WAVES) k_fus_run(FusSta
             }
             continue;
         }
+#if defined(PW_FUS_KO) && (PW_FUS_KO == 2 || PW_FUS_KO == 3)      // (... before the outcome is compared and written)
+        if (lane == 0) { s.o_sz[slot] = old_sz; s.o_ran[slot] = old_ran; s.o_absn[slot] = old_absn; s.o_adjn[slot] = old_adjn; s.o_ptr[slot] = old_ptr; s.o_dirty[slot] = 0; s.o_oldptr[slot] = old_ptr; s.o_oldabsn[slot] = old_absn; }
+        if (w.qn != -12345) continue;
+#endif
         // outcome: absorbed nodes then adjacent nodes, each in search order; unchanged lists keep their place in the arena
         const int total = ran ? w.qn - 1 : 0;
         const int nadj = total - nabs;
@@ -1689,9 +1699,23 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
                 const int h0 = halves ? part_begin[half] : 0, hn = halves ? part_end[half] - part_begin[half] : nW;
                 s.slot0 = h0;
                 if (half > 0) HIPCHK(ctx, hipMemsetAsync(ws.ctr.p + 3, 0, sizeof(int), st));
+#ifdef PW_FUS_KO
+                hipEvent_t ko_e0, ko_e1;
+                (void)hipEventCreate(&ko_e0); (void)hipEventCreate(&ko_e1);
+                (void)hipEventRecord(ko_e0, st);
+#endif
                 hipLaunchKernelGGL((k_fus_run<kFusQueueS, kFusHashS, kFusWaves>), dim3((unsigned)std::min(div_up(div_up(hn, chunk), kFusWaves), kFusGridCap)),
                                    dim3(64 * kFusWaves), 0, st,
                                    s, hn, chunk, (const int*)nullptr, (const int*)nullptr, ws.ovf.p, ws.ctr.p + 3);
+#ifdef PW_FUS_KO
+                (void)hipEventRecord(ko_e1, st);
+                (void)hipEventSynchronize(ko_e1);
+                float ko_ms = 0.f;
+                (void)hipEventElapsedTime(&ko_ms, ko_e0, ko_e1);
+                fprintf(stderr, "[pwicp knock-out %d] round %d sweep %d part %d: %d centres, k_fus_run %.3f ms\n", PW_FUS_KO, round, sweeps, half, hn, ko_ms);
+                (void)hipEventDestroy(ko_e0); (void)hipEventDestroy(ko_e1);
+                if (half + 1 == (halves ? n_parts : 1)) { HIPCHK(ctx, hipStreamSynchronize(st)); *gave_up = true; return PWICP_OK; }
+#endif
                 hipLaunchKernelGGL((k_fus_run<kFusQueue, kFusHash, 1>), dim3(256), dim3(64), 0, st, s, 0, 1, (const int*)ws.ovf.p,
                                    (const int*)(ws.ctr.p + 3), (int*)nullptr, (int*)nullptr);
                 hipLaunchKernelGGL(k_fus_retract, grid1(hn), dim3(256), 0, st, s, hn);
