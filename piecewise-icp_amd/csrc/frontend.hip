@@ -370,8 +370,7 @@ __device__ __forceinline__ int fus_chunk_index(const FusWave& w, int c) {
 
 // absorber of x as the running sweep knows it: the standing one, unless it belongs to a centre of the chunk that has run
 // again (then only the claims that centre has just made count)
-__device__ __forceinline__ int fus_absorber(const FusState& s, const FusWave& w, int x) {
-    int c = s.ab[x];
+__device__ __forceinline__ int fus_absorber_from(const FusState& s, const FusWave& w, int x, int c) {
     if (w.ndone) {
         if (c != kNone && fus_chunk_index(w, c) >= 0) c = kNone;
         if (w.nfresh) {
@@ -386,6 +385,7 @@ __device__ __forceinline__ int fus_absorber(const FusState& s, const FusWave& w,
     }
     return c;
 }
+__device__ __forceinline__ int fus_absorber(const FusState& s, const FusWave& w, int x) { return fus_absorber_from(s, w, x, s.ab[x]); }
 
 __device__ __forceinline__ int fus_root_at(const FusState& s, const FusWave& w, int y, int t) {
     int x = y, g = -1;                 // (y is a root of the round's start: base lists are resolved, outcome lists hold roots)
@@ -450,6 +450,24 @@ __device__ __forceinline__ bool fus_loss_decides(const FusState& s, const float4
     return fabs(imp) > bound;
 }
 
+// The words a run starts from - the centre's standing outcome (rec_*), its size, list and absorber - one per lane (lane 0 ... 10), so
+// that they can be requested for the NEXT centre of the chunk while this one runs: the work-list entry and these words were two
+// round trips at the head of every run (16 % of it, tools/fus_knockout.sh).  None of them is written inside the kernel.
+__device__ __forceinline__ int fus_head_words(const FusState& s, int lane, int i) {
+    const int* p = s.rec_ran + i;
+    p = lane == 1 ? s.rec_sz + i : p;
+    p = lane == 2 ? s.rec_absn + i : p;
+    p = lane == 3 ? s.rec_adjn + i : p;
+    p = lane == 4 ? reinterpret_cast<const int*>(s.rec_ptr + i) : p;
+    p = lane == 5 ? reinterpret_cast<const int*>(s.rec_ptr + i) + 1 : p;
+    p = lane == 6 ? s.s0 + i : p;
+    p = lane == 7 ? s.len0 + i : p;
+    p = lane == 8 ? reinterpret_cast<const int*>(s.off0 + i) : p;
+    p = lane == 9 ? reinterpret_cast<const int*>(s.off0 + i) + 1 : p;
+    p = lane == 10 ? s.ab + i : p;
+    return lane <= 10 ? *p : 0;
+}
+
 // QCAP / HCAP: capacity of the search queue / visited hash; WAVES wavefronts per block.  list == nullptr: the work list W in
 // chunks; else the slots on `list` (the centres whose search outgrew the small configuration), one at a time.
 template <int QCAP, int HCAP, int WAVES>
@@ -484,18 +502,48 @@ __global__ void __launch_bounds__(64 * WAVES, PW_FUS_MIN_WAVES) k_fus_run(FusSta
           WSYNC();
       }
       const int slot_end = min(nW, (ci + 1) * chunk);
+#ifndef PW_FUS_NO_PREFETCH
+      // the chunk's work-list entries in one load (lane t: the t-th), the head words of its first centre
+      const int chunk_n = slot_end - ci * chunk;
+      int slot_v = 0, cen_v = 0;
+      if (lane < chunk_n) {
+          slot_v = list ? list[ci * chunk + lane] : s.slot0 + ci * chunk + lane;
+          cen_v = s.W[slot_v];
+      }
+      int head_next = fus_head_words(s, lane, __builtin_amdgcn_readlane(cen_v, 0));
+#endif
       for (int sl_i = ci * chunk; sl_i < slot_end; ++sl_i) {
+#ifndef PW_FUS_NO_PREFETCH
+        const int t_in = sl_i - ci * chunk;
+        const int slot = __builtin_amdgcn_readlane(slot_v, t_in);
+        const int i = __builtin_amdgcn_readlane(cen_v, t_in);
+        const int head = head_next;
+        if (sl_i + 1 < slot_end) head_next = fus_head_words(s, lane, __builtin_amdgcn_readlane(cen_v, t_in + 1));   // (in flight during this run)
+        if (lane == 0) { s.slot_of[i] = slot; s.wake[i] = 0; }
+        const int old_ran = __builtin_amdgcn_readlane(head, 0), old_sz = __builtin_amdgcn_readlane(head, 1);
+        const int old_absn = __builtin_amdgcn_readlane(head, 2), old_adjn = __builtin_amdgcn_readlane(head, 3);
+        const long long old_ptr = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(head, 5) << 32) |
+                                              (unsigned long long)(unsigned)__builtin_amdgcn_readlane(head, 4));
+        const int s0_i = __builtin_amdgcn_readlane(head, 6), len0_i = __builtin_amdgcn_readlane(head, 7);
+        const long long off0_i = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(head, 9) << 32) |
+                                             (unsigned long long)(unsigned)__builtin_amdgcn_readlane(head, 8));
+        const int ab_i = __builtin_amdgcn_readlane(head, 10);
+#else
         const int slot = list ? list[sl_i] : s.slot0 + sl_i;
         const int i = s.W[slot];
         if (lane == 0) { s.slot_of[i] = slot; s.wake[i] = 0; }
         const int old_ran = s.rec_ran[i], old_sz = s.rec_sz[i], old_absn = s.rec_absn[i], old_adjn = s.rec_adjn[i];
         const long long old_ptr = s.rec_ptr[i];
-        int ran = 0, size_i = s.s0[i], nabs = 0;
+        const int s0_i = s.s0[i], len0_i = s.len0[i];
+        const long long off0_i = s.off0[i];
+        const int ab_i = s.ab[i];
+#endif
+        int ran = 0, size_i = s0_i, nabs = 0;
         w.qn = 1; w.gcount = 0; w.overflow = false;
 #if defined(PW_FUS_KO) && PW_FUS_KO == 1      // (knock-out profiling, tools/fus_knockout.sh: the run ends after its prologue)
         if (old_ran + old_sz + old_absn + old_adjn + (int)old_ptr != -12345) { if (lane == 0) { s.o_sz[slot] = old_sz; s.o_ran[slot] = old_ran; s.o_absn[slot] = old_absn; s.o_adjn[slot] = old_adjn; s.o_ptr[slot] = old_ptr; s.o_dirty[slot] = 0; s.o_oldptr[slot] = old_ptr; s.o_oldabsn[slot] = old_absn; } continue; }
 #endif
-        if (s.len0[i] != 0 && !(fus_absorber(s, w, i) < i)) {
+        if (len0_i != 0 && !(fus_absorber_from(s, w, i, ab_i) < i)) {
             ran = 1;
             {   // (four entries per store)
                 int4* k4 = reinterpret_cast<int4*>(w.keys);
@@ -509,7 +557,7 @@ __global__ void __launch_bounds__(64 * WAVES, PW_FUS_MIN_WAVES) k_fus_run(FusSta
                 w.queue[0] = i;
             }
             WSYNC();
-            fus_expand<HCAP>(s, w, s.arena0 + s.off0[i], s.len0[i], i, lane);
+            fus_expand<HCAP>(s, w, s.arena0 + off0_i, len0_i, i, lane);
             const float4 me0 = s.Pf[2 * (size_t)i], me1 = s.Pf[2 * (size_t)i + 1];
             int front = 1;
 #if defined(PW_FUS_KO) && PW_FUS_KO == 2      // (... after the search has taken in the centre's own list)
