@@ -155,7 +155,7 @@ bool prepare_gpu(pwicp_context* ctx, const std::vector<float>& raw, float Res, f
 // Auxiliary contexts (= streams) of one device: the front ends of several clouds run side by side, each on its own stream
 // and host thread (a front end is hundreds of small dependent launches: one alone leaves most of the GPU idle).
 struct AuxContexts {
-    int device = 0, limit = 3, made = 0;
+    int device = 0, limit = 3, made = 0;          // (limit: raised by size_for once the clouds' size is known)
     bool limit_from_env = false;
     std::mutex m;
     std::condition_variable cv;
@@ -164,13 +164,13 @@ struct AuxContexts {
         if (const char* e = std::getenv("PWICP_FRONTEND_STREAMS")) { limit = std::max(1, std::min(atoi(e), 16)); limit_from_env = true; }
     }
     // Streams by the size of the clouds they will segment: the front end of a 1 M-point cloud fills the device for most of its
-    // time and three of them side by side saturate it (3 / 4 / 6 streams: 0.41 / 0.40 / 0.41 s for 8 pairs); that of a 140 k-point
+    // time and three or four of them side by side saturate it (3 / 4 / 5 streams: 0.387 / 0.377 / 0.379 s for 8 pairs); that of a 140 k-point
     // scan is a chain of small launches - the reference's 19 pairs: 0.28 - 0.32 s with three streams, 0.23 - 0.25 s with six
     // ($PWICP_FRONTEND_STREAMS decides when it is set).
     void size_for(long long points_per_cloud) {
         if (limit_from_env) return;
         std::lock_guard<std::mutex> lk(m);
-        limit = std::max(limit, points_per_cloud < 400000 ? 6 : 3);
+        limit = std::max(limit, points_per_cloud < 400000 ? 6 : 4);
     }
     AuxContexts(const AuxContexts&) = delete;
     AuxContexts& operator=(const AuxContexts&) = delete;
