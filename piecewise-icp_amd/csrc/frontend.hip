@@ -1113,7 +1113,7 @@ __global__ void k_fus_next_lists(const int* __restrict__ cen, int nc, const int*
                                  const int* __restrict__ sa, const int* __restrict__ arena_old, const long long* __restrict__ off_old,
                                  const int* __restrict__ len_old, int* __restrict__ arena_new, long long* __restrict__ off_new,
                                  int* __restrict__ len_new, int* __restrict__ s0, int* __restrict__ cen_new,
-                                 const int* __restrict__ root_new) {
+                                 const int* __restrict__ root_new, int* __restrict__ rev_count) {
     const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (t >= nc) return;
     const int c = cen[t];
@@ -1126,7 +1126,12 @@ __global__ void k_fus_next_lists(const int* __restrict__ cen, int nc, const int*
     int* dst = arena_new + len_scan[t];
     // every entry as the root it has at the start of the next round (k_fus_new_roots has run): the searches and the reverse index
     // of that round then read the list and nothing else - one dependent gather less per entry, in every run of every sweep
-    for (int e = lane; e < m; e += 64) dst[e] = root_new[src[e]];
+    // ... and counted for the next round's reverse index on the way (what k_fus_reverse<0> would read the lists again for)
+    for (int e = lane; e < m; e += 64) {
+        const int r = root_new[src[e]];
+        dst[e] = r;
+        atomicAdd(&rev_count[r], 1);
+    }
     if (lane == 0) {
         len_new[c] = m; off_new[c] = len_scan[t];
         s0[c] = rec_sz[c];
@@ -1570,6 +1575,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     DevBuf<int>* arena_next = &ws.arenaA;
     DevBuf<int>* arena_cur = &ws.arenaB;       // (the one arena0 points into from the second round on)
     int nc = n, round = 0;
+    bool rev_counted = false;
     long long count = n;
     HIPCHK(ctx, ws.Pf.reserve(2 * N));
     hipLaunchKernelGGL(k_fus_pack_single, grid1(n), dim3(256), 0, st, dP, n, ws.Pf.p);
@@ -1609,8 +1615,10 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
         hipLaunchKernelGGL(k_fus_reset, grid1(n), dim3(256), 0, st, n, ws.s0.p, ws.ab.p, ws.ab_prev.p, ws.rec_sz.p, ws.rec_ran.p, ws.rec_absn.p, ws.rec_adjn.p,
                            ws.rec_ptr.p, ws.wake.p, ws.dflag.p, ws.cflag.p, ws.dtmin.p, ws.slot_of.p);
         // reverse index of the base lists
-        HIPCHK(ctx, hipMemsetAsync(ws.revoff.p, 0, sizeof(int) * (N + 1), st));
-        hipLaunchKernelGGL(k_fus_reverse<0>, grid1(nc), dim3(256), 0, st, cen, nc, ws.root0.p, len0, off0, arena0, ws.revoff.p, (int*)nullptr);
+        if (!rev_counted) {                        // (from the second round on k_fus_next_lists has counted the entries per root)
+            HIPCHK(ctx, hipMemsetAsync(ws.revoff.p, 0, sizeof(int) * (N + 1), st));
+            hipLaunchKernelGGL(k_fus_reverse<0>, grid1(nc), dim3(256), 0, st, cen, nc, ws.root0.p, len0, off0, arena0, ws.revoff.p, (int*)nullptr);
+        }
         PWCHK(pw_exclusive_scan(ctx, ws.revoff.p, (long long)n + 1, &ws.tmp));
         int n_entries = 0;
         HIPCHK(ctx, hipMemcpyAsync(&n_entries, ws.revoff.p + n, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1859,9 +1867,11 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
         HIPCHK(ctx, hipMemcpyAsync(&n_list, ws.newlen.p + nc, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         HIPCHK(ctx, arena_next->reserve((size_t)std::max(n_list, 1)));
+        HIPCHK(ctx, hipMemsetAsync(ws.revoff.p, 0, sizeof(int) * (N + 1), st));        // (the closed round's index is no longer read)
+        rev_counted = true;
         hipLaunchKernelGGL(k_fus_next_lists, grid1((long long)nc * 64), dim3(256), 0, st, cen, nc, ws.alive.p, ws.newlen.p, ws.ab.p, ws.rec_ran.p, ws.rec_sz.p,
                            ws.rec_absn.p, ws.rec_adjn.p, ws.rec_ptr.p, ws.sa.p, arena0, off0, len0, arena_next->p, off1, len1, ws.s0.p, cen1,
-                           (const int*)ws.root0.p);
+                           (const int*)ws.root0.p, ws.revoff.p);
         arena0 = arena_next->p;
         std::swap(arena_next, arena_cur);
         std::swap(len0, len1); std::swap(off0, off1); std::swap(cen, cen1);
