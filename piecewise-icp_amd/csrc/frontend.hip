@@ -1012,7 +1012,9 @@ __global__ void k_fus_count_below(const unsigned* __restrict__ keys, int n, unsi
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n && keys[t] < limit && (t + 1 == n || keys[t + 1] >= limit)) *out = t + 1;
 }
-__global__ void k_fus_min_metric(const FePt* __restrict__ P, const int* __restrict__ nb, int k, int n, double res, double* __restrict__ out) {
+// (... and the entries per node of the first round's reverse index counted on the way, rev_count: k_fus_reverse<0>'s job)
+__global__ void k_fus_min_metric(const FePt* __restrict__ P, const int* __restrict__ nb, int k, int n, double res, double* __restrict__ out,
+                                 int* __restrict__ rev_count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int* row = nb + (size_t)i * k;
@@ -1025,6 +1027,9 @@ __global__ void k_fus_min_metric(const FePt* __restrict__ P, const int* __restri
         for (int u = 0; u < 8; ++u) j[u] = (e0 + u < k) ? row[e0 + u] : i;
 #pragma unroll
         for (int u = 0; u < 8; ++u) pj[u] = P[j[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e0 + u < k) atomicAdd(&rev_count[j[u]], 1);
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if (j[u] != i) d = fmin(d, sv_metric(me, pj[u], res));
@@ -1532,7 +1537,9 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     double lambda;
     {
         HIPCHK(ctx, ws.dmin.reserve((size_t)n));
-        hipLaunchKernelGGL(k_fus_min_metric, grid1(n), dim3(256), 0, st, dP, d_nb, k, n, res, ws.dmin.p);
+        HIPCHK(ctx, ws.revoff.reserve((size_t)n + 1));
+        HIPCHK(ctx, hipMemsetAsync(ws.revoff.p, 0, sizeof(int) * ((size_t)n + 1), st));
+        hipLaunchKernelGGL(k_fus_min_metric, grid1(n), dim3(256), 0, st, dP, d_nb, k, n, res, ws.dmin.p, ws.revoff.p);
         // median = the value of rank n / 2 (what std::nth_element(v.begin() + v.size() / 2) leaves there)
         HIPCHK(ctx, ws.sel_state.reserve(4));
         HIPCHK(ctx, ws.sel_hist.reserve(256));
@@ -1575,7 +1582,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     DevBuf<int>* arena_next = &ws.arenaA;
     DevBuf<int>* arena_cur = &ws.arenaB;       // (the one arena0 points into from the second round on)
     int nc = n, round = 0;
-    bool rev_counted = false;
+    bool rev_counted = true;               // (the first round's counts come from k_fus_min_metric, the later ones' from k_fus_next_lists)
     long long count = n;
     HIPCHK(ctx, ws.Pf.reserve(2 * N));
     hipLaunchKernelGGL(k_fus_pack_single, grid1(n), dim3(256), 0, st, dP, n, ws.Pf.p);
