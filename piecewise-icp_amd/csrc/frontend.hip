@@ -1269,7 +1269,6 @@ struct FeWorkspace {
         dflag, cflag, dtmin, Wa, Wb, dq, dq2, ovf, o_sz, o_ran, o_absn, o_adjn, o_dirty, o_oldabsn, alive, newlen, cut, arenaA, arenaB, sa, ctr;
     DevBuf<long long> offA, offB, rec_ptr, o_ptr, o_oldptr;
     DevBuf<unsigned long long> big;     // [0] absorbed in the round, [16 * (1 + r)] bump pointer of arena region r
-    DevBuf<int> chg;                    // FusState::changed
     DevBuf<int> cen_t;                  // the centres of a round in TILE order (fusion_device: full sweeps)
     DevBuf<unsigned> tkey, tkey2;
     DevBuf<unsigned char> tsort;
@@ -1565,8 +1564,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
         HIPCHK(ctx, b->reserve(N));
     for (DevBuf<int>* b : {&ws.revoff, &ws.alive, &ws.newlen}) HIPCHK(ctx, b->reserve(N + 1));
     for (DevBuf<long long>* b : {&ws.offA, &ws.offB, &ws.rec_ptr, &ws.o_ptr, &ws.o_oldptr}) HIPCHK(ctx, b->reserve(N));
-    HIPCHK(ctx, ws.ctr.reserve(16));
-    HIPCHK(ctx, ws.chg.reserve(16 * 32));
+    HIPCHK(ctx, ws.ctr.reserve(16 + 16 * 32));        // (the sweep's counters and, behind them, FusState::changed: one memset per sweep)
     HIPCHK(ctx, ws.big.reserve(16 * (kFusArenas + 1)));
     // lists of changed outcomes are appended, nothing is freed inside a round: 2.2 n k entries at most on the clouds measured
     // (the round after the first one).  3 n k = 0.54 GB per 1 M points; a round that overflows it is retried once with 6 n k
@@ -1750,9 +1748,8 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
             const auto t_sweep = std::chrono::steady_clock::now();
             const int nW_sweep = nW;
             const bool cert_sweep = certify;
-            HIPCHK(ctx, hipMemsetAsync(ws.ctr.p, 0, sizeof(int) * 16, st));
-            HIPCHK(ctx, hipMemsetAsync(ws.chg.p, 0, sizeof(int) * 16 * 32, st));
-            s.changed = certify ? nullptr : ws.chg.p;
+            HIPCHK(ctx, hipMemsetAsync(ws.ctr.p, 0, sizeof(int) * (16 + 16 * 32), st));
+            s.changed = certify ? nullptr : ws.ctr.p + 16;
             const int chunk = certify ? 1 : std::max(1, std::min(std::min(nW / chunk_div, kFusChunk), gs_chunk));
             // A sweep over ALL centres in tile order runs colour by colour: the tiles of one colour (no two of them neighbours), their
             // outcomes and claims made standing, then the next colour - which sees what its neighbours of the colours before have just
