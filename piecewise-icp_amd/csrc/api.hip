@@ -5,6 +5,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -24,6 +25,14 @@ struct StreamPool {
     std::map<int, std::vector<hipStream_t>> idle;
     static StreamPool& get() { static StreamPool* p = new StreamPool; return *p; }     // (never destructed: no HIP call at exit)
 };
+// The runtime serves a process's streams from FOUR hardware queues unless $GPU_MAX_HW_QUEUES says otherwise, and it reads the
+// variable when it starts.  A series worker runs five streams (its own and four front ends), pairs side by side one each: on four
+// queues two of them share one and wait for each other - 8 x 1 M points 0.40 - 0.43 s instead of 0.37 s.  So, before the library's first
+// HIP call and only if the caller has not set it: eight.  (A host program that has already started the runtime keeps what it had.)
+void runtime_defaults() {
+    static std::once_flag once;
+    std::call_once(once, [] { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); });
+}
 }  // namespace
 
 extern "C" {
@@ -31,6 +40,7 @@ extern "C" {
 const char* pwicp_version(void) { return "pwicp-mi355x 0.1 (gfx950, HIP)"; }
 
 int pwicp_device_count(void) {
+    runtime_defaults();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
@@ -39,6 +49,7 @@ int pwicp_device_count(void) {
 int pwicp_create(pwicp_context** out, int device_id) {
     if (!out) return PWICP_E_INVALID;
     *out = nullptr;
+    runtime_defaults();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return PWICP_E_NO_DEVICE;   // fail loudly: no CPU fallback
     if (device_id < 0 || device_id >= n) return PWICP_E_INVALID;

@@ -143,6 +143,7 @@ extern "C" {
 PWICP_API int pwicp_comm_init(int rank, int world, int device, const char* id_file, pwicp_comm** out) {
     if (!out || world < 1 || rank < 0 || rank >= world || (world > 1 && (!id_file || !*id_file))) return PWICP_E_INVALID;
     *out = nullptr;
+    (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);       // (as pwicp_create does: read by the runtime when it starts, csrc/api.hip)
     if (!g_rccl.load()) return PWICP_E_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return PWICP_E_NO_DEVICE;
     ncclUniqueId id;
