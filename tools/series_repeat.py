@@ -6,7 +6,7 @@ import os, sys, tempfile, time, shutil
 import numpy as np
 R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R_ + '/piecewise-icp_amd')
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (GPU_MAX_HW_QUEUES: left to the library, which asks for eight when the variable is not set)
 import pwicp_amd as P
 from pwicp_amd import synth
 from pwicp_amd.pcd import write_pcd_binary
