@@ -375,6 +375,11 @@ PWICP_API int  pwicp_comm_rank(const pwicp_comm* comm);
 PWICP_API int  pwicp_comm_world(const pwicp_comm* comm);
 PWICP_API int  pwicp_comm_allgather(pwicp_comm* comm, const void* send, size_t bytes, void* recv /* world * bytes */);
 PWICP_API int  pwicp_comm_broadcast(pwicp_comm* comm, void* buf, size_t bytes, int root);
+/* Test hook of the id file's acceptance rules (no GPU, no RCCL): op 0 writes an id file with this process's job token dated age_s
+ * seconds back (returns 1), op 1 reads it as a rank != 0 would: 1 accepted, 0 rejected.  A rank accepts a file only if it carries its
+ * launch's token ($PWICP_JOB_ID / $TORCHELASTIC_RUN_ID / MASTER_ADDR / MASTER_PORT / WORLD_SIZE), is younger than 600 s AND was not
+ * written more than 30 s before the reading process started (an earlier launch with the same token that was killed). */
+PWICP_API int  pwicp_comm_debug_id_file(const char* path, int op, long age_s);
 /* One rank of PiecewiseICP_4D_call sharded over `world` processes: pair p -> rank p mod world, adaptive pair map from rank 0
  * (broadcast), one all-gather of the 384-byte records, rank 0 writes the files.  Returns the same value on every rank.
  * PiecewiseICP_4D_call takes this path by itself when $PWICP_RCCL=1 and $WORLD_SIZE > 1 (rank / device from $RANK /

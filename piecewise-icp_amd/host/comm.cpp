@@ -25,7 +25,9 @@
 #include <ctime>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <iostream>
+#include <sstream>
 #include <string>
 #include <thread>
 #include <vector>
@@ -81,8 +83,40 @@ struct IdFile {                  // content of the rendezvous file
 };
 constexpr uint64_t kIdMagic = 0x5057494350494431ull;     // "PWICPID1"
 constexpr int64_t kIdMaxAgeSeconds = 600;
+// The ranks of one launch are started by one launcher within seconds of each other, and rank 0 writes the file after ITS start: a file
+// written more than this long before the reading process started belongs to an earlier launch - also when its token is the same
+// (torchrun's static rendezvous: TORCHELASTIC_RUN_ID "none", default port, same world size, no $PWICP_JOB_ID) and it is younger than
+// kIdMaxAgeSeconds (an earlier launch that was killed a minute ago).
+constexpr int64_t kLauncherStaggerSeconds = 30;
 
-bool write_id_file(const std::string& path, const ncclUniqueId& id) {
+// start of this process, seconds since the epoch: /proc/self/stat field 22 (clock ticks since boot) + btime of /proc/stat; without
+// procfs the first call into this file stands in for it
+int64_t process_start_epoch() {
+    static const int64_t t = [] {
+        const int64_t fallback = (int64_t)std::time(nullptr);
+        std::ifstream st("/proc/self/stat");
+        std::string line;
+        if (!st || !std::getline(st, line)) return fallback;
+        const size_t rp = line.rfind(')');              // the command name may hold blanks and brackets
+        if (rp == std::string::npos) return fallback;
+        std::istringstream is(line.substr(rp + 1));
+        std::string tok;
+        unsigned long long ticks = 0;
+        for (int field = 3; field <= 22 && (is >> tok); ++field)
+            if (field == 22) ticks = std::strtoull(tok.c_str(), nullptr, 10);
+        if (!ticks) return fallback;
+        std::ifstream ps("/proc/stat");
+        int64_t btime = 0;
+        while (ps && std::getline(ps, line))
+            if (line.compare(0, 6, "btime ") == 0) { btime = std::strtoll(line.c_str() + 6, nullptr, 10); break; }
+        const long hz = sysconf(_SC_CLK_TCK);
+        if (btime <= 0 || hz <= 0) return fallback;
+        return std::min<int64_t>(btime + (int64_t)(ticks / (unsigned long long)hz), fallback);
+    }();
+    return t;
+}
+
+bool write_id_file(const std::string& path, const ncclUniqueId& id, int64_t written_at = 0) {
     const std::string tmp = path + ".tmp";
     (void)unlink(path.c_str());
     (void)unlink(tmp.c_str());
@@ -90,7 +124,7 @@ bool write_id_file(const std::string& path, const ncclUniqueId& id) {
     if (fd < 0) return false;
     IdFile f;
     std::memset(&f, 0, sizeof(f));
-    f.magic = kIdMagic; f.token = job_token(); f.written_at = (int64_t)std::time(nullptr); f.id = id;
+    f.magic = kIdMagic; f.token = job_token(); f.written_at = written_at ? written_at : (int64_t)std::time(nullptr); f.id = id;
     const bool ok = write(fd, &f, sizeof(f)) == (ssize_t)sizeof(f);
     close(fd);
     if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) { (void)unlink(tmp.c_str()); return false; }
@@ -115,6 +149,15 @@ int read_id_file(const std::string& path, ncclUniqueId* id) {
     }
     if (!ok || f.magic != kIdMagic || f.token != job_token()) return 0;                 // another job's, or a torn write
     if ((int64_t)std::time(nullptr) - f.written_at > kIdMaxAgeSeconds) return 0;        // left behind by an earlier run
+    if (f.written_at < process_start_epoch() - kLauncherStaggerSeconds) {               // ... also one with THIS launch's token
+        static bool told_stale = false;
+        if (!told_stale) {
+            told_stale = true;
+            std::cerr << "pwicp: " << path << " was written " << (process_start_epoch() - f.written_at) << " s before this process started: "
+                         "an earlier launch's id (same job token) - waiting for rank 0 to replace it\n";
+        }
+        return 0;
+    }
     *id = f.id;
     return 1;
 }
@@ -143,7 +186,6 @@ extern "C" {
 PWICP_API int pwicp_comm_init(int rank, int world, int device, const char* id_file, pwicp_comm** out) {
     if (!out || world < 1 || rank < 0 || rank >= world || (world > 1 && (!id_file || !*id_file))) return PWICP_E_INVALID;
     *out = nullptr;
-    (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);       // (as pwicp_create does: read by the runtime when it starts, csrc/api.hip)
     if (!g_rccl.load()) return PWICP_E_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return PWICP_E_NO_DEVICE;
     ncclUniqueId id;
@@ -183,6 +225,16 @@ PWICP_API int pwicp_comm_init(int rank, int world, int device, const char* id_fi
     }
     *out = c;
     return PWICP_OK;
+}
+
+// Test hook of the rendezvous file (no GPU, no RCCL): op 0 writes an id file (zero id, this process's job token) dated `age_s` seconds
+// back, op 1 reads it as a rank != 0 would - 1: accepted, 0: not (yet) acceptable.
+PWICP_API int pwicp_comm_debug_id_file(const char* path, int op, long age_s) {
+    if (!path || !*path) return PWICP_E_INVALID;
+    ncclUniqueId id;
+    std::memset(&id, 0, sizeof(id));
+    if (op == 0) return write_id_file(path, id, (int64_t)std::time(nullptr) - (int64_t)age_s) ? 1 : 0;
+    return read_id_file(path, &id);
 }
 
 PWICP_API void pwicp_comm_destroy(pwicp_comm* c) {

@@ -53,3 +53,9 @@ def euler(T):
     ay = -np.arcsin(T[2, 0])
     return np.array([np.arctan2(T[2, 1] / np.cos(ay), T[2, 2] / np.cos(ay)), ay,
                      np.arctan2(T[1, 0] / np.cos(ay), T[0, 0] / np.cos(ay))])
+
+
+def printed_sigmas(V):
+    """The six Std_ lines of a result file from a 6x6 VCM (Registration.cpp:524-537: mgon = 1000 * 200/pi * sqrt, mm = 1000 * sqrt)."""
+    d = np.diag(np.asarray(V, float).reshape(6, 6))
+    return np.concatenate([1000 * 63.6619772368 * np.sqrt(d[:3]), 1000 * np.sqrt(d[3:])])

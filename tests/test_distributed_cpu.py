@@ -211,3 +211,35 @@ def test_bench_refuses_a_launcher_world_other_than_gpus():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=120)
     assert p.returncode != 0 and "--gpus 8" in p.stderr and not p.stdout.strip()
+
+
+def test_rccl_id_file_of_an_earlier_launch_with_the_same_token_is_not_taken(tmp_path):
+    """ADVICE r4 (host/comm.cpp): under a static rendezvous two launches carry the same job token; the id file an earlier one left
+    behind when it was killed is younger than the 600 s age limit - a rank that polls before rank 0 has replaced it must not take
+    it (ncclCommInitRank would hang).  The file is accepted only if it was not written more than 30 s before the reading
+    process started.  No GPU: the acceptance rules through their test hook."""
+    import ctypes as C
+    import pwicp_amd as P
+    L = P.load_library()
+    L.pwicp_comm_debug_id_file.argtypes = [C.c_char_p, C.c_int, C.c_long]
+    L.pwicp_comm_debug_id_file.restype = C.c_int
+    path = str(tmp_path / "rccl.id").encode()
+    assert L.pwicp_comm_debug_id_file(path, 1, 0) == 0                # nothing there yet
+    assert L.pwicp_comm_debug_id_file(path, 0, 0) == 1                # this launch's rank 0 writes now
+    assert L.pwicp_comm_debug_id_file(path, 1, 0) == 1
+    # the same token, 120 s old (< 600 s): this process (started with the test session, about as long ago as that or later)
+    # must refuse a file dated before its own start minus the launcher's stagger
+    import psutil, time
+    since_start = time.time() - psutil.Process().create_time()
+    assert L.pwicp_comm_debug_id_file(path, 0, int(since_start) + 60) == 1
+    assert L.pwicp_comm_debug_id_file(path, 1, 0) == 0
+    assert L.pwicp_comm_debug_id_file(path, 0, 700 + int(since_start)) == 1   # older than the age limit
+    assert L.pwicp_comm_debug_id_file(path, 1, 0) == 0
+    # another launch's token: not taken however fresh (a subprocess with another PWICP_JOB_ID writes, this process reads)
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); import pwicp_amd as P; L = P.load_library(); "
+            "L.pwicp_comm_debug_id_file.argtypes = [C.c_char_p, C.c_int, C.c_long]; "
+            "sys.exit(0 if L.pwicp_comm_debug_id_file(%r, 0, 0) == 1 else 1)" % (os.path.join(ROOT, "piecewise-icp_amd"), path))
+    env = dict(os.environ, PWICP_JOB_ID="another-launch")
+    assert subprocess.run([sys.executable, "-c", code], env=env).returncode == 0
+    assert L.pwicp_comm_debug_id_file(path, 1, 0) == 0
+    assert L.pwicp_comm_debug_id_file(path, 0, 0) == 1 and L.pwicp_comm_debug_id_file(path, 1, 0) == 1

@@ -54,6 +54,22 @@ TOL = {m: {int(e): tuple(v) for e, v in t.items()} for m, t in _TT["tol"].items(
 GOLD_TOL = TOL["Direct2Ref"]
 AMAP = {int(e): t for e, t in _TT["pair_map"]["Adaptive"].items()}
 FMAP = {int(e): t for e, t in _TT["pair_map"]["Fixed"].items()}
+# a11: [relative tolerance of the six printed sigmas, absolute tolerance of the 36 printed VCM entries] per file, same table
+STOL = {m: {int(e): tuple(v) for e, v in t.items()} for m, t in _TT["sigma_vcm_tol"].items()}
+# the series files of the run (pairMode -1) against the reference's checked-in ones: twice the distances measured on the GPU
+# (profiles/r05_entry_point_distances.json), floored at print precision.  Matrices: (entry, VCM entry relative to the largest of
+# its matrix); parameter files: (angles in gon, translations in m, sigmas relative); error report: (mgon, mm)
+COMPOSED_TOL = {"TransMatrices.txt": (1e-6, 2e-3), "TransMatrices_toRef.txt": (5e-6, 2e-3),
+                "TransParameters.txt": (2e-5, 2e-6, 2e-3), "TransParameters_toRef.txt": (1e-4, 1e-5, 2e-3),
+                "TransPara_AbsError.txt": (0.1, 0.01)}
+
+
+def _record_distances(name, d):
+    """Measured distances to the reference's files, kept beside the run (tools/publish_profiles.sh copies them to profiles/)."""
+    dst = os.path.join(os.path.dirname(G.HERE), "gpurun_out")
+    if os.path.isdir(dst):
+        with open(os.path.join(dst, "r05_distances_%s.json" % name), "w") as f:
+            json.dump({str(k): v for k, v in d.items()}, f, indent=1)
 
 
 @pytest.mark.parametrize("epoch", list(range(2, 21)))
@@ -247,6 +263,10 @@ def test_the_references_own_run_through_the_exported_entry_point(tmp_path, ctx, 
                 "float PCres1 (m): 0.005\nfloat PCres2 (m): 0.005\nfloat SVsize1 (m): 0.05\nfloat SVsize2 (m): 0.05\n"
                 "bool isSetDTinit (yes-1, no-0): 1\nfloat DTinit (m): 0.05\nfloat DTmin (m): 0.004\nbool isVisual (yes-1, no-0): 0"
                 % (os.path.join(G.GOLD, "inputs"), out))
+    # the ground truth of the series where the reference looks for it (R.cpp:209-211: relative to the working directory)
+    os.makedirs(tmp_path / "data" / "data_synthetic")
+    with open(os.path.join(G.GOLD, "reference_results", "defined_transformations.txt"), "rb") as f:
+        (tmp_path / "data" / "data_synthetic" / "defined_transformations.txt").write_bytes(f.read())
     cwd = os.getcwd()
     os.chdir(tmp_path)
     try:
@@ -260,15 +280,48 @@ def test_the_references_own_run_through_the_exported_entry_point(tmp_path, ctx, 
         for a, b in pairs:
             got[max(a, b) + 1] = min(a, b) + 1          # the file is 0-based (R.cpp:578-586)
         assert got == AMAP, got
-    bad = {}
+    bad, dist = {}, {}
     for e in range(2, 21):
-        T, _, stds = G.parse_transmatrix_file(out + "%d_%s_TransMatrix.txt" % (e, mode))
-        Tg, _, stds_g = G.parse_transmatrix_file(os.path.join(G.GOLD, "reference_results", "%d_%s_TransMatrix.txt" % (e, mode)))
+        T, V, stds = G.parse_transmatrix_file(out + "%d_%s_TransMatrix.txt" % (e, mode))
+        Tg, Vg, stds_g = G.parse_transmatrix_file(os.path.join(G.GOLD, "reference_results", "%d_%s_TransMatrix.txt" % (e, mode)))
         da, dt = float(np.abs(G.euler(T) - G.euler(Tg)).max()), float(np.abs(T[:3, 3] - Tg[:3, 3]).max())
-        if not (da < TOL[mode][e][0] and dt < TOL[mode][e][1] and da < 1e-5 and dt < 1e-4):
-            bad[e] = (da, dt, TOL[mode][e])
+        # a11: the six printed sigmas and the 6x6 VCM of the SAME file (calTransParaVCM, R.cpp:1273-1343, written R.cpp:520-537)
+        ds, dv = float(np.abs(stds / stds_g - 1).max()), float(np.abs(V - Vg).max())
+        dist[e] = (da, dt, ds, dv)
+        if not (da < TOL[mode][e][0] and dt < TOL[mode][e][1] and da < 1e-5 and dt < 1e-4 and
+                ds < STOL[mode][e][0] and dv < STOL[mode][e][1]):
+            bad[e] = (da, dt, TOL[mode][e], ds, dv, STOL[mode][e])
+    _record_distances("entry_point_%s" % mode, dist)
     assert not bad, bad
+    # every printed digit of the VCM and five digits of the sigmas on (nearly) all files, as for the oracle
+    assert sum(1 for v in dist.values() if v[2] < 2e-5 and v[3] < 1.5e-12) >= 14      # (the oracle: 14 / 19 / 17)
     assert os.path.exists(out + "TransMatrices_toRef.txt") and os.path.exists(out + "TransParameters_toRef.txt")
+    if pair_mode < 0:
+        # the reference's checked-in series files are those of main.cpp's own call (pairMode -1): the run's composed outputs
+        # (calTransToReferenceEpoch, R.cpp:977-1153) and its error report (calAbsErrorOfTransPara, R.cpp:1157-1251) against them
+        from test_distributed_cpu import _read_matrices
+        gold = os.path.join(G.GOLD, "reference_results")
+        comp = {}
+        for name in ("TransMatrices.txt", "TransMatrices_toRef.txt"):
+            Tm, Vm = _read_matrices(out + name, 19)
+            Tr, Vr = _read_matrices(os.path.join(gold, name), 19)
+            comp[name] = (max(float(np.abs(Tm[i].astype(float) - Tr[i]).max()) for i in range(19)),
+                          max(float(np.abs(Vm[i] - Vr[i]).max() / np.abs(Vr[i]).max()) for i in range(19)))
+        for name in ("TransParameters.txt", "TransParameters_toRef.txt"):
+            a, b = np.loadtxt(out + name, skiprows=1), np.loadtxt(os.path.join(gold, name), skiprows=1)
+            assert a.shape == b.shape == (19, 13) and np.array_equal(a[:, 0], b[:, 0])
+            comp[name] = (float(np.abs(a[:, 1:4] - b[:, 1:4]).max()), float(np.abs(a[:, 4:7] - b[:, 4:7]).max()),
+                          float(np.abs(a[:, 7:] / b[:, 7:] - 1).max()))
+        a, b = np.loadtxt(out + "TransPara_AbsError.txt", skiprows=1), np.loadtxt(os.path.join(gold, "TransPara_AbsError.txt"), skiprows=1)
+        assert a.shape == b.shape == (19, 6)
+        comp["TransPara_AbsError.txt"] = (float(np.abs(a[:, :3] - b[:, :3]).max()), float(np.abs(a[:, 3:] - b[:, 3:]).max()))
+        _record_distances("entry_point_composed", comp)
+        for name in ("TransMatrices.txt", "TransMatrices_toRef.txt"):
+            # matrix entries: float print precision of a chain of up to six float products; VCM entries relative to the largest
+            assert comp[name][0] < COMPOSED_TOL[name][0] and comp[name][1] < COMPOSED_TOL[name][1], (name, comp[name])
+        for name in ("TransParameters.txt", "TransParameters_toRef.txt"):
+            assert all(c < t for c, t in zip(comp[name], COMPOSED_TOL[name])), (name, comp[name])      # gon, m, relative sigma
+        assert all(c < t for c, t in zip(comp["TransPara_AbsError.txt"], COMPOSED_TOL["TransPara_AbsError.txt"])), comp   # mgon, mm
 
 
 @pytest.mark.parametrize("shape", ["steep_z", "face_yz", "diagonal"])

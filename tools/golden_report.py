@@ -18,11 +18,12 @@ AMAP = {2: 1, 3: 1, 4: 1, 5: 1, 6: 1, 7: 3, 8: 4, 9: 4, 10: 5, 11: 6, 12: 6, 13:
 FMAP = {e: (1 if e <= 4 else e - 3) for e in range(2, 21)}            # pairMode 3 (R.cpp:94-97)
 DMAP = {e: 1 for e in range(2, 21)}
 FLOOR = (2e-7, 3e-7)
+SIGMA_FLOOR, VCM_FLOOR = 2e-5, 1.5e-12     # relative on the printed Std_ values; absolute on the 12-decimal VCM entries
 
 if __name__ == "__main__":
-    out, tol, done = {}, {}, {}
+    out, tol, stol, done = {}, {}, {}, {}
     for mode, M in (("Direct2Ref", DMAP), ("Adaptive", AMAP), ("Fixed", FMAP)):
-        out[mode], tol[mode] = {}, {}
+        out[mode], tol[mode], stol[mode] = {}, {}, {}
         for e in range(2, 21):
             key = (M[e], e)
             if key not in done:
@@ -31,12 +32,17 @@ if __name__ == "__main__":
             c, r = done[key]
             Tg, _, _ = RC.G.parse_transmatrix_file(os.path.join(RC.G.REF_ROOT, "results/4DPCReg", "%d_%s_TransMatrix.txt" % (e, mode)))
             assert (Tg == c.Tg).all(), (mode, e)      # the same pair in another family: the reference wrote the same numbers
-            out[mode][str(e)] = dict(target=M[e], d_angle_rad=r["da"], d_trans_m=r["dt"], d_sigma_rel=r["dstd"], outer=r["outer"],
+            out[mode][str(e)] = dict(target=M[e], d_angle_rad=r["da"], d_trans_m=r["dt"], d_sigma_rel=r["dstd"], d_vcm_abs=r["dvcm"], outer=r["outer"],
                                      inner=r["inner"], stable=r["stable"])
             tol[mode][str(e)] = [float("%.1e" % max(2 * r["da"], FLOOR[0])), float("%.1e" % max(2 * r["dt"], FLOOR[1]))]
-            print(mode, e, M[e], RC.fmt(r), flush=True)
+            # a11 (calTransParaVCM, R.cpp:1273-1343): the six printed sigmas (relative) and the 6x6 matrix (absolute; the file
+            # prints 12 decimals, half a step = 5e-13) of the same file, same rule
+            stol[mode][str(e)] = [float("%.1e" % max(2 * r["dstd"], SIGMA_FLOOR)), float("%.1e" % max(2 * r["dvcm"], VCM_FLOOR))]
+            print(mode, e, M[e], RC.fmt(r), "d_vcm %.1e" % r["dvcm"], flush=True)
     gold = os.path.join(RC.ROOT, "tests", "golden")
     with open(os.path.join(gold, "oracle_vs_reference.json"), "w") as f:
         json.dump(out, f, indent=1)
     with open(os.path.join(gold, "tolerance_table.json"), "w") as f:
-        json.dump(dict(unit=["rad", "m"], rule="max(2 x oracle-vs-file, [2e-7, 3e-7])", pair_map=dict(Adaptive=AMAP, Fixed=FMAP), tol=tol), f, indent=1)
+        json.dump(dict(unit=["rad", "m"], rule="max(2 x oracle-vs-file, [2e-7, 3e-7])", pair_map=dict(Adaptive=AMAP, Fixed=FMAP), tol=tol,
+                       sigma_vcm_rule="[max(2 x rel. distance of the six Std_ values, 2e-5), max(2 x abs. distance of the VCM entries, 1.5e-12)]",
+                       sigma_vcm_tol=stol), f, indent=1)

@@ -90,7 +90,8 @@ class Case:
         V = np.array(io.VCM).reshape(6, 6)
         mine = np.concatenate([1000 * 63.6619772368 * np.sqrt(np.diag(V)[:3]), 1000 * np.sqrt(np.diag(V)[3:])])
         dstd = float(np.abs(mine / self.stds - 1).max())
-        return dict(da=da, dt=dt, dstd=dstd, outer=io.n_outer, inner=list(io.n_inner[:io.n_outer]),
+        dvcm = float(np.abs(V - self.Vg).max())      # the file prints 12 decimals: entries of 1e-10 .. 1e-8 with 1e-12 steps
+        return dict(da=da, dt=dt, dstd=dstd, dvcm=dvcm, outer=io.n_outer, inner=list(io.n_inner[:io.n_outer]),
                     stable=list(io.n_stable[:io.n_outer]), status=io.status), recs
 
 
