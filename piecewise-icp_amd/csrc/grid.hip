@@ -465,6 +465,264 @@ __global__ void __launch_bounds__(kDenseBlock) k_nn_dense_disc(GridLevel dl, Gri
     if (fs.scratch) fs_pass0_epilogue(s_hist, fs);
 }
 
+// ---- the same search with the candidates of a WAVE staged in LDS (round 5; levels of COLUMNS only) ---------------------------
+// In strip order the 64 queries of a wave lie along one row of the searched level (two where a wave crosses a row end: the rows of
+// a block are walked boustrophedon, so the wave stays in one place), and everything their balls can touch is a WINDOW of the level:
+// the rows [rmin - 2, rmax + 2] x the cells [xmin - 2, xmax + 2], i.e. ONE contiguous span of points per row.  The wave reads the
+// begin / end words of the window's cells (one coalesced load per row) and the spans themselves (coalesced 12-byte loads) into LDS
+// and every lane runs the disc search of k_nn_dense_disc on the copy: the same rows, the same cells, the same float expression per
+// candidate - but a gather is an LDS read of ~64 cycles instead of a vector-memory round trip through the address / tag pipe
+// (20 -> 13 cache lines per gather was what rounds 3 - 4 bought; this is ~0.2), and a wave's chain of eight dependent global
+// round trips is three (query, table, points).  A lane whose ball leaves the window (or that finds no candidate) goes to the far
+// path with what it has, as before; a wave whose window does not fit (queries that have drifted apart after an update, a block
+// edge) runs the search from global memory as k_nn_dense_disc does.  Exact by the same argument: every cell the ball touches is
+// either scanned from the copy or the lane is handed on.
+#ifndef PW_WIN_PTS
+#define PW_WIN_PTS 512
+#endif
+#ifndef PW_WIN_HALO
+#define PW_WIN_HALO 2
+#endif
+constexpr int kWinHalo = PW_WIN_HALO;   // rows / cells kept on either side of the wave's queries
+constexpr int kWinRows = 8;             // most rows of a window
+constexpr int kWinCells = 40;           // most cells of a window row
+constexpr int kWinTab = kWinCells + 1;  // begin words of the cells + the end of the last one
+constexpr int kWinPts = PW_WIN_PTS;     // most points of a window (16 bytes each in LDS)
+
+template <int PERM>
+__device__ __forceinline__ void scan_lds4(const float4* __restrict__ sp, int lo, int hi, float qx, float qy, float qz, float& best) {
+    int j = lo;
+    for (; j + 4 <= hi; j += 4) {
+        const float4 a = sp[j], b = sp[j + 1], c = sp[j + 2], d = sp[j + 3];
+        nn_consider_d2<PERM>(a, qx, qy, qz, best);
+        nn_consider_d2<PERM>(b, qx, qy, qz, best);
+        nn_consider_d2<PERM>(c, qx, qy, qz, best);
+        nn_consider_d2<PERM>(d, qx, qy, qz, best);
+    }
+    if (j + 2 <= hi) {
+        const float4 a = sp[j], b = sp[j + 1];
+        nn_consider_d2<PERM>(a, qx, qy, qz, best);
+        nn_consider_d2<PERM>(b, qx, qy, qz, best);
+        j += 2;
+    }
+    if (j < hi) nn_consider_d2<PERM>(sp[j], qx, qy, qz, best);
+}
+
+typedef unsigned short pw_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b) {
+    const pw_u16x2 r = __builtin_elementwise_min(__builtin_bit_cast(pw_u16x2, a), __builtin_bit_cast(pw_u16x2, b));
+    return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
+    const pw_u16x2 r = __builtin_elementwise_max(__builtin_bit_cast(pw_u16x2, a), __builtin_bit_cast(pw_u16x2, b));
+    return __builtin_bit_cast(unsigned, r);
+}
+
+template <int PERM, bool FARG>
+__global__ void __launch_bounds__(kDenseBlock) k_nn_dense_win(GridLevel dl, GridDesc far, const float4* __restrict__ pat,
+                                                         const int* __restrict__ qorder, const int* __restrict__ qpatch,
+                                                         const int* __restrict__ stable, int nq,
+                                                         float* __restrict__ d2out,
+                                                         unsigned long long* __restrict__ examined, int chunk, FusedSelect fs,
+                                                         DenseFarList fl, const float4* __restrict__ patq, int sub) {
+    constexpr int NW = kDenseBlock / 64;
+    constexpr int kWinBytes = NW * (kWinPts * 16 + kWinRows * kWinTab * 4);
+    constexpr int kTailBytes = kFsBins * 4 + kDenseBlock * 16 + kDenseBlock * 4;
+    // the windows of the block's waves; once every wave is done with its window the same bytes hold the bins of the selection's
+    // pass 0 and the block's list of far queries
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kWinBytes > kTailBytes ? kWinBytes : kTailBytes];
+    __shared__ int s_wcnt[NW];
+    const int xr = (int)(blockIdx.x / kXcds);
+    const int tile = chunk > 0 ? (xr / sub) * (kXcds * sub) + (int)(blockIdx.x % kXcds) * sub + xr % sub : (int)blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float4* const s_pts = (float4*)smem + wave * kWinPts;
+    int* const s_tab = (int*)(smem + NW * kWinPts * 16) + wave * (kWinRows * kWinTab);
+    unsigned* const s_hist = (unsigned*)smem;
+    float4* const s_q = (float4*)(smem + kFsBins * 4);
+    int* const s_slot = (int*)(smem + kFsBins * 4 + kDenseBlock * 16);
+    const int i = tile * kDenseBlock + tid;
+    unsigned cnt = 0;
+    bool unresolved = false, resolved = false;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    float best = INFINITY;
+    int st = 0;
+    if (i < nq) {
+        const int p = patq ? 0 : qorder[i], pa = qpatch[i];
+        if (patq) { q = patq[i]; st = stable[pa]; }
+        else { st = p >= 0 ? stable[pa] : 0; q = pat[max(p, 0)]; }
+        if (!st) d2out[i] = __uint_as_float(kSentinel);
+    }
+    const float ux = PERM == 0 ? q.x : (PERM == 1 ? q.y : q.z), uy = PERM == 0 ? q.y : (PERM == 1 ? q.z : q.x),
+                uz = PERM == 0 ? q.z : (PERM == 1 ? q.x : q.y);
+    // a level of columns: cells along x, rows along ONE of the other two axes
+    const bool rowz = dl.inv_hy == 0.0f;
+    const float ur = rowz ? uz : uy, orr = rowz ? dl.oz : dl.oy;
+    const int nrow = rowz ? dl.nz : dl.ny;
+    const int cx = cell_of(ux, dl.ox, dl.inv_h), cr = cell_of(ur, orr, dl.inv_h);
+    const bool ing = st && cx >= 0 && cx < dl.nx && cr >= 0 && cr < nrow;
+    // the wave's box of cells: packed (row, cell) minima / maxima
+    unsigned kmin = ing ? ((unsigned)cr << 16) | (unsigned)cx : 0xffffffffu, kmax = ing ? ((unsigned)cr << 16) | (unsigned)cx : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        kmin = pk_min_u16(kmin, (unsigned)__shfl_xor((int)kmin, o));
+        kmax = pk_max_u16(kmax, (unsigned)__shfl_xor((int)kmax, o));
+    }
+    kmin = (unsigned)__builtin_amdgcn_readfirstlane((int)kmin);
+    kmax = (unsigned)__builtin_amdgcn_readfirstlane((int)kmax);
+    const bool any = kmin != 0xffffffffu;
+    const int X0 = max((int)(kmin & 0xffffu) - kWinHalo, 0), X1 = min((int)(kmax & 0xffffu) + kWinHalo, dl.nx - 1);
+    const int R0 = max((int)(kmin >> 16) - kWinHalo, 0), R1 = min((int)(kmax >> 16) + kWinHalo, nrow - 1);
+    const int nwc = X1 - X0 + 1, nwr = R1 - R0 + 1;
+    bool win = any && nwc <= kWinCells && nwr <= kWinRows;
+    int start[kWinRows], len[kWinRows], base[kWinRows];
+    if (win) {
+        int t[kWinRows];
+#pragma unroll
+        for (int w = 0; w < kWinRows; ++w) t[w] = (w < nwr && lane <= nwc) ? dl.cell_start[(R0 + w) * dl.nx + X0 + lane] : 0;
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < kWinRows; ++w) {
+            start[w] = __builtin_amdgcn_readlane(t[w], 0);
+            len[w] = __builtin_amdgcn_readlane(t[w], nwc) - start[w];
+            base[w] = total;
+            total += len[w];
+        }
+        win = total <= kWinPts;
+        if (win) {
+#pragma unroll
+            for (int w = 0; w < kWinRows; ++w)
+                if (w < nwr && lane <= nwc) s_tab[w * kWinTab + lane] = t[w] - start[w] + base[w];
+            const PwXyz3* __restrict__ p3 = (const PwXyz3*)dl.pts3;
+            PwXyz3 a[kWinRows], b[kWinRows];
+#pragma unroll
+            for (int w = 0; w < kWinRows; ++w) {
+                if (lane < len[w]) a[w] = p3[start[w] + lane];
+                if (lane + 64 < len[w]) b[w] = p3[start[w] + lane + 64];
+            }
+#pragma unroll
+            for (int w = 0; w < kWinRows; ++w) {
+                if (lane < len[w]) s_pts[base[w] + lane] = make_float4(a[w].x, a[w].y, a[w].z, 0.f);
+                if (lane + 64 < len[w]) s_pts[base[w] + lane + 64] = make_float4(b[w].x, b[w].y, b[w].z, 0.f);
+            }
+#pragma unroll
+            for (int w = 0; w < kWinRows; ++w)
+                for (int j = lane + 128; j < len[w]; j += 64) {
+                    const PwXyz3 c = p3[start[w] + j];
+                    s_pts[base[w] + j] = make_float4(c.x, c.y, c.z, 0.f);
+                }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (st) {
+        if (win && ing) {
+            const float slack2 = 2.0f * dl.slack;
+            const int sx0 = max(cx - 1, 0), sx1 = min(cx + 1, dl.nx - 1);
+            const int tb0 = (cr - R0) * kWinTab - X0;
+            const int a0 = s_tab[tb0 + sx0], a1 = s_tab[tb0 + sx1 + 1];
+            scan_lds4<PERM>(s_pts, a0, a1, ux, uy, uz, best);
+            cnt += (unsigned)(a1 - a0);
+            if (!(best < INFINITY)) {
+                // nothing in the query's own three cells: the rows above and below before giving up on the window
+#pragma unroll
+                for (int dr = -1; dr <= 1; dr += 2) {
+                    const int r = cr + dr;
+                    if (r >= R0 && r <= R1) {
+                        const int tb = (r - R0) * kWinTab - X0;
+                        const int lo = s_tab[tb + sx0], hi = s_tab[tb + sx1 + 1];
+                        scan_lds4<PERM>(s_pts, lo, hi, ux, uy, uz, best);
+                        cnt += (unsigned)(hi - lo);
+                    }
+                }
+            }
+            bool done = false;
+            if (best < INFINITY) {
+                const float rho = fast_sqrt_up(best) + slack2;
+                const int r0 = max(icell(ur - rho, orr, dl.inv_h), 0), r1 = min(icell(ur + rho, orr, dl.inv_h), nrow - 1);
+                if (r0 >= R0 && r1 <= R1) {
+                    const float rho2 = rho * rho;
+                    done = true;
+                    for (int r = r0; r <= r1; ++r) {
+                        const float l = orr + (float)r * dl.h;
+                        const float e = fmaxf(fmaxf(l - ur, ur - (l + dl.h)) - slack2, 0.0f);
+                        const float rem = rho2 - e * e;
+                        if (!(rem > 0.0f)) continue;
+                        const float rx = fast_sqrt_up(rem) + slack2;
+                        const int x0 = max(icell(ux - rx, dl.ox, dl.inv_h), 0), x1 = min(icell(ux + rx, dl.ox, dl.inv_h), dl.nx - 1);
+                        if (x0 > x1) continue;
+                        if (x0 < X0 || x1 > X1) { done = false; break; }       // the ball leaves the window: handed on
+                        const int tb = (r - R0) * kWinTab - X0;
+                        if (r == cr) {
+                            if (x0 < sx0) { const int lo = s_tab[tb + x0]; scan_lds4<PERM>(s_pts, lo, a0, ux, uy, uz, best); cnt += (unsigned)(a0 - lo); }
+                            if (x1 > sx1) { const int hi = s_tab[tb + x1 + 1]; scan_lds4<PERM>(s_pts, a1, hi, ux, uy, uz, best); cnt += (unsigned)(hi - a1); }
+                        } else {
+                            const int lo = s_tab[tb + x0], hi = s_tab[tb + x1 + 1];
+                            scan_lds4<PERM>(s_pts, lo, hi, ux, uy, uz, best);
+                            cnt += (unsigned)(hi - lo);
+                        }
+                    }
+                }
+            }
+            if (done) { d2out[i] = best; resolved = true; }
+            else unresolved = true;
+        } else if (win || !any) {
+            unresolved = true;          // a query outside the level's grid
+        } else {
+            // the wave's window does not fit: the search of k_nn_dense_disc, from global memory
+            const int cy = cell_of(uy, dl.oy, dl.inv_hy), cz = cell_of(uz, dl.oz, dl.inv_hz);
+            int loA, hiA;
+            row_range(dl, cy, cz, cx - 1, cx + 1, loA, hiA);
+            scan_d2_level<PERM>(dl, loA, hiA, ux, uy, uz, best);
+            cnt += (unsigned)(hiA - loA);
+            const float rho = fast_sqrt_up(best) + 2.0f * dl.slack;
+            if (best < INFINITY && rho <= kMaxRhoCells * dl.h) {
+                const bool in = cy >= 0 && cy < dl.ny && cz >= 0 && cz < dl.nz && max(cx - 1, 0) <= min(cx + 1, dl.nx - 1);
+                cnt += scan_disc_lean<PERM, false, true>(dl, ux, uy, uz, rho, in ? cy : INT_MIN, in ? cz : INT_MIN, max(cx - 1, 0),
+                                                         min(cx + 1, dl.nx - 1), loA, hiA, best);
+                d2out[i] = best;
+                resolved = true;
+            } else {
+                unresolved = true;
+            }
+        }
+    }
+    __syncthreads();                       // every wave is done with its window: the bytes change hands
+    if (fs.scratch)
+        for (int t = tid; t < kFsBins; t += kDenseBlock) s_hist[t] = 0u;
+    const unsigned long long mask = __ballot(unresolved);
+    const int before = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wcnt[wave] = __popcll(mask);
+    __syncthreads();
+    if (resolved && fs.scratch) atomicAdd(&s_hist[__float_as_uint(best) >> 21], 1u);
+    int bs = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        if (w < wave) bs += s_wcnt[w];
+        total += s_wcnt[w];
+    }
+    if (unresolved) {
+        s_q[bs + before] = make_float4(q.x, q.y, q.z, best);
+        s_slot[bs + before] = i;
+    }
+    __syncthreads();
+    if (FARG) {
+        __shared__ unsigned s_base;
+        if (tid == 0 && total > 0) s_base = atomicAdd(fl.count, (unsigned)total);
+        __syncthreads();
+        if (tid < total) {
+            fl.q[s_base + tid] = s_q[tid];
+            fl.slot[s_base + tid] = s_slot[tid];
+        }
+    } else if (tid < total) {
+        const float4 u = s_q[tid];
+        const float d = dense_far_path(far, u, u.w, cnt);
+        d2out[s_slot[tid]] = d;
+        if (fs.scratch) atomicAdd(&s_hist[__float_as_uint(d) >> 21], 1u);
+    }
+    add_examined(examined, cnt);
+    if (fs.scratch) fs_pass0_epilogue(s_hist, fs);
+}
+
 #ifndef PW_FAR_RUN
 #define PW_FAR_RUN 4
 #endif
@@ -700,7 +958,7 @@ __global__ void k_morton_keys(GridLevel g, const float4* __restrict__ p, int n, 
 // keys of the STRIP order: the cells of level g (axis roles g.perm) in blocks of xb cells along the row direction by rb rows;
 // blocks row-major, rows inside a block one after the other, cells of a row segment left to right.  64 consecutive queries
 // then lie along one row: their candidate ranges tile one contiguous span of the row's points.
-__global__ void k_strip_keys(GridLevel g, const float4* __restrict__ p, int n, int xb, int rb, unsigned* __restrict__ keys,
+__global__ void k_strip_keys(GridLevel g, const float4* __restrict__ p, int n, int xb, int rb, int serp, unsigned* __restrict__ keys,
                              int* __restrict__ vals) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -711,7 +969,9 @@ __global__ void k_strip_keys(GridLevel g, const float4* __restrict__ p, int n, i
     const unsigned cy = (unsigned)min(max(cell_of(uy, g.oy, g.inv_hy), 0), g.ny - 1);
     const unsigned cz = (unsigned)min(max(cell_of(uz, g.oz, g.inv_hz), 0), g.nz - 1);
     const unsigned row = cz * (unsigned)g.ny + cy, nxb = ((unsigned)g.nx + xb - 1) / xb;
-    keys[i] = ((row / rb) * nxb + cx / xb) * (unsigned)(rb * xb) + (row % rb) * xb + cx % xb;
+    // (serp: the rows of a block boustrophedon - a wave that crosses a row end stays in one place, k_nn_dense_win)
+    const unsigned xin = cx % xb, rin = row % rb;
+    keys[i] = ((row / rb) * nxb + cx / xb) * (unsigned)(rb * xb) + rin * xb + ((serp && (rin & 1u)) ? (unsigned)xb - 1u - xin : xin);
     vals[i] = i;
 }
 
@@ -1360,12 +1620,28 @@ int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pa
         const int sub = sub_env > 0 ? std::min(sub_env, chunk) : chunk;
         chunk = div_up(chunk, sub) * sub;
         FusedSelect none{};
+        // the window search (k_nn_dense_win) on a level of columns whose cell indices fit 16 bits; PWICP_DENSE_WIN=0: the search
+        // from global memory on every level
+        static int win_env = -1;
+        if (win_env < 0) { const char* e = getenv("PWICP_DENSE_WIN"); win_env = e ? atoi(e) : 1; }
+        const bool columns = (dense->inv_hy == 0.0f) != (dense->inv_hz == 0.0f);
+        const bool use_win = win_env && columns && dense->pts3 && dense->nx < 65535 && std::max(dense->ny, dense->nz) < 65535;
+#define PW_DENSE_W(PERM_, FARG_)                                                                                            \
+    hipLaunchKernelGGL((k_nn_dense_win<PERM_, FARG_>), dim3(chunk * kXcds), dim3(kDenseBlock), 0, ctx->stream, *dense, g, d_pat, d_qorder, \
+                       d_qpatch, d_stable, nq, d_d2, d_examined, chunk, fs ? *fs : none, fl, d_patq, sub)
+        if (use_win) {
+            if (far_group) { if (dense->perm == 0) PW_DENSE_W(0, true); else if (dense->perm == 1) PW_DENSE_W(1, true); else PW_DENSE_W(2, true); }
+            else { if (dense->perm == 0) PW_DENSE_W(0, false); else if (dense->perm == 1) PW_DENSE_W(1, false); else PW_DENSE_W(2, false); }
+        } else
 #define PW_DENSE(PERM_, FARG_)                                                                                              \
     hipLaunchKernelGGL((k_nn_dense_disc<PERM_, FARG_>), dim3(chunk * kXcds), dim3(kDenseBlock), 0, ctx->stream, *dense, g, d_pat, d_qorder, \
                        d_qpatch, d_stable, nq, d_d2, d_examined, chunk, fs ? *fs : none, fl, d_patq, sub)
+        {
         if (far_group) { if (dense->perm == 0) PW_DENSE(0, true); else if (dense->perm == 1) PW_DENSE(1, true); else PW_DENSE(2, true); }
         else { if (dense->perm == 0) PW_DENSE(0, false); else if (dense->perm == 1) PW_DENSE(1, false); else PW_DENSE(2, false); }
+        }
 #undef PW_DENSE
+#undef PW_DENSE_W
         if (far_group)
         {
             // blocks per CU: four, each walking its share of the list (measured on the reference's scans, 120 k far queries: loop
@@ -1400,10 +1676,11 @@ int pw_morton_order(pwicp_context* ctx, const GridDesc& g, const float4* d_pts, 
     // In Morton order (round 3) the 64 queries of a wave sit in ~4 x 4 cells of four rows and every gather of the wave touches
     // ~20 cache lines (TCP_TOTAL_CACHE_ACCESSES / SQ_INSTS_VMEM_RD); along a row their windows tile one span of the row's
     // points.  41.3 -> 39.1 us.  PWICP_QUERY_ORDER="xb,rb" (0: Morton order of the fine cells).
-    static int xb = -1, rb = 8;
+    static int xb = -1, rb = 8, serp = 1;
     if (xb < 0) {
         xb = 32;
         if (const char* e = getenv("PWICP_QUERY_ORDER")) { xb = std::max(atoi(e), 0); if (const char* c = strchr(e, ',')) rb = std::max(atoi(c + 1), 1); }
+        if (const char* e = getenv("PWICP_QUERY_SERP")) serp = atoi(e);
     }
     if (xb > 0 && strip_lv && (double)strip_lv->nx * strip_lv->ny * strip_lv->nz * 1.1 + (double)xb * rb * 2 < 4.0e9) {
         DevBuf<unsigned> keys, keys_out;
@@ -1411,7 +1688,7 @@ int pw_morton_order(pwicp_context* ctx, const GridDesc& g, const float4* d_pts, 
         HIPCHK(ctx, keys.reserve((size_t)n));
         HIPCHK(ctx, keys_out.reserve((size_t)n));
         HIPCHK(ctx, vals.reserve((size_t)n));
-        hipLaunchKernelGGL(k_strip_keys, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, *strip_lv, d_pts, n, xb, rb, keys.p, vals.p);
+        hipLaunchKernelGGL(k_strip_keys, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, *strip_lv, d_pts, n, xb, rb, serp, keys.p, vals.p);
         size_t tbytes = 0;
         HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tbytes, keys.p, keys_out.p, vals.p, order->p, n, 0, 32, ctx->stream));
         DevBuf<unsigned char> tmp;

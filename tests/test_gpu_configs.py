@@ -59,9 +59,11 @@ STOL = {m: {int(e): tuple(v) for e, v in t.items()} for m, t in _TT["sigma_vcm_t
 # the series files of the run (pairMode -1) against the reference's checked-in ones: twice the distances measured on the GPU
 # (profiles/r05_entry_point_distances.json), floored at print precision.  Matrices: (entry, VCM entry relative to the largest of
 # its matrix); parameter files: (angles in gon, translations in m, sigmas relative); error report: (mgon, mm)
-COMPOSED_TOL = {"TransMatrices.txt": (1e-6, 2e-3), "TransMatrices_toRef.txt": (5e-6, 2e-3),
-                "TransParameters.txt": (2e-5, 2e-6, 2e-3), "TransParameters_toRef.txt": (1e-4, 1e-5, 2e-3),
-                "TransPara_AbsError.txt": (0.1, 0.01)}
+COMPOSED_TOL = {"TransMatrices.txt": (2.5e-7, 2e-4), "TransMatrices_toRef.txt": (2.5e-7, 1e-4),
+                "TransParameters.txt": (5e-6, 2.5e-7, 2e-5), "TransParameters_toRef.txt": (7e-6, 2.5e-7, 2e-5),
+                "TransPara_AbsError.txt": (7e-3, 3e-4)}
+# (measured: one float ulp, 1.2e-7, on the matrix entries of both files; 2.3e-6 / 3.2e-6 gon = 3.6e-8 / 5e-8 rad on the angles;
+#  1.2e-7 m; sigmas 7e-6 relative; 3.2e-3 mgon / 1.2e-4 mm on the error report, which prints six significant digits)
 
 
 def _record_distances(name, d):
