@@ -433,12 +433,64 @@ __device__ __forceinline__ void scan_d2x4(const float4* __restrict__ pts, int lo
 
 // the same on a level of the dense search: from the packed 12-byte copy of its points (global_load_dwordx3: 10.7 instead of 8
 // points per 128-byte line - a vector-memory instruction of this search costs by the cache lines it touches: 39.6 -> 38.3 us;
-// -DPW_DENSE_XYZ4: the 16-byte points)
+// -DPW_DENSE_XYZ4: the 16-byte points).
+// Round 5, PW_DENSE_SCAN: how the range [lo, hi) is walked.  The minimum over ALL target points is what the search returns, so a
+// candidate beyond the range's end (a real target point of the next cell) can never make the result wrong - only reading outside
+// the array must not happen, and the packed copy ends in kPts3Pad far-away points.
+//   0  four per pass, then a tail of two and of one (rounds 2 - 4)
+//   1  four per pass, no tails: the last pass reads up to three points past `hi`
+//   2  the packed copy holds the points in PAIRS (x0, x1, y0, y1, z0, z1: 24 bytes per two points), two pairs per pass from the even
+//      index at or below `lo`: the three differences, three squares and two sums of TWO candidates are one v_pk_add_f32 /
+//      v_pk_mul_f32 each (the vector ALU issues a packed instruction in the time of a plain one) and the minimum of both one
+//      v_min3_f32 - 4.5 instead of 6.5 vector instructions per candidate, same float expression per candidate.
+#ifndef PW_DENSE_SCAN
+#define PW_DENSE_SCAN 1
+#endif
+constexpr int kPts3Pad = 8;            // far-away points behind the last one of a packed copy
 struct PwXyz3 { float x, y, z; };
+typedef float pw_f2 __attribute__((ext_vector_type(2)));
+template <int PERM = 0>
+__device__ __forceinline__ void nn_consider_d2_pair(const pw_f2 px, const pw_f2 py, const pw_f2 pz, float qx, float qy, float qz, float& best) {
+    const pw_f2 d0 = qx - px, d1 = qy - py, d2_ = qz - pz;
+    const pw_f2 dx = PERM == 0 ? d0 : (PERM == 1 ? d2_ : d1);
+    const pw_f2 dy = PERM == 0 ? d1 : (PERM == 1 ? d0 : d2_);
+    const pw_f2 dz = PERM == 0 ? d2_ : (PERM == 1 ? d1 : d0);
+    pw_f2 s = dx * dx;
+    s = s + dy * dy;
+    s = s + dz * dz;
+    best = fminf(fminf(best, s.x), s.y);
+}
+// point i of a packed copy, whatever its layout (the window search copies spans of it; diagnostics)
+__device__ __forceinline__ PwXyz3 pts3_point(const float* __restrict__ p3, int i) {
+#if PW_DENSE_SCAN == 2
+    const float* b = p3 + 6 * (size_t)(i >> 1) + (i & 1);
+    return PwXyz3{b[0], b[2], b[4]};
+#else
+    const float* b = p3 + 3 * (size_t)i;
+    return PwXyz3{b[0], b[1], b[2]};
+#endif
+}
 template <int PERM = 0, bool P3 = true>
 __device__ __forceinline__ void scan_d2_level(const GridLevel& g, int lo, int hi, float qx, float qy, float qz, float& best) {
 #ifndef PW_DENSE_XYZ4
     if (!P3) { scan_d2x4<PERM>(g.pts, lo, hi, qx, qy, qz, best); return; }      // (a level without the packed copy)
+#if PW_DENSE_SCAN == 2
+    const pw_f2* __restrict__ pp = (const pw_f2*)g.pts3;
+    for (int b = lo >> 1, be = (hi + 1) >> 1; b < be; b += 2) {
+        const pw_f2 x0 = pp[3 * b], y0 = pp[3 * b + 1], z0 = pp[3 * b + 2], x1 = pp[3 * b + 3], y1 = pp[3 * b + 4], z1 = pp[3 * b + 5];
+        nn_consider_d2_pair<PERM>(x0, y0, z0, qx, qy, qz, best);
+        nn_consider_d2_pair<PERM>(x1, y1, z1, qx, qy, qz, best);
+    }
+#elif PW_DENSE_SCAN == 1
+    const PwXyz3* __restrict__ p3 = (const PwXyz3*)g.pts3;
+    for (int j = lo; j < hi; j += 4) {
+        const PwXyz3 a = p3[j], b = p3[j + 1], c = p3[j + 2], d = p3[j + 3];
+        nn_consider_d2<PERM>(make_float4(a.x, a.y, a.z, 0.f), qx, qy, qz, best);
+        nn_consider_d2<PERM>(make_float4(b.x, b.y, b.z, 0.f), qx, qy, qz, best);
+        nn_consider_d2<PERM>(make_float4(c.x, c.y, c.z, 0.f), qx, qy, qz, best);
+        nn_consider_d2<PERM>(make_float4(d.x, d.y, d.z, 0.f), qx, qy, qz, best);
+    }
+#else
     const PwXyz3* __restrict__ p3 = (const PwXyz3*)g.pts3;
     int j = lo;
     for (; j + 4 <= hi; j += 4) {
@@ -455,6 +507,7 @@ __device__ __forceinline__ void scan_d2_level(const GridLevel& g, int lo, int hi
         j += 2;
     }
     if (j < hi) { const PwXyz3 a = p3[j]; nn_consider_d2<PERM>(make_float4(a.x, a.y, a.z, 0.f), qx, qy, qz, best); }
+#endif
 #else
     scan_d2x4<PERM>(g.pts, lo, hi, qx, qy, qz, best);
 #endif

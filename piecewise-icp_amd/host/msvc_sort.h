@@ -28,6 +28,8 @@
 #include <utility>
 #include <vector>
 
+#include "parallel.h"
+
 namespace pwhost {
 namespace msvc_order {
 
@@ -167,9 +169,8 @@ class Sorter {
         // (only sub-ranges of kParallelMin elements or more become tasks: more workers than that never have work, and starting a
         // thread is ~30 us - 32 of them for a 140 k-element sort were a quarter of its 4 ms)
         const int nt = (int)std::min<std::ptrdiff_t>(nthreads_, std::max<std::ptrdiff_t>(1, (last - first) / kParallelMin));
-        std::vector<std::thread> th;
-        for (int t = 0; t < nt; ++t) th.emplace_back([this] { worker(); });
-        for (auto& t : th) t.join();
+        // (on the process's pool, host/parallel.h: a late starter finds nothing pending and returns)
+        pwhost::Pool::get().run(nt, [this](int) { worker(); });
         return ok_.load();
     }
 

@@ -10,7 +10,8 @@ src = open("/root/repo/tools/dense_variants.py").read()
 m = re.search(r"WORKER = r'''(.*?)''' % ROOT", src, re.S)
 print(m.group(1).replace("%r", repr("/root/repo")))
 PY
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $R/gpurun_out/dpmc_$TAG -o t -- python $R/gpurun_out/dprof_worker.py > $R/gpurun_out/dpmc_$TAG.log 2>&1
+PMC=${PMC:-SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY}      # (PMC="...": another group)
+rocprofv3 --pmc $PMC --output-format csv -d $R/gpurun_out/dpmc_$TAG -o t -- python $R/gpurun_out/dprof_worker.py > $R/gpurun_out/dpmc_$TAG.log 2>&1
 cd $R
 F=$(find gpurun_out/dpmc_$TAG -name "*counter_collection.csv" | head -1)
 python - "$F" <<'PY'

@@ -54,7 +54,7 @@ if __name__ == "__main__":
     variants = [a.split(",") for a in sys.argv[1:]] or [["PWICP_DISC_CELL_FACTOR=0"], ["PWICP_DISC_CELL_FACTOR=1.5"]]
     ref = None
     for v in variants:
-        env = dict(kv.split("=", 1) for kv in v if kv)
+        env = dict(kv.split("=", 1) for kv in v if "=" in kv)
         r = run(env)
         if "error" in r:
             print(v, "ERROR", r["error"]); continue
