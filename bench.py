@@ -91,8 +91,9 @@ FRONTEND_S = 0.0
 
 
 def segment(cloud, sv, ctx):
-    """Supervoxel labels from the product's own front end (k-NN graph on the GPU, normals + fusion on the host;
-    setup, outside the timed hot path); `--labels grid` substitutes square grid cells."""
+    """Supervoxel labels from the product's own front end (csrc/frontend.hip: k-NN graph, fusion and refinement on the GPU, only the
+    closed-form eigen step of the normals on host threads; setup, outside the timed hot path); `--labels grid`
+    substitutes square grid cells."""
     from pwicp_amd import synth
     if LABELS == "grid":
         return synth.grid_labels(cloud, sv)
@@ -343,9 +344,10 @@ def series_end_to_end(args, P, rank, world, local_rank, dist, dev, barrier):
     _, recs, table, stages = warm[mid]
     ok = all(bool(np.all(w[1]["status"] == 0)) if len(w[1]) else True for w in warm)
     if rank == 0:
-        out = {"metric": "pairs/sec, PCD files -> transforms (Direct2Ref series of %d source epochs x %d pts, pairs dealt over the GPUs)" % (E, n),
-               "value": round(E / tmax, 3), "unit": "pairs/s", "scaling": "strong", "n_gpus": world, "pairs": E, "wall_s": round(tmax, 3),
-               "cold_wall_s": round(tcold, 3), "warm_walls_s": [round(x, 3) for x in walls], "all_pairs_ok": ok,
+        out = {"metric": "pairs/sec of a WARM process, PCD files -> transforms (Direct2Ref series of %d source epochs x %d pts, pairs dealt over "
+                         "the GPUs; cold_value: the first series of the process, what a fresh reference process or rounds 1 - 3 are comparable with)" % (E, n),
+               "value": round(E / tmax, 3), "cold_value": round(E / tcold, 3), "unit": "pairs/s", "scaling": "strong", "n_gpus": world,
+               "pairs": E, "wall_s": round(tmax, 3), "cold_wall_s": round(tcold, 3), "warm_walls_s": [round(x, 3) for x in walls], "all_pairs_ok": ok,
                "rank0_stage_wall_ms": {k: round(v, 1) for k, v in stages.items() if k.endswith("_ms")},
                "rank0_scan_bytes_to_gpu": stages["scan_bytes"],
                "note": "stages of rank 0 (its share of the pairs + the shared target): reading scans, GPU preparation (voxel grid incl. the "
@@ -433,6 +435,8 @@ def launch_ranks(n):
     env.setdefault("PWICP_JOB_ID", uuid.uuid4().hex)          # the token of the library's own RCCL rendezvous (host/comm.cpp)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, cpu_budget() // n)))
+    # the library's host-thread pool (host/parallel.h) divides the CPUs it may use by $LOCAL_WORLD_SIZE by itself; said here too
+    env.setdefault("PWICP_HOST_THREADS", str(max(1, cpu_budget() // n)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.exit(subprocess.call(cmd, env=env))
@@ -586,7 +590,7 @@ def main():
         t_inner_ms += rp.t_inner_ms
         n_inner_prof += int(rp.n_inner_total)
     pair.set_profiling(1)
-    # ---- roofline of the dominant kernel (dense 1-NN, k_nn_patches), measured live with HIP events -------
+    # ---- roofline of the dominant kernel (dense 1-NN, k_nn_dense_disc), measured live with HIP events -------
     n_launch = sum(rr.n_dense_nn_launches for rr in results)
     t_dense_ms = sum(rr.t_dense_nn_ms for rr in results)
     roofline = None
@@ -628,9 +632,17 @@ def main():
                     "compulsory_bytes_per_launch": int(compulsory),
                     "valu_issue_frac": (round(valu * 4.0 / (1024 * 2.4e9 * dur_s), 3) if valu else None),
                     "traffic_over_compulsory": (round(traffic / compulsory, 2) if traffic else None),
-                    "note": "achieved/frac = PHYSICAL HBM bytes per launch / HIP-event time / 8 TB/s; model_gbs = SURVEY 8d's algorithmic "
-                            "stream (cache hits included) for reference.  The kernel is bound by the vector-memory pipe (cache lines "
-                            "touched per gather) and vector-ALU issue, not by HBM (DESIGN.md 4.1)"}
+                    # the same fraction on the USEFUL bytes only (queries in, d2 out, the target once): what an ideal kernel would move
+                    "frac_useful": round(compulsory / dur_s / 1e9 / HBM_PEAK_GBS, 4),
+                    "fetch_correction": "FETCH_SIZE x 1.974 (k_transform_all's 16-B stream); holds for this kernel's 12-B gathers: the "
+                                        "L2 fetches 128-B lines whatever the load width and the counter tallies 64 B per request "
+                                        "(profiles/r05_gather_calibration.txt)",
+                    "note": "achieved/frac = PHYSICAL fabric bytes per launch / HIP-event time / 8 TB/s; frac_useful = the compulsory bytes "
+                            "over the same time; model_gbs = SURVEY 8d's algorithmic stream (cache hits included) for reference.  The 27 MB "
+                            "working set of the pair stays in the 256 MiB Infinity Cache across the timed steps (the counters include its "
+                            "hits), so 'HBM' here is fabric traffic.  The launch is ~19 us of vector-ALU-bound throughput plus ~12 us "
+                            "that do not shrink with the work (one wave's chain of dependent round trips, ramp and drain): "
+                            "profiles/r05_dense_variants.txt (4), DESIGN.md 4.1"}
         if stale:
             roofline["stale_profile"] = stale
 

@@ -1027,6 +1027,34 @@ __global__ void k_strip_keys(GridLevel g, const float4* __restrict__ p, int n, i
     vals[i] = i;
 }
 
+// ---- calibration of the PMC byte counters for THIS search's access pattern (tools/gather_calibration.py) ----------------------
+// FETCH_SIZE is calibrated for wide coalesced streams (MI355X_MICROARCH.md: x2 for 16 B / lane); the dense search gathers 12-byte
+// candidates at per-lane addresses.  This kernel does exactly that with a byte count known by construction: lane t reads the 12
+// bytes at offset t * stride of a buffer far larger than the Infinity Cache (so every line comes from HBM, once).
+__global__ void __launch_bounds__(256) k_gather_calibration(const float* __restrict__ buf, long long n, int stride_floats, float* __restrict__ out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const PwXyz3 p = *(const PwXyz3*)(buf + t * (long long)stride_floats);
+    const float s = p.x + p.y + p.z;
+    if (s == 12345.678f) out[0] = s;               // (never: keeps the load)
+}
+}  // namespace
+extern "C" __attribute__((visibility("default"))) int pwicp_debug_gather_calibration(pwicp_context* ctx, long long n_gathers, int stride_bytes, int launches) {
+    if (!ctx || n_gathers <= 0 || stride_bytes < 12 || stride_bytes % 4) return PWICP_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevBuf<float> buf, out;
+    HIPCHK(ctx, buf.reserve((size_t)n_gathers * (size_t)(stride_bytes / 4) + 4));
+    HIPCHK(ctx, out.reserve(4));
+    HIPCHK(ctx, hipMemsetAsync(buf.p, 0, ((size_t)n_gathers * (size_t)(stride_bytes / 4) + 4) * sizeof(float), ctx->stream));
+    for (int l = 0; l < launches; ++l)
+        hipLaunchKernelGGL(k_gather_calibration, dim3((unsigned)((n_gathers + 255) / 256)), dim3(256), 0, ctx->stream, buf.p, n_gathers,
+                           stride_bytes / 4, out.p);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PWICP_OK;
+}
+namespace {
+
 // ---- exact k-NN of every point of a cloud within the cloud itself (segmentation front end) ------------------------
 // Replaces the per-point cl::KDTree::FindKNearestNeighbors loop of PatchGenerationAndRefinement
 // (src/Segmentation.cpp:30-41; codelibrary/util/tree/kd_tree.h:266-280): the k nearest points (the query itself
