@@ -315,12 +315,14 @@ def series_end_to_end(args, P, rank, world, local_rank, dist, dev, barrier):
             series = P.Series(cfg, 0, E + 1, 0, 0.75, local_rank)
             barrier()
             t0 = time.perf_counter()
-            recs = series.run_pairs(mine) if mine else np.zeros(0, fourd.RECORD)
+            from pwicp_amd.series import run_pairs_sharing_target
+            recs = run_pairs_sharing_target(series, mine, 0, rank, world, dist, dev)       # (the target is segmented once, by rank 0)
             table = fourd.gather_records([recs[k:k + 1] for k in range(len(recs))], E, world, dist=dist, device=dev)
             assert len(table) == E, "record gather incomplete"
             barrier()
             wall = time.perf_counter() - t0
             stages = series.stage_times()
+            stages["target_labels_received"], stages["target_labels_segmented"] = series.target_label_counts()
             series.close()                       # (its contexts and front-end work spaces stay parked for the next series)
             return wall, recs, table, stages
         # first series of the process: device contexts, ~2 GB of front-end work space per stream, pinned staging buffers and kernel
@@ -343,6 +345,13 @@ def series_end_to_end(args, P, rank, world, local_rank, dist, dev, barrier):
     tmax = walls[mid]
     _, recs, table, stages = warm[mid]
     ok = all(bool(np.all(w[1]["status"] == 0)) if len(w[1]) else True for w in warm)
+    # who segmented the shared target: [received from rank 0, segmented here] of every rank (Direct2Ref: one target)
+    labels_by_rank = [[stages["target_labels_received"], stages["target_labels_segmented"]]]
+    if dist is not None:
+        t = torch.tensor(labels_by_rank[0], dtype=torch.int32, device=dev)
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        labels_by_rank = [[int(x) for x in p_.tolist()] for p_ in parts]
     if rank == 0:
         out = {"metric": "pairs/sec of a WARM process, PCD files -> transforms (Direct2Ref series of %d source epochs x %d pts, pairs dealt over "
                          "the GPUs; cold_value: the first series of the process, what a fresh reference process or rounds 1 - 3 are comparable with)" % (E, n),
@@ -350,6 +359,9 @@ def series_end_to_end(args, P, rank, world, local_rank, dist, dev, barrier):
                "pairs": E, "wall_s": round(tmax, 3), "cold_wall_s": round(tcold, 3), "warm_walls_s": [round(x, 3) for x in walls], "all_pairs_ok": ok,
                "rank0_stage_wall_ms": {k: round(v, 1) for k, v in stages.items() if k.endswith("_ms")},
                "rank0_scan_bytes_to_gpu": stages["scan_bytes"],
+               "target_labels_by_rank": labels_by_rank,
+               "target_labels_note": "[taken from rank 0's broadcast, made by the rank's own front end] per rank: the shared target of "
+                                     "the series is segmented once, by rank 0 (pwicp_amd.series.run_pairs_sharing_target)",
                "note": "stages of rank 0 (its share of the pairs + the shared target): reading scans, GPU preparation (voxel grid incl. the "
                        "host-side std::sort order, SOR, reduction), what is left of the front ends after that, registrations; the "
                        "front end of a cloud (~65 ms per 1 M points alone, ~45 ms with several side by side) is what a pair costs, the "

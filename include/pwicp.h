@@ -365,6 +365,24 @@ PWICP_API int pwicp_series_write_results(pwicp_series* s, const pwicp_pair_recor
 PWICP_API int pwicp_series_set_devices(pwicp_series* s, const int32_t* devices, int n);
 PWICP_API int pwicp_series_num_devices(const pwicp_series* s);
 
+/* ---- a target that several PROCESSES share (Direct2Ref: every pair has the reference epoch as its target; the reference rebuilds
+ * it for every pair, Registration.cpp:653).  One rank segments it; the others preprocess it themselves (they need its centroid for
+ * their source, Registration.cpp:419-436) and take the supervoxel labels - 4 bytes per point - from that rank instead of running the
+ * front end (Segmentation.cpp:18-68) once more per rank.  The labelling is a pure function of the preprocessed cloud: the records
+ * are the ones every rank would have computed alone.  On the ranks that take: pwicp_series_expect_target_labels(scan) before
+ * pwicp_series_run_pairs, then - from another thread, while the run preprocesses and segments this rank's sources -
+ * pwicp_series_supply_target_labels with what the exchange delivered (m < 0, or a count that does not fit: the run segments the
+ * target itself).  On the rank that gives: pwicp_series_wait_target_labels from another thread while its own run is under way
+ * (labels == NULL: sizes only; PWICP_E_INTERNAL: the run failed on that target or ended without it), and
+ * pwicp_series_close_target_labels once its run has returned.  pwicp_series_run_distributed and pwicp_amd.series do this with a
+ * broadcast of their communicator.  `scan`: index into the folder's sorted scan files (startEpoch for a Direct2Ref series). */
+PWICP_API int  pwicp_series_expect_target_labels(pwicp_series* s, int scan);
+PWICP_API int  pwicp_series_supply_target_labels(pwicp_series* s, int scan, int m, int n_supervoxels, const int32_t* labels);
+PWICP_API int  pwicp_series_wait_target_labels(pwicp_series* s, int scan, int timeout_ms, int* m, int* n_supervoxels, int32_t* labels, int cap);
+PWICP_API void pwicp_series_close_target_labels(pwicp_series* s);
+/* diagnostic: targets of this series whose labels came from another rank / were made by this one, so far */
+PWICP_API int  pwicp_series_target_label_counts(pwicp_series* s, int* received, int* segmented);
+
 /* ---- several PROCESSES, one GPU each: the series' one exchange over RCCL directly (no Python, no torch) -----------------------
  * librccl.so is opened with dlopen on first use.  Rendezvous of the ncclUniqueId through `id_file` (single node): rank 0
  * writes it, the others poll for it.  Buffers are host memory (staged through device memory: RCCL moves it over xGMI). */

@@ -346,7 +346,37 @@ PWICP_API bool pwicp_series_run_distributed(const char* confile, int startEpoch,
         for (int p = rank; p < n; p += world) mine.push_back(p);
         std::vector<pwicp_pair_record> loc((size_t)std::max(slots, 1));
         for (auto& r : loc) { std::memset(&r, 0, sizeof(r)); r.pair = -1; }
+        // Direct2Ref: the pairs of every rank have the SAME target (the reference epoch).  Rank 0 - the owner of pair 0 - segments
+        // it as part of its run; the others preprocess it themselves and take its labels (4 bytes per point) from a broadcast
+        // that a helper thread runs beside the rank's own preparation (pwicp_series_*_target_labels).  Every rank takes part in
+        // the two broadcasts whether or not it has pairs; a failure on rank 0 travels as m = -1 and the others segment for themselves.
+        const bool share_target = pairMode == 0 && world > 1 && n > 0 && !(getenv("PWICP_SHARE_TARGET") && atoi(getenv("PWICP_SHARE_TARGET")) == 0);
+        std::thread label_thread;
+        if (share_target) {
+            if (rank != 0) (void)pwicp_series_expect_target_labels(s, startEpoch);
+            label_thread = std::thread([&, s] {
+                int32_t hdr[2] = {-1, 0};
+                std::vector<int32_t> lab;
+                if (rank == 0) {
+                    int m = 0, nsv = 0;
+                    if (pwicp_series_wait_target_labels(s, startEpoch, 3600 * 1000, &m, &nsv, nullptr, 0) == PWICP_OK) {
+                        lab.resize((size_t)std::max(m, 1));
+                        if (pwicp_series_wait_target_labels(s, startEpoch, 0, &m, &nsv, lab.data(), m) == PWICP_OK) { hdr[0] = m; hdr[1] = nsv; }
+                    }
+                }
+                bool got = pwicp_comm_broadcast(comm, hdr, sizeof(hdr), 0) == PWICP_OK;
+                if (got && hdr[0] > 0) {
+                    lab.resize((size_t)hdr[0]);
+                    got = pwicp_comm_broadcast(comm, lab.data(), sizeof(int32_t) * (size_t)hdr[0], 0) == PWICP_OK;
+                }
+                if (rank != 0) (void)pwicp_series_supply_target_labels(s, startEpoch, (got && hdr[0] > 0) ? hdr[0] : -1, hdr[1], lab.data());
+            });
+        }
         if (!mine.empty()) ok = pwicp_series_run_pairs(s, mine.data(), (int)mine.size(), loc.data()) != PWICP_E_NO_DEVICE;
+        if (share_target) {
+            pwicp_series_close_target_labels(s);          // (rank 0: a run that never reached its target wakes the helper)
+            label_thread.join();
+        }
         if (!agree(ok)) break;
         std::vector<pwicp_pair_record> all((size_t)std::max(slots, 1) * (size_t)world);
         ok = slots == 0 || pwicp_comm_allgather(comm, loc.data(), sizeof(pwicp_pair_record) * (size_t)slots, all.data()) == PWICP_OK;

@@ -20,6 +20,7 @@
 #include <iostream>
 #include <condition_variable>
 #include <map>
+#include <set>
 #include <memory>
 #include <mutex>
 #include <sstream>
@@ -676,6 +677,22 @@ struct pwicp_series {
     std::vector<int> scan_lru;                    // least recently used first; all dropped once the map is known
     std::vector<std::unique_ptr<SeriesWorker>> workers;      // [0] = `device`; more after pwicp_series_set_devices
 
+    // The supervoxel labels of a target that several PROCESSES share (Direct2Ref: every pair has the reference epoch as its target;
+    // the reference rebuilds it per pair, R.cpp:653): one rank segments it, the others preprocess it themselves (17 ms at 1 M points,
+    // they need its centroid before their source) and take the labels - 4 bytes per point - from that rank instead of running the
+    // 60 ms front end once more per rank.  pwicp_series_expect / supply / wait_target_labels, include/pwicp.h; the labelling is a
+    // pure function of the preprocessed cloud, so the records are the ones every rank would have computed alone.
+    struct LabelExchange {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::set<int> expected;                                        // scans whose labels another rank supplies
+        struct Supplied { int m = -1, nsv = 0; std::vector<int32_t> lab; };
+        std::map<int, Supplied> supplied;                              // ... as they arrived (m < 0: the supplier failed)
+        std::map<int, std::shared_ptr<Prepared>> done;                 // targets segmented HERE (nullptr: failed), for wait_target_labels
+        bool closed = false;                                           // the run is over: nothing more will become ready
+        int n_received = 0, n_segmented = 0;                           // targets of this series whose labels arrived / were made here
+    } lx;
+
     SeriesWorker* w0() {
         if (workers.empty()) { workers.emplace_back(new SeriesWorker); workers[0]->device = device; }
         return workers[0].get();
@@ -803,6 +820,8 @@ PWICP_API void pwicp_series_release_parked(void) { WorkerParking::get().release_
 
 PWICP_API void pwicp_series_close(pwicp_series* s) {
     if (!s) return;
+    { std::lock_guard<std::mutex> g(s->lx.mu); s->lx.done.clear(); s->lx.closed = true; }      // (device-side targets go before their context)
+    s->lx.cv.notify_all();
     for (auto& w : s->workers) w->close();
     delete s;
 }
@@ -853,6 +872,38 @@ PWICP_API int pwicp_series_adaptive_targets(const pwicp_series* s, int32_t* targ
     if (!s || !targets || n != (int)s->regPairs.size()) return PWICP_E_INVALID;
     for (int k = 0; k < n; ++k) { auto it = s->regPairs.find(k + 1); targets[k] = it == s->regPairs.end() ? -1 : it->second; }
     return PWICP_OK;
+}
+
+// labels of a target cloud of a series: taken from the rank that segments it when they were announced
+// (pwicp_series_expect_target_labels), else made here - and then offered to pwicp_series_wait_target_labels
+static bool target_labels(pwicp_series* s, int scan, const std::shared_ptr<Prepared>& t, AuxContexts* aux) {
+    auto& lx = s->lx;
+    bool expected;
+    { std::lock_guard<std::mutex> g(lx.mu); expected = lx.expected.count(scan) > 0; }
+    if (expected) {
+        double tmo_s = 600.0;
+        if (const char* e = std::getenv("PWICP_LABEL_TIMEOUT_S")) tmo_s = std::max(atof(e), 1.0);
+        timeline("target labels: waiting for the rank that segments it", scan);
+        std::unique_lock<std::mutex> g(lx.mu);
+        const bool came = lx.cv.wait_for(g, std::chrono::duration<double>(tmo_s), [&] { return lx.supplied.count(scan) > 0; });
+        if (came && lx.supplied[scan].m == t->m && (int)lx.supplied[scan].lab.size() == t->m) {
+            t->lab = std::move(lx.supplied[scan].lab);
+            t->nsv = lx.supplied[scan].nsv;
+            t->segmented = true;
+            lx.supplied.erase(scan);
+            ++lx.n_received;
+            g.unlock();
+            timeline("target labels: received", scan);
+            return true;
+        }
+        std::cerr << "[pwicp] labels of target scan " << scan << (came ? " do not fit this rank's preprocessed cloud" : " did not arrive")
+                  << ": segmenting it here.\n";
+        lx.supplied.erase(scan);
+    }
+    const bool ok = prepare_labels(t.get(), aux);
+    { std::lock_guard<std::mutex> g(lx.mu); lx.done[scan] = ok ? t : nullptr; if (ok) ++lx.n_segmented; }
+    lx.cv.notify_all();
+    return ok;
 }
 
 // Iterations of the pair loop R.cpp:89-150 (without their file output) for any subset of the pairs.  The pairs are
@@ -953,10 +1004,13 @@ static int run_pairs_on(pwicp_series* s, SeriesWorker* w, const int32_t* pairs, 
                 if (good) good = prepare_gpu(w->ctx, kv.second, Res1, SVRes1, sor_mult, nullptr, t.get(), share_pre ? &pre : nullptr, kv.first);
                 if (good) {
                     w->targets[kv.first] = t;
-                    Prepared* p = t.get();
                     char* flag = &okt[ti];
                     AuxContexts* aux = w->aux.get();
-                    th.emplace_back([p, flag, aux] { *flag = prepare_labels(p, aux) ? 1 : 0; });
+                    const int scan = kv.first;
+                    th.emplace_back([s, scan, t, flag, aux] { *flag = target_labels(s, scan, t, aux) ? 1 : 0; });
+                } else {
+                    { std::lock_guard<std::mutex> g(s->lx.mu); s->lx.done[kv.first] = nullptr; }      // (a waiter learns it at once)
+                    s->lx.cv.notify_all();
                 }
                 std::vector<float>().swap(kv.second);
                 ++ti;
@@ -1040,6 +1094,62 @@ static int run_pairs_on(pwicp_series* s, SeriesWorker* w, const int32_t* pairs, 
         }
     }
     return PWICP_OK;
+}
+
+// ---- labels of a shared target across processes (see pwicp_series::LabelExchange) -----------------------------------------------
+PWICP_API int pwicp_series_expect_target_labels(pwicp_series* s, int scan) {
+    if (!s || scan < 0 || scan >= (int)s->files.size()) return PWICP_E_INVALID;
+    std::lock_guard<std::mutex> g(s->lx.mu);
+    s->lx.expected.insert(scan);
+    return PWICP_OK;
+}
+
+PWICP_API int pwicp_series_supply_target_labels(pwicp_series* s, int scan, int m, int nsv, const int32_t* labels) {
+    if (!s || scan < 0 || scan >= (int)s->files.size() || (m > 0 && !labels)) return PWICP_E_INVALID;
+    {
+        std::lock_guard<std::mutex> g(s->lx.mu);
+        auto& sp = s->lx.supplied[scan];
+        sp.m = m; sp.nsv = nsv;
+        sp.lab.assign(labels, labels + std::max(m, 0));
+    }
+    s->lx.cv.notify_all();
+    return PWICP_OK;
+}
+
+// blocks until a pwicp_series_run_pairs of this process (another thread) has segmented target `scan`, or failed to, or ended
+// (PWICP_E_INTERNAL), or timeout_ms has passed (PWICP_E_INVALID).  labels == nullptr: only the sizes.
+PWICP_API int pwicp_series_wait_target_labels(pwicp_series* s, int scan, int timeout_ms, int* m, int* nsv, int32_t* labels, int cap) {
+    if (!s || scan < 0 || scan >= (int)s->files.size()) return PWICP_E_INVALID;
+    auto& lx = s->lx;
+    std::unique_lock<std::mutex> g(lx.mu);
+    const bool came = lx.cv.wait_for(g, std::chrono::milliseconds(std::max(timeout_ms, 0)), [&] { return lx.done.count(scan) > 0 || lx.closed; });
+    if (!came) return PWICP_E_INVALID;
+    auto it = lx.done.find(scan);
+    if (it == lx.done.end() || !it->second) return PWICP_E_INTERNAL;
+    const Prepared& t = *it->second;
+    if (m) *m = t.m;
+    if (nsv) *nsv = t.nsv;
+    if (labels) {
+        if (cap < t.m) return PWICP_E_INVALID;
+        std::memcpy(labels, t.lab.data(), (size_t)t.m * sizeof(int32_t));
+    }
+    return PWICP_OK;
+}
+
+// how many targets of this series took their labels from another rank / were segmented by this one (so far)
+PWICP_API int pwicp_series_target_label_counts(pwicp_series* s, int* received, int* segmented) {
+    if (!s) return PWICP_E_INVALID;
+    std::lock_guard<std::mutex> g(s->lx.mu);
+    if (received) *received = s->lx.n_received;
+    if (segmented) *segmented = s->lx.n_segmented;
+    return PWICP_OK;
+}
+
+// tells waiters that no run is (any longer) going to segment anything: called by the client after its pwicp_series_run_pairs
+PWICP_API void pwicp_series_close_target_labels(pwicp_series* s) {
+    if (!s) return;
+    { std::lock_guard<std::mutex> g(s->lx.mu); s->lx.closed = true; }
+    s->lx.cv.notify_all();
 }
 
 PWICP_API int pwicp_series_run_pairs(pwicp_series* s, const int32_t* pairs, int n_pairs, pwicp_pair_record* recs) {

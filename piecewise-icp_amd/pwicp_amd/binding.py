@@ -140,6 +140,12 @@ def load_library():
     L.pwicp_series_run_pair.argtypes = [vp, C.c_int, vp]
     L.pwicp_series_run_pairs.argtypes = [vp, ip, C.c_int, vp]
     L.pwicp_series_write_results.argtypes = [vp, vp, C.c_int]
+    L.pwicp_series_expect_target_labels.argtypes = [vp, C.c_int]
+    L.pwicp_series_supply_target_labels.argtypes = [vp, C.c_int, C.c_int, C.c_int, ip]
+    L.pwicp_series_wait_target_labels.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), ip, C.c_int]
+    L.pwicp_series_close_target_labels.argtypes = [vp]
+    L.pwicp_series_target_label_counts.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.pwicp_series_close_target_labels.restype = None
     L.pwicp_pc_resolution_dev.argtypes = [vp, fp, C.c_int, fp]
     L.pwicp_preprocess_dev.argtypes = [vp, fp, C.c_int, C.c_float, C.c_int, C.c_double, fp, ip]
     L.pwicp_preprocess.argtypes = [fp, C.c_int, C.c_float, C.c_int, C.c_double, fp, ip]
@@ -358,6 +364,44 @@ class Series:
         if rc != 0:
             raise PwicpError(rc, "pwicp_series_run_pairs")
         return recs
+
+    # ---- labels of a target that several processes share (pwicp.h: pwicp_series_*_target_labels) ----
+    def expect_target_labels(self, scan):
+        """The labels of target `scan` will come from another rank (supply_target_labels, from another thread, during run_pairs)."""
+        rc = self._L.pwicp_series_expect_target_labels(self._h, int(scan))
+        if rc != 0:
+            raise PwicpError(rc, "pwicp_series_expect_target_labels")
+
+    def supply_target_labels(self, scan, labels, n_supervoxels):
+        """labels None: the supplier failed - the run segments the target itself."""
+        if labels is None:
+            rc = self._L.pwicp_series_supply_target_labels(self._h, int(scan), -1, 0, None)
+        else:
+            lab = np.ascontiguousarray(labels, np.int32)
+            rc = self._L.pwicp_series_supply_target_labels(self._h, int(scan), len(lab), int(n_supervoxels), _p(lab, ip))
+        if rc != 0:
+            raise PwicpError(rc, "pwicp_series_supply_target_labels")
+
+    def wait_target_labels(self, scan, timeout_s=3600.0):
+        """Blocks until a run_pairs of this process (another thread) has segmented target `scan`; (labels, n_supervoxels), or None
+        when that run failed on the target or ended without it."""
+        m, nsv = C.c_int(0), C.c_int(0)
+        rc = self._L.pwicp_series_wait_target_labels(self._h, int(scan), int(timeout_s * 1000), C.byref(m), C.byref(nsv), None, 0)
+        if rc != 0:
+            return None
+        lab = np.zeros(max(m.value, 1), np.int32)
+        rc = self._L.pwicp_series_wait_target_labels(self._h, int(scan), 0, C.byref(m), C.byref(nsv), _p(lab, ip), len(lab))
+        return (lab[:m.value], nsv.value) if rc == 0 else None
+
+    def target_label_counts(self):
+        """(targets whose labels came from another rank, targets segmented by this one)"""
+        a, b = C.c_int(0), C.c_int(0)
+        self._L.pwicp_series_target_label_counts(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def close_target_labels(self):
+        self._L.pwicp_series_close_target_labels.restype = None
+        self._L.pwicp_series_close_target_labels(self._h)
 
     def set_devices(self, devices):
         """Several GPUs in this process: pairs of a run_pairs call are dealt to them (pair k -> device k mod n)."""

@@ -9,7 +9,8 @@ pairs p with p mod world == rank through libpwicp.so, the 384-byte records are a
 xGMI; gloo for debugging) and rank 0 writes the reference's result files and the composition to the reference epoch.
 In adaptive mode the overlap ratios behind the pair map (dense NN of raw scans, R.cpp:593-614) are dealt to the ranks and
 every rank replays the target scan (R.cpp:552-589) on the gathered table.
-In Direct2Ref mode every rank prepares the shared target scan once (preprocessing + supervoxels), not once per pair."""
+In Direct2Ref mode the shared target scan is segmented ONCE, by rank 0; the other ranks preprocess it themselves and take its labels
+from a broadcast that runs beside their own preparation (run_pairs_sharing_target)."""
 import argparse
 import os
 import sys
@@ -30,6 +31,56 @@ def _agree(dist, dev, ok):
     f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
     dist.all_reduce(f, op=dist.ReduceOp.MIN)
     return bool(f.item())
+
+
+def run_pairs_sharing_target(series, mine, scan, rank, world, dist, dev):
+    """series.run_pairs(mine) of a Direct2Ref series on `world` ranks whose pairs all have target `scan`: rank 0 (the owner of pair
+    0) segments the target as part of its run, the others preprocess it themselves and take its supervoxel labels - 4 bytes per
+    point - from a broadcast that a helper thread runs beside the rank's own preparation, instead of running the front end once
+    more per rank (pwicp.h: pwicp_series_*_target_labels).  EVERY rank calls this (two broadcasts are collective), with or
+    without pairs of its own.  A failure on rank 0 travels as a count of -1 and the others segment for themselves.  Returns the
+    records of `mine`; $PWICP_SHARE_TARGET=0: every rank segments the target itself (round 4)."""
+    from .fourd import RECORD
+    if dist is None or world <= 1 or os.environ.get("PWICP_SHARE_TARGET", "1") == "0":
+        return series.run_pairs(mine) if len(mine) else np.zeros(0, RECORD)
+    import threading
+    import torch
+    if rank != 0:
+        series.expect_target_labels(scan)
+    err = []
+
+    def exchange():
+        try:
+            hdr = torch.tensor([-1, 0], dtype=torch.int32)
+            lab = None
+            if rank == 0:
+                got = series.wait_target_labels(scan)
+                if got is not None:
+                    lab = torch.from_numpy(got[0].copy())
+                    hdr = torch.tensor([len(got[0]), got[1]], dtype=torch.int32)
+            hdr = hdr.to(dev)
+            dist.broadcast(hdr, src=0)
+            m, nsv = int(hdr[0].item()), int(hdr[1].item())
+            if m > 0:
+                lab = (lab if rank == 0 else torch.empty(m, dtype=torch.int32)).to(dev)
+                dist.broadcast(lab, src=0)
+            if rank != 0:
+                series.supply_target_labels(scan, lab.cpu().numpy() if m > 0 else None, nsv)
+        except Exception as e:                               # noqa: BLE001 - the run must not wait for labels that will not come
+            err.append(e)
+            if rank != 0:
+                series.supply_target_labels(scan, None, 0)
+
+    th = threading.Thread(target=exchange, daemon=True)
+    th.start()
+    try:
+        recs = series.run_pairs(mine) if len(mine) else np.zeros(0, RECORD)
+    finally:
+        series.close_target_labels()                         # (rank 0: a run that never reached its target wakes the helper)
+        th.join()
+    if err:
+        print("pwicp series: rank %d: label exchange of target %d failed (%s); segmented locally" % (rank, scan, err[0]), file=sys.stderr)
+    return recs
 
 
 def run_series(confile, start_epoch, epoch_num, pair_mode, overlap_thd=0.75, backend="nccl", single_device=False,
@@ -108,7 +159,11 @@ def run_series(confile, start_epoch, epoch_num, pair_mode, overlap_thd=0.75, bac
         n = series.num_pairs
         mine = []
         try:
-            done = series.run_pairs([p for p in range(n) if p % world == rank])
+            todo = [p for p in range(n) if p % world == rank]
+            if pair_mode == 0 and n > 0:
+                done = run_pairs_sharing_target(series, todo, start_epoch, rank, world, dist, dev)
+            else:
+                done = series.run_pairs(todo)
             mine = [done[k:k + 1] for k in range(len(done))]
         except Exception as e:                              # noqa: BLE001
             print("pwicp series: rank %d failed while running its pairs: %s" % (rank, e), file=sys.stderr)

@@ -6,6 +6,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 import _golden as G
 from pwicp_amd import fourd
@@ -243,3 +244,115 @@ def test_rccl_id_file_of_an_earlier_launch_with_the_same_token_is_not_taken(tmp_
     assert subprocess.run([sys.executable, "-c", code], env=env).returncode == 0
     assert L.pwicp_comm_debug_id_file(path, 1, 0) == 0
     assert L.pwicp_comm_debug_id_file(path, 0, 0) == 1 and L.pwicp_comm_debug_id_file(path, 1, 0) == 1
+
+
+LABEL_WORKER = textwrap.dedent('''
+    import os, sys, threading, time
+    import numpy as np
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(%(root)r, "piecewise-icp_amd"))
+    from pwicp_amd import fourd
+    from pwicp_amd.series import run_pairs_sharing_target
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    import torch
+    dev = torch.device("cpu")
+
+    class FakeSeries:
+        """the label hand-over of a series without its GPU work: run_pairs 'segments' the target after a while on rank 0 and
+        waits for the supplied labels on the others (what pwicp_series_run_pairs does, host/registration.cpp target_labels)"""
+        def __init__(self, fail):
+            self.cv = threading.Condition(); self.done = None; self.closed = False; self.supplied = "none"; self.expected = False
+            self.fail = fail
+        def expect_target_labels(self, scan): self.expected = True
+        def supply_target_labels(self, scan, labels, nsv):
+            with self.cv: self.supplied = (None if labels is None else (np.array(labels), nsv)); self.cv.notify_all()
+        def wait_target_labels(self, scan, timeout_s=60.0):
+            with self.cv:
+                self.cv.wait_for(lambda: self.done is not None or self.closed, timeout_s)
+                return self.done if self.done else None
+        def close_target_labels(self):
+            with self.cv: self.closed = True; self.cv.notify_all()
+        def run_pairs(self, mine):
+            recs = np.zeros(len(mine), fourd.RECORD)
+            if self.expected:
+                with self.cv: assert self.cv.wait_for(lambda: self.supplied != "none", 60.0)
+                self.got = self.supplied
+            else:
+                time.sleep(0.2)
+                if not self.fail:
+                    with self.cv: self.done = (np.arange(1000, dtype=np.int32) %% 37, 37); self.cv.notify_all()
+            recs["pair"] = mine
+            return recs
+
+    for fail in (False, True):
+        s = FakeSeries(fail)
+        mine = [p for p in range(3) if p %% world == rank]
+        recs = run_pairs_sharing_target(s, mine, 0, rank, world, dist, dev)
+        assert list(recs["pair"]) == mine
+        if rank != 0:
+            if fail:
+                assert s.got is None                                   # rank 0 failed on the target: this rank segments for itself
+            else:
+                lab, nsv = s.got
+                assert nsv == 37 and np.array_equal(lab, np.arange(1000, dtype=np.int32) %% 37)
+        dist.barrier()
+    # a rank without pairs of its own still takes part in the two broadcasts
+    s = FakeSeries(False)
+    recs = run_pairs_sharing_target(s, [0] if rank == 0 else [], 0, rank, world, dist, dev)
+    assert len(recs) == (1 if rank == 0 else 0)
+    dist.barrier()
+    if rank == 0:
+        print("LABELS_OK")
+    dist.destroy_process_group()
+''')
+
+
+def test_shared_target_labels_travel_from_rank0_world2_gloo(tmp_path):
+    """VERDICT r4 item 3a: in a Direct2Ref series on several ranks the target is segmented once, by rank 0; the other ranks take
+    its labels from a broadcast that runs beside their own preparation (pwicp_amd.series.run_pairs_sharing_target).  The
+    collective part without the GPU work: labels arrive intact, a failure on rank 0 arrives as 'segment it yourself', a rank
+    without pairs takes part.  (The GPU side - records byte-equal to one rank's, the front end run once - is
+    tests/test_gpu_bench_ranks.py.)"""
+    script = tmp_path / "labels.py"
+    script.write_text(LABEL_WORKER % {"root": ROOT})
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "LABELS_OK" in res.stdout
+
+
+def test_target_label_exchange_entry_points_without_a_run(tmp_path):
+    """The C side of the hand-over (include/pwicp.h: pwicp_series_*_target_labels) as far as it goes without a GPU: a waiter
+    learns at once that a run has ended without the target (close), supplied labels are kept for the run that expects them,
+    bad arguments are error codes."""
+    import ctypes as C
+    import pwicp_amd as P
+    from pwicp_amd.pcd import write_pcd_binary as write_pcd
+    inp = tmp_path / "scans"
+    inp.mkdir()
+    for e in range(1, 4):
+        write_pcd(str(inp / ("Epoch_%03d.pcd" % e)), np.zeros((3, 3), np.float32))
+    cfg = tmp_path / "cfg.txt"
+    cfg.write_text("string FolderFilePath1: %s\nstring FolderFilePath2: %s\nbool isSetResSVsize (yes-1, no-0): 1\n"
+                   "float PCres1 (m): 0.005\nfloat PCres2 (m): 0.005\nfloat SVsize1 (m): 0.05\nfloat SVsize2 (m): 0.05\n"
+                   "bool isSetDTinit (yes-1, no-0): 1\nfloat DTinit (m): 0.05\nfloat DTmin (m): 0.004\n"
+                   "bool isVisual (yes-1, no-0): 0" % (str(inp), str(tmp_path) + "/res_"))
+    with P.Series(str(cfg), 0, 3, 0, 0.75, 0) as s:
+        assert s.target_label_counts() == (0, 0)
+        s.expect_target_labels(0)
+        s.supply_target_labels(0, np.arange(10, dtype=np.int32), 4)
+        s.supply_target_labels(0, None, 0)
+        with pytest.raises(P.PwicpError):
+            s.expect_target_labels(99)
+        import threading, time
+        out = []
+        th = threading.Thread(target=lambda: out.append(s.wait_target_labels(0, 30.0)))
+        th.start()
+        time.sleep(0.2)
+        assert th.is_alive()                       # nothing has segmented the target yet
+        s.close_target_labels()
+        th.join(10.0)
+        assert not th.is_alive() and out == [None]

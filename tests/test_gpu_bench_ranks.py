@@ -55,6 +55,19 @@ def test_bench_gpus_2_starts_two_ranks_and_gathers_the_same_records(tmp_path, on
     # weak scaling of the loop-only figure: both ranks ran `steps` registrations
     assert line["config"]["correspondences_per_step"] == line1["config"]["correspondences_per_step"]
     _same_records(np.load(tmp_path / "r2.npy"), rec1)
+    # the shared target of the series was segmented ONCE: by rank 0; rank 1 preprocessed it and took the labels from the broadcast
+    #  - and the records above are byte-equal to one rank's all the same
+    assert s["target_labels_by_rank"] == [[0, 1], [1, 0]], s["target_labels_by_rank"]
+    assert line1["series_end_to_end"]["target_labels_by_rank"] == [[0, 1]]
+
+
+def test_bench_two_ranks_each_segmenting_the_target_give_the_same_records(tmp_path, one_rank):
+    """PWICP_SHARE_TARGET=0 (round 4: every rank runs the target's front end itself): the same records."""
+    _, rec1 = one_rank
+    p, line = _bench(["--gpus", "2", "--single-device", "--backend", "gloo"], tmp_path / "r2.npy", env_extra={"PWICP_SHARE_TARGET": "0"})
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert line["series_end_to_end"]["target_labels_by_rank"] == [[0, 1], [0, 1]]
+    _same_records(np.load(tmp_path / "r2.npy"), rec1)
 
 
 def test_bench_refuses_a_world_other_than_gpus(tmp_path):
