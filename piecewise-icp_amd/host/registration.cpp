@@ -173,6 +173,13 @@ struct AuxContexts {
         std::lock_guard<std::mutex> lk(m);
         limit = std::max(limit, points_per_cloud < 400000 ? 6 : 4);
     }
+    // a parked set taken over by the next series: the limit starts over (streams beyond it stay idle in the list - a stream that was
+    // sized for small scans is not handed a 5 M-point cloud just because an earlier series had six of them)
+    void reset_limit() {
+        if (limit_from_env) return;
+        std::lock_guard<std::mutex> lk(m);
+        limit = 3;
+    }
     AuxContexts(const AuxContexts&) = delete;
     AuxContexts& operator=(const AuxContexts&) = delete;
     ~AuxContexts() { for (pwicp_context* c : idle) pwicp_destroy(c); }
@@ -584,6 +591,8 @@ PWICP_API int pwicp_write_trans_matrix_file(const char* path, const float* T16, 
 // takes them over warm: the second PiecewiseICP_4D_call of a process costs what its clouds cost.  One set per device is kept
 // ($PWICP_SERIES_KEEP=0: none) until pwicp_series_release_parked() or the end of the process.
 struct ParkedWorker { pwicp_context* ctx = nullptr; std::unique_ptr<AuxContexts> aux; };
+bool pw_set_release_parked_hook(bool (*fn)());        // csrc/api.hip (library-internal)
+
 struct WorkerParking {
     std::mutex mu;
     std::map<int, ParkedWorker> by_device;
@@ -592,15 +601,22 @@ struct WorkerParking {
     static WorkerParking& get() { static WorkerParking* p = new WorkerParking; return *p; }       // (the object itself is never deleted)
     // destroys what is parked (pwicp_series_release_parked, and once at exit: registered when the first set is parked, i.e. after
     // the HIP runtime has registered its own exit work, so it runs before the runtime goes away)
-    void release_all() {
+    bool release_all() {
         std::map<int, ParkedWorker> take;
         std::map<int, pwicp_context*> take_pair;
         { std::lock_guard<std::mutex> g(mu); take.swap(by_device); take_pair.swap(pair_by_device); }
         for (auto& kv : take) { kv.second.aux.reset(); if (kv.second.ctx) pwicp_destroy(kv.second.ctx); }
         for (auto& kv : take_pair) if (kv.second) pwicp_destroy(kv.second);
+        return !take.empty() || !take_pair.empty();
     }
     void hook_exit() {          // (call with mu held)
-        if (!exit_hook) { exit_hook = true; std::atexit([] { WorkerParking::get().release_all(); }); }
+        if (!exit_hook) {
+            exit_hook = true;
+            std::atexit([] { (void)WorkerParking::get().release_all(); });
+            // an allocation anywhere in the process that runs out of device memory gets the parked sets back before it fails
+            // (csrc/common.h PwPool::take: after its own cache and every other cache of the device)
+            pw_set_release_parked_hook([] { return WorkerParking::get().release_all(); });
+        }
     }
     static bool enabled() { static const bool on = !(std::getenv("PWICP_SERIES_KEEP") && atoi(std::getenv("PWICP_SERIES_KEEP")) == 0); return on; }
 };
@@ -637,7 +653,10 @@ struct SeriesWorker {
             WorkerParking& pk = WorkerParking::get();
             std::lock_guard<std::mutex> g(pk.mu);
             auto it = pk.by_device.find(device);
-            if (it != pk.by_device.end()) { ctx = it->second.ctx; aux = std::move(it->second.aux); pk.by_device.erase(it); }
+            if (it != pk.by_device.end()) {
+                ctx = it->second.ctx; aux = std::move(it->second.aux); pk.by_device.erase(it);
+                if (aux) aux->reset_limit();                     // (sized again for THIS series' clouds, size_for)
+            }
         }
         if (!aux) aux.reset(new AuxContexts(device));
         if (ctx) return true;
@@ -816,7 +835,7 @@ PWICP_API int pwicp_series_open(const char* confile, int startEpoch, int epochNu
 }
 
 // frees what closed series have left parked per device (contexts, front-end work spaces): for hosts that are done with series
-PWICP_API void pwicp_series_release_parked(void) { WorkerParking::get().release_all(); }
+PWICP_API void pwicp_series_release_parked(void) { (void)WorkerParking::get().release_all(); }
 
 PWICP_API void pwicp_series_close(pwicp_series* s) {
     if (!s) return;

@@ -480,7 +480,8 @@ print("FINGERPRINT", h.hexdigest())
 @pytest.mark.gpu
 def test_scheduling_switches_do_not_change_a_bit(tmp_path):
     """Stage guard (the Stage-1 -> Stage-2 decision on the device), speculative first dense search, fused percentile selection,
-    the closing stream synchronisation, the allocation pool, the form of the dense search's far path and the lanes per front
+    the closing stream synchronisation, the allocation pool, the form of the dense search's far path, the stream the first dense search
+    runs on, the memory it takes its candidates from and the lanes per front
     query only change WHEN things are launched, by how many lanes, and where buffers come from: T, VCM, every per-iteration series and the moved source cloud are bit-identical with each of them switched off.
     So they are without the per-iteration SOURCE patch normals (R.cpp:823-824): PCL's point-to-plane estimate reads the target's
     normals only, the source's are dead values in the reference (loop.hip: source_normals())."""
@@ -497,10 +498,13 @@ def test_scheduling_switches_do_not_change_a_bit(tmp_path):
                         ("far queries inside the search's blocks, 8 lanes per front query", {"PWICP_DENSE_FAR_GROUP": "0", "PWICP_FRONT_QUERY_LANES": "8"}),
                         ("4 lanes per front query", {"PWICP_FRONT_QUERY_LANES": "4"}),
                         ("source patch normals left out", {"PWICP_SOURCE_NORMALS": "0"}),
-                        ("dense search gathers its queries through the order array", {"PWICP_DENSE_QUERY_COPY": "0"})):
+                        ("dense search gathers its queries through the order array", {"PWICP_DENSE_QUERY_COPY": "0"}),
+                        ("first dense search on the context's second stream, beside the ICP", {"PWICP_DENSE_SIDE_STREAM": "1"}),
+                        ("dense search on the LDS window of its block", {"PWICP_DENSE_WIN": "1"})):
         env = dict(os.environ)
         for k in ("PWICP_STAGE_GUARD", "PWICP_SPECULATE_DENSE", "PWICP_FUSED_SELECT", "PWICP_POOL_MB", "PWICP_RUN_SYNC",
-                  "PWICP_DENSE_FAR_GROUP", "PWICP_FRONT_QUERY_LANES", "PWICP_SOURCE_NORMALS", "PWICP_DENSE_QUERY_COPY"):
+                  "PWICP_DENSE_FAR_GROUP", "PWICP_FRONT_QUERY_LANES", "PWICP_SOURCE_NORMALS", "PWICP_DENSE_QUERY_COPY", "PWICP_DENSE_SIDE_STREAM",
+                  "PWICP_DENSE_WIN"):
             env.pop(k, None)
         env.update(extra)
         out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
