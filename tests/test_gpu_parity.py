@@ -500,11 +500,14 @@ def test_scheduling_switches_do_not_change_a_bit(tmp_path):
                         ("source patch normals left out", {"PWICP_SOURCE_NORMALS": "0"}),
                         ("dense search gathers its queries through the order array", {"PWICP_DENSE_QUERY_COPY": "0"}),
                         ("first dense search on the context's second stream, beside the ICP", {"PWICP_DENSE_SIDE_STREAM": "1"}),
-                        ("dense search on the LDS window of its block", {"PWICP_DENSE_WIN": "1"})):
+                        ("dense search on the LDS window of its block", {"PWICP_DENSE_WIN": "1"}),
+                        # (the pairs of the worker have <= 3072 patches: their inner-ICP batches as ONE launch of one workgroup,
+                        #  k_icp_small - same sums in the same order as one k_icp_iter launch per iteration)
+                        ("inner-ICP batches of small problems in one launch of one workgroup", {"PWICP_ICP_SMALL": "1"})):
         env = dict(os.environ)
         for k in ("PWICP_STAGE_GUARD", "PWICP_SPECULATE_DENSE", "PWICP_FUSED_SELECT", "PWICP_POOL_MB", "PWICP_RUN_SYNC",
                   "PWICP_DENSE_FAR_GROUP", "PWICP_FRONT_QUERY_LANES", "PWICP_SOURCE_NORMALS", "PWICP_DENSE_QUERY_COPY", "PWICP_DENSE_SIDE_STREAM",
-                  "PWICP_DENSE_WIN"):
+                  "PWICP_DENSE_WIN", "PWICP_ICP_SMALL"):
             env.pop(k, None)
         env.update(extra)
         out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
