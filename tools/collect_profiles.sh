@@ -22,6 +22,9 @@ done
 for N in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $N --output-format csv -d $OUT/pmc -o cal_$N -- python $R/tools/pmc_calibration.py > $OUT/pmc_cal_$N.log 2>&1
 done
+# FETCH_SIZE on 12-byte divergent gathers with a byte count known by construction (tools/gather_calibration.py, k_gather_calibration)
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc -o gcal_FETCH_SIZE -- python $R/tools/gather_calibration.py > $OUT/pmc_gcal_FETCH_SIZE.log 2>&1
+timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $OUT/pmc -o gcal_RDREQ -- python $R/tools/gather_calibration.py > $OUT/pmc_gcal_RDREQ.log 2>&1
 # the segmentation front end (row f1): kernel statistics of one warm-up + 3 timed clouds of 1 M points
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_frontend -o fe -- python $R/bench.py --workload frontend --steps 3 > $OUT/bench_frontend_trace.log 2>&1
 cd $R
@@ -30,6 +33,9 @@ timeout 600 python bench.py --workload frontend --steps 5 > $OUT/bench_frontend.
 timeout 600 python bench.py --workload series --epochs 4 --points 5000000 > $OUT/bench_series.log 2>&1
 # the loop on two of the reference's own pairs, with the kernel timeline of their last run
 bash tools/real_pair_trace.sh > $OUT/real_pair_timeline.txt 2>&1
+# the 2-rank / CPU-share rehearsals of the shared-target series
+taskset -c 0-3 python bench.py --gpus 2 --single-device --backend gloo --steps 3 --warmup 1 --no-cpu-baseline --no-inner-timing --series-epochs 2 --pairs-in-flight 0 2>/dev/null | tail -1 > $OUT/rehearsal_2ranks_4cpus.json
+taskset -c 0-1 python bench.py --no-cpu-baseline --steps 5 --warmup 2 --pairs-in-flight 0 2>/dev/null | tail -1 > $OUT/taskset_2cpus_bench.json
 # N = 2 rehearsal on this box's one GPU (bench.py starts the ranks itself)
 timeout 600 python bench.py --gpus 2 --single-device --backend gloo --steps 5 --warmup 1 --no-cpu-baseline --no-inner-timing --series-epochs 4 --pairs-in-flight 0 > $OUT/bench_gpus2.log 2>/dev/null
 python tools/summarize_pmc.py $OUT > $OUT/summary.log 2>&1

@@ -12,4 +12,5 @@ cp $S/real_pair_timeline.txt $D/${TAG}_real_pair_timeline.txt
 for f in final:bench_line frontend:bench_frontend_line series:bench_series_line gpus2:bench_line_gpus2_single_device; do
   grep '^{' $S/bench_${f%%:*}.log | tail -1 > $D/${TAG}_${f##*:}.json
 done
+for f in rehearsal_2ranks_4cpus taskset_2cpus_bench; do [ -s $S/$f.json ] && cp $S/$f.json $D/${TAG}_$f.json; done
 ls -la $D | grep $TAG
