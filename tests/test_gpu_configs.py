@@ -358,6 +358,8 @@ def test_loop_parity_on_cliff_like_scenes(ctx, oracle, shape):
 
 
 # ---- the reference's SECOND input set: data/data_synthetic/syntheticPC_no_transformations -----------------------------------
+# (SELF-CONSISTENCY, not parity: the reference holds no result files for this set - the expected values are this repository's own
+#  oracle's, tests/golden/README.md; the parity gate is the 57 files of tests/golden/reference_results)
 _NT = json.load(open(os.path.join(G.GOLD, "no_transformations_expected.json")))["pairs"]
 NT_INPUTS = os.path.join(G.GOLD, "inputs_no_transformations")
 # the reference's own accuracy on the transformed set (largest entries of its TransPara_AbsError.txt: 57.1 mgon, 1.14 mm)
