@@ -405,6 +405,11 @@ PWICP_API int  pwicp_comm_debug_id_file(const char* path, int op, long age_s);
 PWICP_API bool pwicp_series_run_distributed(const char* confile, int startEpoch, int epochNum, int pairMode, float overlapThd,
                                             int rank, int world, int device, const char* id_file);
 
+/* Host threads the library's one pool (host/parallel.h) works with in this process: the CPUs it may really use - affinity mask, cut by
+ * the cgroup CPU quota, divided by $LOCAL_WORLD_SIZE (the ranks of a node share its CPUs) - at most 32, at least 1;
+ * $PWICP_HOST_THREADS overrides.  Fixed at the first use. */
+PWICP_API int pwicp_host_threads(void);
+
 /* A series that is closed leaves its device contexts and front-end work spaces PARKED (one set per device) for the next series of
  * the process on that device: setting them up costs 0.15 - 0.25 s, a third of an 8 x 1 M-point series ($PWICP_SERIES_KEEP=0: off).
  * PiecewiseICP_pair_call parks its context the same way.  This frees both (also done at process exit). */

@@ -834,6 +834,8 @@ PWICP_API int pwicp_series_open(const char* confile, int startEpoch, int epochNu
     return PWICP_OK;
 }
 
+PWICP_API int pwicp_host_threads(void) { return pwhost::host_threads(); }
+
 // frees what closed series have left parked per device (contexts, front-end work spaces): for hosts that are done with series
 PWICP_API void pwicp_series_release_parked(void) { (void)WorkerParking::get().release_all(); }
 

@@ -17,8 +17,8 @@ out = (C.c_ulonglong * 16)()
 L.pwicp_debug_win_stats(out, 1)
 res = pair.run()
 L.pwicp_debug_win_stats(out, 1)
-names = ["waves with a query", "windows that fitted", "  rows (sum)", "  cells (sum)", "  points (sum)", "lanes resolved on the window",
-         "lanes without a candidate", "lanes whose ball left the window", "lanes of waves searching global memory", "lanes outside the grid",
+names = ["blocks with a query", "windows that fitted", "  rows (sum)", "  cells (sum)", "  points (sum)", "lanes resolved on the window",
+         "lanes without a candidate", "lanes whose ball left the window", "lanes of blocks searching global memory", "lanes outside the grid",
          "windows refused: rows", "windows refused: cells", "windows refused: points"]
 print("dense launches %d, dense queries %d" % (res.n_dense_nn_launches, res.n_corr_dense))
 for k, nme in enumerate(names): print("  %-42s %10d" % (nme, out[k]))
