@@ -51,6 +51,8 @@ def run_pairs_sharing_target(series, mine, scan, rank, world, dist, dev):
 
     def exchange():
         try:
+            if dev is not None and dev.type == "cuda":
+                torch.cuda.set_device(dev)                   # (the current device is per thread)
             hdr = torch.tensor([-1, 0], dtype=torch.int32)
             lab = None
             if rank == 0:
