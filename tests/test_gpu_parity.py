@@ -686,3 +686,28 @@ def test_dense_search_against_brute_force(ctx, oracle, scene, far_group):
     if scene == "beyond_coverage":
         assert (np.sqrt(d2) > 0.1).sum() > 2000
     pair.close()
+
+
+@pytest.mark.parametrize("name,env,select", [
+    ("dense search on the LDS window of its block (strips of 16 cells)", {"PWICP_DENSE_WIN": "1", "PWICP_QUERY_ORDER": "16:128"},
+     "dense_search_against_brute or cliff or rockfall or (loop_parity_with_oracle and 200000)"),
+    ("inner-ICP batches of small problems in one workgroup", {"PWICP_ICP_SMALL": "1"},
+     "inner_icp or too_few or test_golden_epoch2_through_gpu or (loop_parity_with_oracle and 20000)"),
+    ("first dense search on the second stream", {"PWICP_DENSE_SIDE_STREAM": "1"},
+     "deterministic or single_iteration_steps or (loop_parity_with_oracle and 200000)"),
+], ids=["dense_win", "icp_small", "side_stream"])
+def test_measured_but_not_default_paths_stay_exact(name, env, select):
+    """Round 5's three measured-and-not-kept designs stay in the library behind switches (profiles/r05_dense_variants.txt,
+    r05_icp_small.txt): each must keep passing the parity tests of the stage it replaces - run here in a process of its
+    own, because the switches are read once per process."""
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"),
+                          os.path.join(root, "tests", "test_gpu_configs.py"), "-m", "gpu", "-x", "-q", "-k",
+                          "(%s) and not measured_but_not_default" % select], capture_output=True, text=True, timeout=1200, env=e, cwd=root)
+    tail = (out.stdout + out.stderr)[-1500:]
+    assert out.returncode == 0, name + ": " + tail
+    assert " passed" in out.stdout and "no tests ran" not in out.stdout, name + ": " + tail
