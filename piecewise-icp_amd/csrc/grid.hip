@@ -358,8 +358,40 @@ __device__ __forceinline__ float dense_far_path(const GridDesc& far, float4 q, f
 #define PW_DENSE_BLOCK 256
 #endif
 constexpr int kDenseBlock = PW_DENSE_BLOCK;     // threads per block of the dense search (a multiple of 64)
+#ifdef PW_DENSE_BLOCKTRACE
+// -DPW_DENSE_BLOCKTRACE (tools/dense_blocktrace.py): start / end (s_memrealtime, 10 ns) and XCD of every block of the last dense launch
+__device__ unsigned long long pw_dense_bt[3 * 8192];
+extern "C" __attribute__((visibility("default"))) int pwicp_debug_dense_blocktrace(unsigned long long* out, int n3) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pw_dense_bt), sizeof(unsigned long long) * (size_t)n3) == hipSuccess ? 0 : -1;
+}
+#endif
+// The cell a query takes its FIRST candidate from (phase A: that cell and its two row neighbours): its own cell - or, for a query
+// outside the level's grid (source points beyond the target's extent: the edge tiles of every pair), the grid cell nearest to it.
+// Any target point is a valid first candidate - the disc scan that follows is exact around the TRUE query position - and it spares
+// such a query the candidate-less general search (shell after shell on the coarse level, 15 - 30 us for the one wave that runs
+// them): round 5's block trace (tools/dense_blocktrace.py) showed the launch waiting for exactly those blocks, the first and the
+// last tiles of the strip order.  PW_DENSE_HOME_CLAMP=0: the query's own cell, inside the grid or not (rounds 2 - 4).
+#ifndef PW_DENSE_HOME_CLAMP
+#define PW_DENSE_HOME_CLAMP 1
+#endif
+__device__ __forceinline__ int dense_home_cell(int c, int n) {
+#if PW_DENSE_HOME_CLAMP
+    return min(max(c, 0), n - 1);
+#else
+    return c;
+#endif
+}
+
+#ifndef PW_DENSE_SGPR
+#define PW_DENSE_SGPR 0
+#endif
+#if PW_DENSE_SGPR > 0
+#define PW_DENSE_SGPR_ATTR __attribute__((amdgpu_num_sgpr(PW_DENSE_SGPR)))
+#else
+#define PW_DENSE_SGPR_ATTR
+#endif
 template <int PERM, bool FARG>
-__global__ void __launch_bounds__(kDenseBlock) k_nn_dense_disc(GridLevel dl, GridDesc far, const float4* __restrict__ pat,
+__global__ void __launch_bounds__(kDenseBlock) PW_DENSE_SGPR_ATTR k_nn_dense_disc(GridLevel dl, GridDesc far, const float4* __restrict__ pat,
                                                           const int* __restrict__ qorder, const int* __restrict__ qpatch,
                                                           const int* __restrict__ stable, int nq,
                                                           float* __restrict__ d2out,
@@ -369,11 +401,18 @@ __global__ void __launch_bounds__(kDenseBlock) k_nn_dense_disc(GridLevel dl, Gri
     __shared__ float4 s_q[kDenseBlock];          // .w carries the candidate d2 of an unresolved query
     __shared__ int s_slot[kDenseBlock];
     __shared__ int s_wcnt[kDenseBlock / 64];
+#ifdef PW_DENSE_BLOCKTRACE
+    if (threadIdx.x == 0 && blockIdx.x < 8192) { pw_dense_bt[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime(); pw_dense_bt[3 * blockIdx.x + 2] = blockIdx.x % kXcds; }
+#endif
     // block b runs on XCD b % 8: the XCDs take the ordered tiles in runs of `sub`.  One contiguous eighth of the list per XCD
     // (round 3) left the kernel waiting for the XCD whose eighth happened to be the expensive one (TA_BUSY max / mean 1.7 over
     // the CUs): 47.2 us -> 41.1 us with runs of four tiles; L2 locality does not show (runs of 1: 41.6, of 64: 44.7).
+    // (Round 5, tools/dense_blocktrace.py: the launch drains for one block lifetime, ~11 us, after its last block has started.  Taking
+    // the runs from both ends of the list alternately, or starting 1 / 4 ... 1 / 16 of the list before its end - so that the cloud's
+    // edge tiles start first - was measured and is not in: 31.5 / 30.3 - 31.1 us against 30.3.)
     const int xr = (int)(blockIdx.x / kXcds);
-    const int tile = chunk > 0 ? (xr / sub) * (kXcds * sub) + (int)(blockIdx.x % kXcds) * sub + xr % sub : (int)blockIdx.x;
+    const int run = xr / sub;
+    const int tile = chunk > 0 ? run * (kXcds * sub) + (int)(blockIdx.x % kXcds) * sub + xr % sub : (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = tile * kDenseBlock + tid;
     unsigned cnt = 0;
@@ -394,7 +433,8 @@ __global__ void __launch_bounds__(kDenseBlock) k_nn_dense_disc(GridLevel dl, Gri
         if (patq) {
             q = patq[i];
             ux = PERM == 0 ? q.x : (PERM == 1 ? q.y : q.z); uy = PERM == 0 ? q.y : (PERM == 1 ? q.z : q.x); uz = PERM == 0 ? q.z : (PERM == 1 ? q.x : q.y);
-            cx = cell_of(ux, dl.ox, dl.inv_h); cy = cell_of(uy, dl.oy, dl.inv_hy); cz = cell_of(uz, dl.oz, dl.inv_hz);
+            cx = dense_home_cell(cell_of(ux, dl.ox, dl.inv_h), dl.nx); cy = dense_home_cell(cell_of(uy, dl.oy, dl.inv_hy), dl.ny);
+            cz = dense_home_cell(cell_of(uz, dl.oz, dl.inv_hz), dl.nz);
             row_range(dl, cy, cz, cx - 1, cx + 1, loA, hiA);
             st = stable[pa];
         } else {
@@ -406,7 +446,8 @@ __global__ void __launch_bounds__(kDenseBlock) k_nn_dense_disc(GridLevel dl, Gri
                 ux = PERM == 0 ? q.x : (PERM == 1 ? q.y : q.z);       // the query in the level's axis order
                 uy = PERM == 0 ? q.y : (PERM == 1 ? q.z : q.x);
                 uz = PERM == 0 ? q.z : (PERM == 1 ? q.x : q.y);
-                cx = cell_of(ux, dl.ox, dl.inv_h); cy = cell_of(uy, dl.oy, dl.inv_hy); cz = cell_of(uz, dl.oz, dl.inv_hz);
+                cx = dense_home_cell(cell_of(ux, dl.ox, dl.inv_h), dl.nx); cy = dense_home_cell(cell_of(uy, dl.oy, dl.inv_hy), dl.ny);
+                cz = dense_home_cell(cell_of(uz, dl.oz, dl.inv_hz), dl.nz);
                 row_range(dl, cy, cz, cx - 1, cx + 1, loA, hiA);
             }
             scan_d2_level<PERM>(dl, loA, hiA, ux, uy, uz, best);
@@ -463,6 +504,10 @@ __global__ void __launch_bounds__(kDenseBlock) k_nn_dense_disc(GridLevel dl, Gri
     }
     add_examined(examined, cnt);
     if (fs.scratch) fs_pass0_epilogue(s_hist, fs);
+#ifdef PW_DENSE_BLOCKTRACE
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < 8192) pw_dense_bt[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---- the same search with the candidates of a BLOCK staged in LDS (round 5; levels of COLUMNS only) ---------------------------
