@@ -360,9 +360,9 @@ __device__ __forceinline__ float dense_far_path(const GridDesc& far, float4 q, f
 constexpr int kDenseBlock = PW_DENSE_BLOCK;     // threads per block of the dense search (a multiple of 64)
 #ifdef PW_DENSE_BLOCKTRACE
 // -DPW_DENSE_BLOCKTRACE (tools/dense_blocktrace.py): start / end (s_memrealtime, 10 ns) and XCD of every block of the last dense launch
-__device__ unsigned long long pw_dense_bt[3 * 8192];
+__device__ unsigned long long pw_dense_bt[8 * 8192];       // per block: start, end, xcd, after the query, after phase A, after the ball, after the far queries, -
 extern "C" __attribute__((visibility("default"))) int pwicp_debug_dense_blocktrace(unsigned long long* out, int n3) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pw_dense_bt), sizeof(unsigned long long) * (size_t)n3) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pw_dense_bt), sizeof(unsigned long long) * (size_t)n3) == hipSuccess ? 0 : -1;   // (n3 <= 8 * 8192)
 }
 #endif
 // The cell a query takes its FIRST candidate from (phase A: that cell and its two row neighbours): its own cell - or, for a query
@@ -402,7 +402,10 @@ __global__ void __launch_bounds__(kDenseBlock) PW_DENSE_SGPR_ATTR k_nn_dense_dis
     __shared__ int s_slot[kDenseBlock];
     __shared__ int s_wcnt[kDenseBlock / 64];
 #ifdef PW_DENSE_BLOCKTRACE
-    if (threadIdx.x == 0 && blockIdx.x < 8192) { pw_dense_bt[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime(); pw_dense_bt[3 * blockIdx.x + 2] = blockIdx.x % kXcds; }
+    if (threadIdx.x == 0 && blockIdx.x < 8192) { pw_dense_bt[8 * blockIdx.x] = __builtin_amdgcn_s_memrealtime(); pw_dense_bt[8 * blockIdx.x + 2] = blockIdx.x % kXcds; }
+#define PW_BT(k_) do { if (threadIdx.x == 0 && blockIdx.x < 8192) pw_dense_bt[8 * blockIdx.x + (k_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PW_BT(k_) do { } while (0)
 #endif
     // block b runs on XCD b % 8: the XCDs take the ordered tiles in runs of `sub`.  One contiguous eighth of the list per XCD
     // (round 3) left the kernel waiting for the XCD whose eighth happened to be the expensive one (TA_BUSY max / mean 1.7 over
@@ -450,7 +453,9 @@ __global__ void __launch_bounds__(kDenseBlock) PW_DENSE_SGPR_ATTR k_nn_dense_dis
                 cz = dense_home_cell(cell_of(uz, dl.oz, dl.inv_hz), dl.nz);
                 row_range(dl, cy, cz, cx - 1, cx + 1, loA, hiA);
             }
+            PW_BT(3);
             scan_d2_level<PERM>(dl, loA, hiA, ux, uy, uz, best);
+            PW_BT(4);
             cnt += (unsigned)(hiA - loA);
             const float rho = fast_sqrt_up(best) + 2.0f * dl.slack;
             if (best < INFINITY && rho <= kMaxRhoCells * dl.h) {
@@ -467,11 +472,13 @@ __global__ void __launch_bounds__(kDenseBlock) PW_DENSE_SGPR_ATTR k_nn_dense_dis
             d2out[i] = __uint_as_float(kSentinel);
         }
     }
+    PW_BT(5);
     // far queries: compacted inside the block so that their longer scans run on packed waves
     const unsigned long long mask = __ballot(unresolved);
     const int before = __popcll(mask & ((1ull << lane) - 1ull));
     if (lane == 0) s_wcnt[wave] = __popcll(mask);
     __syncthreads();
+    PW_BT(6);
     int base = 0, total = 0;
 #pragma unroll
     for (int w = 0; w < kDenseBlock / 64; ++w) {
@@ -502,11 +509,12 @@ __global__ void __launch_bounds__(kDenseBlock) PW_DENSE_SGPR_ATTR k_nn_dense_dis
         d2out[s_slot[tid]] = d;
         if (fs.scratch) atomicAdd(&s_hist[__float_as_uint(d) >> 21], 1u);
     }
+    PW_BT(7);
     add_examined(examined, cnt);
     if (fs.scratch) fs_pass0_epilogue(s_hist, fs);
 #ifdef PW_DENSE_BLOCKTRACE
     __syncthreads();
-    if (threadIdx.x == 0 && blockIdx.x < 8192) pw_dense_bt[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && blockIdx.x < 8192) pw_dense_bt[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 

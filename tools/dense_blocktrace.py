@@ -15,9 +15,9 @@ pair = P.Pair(ctx, t, l1, n1, s, l2, n2, P.Params(r, r, 10 * r, 10 * r, 1, 10 * 
 for _ in range(3):
     pair.reset(); res = pair.run()
 L = P.load_library()
-buf = (C.c_ulonglong * (3 * 8192))()
-L.pwicp_debug_dense_blocktrace(buf, 3 * 8192)
-a = np.array(buf, dtype=np.uint64).astype(np.int64).reshape(-1, 3)
+buf = (C.c_ulonglong * (8 * 8192))()
+L.pwicp_debug_dense_blocktrace(buf, 8 * 8192)
+a = np.array(buf, dtype=np.uint64).astype(np.int64).reshape(-1, 8)
 a = a[(a[:, 0] > 0) & (a[:, 1] >= a[:, 0])]
 a = a[a[:, 0] > a[:, 0].max() - 100000]              # the LAST launch only (entries of earlier, larger launches stay in the buffer)
 t0 = a[:, 0].min()
@@ -30,5 +30,13 @@ print("lifetime of a block: mean %.1f us, p10 %.1f, p50 %.1f, p90 %.1f, p99 %.1f
 for lo in range(0, min(int(en.max()) + 1, 400), 2):
     live = int(((st <= lo) & (en > lo)).sum())
     print("  t = %4.0f us: %5d blocks resident" % (lo, live))
+# phases of a block as its first thread sees them (stamps 3 .. 7: query there, own row scanned, ball scanned, block's unresolved counted, far queries done)
+ph = a[:, 3:8].astype(np.float64)
+ok = (ph >= a[:, 0:1]).all(axis=1) & (ph <= a[:, 1:2]).all(axis=1)
+if ok.any():
+    rel = (ph[ok] - a[ok, 0:1]) / 100.0
+    names = ["query + own row words there", "own row scanned (phase A)", "ball scanned (phase B)", "barrier: unresolved counted", "far queries done"]
+    print("phases of a block, thread 0 (mean us after the block's start; %d blocks whose thread 0 had a stable query): " % int(ok.sum()) +
+          " | ".join("%s +%.2f" % (nm, rel[:, k].mean()) for k, nm in enumerate(names)) + " | end +%.2f" % life[ok].mean())
 late = np.argsort(-en)[:10]
 print("the ten blocks that end last: " + ", ".join("#%d (xcd %d) %.1f -> %.1f" % (i, int(a[i, 2]), st[i], en[i]) for i in late))
