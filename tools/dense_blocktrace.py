@@ -8,10 +8,19 @@ import pwicp_amd as P
 from pwicp_amd import synth
 n = int(os.environ.get("DV_POINTS", "1000000")); r = 0.005
 ctx = P.Context(0)
-t, _ = synth.make_tile(n, r); s, _ = synth.make_source(n, r, epoch=1); c = t.mean(0)
-t = (t - c).astype(np.float32); s = (s - c).astype(np.float32)
-l1, n1 = synth.grid_labels(t, 10 * r); l2, n2 = synth.grid_labels(s, 10 * r)
-pair = P.Pair(ctx, t, l1, n1, s, l2, n2, P.Params(r, r, 10 * r, 10 * r, 1, 10 * r, 0.8 * r))
+if len(sys.argv) > 2 and sys.argv[1] == "real":          # python tools/dense_blocktrace.py real <epoch>: one of the reference's own pairs
+    from pwicp_amd.pcd import read_pcd
+    g = os.path.join(ROOT, "tests", "golden", "inputs")
+    t = ctx.preprocess(read_pcd(os.path.join(g, "Epoch_001.pcd")), 0.005, 14, 5.0)
+    s = ctx.preprocess(read_pcd(os.path.join(g, "Epoch_%03d.pcd" % int(sys.argv[2]))), 0.005, 14, 5.0)
+    c = t[:, :3].mean(0); t[:, :3] -= c; s[:, :3] -= c
+    l1, n1 = ctx.frontend_segment(t, 0.05, 45, 0.005); l2, n2 = ctx.frontend_segment(s, 0.05, 45, 0.005)
+    pair = P.Pair(ctx, t, l1, n1, s, l2, n2, P.Params(0.005, 0.005, 0.05, 0.05, 1, 0.05, 0.004))
+else:
+    t, _ = synth.make_tile(n, r); s, _ = synth.make_source(n, r, epoch=1); c = t.mean(0)
+    t = (t - c).astype(np.float32); s = (s - c).astype(np.float32)
+    l1, n1 = synth.grid_labels(t, 10 * r); l2, n2 = synth.grid_labels(s, 10 * r)
+    pair = P.Pair(ctx, t, l1, n1, s, l2, n2, P.Params(r, r, 10 * r, 10 * r, 1, 10 * r, 0.8 * r))
 for _ in range(3):
     pair.reset(); res = pair.run()
 L = P.load_library()
