@@ -776,6 +776,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
     // percentile selection riding on the launches that follow (select_dev.h): pass 0 in the dense kernel, pass 1 beside the
     // transform, pass 2 beside the next front (or on its own when no front follows).  `rank_dev`: the rank of the percentile is
     // derived on the device from the slot's stable-point count (speculative enqueue, before the host knows the count).
+    constexpr long long kDenseSmallBlock = 256;       // (threads per block of the dense search, grid.hip: kDenseBlock)
     unsigned sel_seq = 0;
     // ahead_of_icp (out): only the search is enqueued and *ahead_of_icp describes the selection whose passes 1 / 2 the caller puts
     // on the ICP launches that follow (first iteration: the search does not depend on the ICP, and the percentile then arrives
@@ -793,7 +794,13 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         // search handles faster inside its own blocks): their far queries go to a launch that puts eight lanes on each (grid.hip).
         // A later search of the run: when the percentile of the one before was still more than 1.5 cells of the small-cell level.
         static const int far_group_env = getenv("PWICP_DENSE_FAR_GROUP") ? atoi(getenv("PWICP_DENSE_FAR_GROUP")) : -1;
-        const bool far_group_now = far_group_env >= 0 ? far_group_env != 0 : (res->n_dense_nn_launches == 0 ? pr->dense_far0 > 0.3 : (pr->dense_lv && last_d75 > 1.5 * (double)pr->dense_lv->h));
+        // A SMALL search (round 5: at most four blocks per CU - the reference's own scans are < 2) always hands its far queries on: the
+        // chip is nearly empty, and a block's far queries on one lane each of its first wave are half of its life (block trace:
+        // Epoch_002's second search, far queries done +27.9 us of a 28.9 us block).  Epoch_016 / 019: loop 0.98 / 0.99 -> 0.78 / 0.83 ms,
+        // the other scans +-1 %; the 1 M-point pair (3 700 blocks) keeps the rule above (47 instead of 32 us with the far launch).
+        static const bool far_small_env = !(getenv("PWICP_DENSE_FAR_SMALL") && atoi(getenv("PWICP_DENSE_FAR_SMALL")) == 0);      // (0: round 4's rule)
+        const bool small_search = far_small_env && pr->dense_lv && (long long)pr->P2.tot <= 4ll * kDenseSmallBlock * ctx->n_cu;
+        const bool far_group_now = far_group_env >= 0 ? far_group_env != 0 : (small_search || (res->n_dense_nn_launches == 0 ? pr->dense_far0 > 0.3 : (pr->dense_lv && last_d75 > 1.5 * (double)pr->dense_lv->h)));
         FusedSelect fs{};
         if (fused) {
             int kk = (int)((float)nsp * 0.75f);         // C.cpp:177
