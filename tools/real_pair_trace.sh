@@ -4,7 +4,7 @@ for kv in "$@"; do export "$kv"; done
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/real_trace; mkdir -p $OUT
 : > $OUT/timeline.txt
-for E in 2 12; do
+for E in ${REAL_EPOCHS:-2 12}; do
   python tools/real_pair_loop.py $E 30 | tee -a $OUT/timeline.txt
   rm -rf $OUT/e$E
   (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/e$E -o t -- python $GRAFT_REPO_ROOT/tools/real_pair_loop.py $E 6 > $OUT/log$E.txt 2>&1)
