@@ -924,6 +924,10 @@ __global__ void k_fus_sweep_end(FusState s, const int* dq, const int* ndq, const
 
 // Batched sweeps (<= 1024 slots): what k_fus_retract, k_fus_claim and k_fus_dirty0 do, as the phases of ONE block - between
 // dependent launches the device idles ~5 us, which is what a sweep over a few hundred centres is made of.
+// counters of a batch of sweeps: all zero but the number of slots (a kernel argument instead of a 64-byte copy from pageable host memory)
+__global__ void k_fus_batch_init(int* __restrict__ ctr, int nW) {
+    if (threadIdx.x < 16) ctr[threadIdx.x] = threadIdx.x == 4 ? nW : 0;
+}
 __global__ void __launch_bounds__(1024) k_fus_post(FusState s, int* dq, int* ndq) {
     if (*s.stop) return;
     const int nW = *s.nW_dev;
@@ -1029,7 +1033,7 @@ __global__ void k_fus_min_metric(const FePt* __restrict__ P, const int* __restri
         for (int u = 0; u < 8; ++u) pj[u] = P[j[u]];
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (e0 + u < k) atomicAdd(&rev_count[j[u]], 1);
+            if (rev_count && e0 + u < k) atomicAdd(&rev_count[j[u]], 1);
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if (j[u] != i) d = fmin(d, sv_metric(me, pj[u], res));
@@ -1178,8 +1182,8 @@ __global__ void k_fus_compact(const int* __restrict__ cen, int nc, const int* __
 // exactly as the reference does (unit weights; sums divided by the neighbour count).  The smallest eigenvector is taken
 // on the host (pwhost::fe_normals_from_scatter): it needs pow / acos / cos, whose last bit differs between libm and the
 // device library, and a different bit there can move a label.
-__global__ void k_fe_scatter(const float4* __restrict__ cloud, const int* __restrict__ nb, int k, int n, double* __restrict__ S6) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_fe_scatter(const float4* __restrict__ cloud, const int* __restrict__ nb, int k, int i0, int n, double* __restrict__ S6) {
+    const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;       // (points i0 .. n - 1 of the cloud: the sums come down in pieces)
     if (i >= n) return;
     const int* row = nb + (size_t)i * k;
     double m0 = 0, m1 = 0, m2 = 0, count = 0;
@@ -1218,12 +1222,14 @@ __global__ void k_fe_scatter(const float4* __restrict__ cloud, const int* __rest
 }
 
 // number of occupied cells of edge `resolution` (grid_sample.h:30-75): distinct cell keys through an open-addressing table
-__global__ void k_fe_count_cells(const FePt* __restrict__ P, int n, double mn0, double mn1, double mn2, double resolution, int s1, int s2,
+// (from the float cloud: its coordinates as doubles are FePt's, k_fe_assemble - the count does not wait for the normals)
+__global__ void k_fe_count_cells(const float4* __restrict__ cloud, int n, double mn0, double mn1, double mn2, double resolution, int s1, int s2,
                                  int s3, unsigned long long* __restrict__ table, unsigned long long mask, int* __restrict__ count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool fresh = false;
     if (i < n) {
-        int x = (int)((P[i].x - mn0) / resolution), y = (int)((P[i].y - mn1) / resolution), z = (int)((P[i].z - mn2) / resolution);
+        const float4 v = cloud[i];
+        int x = (int)(((double)v.x - mn0) / resolution), y = (int)(((double)v.y - mn1) / resolution), z = (int)(((double)v.z - mn2) / resolution);
         x = min(max(x, 0), s1 - 1); y = min(max(y, 0), s2 - 1); z = min(max(z, 0), s3 - 1);
         const unsigned long long key = ((unsigned long long)(unsigned)x << 42) ^ ((unsigned long long)(unsigned)y << 21) ^ (unsigned long long)(unsigned)z;
         unsigned long long h = (key * 0x9E3779B97F4A7C15ull) >> 20 & mask;
@@ -1274,6 +1280,10 @@ struct FeWorkspace {
     DevBuf<unsigned char> tsort;
     double bb_mn[3] = {0, 0, 0}, bb_mx[3] = {0, 0, 0};      // bounding box of the cloud (set by the driver of the pipeline)
     bool bb_set = false;
+    static constexpr int kPieces = 8;
+    hipEvent_t ev_down[kPieces] = {};   // piece c of the scatter sums is in host memory (the stream goes on with work that needs no normals)
+    bool rev0_ready = false;            // the first round's reverse index (and k_fus_first_round's arrays) stand for a cloud of
+    int rev0_n = 0, rev0_k = 0;         // rev0_n points, rev0_k neighbours: fusion_prepare_first_round ran ahead of the normals
     int sa_factor = 3;                  // list arena = sa_factor * n * k entries (doubled, once, when a round overflows it)
     bool sa_overflow = false;           // set by fusion_device when it gave up because of the arena
     FeWorkspace() = default;
@@ -1284,6 +1294,8 @@ struct FeWorkspace {
         if (hN) (void)hipHostFree(hN);
         if (h_ctr) (void)hipHostFree(h_ctr);
         if (mail_h) (void)hipHostFree(mail_h);
+        for (hipEvent_t e : ev_down)
+            if (e) (void)hipEventDestroy(e);
     }
     hipError_t host_reserve(size_t n) {
         if (!h_ctr) {
@@ -1324,24 +1336,31 @@ FeWorkspace* workspace_of(pwicp_context* ctx) {
 // through a mailbox in pinned host-coherent memory instead, as the registration loop's hand-overs do (common.h: mail_store):
 // a one-wave launch behind the producers copies the words and then a sequence number, the host spins on that word.
 // PWICP_FE_MAILBOX=0: copy + synchronise.
-__global__ void __launch_bounds__(64) k_fe_mail(const unsigned* __restrict__ src, int n, unsigned* __restrict__ dst, unsigned seq) {
+// (clear / n_clear: words zeroed once the source words are read - the counters of a fusion sweep are re-armed for the next one by the
+// launch that reads them, not by a hipMemsetAsync of its own in front of every sweep)
+__global__ void __launch_bounds__(64) k_fe_mail(const unsigned* src, int n, unsigned* __restrict__ dst, unsigned seq, unsigned* clear, int n_clear) {
     const int t = threadIdx.x;
-    if (t < n) mail_store(&dst[t], src[t]);
+    const unsigned word = t < n ? src[t] : 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int u = t; u < n_clear; u += 64) clear[u] = 0u;
+    if (t < n) mail_store(&dst[t], word);
     mail_drain();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
     if (t == 0) mail_publish(&dst[16], seq);
 }
 
-int fe_read_words(pwicp_context* ctx, FeWorkspace& ws, const void* d_src, int n_words, void* h_out) {
+int fe_read_words(pwicp_context* ctx, FeWorkspace& ws, const void* d_src, int n_words, void* h_out, void* d_clear = nullptr, int n_clear = 0) {
     static const bool use_mail = !(getenv("PWICP_FE_MAILBOX") && atoi(getenv("PWICP_FE_MAILBOX")) == 0);
     if (!use_mail || !ws.mail_h || n_words > 16) {
         HIPCHK(ctx, hipMemcpyAsync(h_out, d_src, sizeof(unsigned) * (size_t)n_words, hipMemcpyDeviceToHost, ctx->stream));
+        if (n_clear > 0) HIPCHK(ctx, hipMemsetAsync(d_clear, 0, sizeof(unsigned) * (size_t)n_clear, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         return PWICP_OK;
     }
     const unsigned seq = ++ws.mail_seq;
-    hipLaunchKernelGGL(k_fe_mail, dim3(1), dim3(64), 0, ctx->stream, (const unsigned*)d_src, n_words, ws.mail_d, seq);
+    hipLaunchKernelGGL(k_fe_mail, dim3(1), dim3(64), 0, ctx->stream, (const unsigned*)d_src, n_words, ws.mail_d, seq, (unsigned*)d_clear, n_clear);
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
     while (__atomic_load_n(&ws.mail_h[16], __ATOMIC_ACQUIRE) != seq) {
@@ -1524,6 +1543,29 @@ int refine_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     return PWICP_OK;
 }
 
+// What the first round needs of the k-NN graph alone - its roots, sizes and base lists (k_fus_first_round) and the reverse index of
+// those lists (45 M entries at 1 M points: ~2 ms of atomics and scattered stores) - enqueued by the pipeline's driver BEHIND the
+// download of the scatter sums: it runs while the host does the eigen step of the normals and the stream would otherwise idle.
+int fusion_prepare_first_round(pwicp_context* ctx, const int* d_nb, int k, int n) {
+    hipStream_t st = ctx->stream;
+    FeWorkspace& ws = *workspace_of(ctx);
+    ws.rev0_ready = false;
+    if ((long long)n * k > (long long)INT_MAX - 64 || n < 1) return PWICP_OK;
+    const size_t N = (size_t)n;
+    for (DevBuf<int>* b : {&ws.root0, &ws.s0, &ws.lenA, &ws.cenA, &ws.cursor}) HIPCHK(ctx, b->reserve(N));
+    HIPCHK(ctx, ws.revoff.reserve(N + 1));
+    HIPCHK(ctx, ws.offA.reserve(N));
+    HIPCHK(ctx, ws.revown.reserve(N * (size_t)k));
+    HIPCHK(ctx, hipMemsetAsync(ws.revoff.p, 0, sizeof(int) * (N + 1), st));
+    hipLaunchKernelGGL(k_fus_first_round, grid1(n), dim3(256), 0, st, n, k, ws.root0.p, ws.s0.p, ws.lenA.p, ws.offA.p, ws.cenA.p);
+    hipLaunchKernelGGL(k_fus_reverse<0>, grid1(n), dim3(256), 0, st, ws.cenA.p, n, ws.root0.p, ws.lenA.p, ws.offA.p, d_nb, ws.revoff.p, (int*)nullptr);
+    PWCHK(pw_exclusive_scan(ctx, ws.revoff.p, (long long)n + 1, &ws.tmp));
+    HIPCHK(ctx, hipMemcpyAsync(ws.cursor.p, ws.revoff.p, sizeof(int) * N, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_fus_reverse<1>, grid1(n), dim3(256), 0, st, ws.cenA.p, n, ws.root0.p, ws.lenA.p, ws.offA.p, d_nb, ws.cursor.p, ws.revown.p);
+    ws.rev0_ready = true; ws.rev0_n = n; ws.rev0_k = k;
+    return PWICP_OK;
+}
+
 // Fusion on the device: d_lab[p] = root point of p, *d_roots = the roots in ascending order.  *gave_up: a search queue or
 // the list arena overflowed (the caller falls back to the host pass; nothing else is affected).
 int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, int n, double res, int n_sv_target, int* d_lab,
@@ -1532,13 +1574,17 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     const bool trace = getenv("PWICP_TRACE") != nullptr;
     *gave_up = false;
     FeWorkspace& ws = *workspace_of(ctx);
+    // (the first round's arrays and reverse index may stand already: fusion_prepare_first_round; a second call - the retry with a
+    // larger arena - builds them here again)
+    const bool rev0 = ws.rev0_ready && ws.rev0_n == n && ws.rev0_k == k;
+    ws.rev0_ready = false;
     // lambda0 (:91-102)
     double lambda;
     {
         HIPCHK(ctx, ws.dmin.reserve((size_t)n));
         HIPCHK(ctx, ws.revoff.reserve((size_t)n + 1));
-        HIPCHK(ctx, hipMemsetAsync(ws.revoff.p, 0, sizeof(int) * ((size_t)n + 1), st));
-        hipLaunchKernelGGL(k_fus_min_metric, grid1(n), dim3(256), 0, st, dP, d_nb, k, n, res, ws.dmin.p, ws.revoff.p);
+        if (!rev0) HIPCHK(ctx, hipMemsetAsync(ws.revoff.p, 0, sizeof(int) * ((size_t)n + 1), st));
+        hipLaunchKernelGGL(k_fus_min_metric, grid1(n), dim3(256), 0, st, dP, d_nb, k, n, res, ws.dmin.p, rev0 ? (int*)nullptr : ws.revoff.p);
         // median = the value of rank n / 2 (what std::nth_element(v.begin() + v.size() / 2) leaves there)
         HIPCHK(ctx, ws.sel_state.reserve(4));
         HIPCHK(ctx, ws.sel_hist.reserve(256));
@@ -1572,7 +1618,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     const unsigned long long sa_cap = (unsigned long long)ws.sa_factor * (unsigned long long)n * (unsigned long long)k;
     ws.sa_overflow = false;
     HIPCHK(ctx, ws.sa.reserve((size_t)sa_cap));
-    hipLaunchKernelGGL(k_fus_first_round, grid1(n), dim3(256), 0, st, n, k, ws.root0.p, ws.s0.p, ws.lenA.p, ws.offA.p, ws.cenA.p);
+    if (!rev0) hipLaunchKernelGGL(k_fus_first_round, grid1(n), dim3(256), 0, st, n, k, ws.root0.p, ws.s0.p, ws.lenA.p, ws.offA.p, ws.cenA.p);
     int* len0 = ws.lenA.p; int* len1 = ws.lenB.p;
     long long* off0 = ws.offA.p; long long* off1 = ws.offB.p;
     int* cen = ws.cenA.p; int* cen1 = ws.cenB.p;
@@ -1620,6 +1666,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
         hipLaunchKernelGGL(k_fus_reset, grid1(n), dim3(256), 0, st, n, ws.s0.p, ws.ab.p, ws.ab_prev.p, ws.rec_sz.p, ws.rec_ran.p, ws.rec_absn.p, ws.rec_adjn.p,
                            ws.rec_ptr.p, ws.wake.p, ws.dflag.p, ws.cflag.p, ws.dtmin.p, ws.slot_of.p);
         // reverse index of the base lists
+        if (!(rev0 && round == 0)) {
         if (!rev_counted) {                        // (from the second round on k_fus_next_lists has counted the entries per root)
             HIPCHK(ctx, hipMemsetAsync(ws.revoff.p, 0, sizeof(int) * (N + 1), st));
             hipLaunchKernelGGL(k_fus_reverse<0>, grid1(nc), dim3(256), 0, st, cen, nc, ws.root0.p, len0, off0, arena0, ws.revoff.p, (int*)nullptr);
@@ -1631,6 +1678,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
         HIPCHK(ctx, hipStreamSynchronize(st));
         HIPCHK(ctx, ws.revown.reserve((size_t)std::max(n_entries, 1)));
         hipLaunchKernelGGL(k_fus_reverse<1>, grid1(nc), dim3(256), 0, st, cen, nc, ws.root0.p, len0, off0, arena0, ws.cursor.p, ws.revown.p);
+        }
         HIPCHK(ctx, hipMemsetAsync(ws.big.p, 0, sizeof(unsigned long long) * 16 * (kFusArenas + 1), st));
         s.wake_all_above = std::max(nc / wake_all_div, 64);
         s.lambda = lambda; s.len0 = len0; s.off0 = off0; s.arena0 = arena0; s.revown = ws.revown.p;
@@ -1677,8 +1725,10 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
             }
         }
         int* W = ws.Wa.p; int* Wn = ws.Wb.p;
-        HIPCHK(ctx, hipMemcpyAsync(W, cen_full, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
-        bool w_is_full = true;            // W holds cen_full (all centres, tile order, first colour first)
+        // what a sweep runs: the list in W, or - without a copy of it - all centres in tile order / in plain order (the certificate)
+        const int* Wrun = cen_full;
+        bool w_is_full = true;            // the sweep takes cen_full (all centres, tile order, first colour first)
+        bool ctr_clean = false;           // the sweep's counters are zero (re-armed by the read-back of the sweep before)
         int nW = nc, sweeps = 0;
         long long runs = 0;
         // The round ends with a CERTIFICATE: one sweep over all centres, every one reading the standing state only, that
@@ -1687,10 +1737,11 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
         bool certified = false, certify = false;
         while (!certified) {
             if (nW == 0) {
-                HIPCHK(ctx, hipMemcpyAsync(W, cen, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
+                Wrun = cen;
                 nW = nc;
                 w_is_full = false;
                 certify = true;
+                ctr_clean = false;
                 // absorbers from scratch: the smallest centre whose standing outcome absorbs the node
                 hipLaunchKernelGGL(k_fill<int>, grid1(n), dim3(256), 0, st, ws.ab.p, (long long)n, kNone);
                 hipLaunchKernelGGL(k_fus_claim_all, grid1(nc), dim3(256), 0, st, s, cen, nc);
@@ -1705,12 +1756,16 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
                 *gave_up = true;
                 return PWICP_OK;
             }
-            s.W = W; s.Wnext = Wn;
+            s.W = Wrun; s.Wnext = Wn;
             if (!certify && nW <= batch_cap && batch_sweeps > 1) {
                 // short work list: batch_sweeps sweeps per read-back (a sweep of a few hundred centres is ~50 us of kernels; the
                 // read-back, the wake-up of the host thread and the next enqueue cost as much again)
-                const int init[16] = {0, 0, 0, 0, nW, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                HIPCHK(ctx, hipMemcpyAsync(ws.ctr.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+                if (Wrun != W) {                      // (k_fus_advance writes the list it is given: a tiny round's centres, copied)
+                    HIPCHK(ctx, hipMemcpyAsync(W, Wrun, sizeof(int) * (size_t)nW, hipMemcpyDeviceToDevice, st));
+                    Wrun = W; s.W = W;
+                }
+                if (!ctr_clean) HIPCHK(ctx, hipMemsetAsync(ws.ctr.p + 16, 0, sizeof(int) * 16 * 32, st));
+                hipLaunchKernelGGL(k_fus_batch_init, dim3(1), dim3(64), 0, st, ws.ctr.p, nW);
                 s.nW_dev = ws.ctr.p + 4; s.stop = ws.ctr.p + 5;
                 s.changed = nullptr;
                 for (int b = 0; b < batch_sweeps; ++b) {
@@ -1722,7 +1777,8 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
                                        (const int*)ws.dq2.p);
                 }
                 s.nW_dev = nullptr; s.stop = nullptr;
-                PWCHK(fe_read_words(ctx, ws, ws.ctr.p, 16, h_ctr));
+                PWCHK(fe_read_words(ctx, ws, ws.ctr.p, 16, h_ctr, ws.ctr.p, 16));
+                ctr_clean = true;
                 sweeps += h_ctr[6] - 1;
                 runs += h_ctr[7];
                 if (h_ctr[8] || h_ctr[9]) {
@@ -1731,13 +1787,14 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
                     *gave_up = true;
                     return PWICP_OK;
                 }
-                if (!h_ctr[5]) { nW = h_ctr[4]; w_is_full = false; continue; }      // the batch ran through (W holds the next list, possibly empty)
+                if (!h_ctr[5]) { nW = h_ctr[4]; Wrun = W; w_is_full = false; continue; }      // the batch ran through (W holds the next list, possibly empty)
                 if (h_ctr[3] || h_ctr[10] || h_ctr[11]) {                // everybody runs again ([3]: a search outgrew the small queue)
-                    HIPCHK(ctx, hipMemcpyAsync(W, cen_full, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
+                    Wrun = cen_full;
                     nW = nc;
                     w_is_full = true;
                 } else {                                                 // the next list outgrew the batch: back to single sweeps
                     std::swap(W, Wn);
+                    Wrun = W;
                     nW = h_ctr[0];
                     w_is_full = false;
                 }
@@ -1748,7 +1805,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
             const auto t_sweep = std::chrono::steady_clock::now();
             const int nW_sweep = nW;
             const bool cert_sweep = certify;
-            HIPCHK(ctx, hipMemsetAsync(ws.ctr.p, 0, sizeof(int) * (16 + 16 * 32), st));
+            if (!ctr_clean) HIPCHK(ctx, hipMemsetAsync(ws.ctr.p, 0, sizeof(int) * (16 + 16 * 32), st));
             s.changed = certify ? nullptr : ws.ctr.p + 16;
             const int chunk = certify ? 1 : std::max(1, std::min(std::min(nW / chunk_div, kFusChunk), gs_chunk));
             // A sweep over ALL centres in tile order runs colour by colour: the tiles of one colour (no two of them neighbours), their
@@ -1787,7 +1844,8 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
             hipLaunchKernelGGL(k_fus_wake, dim3((unsigned)std::min(1024, std::max(32, nW / 64))), dim3(256), 0, st, s, ws.dq.p, ndq, ws.dq2.p, ndq + 1);
             hipLaunchKernelGGL(k_fus_sweep_end, dim3((unsigned)std::min(256, std::max(8, nW / 256))), dim3(256), 0, st, s, ws.dq.p, ndq, ws.dq2.p,
                                ndq + 1);
-            PWCHK(fe_read_words(ctx, ws, ws.ctr.p, 16, h_ctr));
+            PWCHK(fe_read_words(ctx, ws, ws.ctr.p, 16, h_ctr, ws.ctr.p, 16 + 16 * 32));
+            ctr_clean = true;
             if (trace && trace_sweeps)
                 fprintf(stderr, "      sweep %d: %d centres%s, %d changed nodes, %.3f ms\n", sweeps, nW_sweep, cert_sweep ? " (certificate)" : "", h_ctr[1],
                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_sweep).count());
@@ -1803,11 +1861,12 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
                 // (the changed nodes may not have been listed at all - k_fus_dirty0 - so their absorbers of this sweep become the
                 // previous ones here, all of them at once, and no flag of a listed node is left standing: none was set)
                 if (h_ctr[11]) HIPCHK(ctx, hipMemcpyAsync(ws.ab_prev.p, ws.ab.p, sizeof(int) * N, hipMemcpyDeviceToDevice, st));
-                HIPCHK(ctx, hipMemcpyAsync(W, cen_full, sizeof(int) * (size_t)nc, hipMemcpyDeviceToDevice, st));
+                Wrun = cen_full;
                 nW = nc;
                 w_is_full = true;
             } else {
                 std::swap(W, Wn);
+                Wrun = W;
                 nW = h_ctr[0];
                 w_is_full = false;
             }
@@ -1999,22 +2058,59 @@ int pw_frontend_segment_device(pwicp_context* ctx, const float* cloud_xyz4, int 
     HIPCHK(ctx, dS.reserve((size_t)n * 6));
     HIPCHK(ctx, dN.reserve((size_t)n * 3));
     HIPCHK(ctx, dP.reserve((size_t)n));
-    hipLaunchKernelGGL(k_fe_scatter, grid1(n), dim3(256), 0, st, pts.p, d_nb.p, k, n, dS.p);
     double* const S6 = ws.hS;
     double* const N3 = ws.hN;
-    HIPCHK(ctx, hipMemcpyAsync(S6, dS.p, sizeof(double) * 6 * (size_t)n, hipMemcpyDeviceToHost, st));
-    // bounding box for the cell count meanwhile (grid_sample.h:36-44)
-    double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
-    for (int i = 0; i < n; ++i)
-        for (int d = 0; d < 3; ++d) {
-            const double c = (double)cloud_xyz4[4 * (size_t)i + d];
-            mn[d] = std::min(mn[d], c); mx[d] = std::max(mx[d], c);
+    // The sums come down in pieces - scatter of piece c, its copy, an event - and the host takes the eigen step of a piece as soon as it
+    // is there, sending its normals back up at once: the eigen step (4.5 ms per 1 M points on the host threads) runs beside the scatter
+    // and the copies (3.9 ms) instead of after them.  The host waits for THOSE copies only; behind them the stream goes on with what
+    // needs the graph and the points but no normals - the first round's reverse index, the occupied cells.
+    // $PWICP_FE_AHEAD=0: one piece, everything else after the normals.
+    static const bool ahead = !(getenv("PWICP_FE_AHEAD") && atoi(getenv("PWICP_FE_AHEAD")) == 0);
+    static const int pieces_env = getenv("PWICP_FE_PIECES") ? std::min(std::max(atoi(getenv("PWICP_FE_PIECES")), 1), (int)FeWorkspace::kPieces) : (int)FeWorkspace::kPieces;
+    const int pieces = ahead && n >= 65536 ? pieces_env : 1;
+    auto piece_lo = [&](int c) { return (int)((long long)n * c / pieces); };
+    for (int c = 0; c < pieces; ++c) {
+        const int lo = piece_lo(c), hi = piece_lo(c + 1);
+        hipLaunchKernelGGL(k_fe_scatter, grid1(hi - lo), dim3(256), 0, st, pts.p, d_nb.p, k, lo, hi, dS.p);
+        HIPCHK(ctx, hipMemcpyAsync(S6 + 6 * (size_t)lo, dS.p + 6 * (size_t)lo, sizeof(double) * 6 * (size_t)(hi - lo), hipMemcpyDeviceToHost, st));
+        if (ahead) {
+            if (!ws.ev_down[c]) HIPCHK(ctx, hipEventCreateWithFlags(&ws.ev_down[c], hipEventDisableTiming));
+            HIPCHK(ctx, hipEventRecord(ws.ev_down[c], st));
         }
-    HIPCHK(ctx, hipStreamSynchronize(st));
+    }
+    if (ahead) PWCHK(fusion_prepare_first_round(ctx, d_nb.p, k, n));
+    // bounding box for the cell count meanwhile (grid_sample.h:36-44)
+    double mn[3], mx[3];
+    pwhost::fe_bounding_box(cloud_xyz4, n, mn, mx);
+    const double res = (double)sv_resolution;
+    const int s1 = (int)((mx[0] - mn[0]) / res + 1), s2 = (int)((mx[1] - mn[1]) / res + 1), s3 = (int)((mx[2] - mn[2]) / res + 1);
+    const bool cells_on_host = std::max(s1, std::max(s2, s3)) > (1 << 21);
+    auto count_cells = [&]() -> int {
+        size_t cap = 1;
+        while (cap < 2 * (size_t)n) cap <<= 1;
+        DevBuf<unsigned long long>& table = ws.table;
+        DevBuf<int>& cnt = ws.cell_cnt;
+        HIPCHK(ctx, table.reserve(cap));
+        HIPCHK(ctx, cnt.reserve(1));
+        HIPCHK(ctx, hipMemsetAsync(table.p, 0xff, sizeof(unsigned long long) * cap, st));
+        HIPCHK(ctx, hipMemsetAsync(cnt.p, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_fe_count_cells, grid1(n), dim3(256), 0, st, pts.p, n, mn[0], mn[1], mn[2], res, s1, s2, s3, table.p,
+                           (unsigned long long)(cap - 1), cnt.p);
+        return PWICP_OK;
+    };
+    if (ahead && !cells_on_host) PWCHK(count_cells());
+    const bool eigen_on_device = getenv("PWICP_NORMALS") && std::string(getenv("PWICP_NORMALS")) == "device";
+    if (!ahead) HIPCHK(ctx, hipStreamSynchronize(st));
     if (getenv("PWICP_TRACE_NORMALS")) tr.lap("  normals: buffers, scatter, sums down, box");
-    pwhost::fe_normals_from_scatter(S6, n, N3);
+    for (int c = 0; c < pieces; ++c) {
+        const int lo = piece_lo(c), hi = piece_lo(c + 1);
+        if (ahead) HIPCHK(ctx, hipEventSynchronize(ws.ev_down[c]));
+        pwhost::fe_normals_from_scatter(S6 + 6 * (size_t)lo, hi - lo, N3 + 3 * (size_t)lo);
+        if (!eigen_on_device)
+            HIPCHK(ctx, hipMemcpyAsync(dN.p + 3 * (size_t)lo, N3 + 3 * (size_t)lo, sizeof(double) * 3 * (size_t)(hi - lo), hipMemcpyHostToDevice, st));
+    }
     if (getenv("PWICP_TRACE_NORMALS")) tr.lap("  normals: eigen step (host)");
-    if (getenv("PWICP_NORMALS") && std::string(getenv("PWICP_NORMALS")) == "device") {
+    if (eigen_on_device) {
         // experiment: eigen step on the device; report how many normals differ from the host's in any bit
         hipLaunchKernelGGL(k_fe_eigen_device, grid1(n), dim3(256), 0, st, dS.p, n, dN.p);
         std::vector<double> dev3((size_t)n * 3);
@@ -2032,35 +2128,20 @@ int pw_frontend_segment_device(pwicp_context* ctx, const float* cloud_xyz4, int 
         }
         fprintf(stderr, "[pwicp front end/dev]   eigen step on the device: %zu of %d normals differ from libm's (largest component difference %.3g)\n",
                 differ, n, worst);
-    } else
-    HIPCHK(ctx, hipMemcpyAsync(dN.p, N3, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
+    }
     hipLaunchKernelGGL(k_fe_assemble, grid1(n), dim3(256), 0, st, pts.p, dN.p, n, dP.p);
     tr.lap("pca normals");
-    const double res = (double)sv_resolution;
     int n_sv = 0;
-    {
-        const int s1 = (int)((mx[0] - mn[0]) / res + 1), s2 = (int)((mx[1] - mn[1]) / res + 1), s3 = (int)((mx[2] - mn[2]) / res + 1);
-        size_t cap = 1;
-        while (cap < 2 * (size_t)n) cap <<= 1;
-        DevBuf<unsigned long long>& table = ws.table;
-        DevBuf<int>& cnt = ws.cell_cnt;
-        HIPCHK(ctx, table.reserve(cap));
-        HIPCHK(ctx, cnt.reserve(1));
-        HIPCHK(ctx, hipMemsetAsync(table.p, 0xff, sizeof(unsigned long long) * cap, st));
-        HIPCHK(ctx, hipMemsetAsync(cnt.p, 0, sizeof(int), st));
-        if (std::max(s1, std::max(s2, s3)) > (1 << 21)) {
-            // the 64-bit cell key packs 21 bits per axis: beyond that (extent / resolution > 2 M cells on an axis; GridSample
-            // allows INT_MAX) the cells are counted by the host pass on the downloaded points
-            std::vector<FePt> hP((size_t)n);
-            HIPCHK(ctx, hipMemcpyAsync(hP.data(), dP.p, sizeof(FePt) * (size_t)n, hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipStreamSynchronize(st));
-            n_sv = pwhost::fe_count_occupied_cells(hP.data(), n, res);
-        } else {
-        hipLaunchKernelGGL(k_fe_count_cells, grid1(n), dim3(256), 0, st, dP.p, n, mn[0], mn[1], mn[2], res, s1, s2, s3, table.p,
-                           (unsigned long long)(cap - 1), cnt.p);
-        HIPCHK(ctx, hipMemcpyAsync(&n_sv, cnt.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (cells_on_host) {
+        // the 64-bit cell key packs 21 bits per axis: beyond that (extent / resolution > 2 M cells on an axis; GridSample
+        // allows INT_MAX) the cells are counted by the host pass on the downloaded points
+        std::vector<FePt> hP((size_t)n);
+        HIPCHK(ctx, hipMemcpyAsync(hP.data(), dP.p, sizeof(FePt) * (size_t)n, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
-        }
+        n_sv = pwhost::fe_count_occupied_cells(hP.data(), n, res);
+    } else {
+        if (!ahead) PWCHK(count_cells());
+        PWCHK(fe_read_words(ctx, ws, ws.cell_cnt.p, 1, &n_sv));
     }
     tr.lap("occupied cells");
     for (int d = 0; d < 3; ++d) { ws.bb_mn[d] = mn[d]; ws.bb_mx[d] = mx[d]; }

@@ -19,6 +19,8 @@ void fe_points_and_normals(const float* cloud_xyz4, int n, const int32_t* nb, in
 void fe_normals_from_scatter(const double* S6, int n, double* normals3);
 // number of occupied cells of edge `resolution` (grid_sample.h:30-75) = the supervoxel count the fusion stops at
 int fe_count_occupied_cells(const FePt* P, int n, double resolution);
+// bounding box of n (x, y, z, -) points, as doubles (grid_sample.h:36-44), on the host threads
+void fe_bounding_box(const float* xyz4, int n, double mn[3], double mx[3]);
 // the serial fusion (supervoxel_segmentation.h:65-170): root point of every point and the roots in ascending order
 int fe_fusion_host(const FePt* P, const int32_t* nb, int k, int n, double resolution, int n_supervoxels, std::vector<int>* root_of,
                    std::vector<int>* roots);
