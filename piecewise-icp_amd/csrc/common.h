@@ -300,7 +300,7 @@ int pw_gather_int_launch(pwicp_context* ctx, const int* d_src, const int* d_orde
 int pw_morton_order(pwicp_context* ctx, const GridDesc& g, const float4* d_pts, int n, DevBuf<int>* order, const GridLevel* strip_lv = nullptr);
 int pw_bbox(pwicp_context* ctx, const float4* d_pts, int n, float mn[3], float mx[3]);
 int pw_check_finite(pwicp_context* ctx, const float4* d_pts, int n);
-int pw_knn_launch(pwicp_context* ctx, const GridDesc& g, int k, int* d_nb);
+int pw_knn_launch(pwicp_context* ctx, const GridDesc& g, int k, int* d_nb, int* d_rev_count = nullptr);
 float pw_estimate_cell_edge(const float* xyz4, int n);     // cell edge of a stand-alone search grid (~2x the point spacing)
 int pw_knn_mean_dist_launch(pwicp_context* ctx, const GridDesc& g, int mean_k, float* d_mean);
 // k-th smallest (0-based) of the non-sentinel entries of n non-negative floats; result written to d_out[0]; scratch >= 3*2048+8 uints

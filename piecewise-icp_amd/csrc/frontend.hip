@@ -310,7 +310,9 @@ struct FusState {
 #define PW_FUS_QUEUE_S 256
 #endif
 #ifndef PW_FUS_MIN_WAVES
-#define PW_FUS_MIN_WAVES 1            // wavefronts per SIMD asked of the compiler for the sweeps' kernel (build parameter, measured)
+#define PW_FUS_MIN_WAVES 6            // wavefronts per SIMD asked of the compiler for the sweeps' kernel: 6 is what the LDS of a block allows
+                                      // (24 per CU), 80 registers with one spilled instead of 84 and five wavefronts: fusion 38.9 -> 37.5 ms
+                                      // per 1 M points (build parameter; 1: the compiler's choice; 7 / 8 with smaller tables: slower)
 #endif
 constexpr int kFusQueueS = PW_FUS_QUEUE_S, kFusHashS = 2 * PW_FUS_QUEUE_S, kFusQueue = 2048, kFusHash = 4096;
 constexpr int kFusArenas = 256;
@@ -471,7 +473,7 @@ __device__ __forceinline__ int fus_head_words(const FusState& s, int lane, int i
 // QCAP / HCAP: capacity of the search queue / visited hash; WAVES wavefronts per block.  list == nullptr: the work list W in
 // chunks; else the slots on `list` (the centres whose search outgrew the small configuration), one at a time.
 template <int QCAP, int HCAP, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES, PW_FUS_MIN_WAVES) k_fus_run(FusState s, int nW, int chunk, const int* __restrict__ list,
+__global__ void __launch_bounds__(64 * WAVES, (QCAP <= 512 ? PW_FUS_MIN_WAVES : 1)) k_fus_run(FusState s, int nW, int chunk, const int* __restrict__ list,
                                                          const int* __restrict__ n_list, int* __restrict__ ovf, int* __restrict__ n_ovf) {
     __shared__ __attribute__((aligned(16))) int s_keys[WAVES][HCAP];
     __shared__ __attribute__((aligned(16))) int s_vals[WAVES][HCAP];
@@ -1282,6 +1284,7 @@ struct FeWorkspace {
     bool bb_set = false;
     static constexpr int kPieces = 8;
     hipEvent_t ev_down[kPieces] = {};   // piece c of the scatter sums is in host memory (the stream goes on with work that needs no normals)
+    bool rev0_counted = false;          // ws.revoff holds the entries per point of the graph's reverse index (counted by the k-NN launch)
     bool rev0_ready = false;            // the first round's reverse index (and k_fus_first_round's arrays) stand for a cloud of
     int rev0_n = 0, rev0_k = 0;         // rev0_n points, rev0_k neighbours: fusion_prepare_first_round ran ahead of the normals
     int sa_factor = 3;                  // list arena = sa_factor * n * k entries (doubled, once, when a round overflows it)
@@ -1556,9 +1559,12 @@ int fusion_prepare_first_round(pwicp_context* ctx, const int* d_nb, int k, int n
     HIPCHK(ctx, ws.revoff.reserve(N + 1));
     HIPCHK(ctx, ws.offA.reserve(N));
     HIPCHK(ctx, ws.revown.reserve(N * (size_t)k));
-    HIPCHK(ctx, hipMemsetAsync(ws.revoff.p, 0, sizeof(int) * (N + 1), st));
     hipLaunchKernelGGL(k_fus_first_round, grid1(n), dim3(256), 0, st, n, k, ws.root0.p, ws.s0.p, ws.lenA.p, ws.offA.p, ws.cenA.p);
-    hipLaunchKernelGGL(k_fus_reverse<0>, grid1(n), dim3(256), 0, st, ws.cenA.p, n, ws.root0.p, ws.lenA.p, ws.offA.p, d_nb, ws.revoff.p, (int*)nullptr);
+    if (!ws.rev0_counted) {
+        HIPCHK(ctx, hipMemsetAsync(ws.revoff.p, 0, sizeof(int) * (N + 1), st));
+        hipLaunchKernelGGL(k_fus_reverse<0>, grid1(n), dim3(256), 0, st, ws.cenA.p, n, ws.root0.p, ws.lenA.p, ws.offA.p, d_nb, ws.revoff.p, (int*)nullptr);
+    }
+    ws.rev0_counted = false;
     PWCHK(pw_exclusive_scan(ctx, ws.revoff.p, (long long)n + 1, &ws.tmp));
     HIPCHK(ctx, hipMemcpyAsync(ws.cursor.p, ws.revoff.p, sizeof(int) * N, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(k_fus_reverse<1>, grid1(n), dim3(256), 0, st, ws.cenA.p, n, ws.root0.p, ws.lenA.p, ws.offA.p, d_nb, ws.cursor.p, ws.revown.p);
@@ -2046,7 +2052,16 @@ int pw_frontend_segment_device(pwicp_context* ctx, const float* cloud_xyz4, int 
     {
         Grid& g = ws.grid;
         PWCHK(pw_grid_build(ctx, pts.p, n, cell_edge > 0.f ? cell_edge : pw_estimate_cell_edge(cloud_xyz4, n), &g));
-        PWCHK(pw_knn_launch(ctx, g.d, k, d_nb.p));                               // S.cpp:30-41
+        // (the sizes of the graph's reverse index are counted on the way: fusion_prepare_first_round)
+        static const bool ahead_k = !(getenv("PWICP_FE_AHEAD") && atoi(getenv("PWICP_FE_AHEAD")) == 0);
+        int* rev_count = nullptr;
+        if (ahead_k && n >= 1 && n > k) {
+            HIPCHK(ctx, ws.revoff.reserve((size_t)n + 1));
+            HIPCHK(ctx, hipMemsetAsync(ws.revoff.p, 0, sizeof(int) * ((size_t)n + 1), st));
+            rev_count = ws.revoff.p;
+        }
+        ws.rev0_counted = rev_count != nullptr;
+        PWCHK(pw_knn_launch(ctx, g.d, k, d_nb.p, rev_count));                    // S.cpp:30-41
         HIPCHK(ctx, hipStreamSynchronize(st));
     }
     tr.lap("k-NN graph");

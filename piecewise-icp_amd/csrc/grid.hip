@@ -1867,7 +1867,8 @@ int pw_morton_order(pwicp_context* ctx, const GridDesc& g, const float4* d_pts, 
 // global memory that is ~24 KB of traffic per point, in LDS it is a handful of ds_read / ds_write per shift.  One
 // wavefront per block; 36.9 KB (double) / 24.6 KB (float) of LDS per block.
 template <typename Real, int KMAX>
-__global__ void __launch_bounds__(64) k_knn_lds(GridLevel g, int k, int* __restrict__ out_nb, float* __restrict__ out_mean) {
+__global__ void __launch_bounds__(64) k_knn_lds(GridLevel g, int k, int* __restrict__ out_nb, float* __restrict__ out_mean,
+                                                int* __restrict__ rev_count = nullptr) {
     __shared__ Real s_d[KMAX * 64];
     __shared__ int s_i[KMAX * 64];
     const int lane = threadIdx.x;
@@ -1968,6 +1969,10 @@ __global__ void __launch_bounds__(64) k_knn_lds(GridLevel g, int k, int* __restr
     }
     if (out_nb)
         for (int e = 0; e < k; ++e) out_nb[(size_t)self * k + e] = (e < cnt) ? ni[e * 64] : -1;
+    // (how often every point occurs in the rows: the sizes of the graph's reverse index, which the front end's fusion builds next -
+    // 45 M atomics that disappear behind this kernel's LDS round trips instead of a 0.8 ms pass of their own)
+    if (rev_count)
+        for (int e = 0; e < cnt; ++e) atomicAdd(&rev_count[ni[e * 64]], 1);
     if (out_mean) {
         double s = 0.0;
         for (int e = 1; e < cnt; ++e) s += (double)sqrtf((float)nd[e * 64]);
@@ -1976,12 +1981,18 @@ __global__ void __launch_bounds__(64) k_knn_lds(GridLevel g, int k, int* __restr
 }
 constexpr int kKnnLdsMax = 48;
 
-int pw_knn_launch(pwicp_context* ctx, const GridDesc& g, int k, int* d_nb) {
+__global__ void k_knn_count_rows(const int* __restrict__ nb, long long m, int* __restrict__ rev_count) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < m && nb[t] >= 0) atomicAdd(&rev_count[nb[t]], 1);
+}
+// (d_rev_count, optional: [n] zeroed by the caller; on return - in stream order - entry x is the number of rows that hold point x)
+int pw_knn_launch(pwicp_context* ctx, const GridDesc& g, int k, int* d_nb, int* d_rev_count) {
     const int n = g.fine.n;
     if (n <= 0) return PWICP_OK;
     static const bool lds_off = getenv("PWICP_KNN_LDS") && atoi(getenv("PWICP_KNN_LDS")) == 0;      // A/B knob
     if (k <= kKnnLdsMax && !lds_off) {
-        hipLaunchKernelGGL((k_knn_lds<double, kKnnLdsMax>), dim3(div_up(n, 64)), dim3(64), 0, ctx->stream, g.fine, k, d_nb, (float*)nullptr);
+        hipLaunchKernelGGL((k_knn_lds<double, kKnnLdsMax>), dim3(div_up(n, 64)), dim3(64), 0, ctx->stream, g.fine, k, d_nb, (float*)nullptr,
+                           d_rev_count);
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         HIPCHK(ctx, hipGetLastError());
         return PWICP_OK;
@@ -1992,6 +2003,9 @@ int pw_knn_launch(pwicp_context* ctx, const GridDesc& g, int k, int* d_nb) {
     HIPCHK(ctx, ni.reserve((size_t)n * k));
     hipLaunchKernelGGL(k_knn<double>, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, g.fine, k, nd.p, ni.p, d_nb,
                        (float*)nullptr);
+    if (d_rev_count)
+        hipLaunchKernelGGL(k_knn_count_rows, dim3((unsigned)div_up((long long)n * k, 256)), dim3(256), 0, ctx->stream, (const int*)d_nb,
+                           (long long)n * k, d_rev_count);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipGetLastError());
     return PWICP_OK;
