@@ -2082,7 +2082,8 @@ int pw_frontend_segment_device(pwicp_context* ctx, const float* cloud_xyz4, int 
     // $PWICP_FE_AHEAD=0: one piece, everything else after the normals.
     static const bool ahead = !(getenv("PWICP_FE_AHEAD") && atoi(getenv("PWICP_FE_AHEAD")) == 0);
     static const int pieces_env = getenv("PWICP_FE_PIECES") ? std::min(std::max(atoi(getenv("PWICP_FE_PIECES")), 1), (int)FeWorkspace::kPieces) : (int)FeWorkspace::kPieces;
-    const int pieces = ahead && n >= 65536 ? pieces_env : 1;
+    // (pieces of at least ~120 k points: a 140 k-point scan in eight pieces is 1 ms slower than in one)
+    const int pieces = ahead ? std::max(1, std::min(pieces_env, n / 120000)) : 1;
     auto piece_lo = [&](int c) { return (int)((long long)n * c / pieces); };
     for (int c = 0; c < pieces; ++c) {
         const int lo = piece_lo(c), hi = piece_lo(c + 1);
