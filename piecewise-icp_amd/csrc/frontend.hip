@@ -2053,7 +2053,7 @@ int pw_frontend_segment_device(pwicp_context* ctx, const float* cloud_xyz4, int 
         Grid& g = ws.grid;
         PWCHK(pw_grid_build(ctx, pts.p, n, cell_edge > 0.f ? cell_edge : pw_estimate_cell_edge(cloud_xyz4, n), &g));
         // (the sizes of the graph's reverse index are counted on the way: fusion_prepare_first_round)
-        static const bool ahead_k = !(getenv("PWICP_FE_AHEAD") && atoi(getenv("PWICP_FE_AHEAD")) == 0);
+        const bool ahead_k = !(getenv("PWICP_FE_AHEAD") && atoi(getenv("PWICP_FE_AHEAD")) == 0);
         int* rev_count = nullptr;
         if (ahead_k && n >= 1 && n > k) {
             HIPCHK(ctx, ws.revoff.reserve((size_t)n + 1));
@@ -2080,8 +2080,8 @@ int pw_frontend_segment_device(pwicp_context* ctx, const float* cloud_xyz4, int 
     // and the copies (3.9 ms) instead of after them.  The host waits for THOSE copies only; behind them the stream goes on with what
     // needs the graph and the points but no normals - the first round's reverse index, the occupied cells.
     // $PWICP_FE_AHEAD=0: one piece, everything else after the normals.
-    static const bool ahead = !(getenv("PWICP_FE_AHEAD") && atoi(getenv("PWICP_FE_AHEAD")) == 0);
-    static const int pieces_env = getenv("PWICP_FE_PIECES") ? std::min(std::max(atoi(getenv("PWICP_FE_PIECES")), 1), (int)FeWorkspace::kPieces) : (int)FeWorkspace::kPieces;
+    const bool ahead = !(getenv("PWICP_FE_AHEAD") && atoi(getenv("PWICP_FE_AHEAD")) == 0);
+    const int pieces_env = getenv("PWICP_FE_PIECES") ? std::min(std::max(atoi(getenv("PWICP_FE_PIECES")), 1), (int)FeWorkspace::kPieces) : (int)FeWorkspace::kPieces;
     // (pieces of at least ~120 k points: a 140 k-point scan in eight pieces is 1 ms slower than in one)
     const int pieces = ahead ? std::max(1, std::min(pieces_env, n / 120000)) : 1;
     auto piece_lo = [&](int c) { return (int)((long long)n * c / pieces); };

@@ -316,6 +316,8 @@ struct DenseFarList {
     float4* q = nullptr;
     int* slot = nullptr;
     unsigned* count = nullptr;      // [0] entries, [1] blocks of k_nn_dense_far that have read it (the last one re-arms both)
+    int edge = 1;                   // > 0: a far query whose distance is PROVED to lie above the percentile is not searched any further
+                                    // (lists of at least `edge` queries; k_nn_dense_far)
 };
 
 // ---- dense 1-NN, distance only, disc-pruned (the default dense kernel) --------------------------------------------------
@@ -937,12 +939,27 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_far(GridDesc far, DenseFarL
     __shared__ int s_blo[kBlock], s_bpre[kBlock];
     __shared__ float s_bred[kBlock / 64];
     const int tid = threadIdx.x;
-    if (fs.scratch)
-        for (int t = tid; t < kFsBins; t += kBlock) s_hist[t] = 0u;
+    // The search only feeds the percentile of the distances (C.cpp:177), and the launch starts with the dense kernel's own values in
+    // the selection's bins: when k + 1 of THOSE already lie below an edge, the percentile does - whatever the far queries add - and a
+    // far query is finished as soon as everything within some radius g of it has been examined without a result below the edge
+    // (min(d, g^2) >= edge: its true distance lies above the percentile, and so does the candidate d - or infinity - written for it:
+    // an upper bound of the true value, so that a block that reads the bins later still counts true values only below ITS edge).
+    // The rank statistics below the edge are untouched: the selected value is bit for bit the one of the exact search.
+    // Source points outside the overlap of a pair are what this is for: the widest balls and the general search.  fl.edge == 0: off.
     if (tid == 0) { s_n = __hip_atomic_load(&fl.count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_nslow = 0u; }
     __syncthreads();
     const int n = (int)s_n;
+    float edge = INFINITY;
+    if (fs.scratch && fl.edge > 0 && n >= fl.edge) {
+        const unsigned eb = fs_partial_edge(s_hist, fs);
+        if (eb != ~0u) edge = __uint_as_float(eb);
+    } else if (fs.scratch) {
+        for (int t = tid; t < kFsBins; t += kBlock) s_hist[t] = 0u;
+        __syncthreads();
+    }
     const int sub = tid % kGroup;
+    // everything within g of the query examined, best result d: is the query's distance known to lie above the percentile?
+    auto above_edge = [&](float d, float g) { return g > 0.0f && fminf(d, g * g * 0.99999f) >= edge; };
     // (entry qi to block qi % #blocks: neighbours on the list are neighbours in space, and the few queries that need the general
     // search come in clusters - dealt out like this they end up on different blocks instead of queueing on one)
     // PW_FAR_RUN consecutive entries stay together (their balls share cache lines), the runs of a block are #blocks runs apart
@@ -970,13 +987,13 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_far(GridDesc far, DenseFarL
                 // (a small ball first: three quarters of a real pair's far queries are within a cell of the surface)
                 const float r1 = kFirstBallCells * L.h;
                 scan_disc_group<kGroup>(L, u.x, u.y, u.z, r1, sub, d);
-                done = d < INFINITY && fast_sqrt_up(d) + sl2 <= r1;
+                done = (d < INFINITY && fast_sqrt_up(d) + sl2 <= r1) || above_edge(d, r1 - sl2);
                 if (done) FAR_STAT(2 + 3 * lv);
                 if (!done) {
                     const float sq2 = d < INFINITY ? fast_sqrt_up(d) + sl2 : INFINITY;
                     const float r2 = fminf(sq2, lim);                  // the candidate's ball if it fits, else the widest
                     scan_disc_group<kGroup>(L, u.x, u.y, u.z, r2, sub, d);
-                    done = sq2 <= lim || (d < INFINITY && fast_sqrt_up(d) + sl2 <= lim);
+                    done = sq2 <= lim || (d < INFINITY && fast_sqrt_up(d) + sl2 <= lim) || above_edge(d, r2 - sl2);
                     if (done) FAR_STAT(3 + 3 * lv);
                 }
             }
@@ -1750,6 +1767,9 @@ int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pa
             HIPCHK(ctx, hipMemsetAsync(far_bufs->count.p, 0, 2 * sizeof(unsigned), ctx->stream));
         }
         fl.q = far_bufs->q.p; fl.slot = far_bufs->slot.p; fl.count = far_bufs->count.p;
+        // (PWICP_DENSE_FAR_EDGE: 0 - every far query searched to the end; n - only lists of at least n far queries look at the bins)
+        static const int far_edge = getenv("PWICP_DENSE_FAR_EDGE") ? std::max(atoi(getenv("PWICP_DENSE_FAR_EDGE")), 0) : 1;
+        fl.edge = far_edge;
     }
     if (dense && d_qpatch && d_qorder) {
         const int tiles = div_up(nq, kDenseBlock);

@@ -105,6 +105,63 @@ __device__ __forceinline__ void fs_pick0(unsigned* h, const FusedSelect& fs, uns
     *krem_out = s_res[1];
 }
 
+// What the values histogrammed SO FAR say about the percentile (k_nn_dense_far, whose launch starts when the dense kernel's own values
+// are all in the bins): if at least k + 1 of them lie in bins <= b, the k-th smallest of ALL values - the ones still to come only add
+// to the counts - is below the upper edge of bin b.  Returns that edge as float bits ((b + 1) << 21), ~0u when the bins do not decide
+// it yet.  Read-only on the global bins; `h` (kFsBins words of LDS) is scratch and left zeroed; blockDim.x == 256.
+__device__ __forceinline__ unsigned fs_partial_edge(unsigned* h, const FusedSelect& fs) {
+    __shared__ unsigned s_w[4], s_edge;
+    const unsigned* g0 = fs.scratch + kFsCtl;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) s_edge = ~0u;
+#pragma unroll
+    for (int j = 0; j < kFsBins / 256; ++j) {
+        const int w = t + 256 * j;
+        unsigned s = 0;
+#pragma unroll
+        for (int r = 0; r < kFsRep; ++r) s += __hip_atomic_load(&g0[r * kFsBins + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        h[(w & 31) * 64 + (w >> 5)] = s;               // inverse of fs_word
+    }
+    __syncthreads();
+    unsigned c[8], local = 0;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        c[b] = h[t * 8 + b];
+        local += c[b];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 8; ++b) h[t * 8 + b] = 0u;
+    unsigned incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = __shfl_up(incl, o);
+        if (lane >= o) incl += u;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    unsigned base = 0;
+    for (int w = 0; w < wave; ++w) base += s_w[w];
+    const unsigned excl = base + incl - local;
+    unsigned k = (unsigned)fs.k;
+    if (fs.n_valid_dev) {
+        const int nv = (int)*fs.n_valid_dev;
+        int kk = (int)((float)nv * 0.75f);
+        if (kk >= nv) kk = nv - 1;
+        k = (unsigned)max(kk, 0);
+    }
+    if (k >= excl && k < excl + local) {
+        unsigned run = excl;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            if (k >= run && k < run + c[b]) { const unsigned bin = (unsigned)(t * 8 + b); s_edge = bin + 1u < (unsigned)kFsBins ? (bin + 1u) << 21 : ~0u; }
+            run += c[b];
+        }
+    }
+    __syncthreads();
+    return s_edge;
+}
+
 // ---- passes 1 and 2 on `fs.nblk` blocks of some other launch; `bidx` = index of this block among them --------------------
 // chain != 0: passes 1 and 2 run in the SAME launch (k_xf_front: pass 1 on the first blocks of the grid, pass 2 on the next).
 // The wave that picks pass 1's bin publishes prefix / rank through device-coherent stores and then the tag `chain`; the blocks

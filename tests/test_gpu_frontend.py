@@ -129,12 +129,15 @@ def test_search_queue_overflow_falls_back_to_the_serial_pass(ctx, capfd):
                                    {"PWICP_FUSION_CHUNK": "3", "PWICP_FUSION_WAKE_DIV": "100000"},
                                    {"PWICP_FUSION_TILE": "0"}, {"PWICP_FUSION_TILE": "4", "PWICP_FUSION_CHUNK_DIV": "64"},
                                    {"PWICP_FUSION_TILE": "300", "PWICP_FUSION_CHUNK": "5"},
-                                   {"PWICP_FUSION_COLOURS": "1"}, {"PWICP_FUSION_COLOURS": "4", "PWICP_FUSION_TILE": "7"}])
+                                   {"PWICP_FUSION_COLOURS": "1"}, {"PWICP_FUSION_COLOURS": "4", "PWICP_FUSION_TILE": "7"},
+                                   {"PWICP_FE_AHEAD": "0"}, {"PWICP_FE_PIECES": "3"}, {"PWICP_FE_PIECES": "1"}])
 def test_labels_do_not_depend_on_the_sweep_schedule(ctx, knobs):
     """The fixed point is the serial result whatever the schedule: chunks of 1 (Jacobi) ... 16 centres per wavefront
     (Gauss-Seidel inside a chunk), work lists from the first sweep on (WAKE_DIV 1) or hardly ever (100000), the full sweeps in
     index order (TILE 0) or tile by tile with tiles of 4 / 300 centres, 64 instead of 2048 chunks wanted per sweep, the tiles of a
-    sweep all at once, in two colours (the default) or in four."""
+    sweep all at once, in two colours (the default) or in four.  And whatever the pipeline around the normals: everything after them
+    (FE_AHEAD 0: no reverse index / cell count beside the host's eigen step, the counts not taken inside the k-NN launch), the scatter
+    sums in three pieces or in one."""
     tgt, _, _ = _data.pair(400000)
     os.environ.update(knobs)
     try:

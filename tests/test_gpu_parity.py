@@ -495,6 +495,8 @@ def test_scheduling_switches_do_not_change_a_bit(tmp_path):
                         ("selection on its own launches", {"PWICP_FUSED_SELECT": "0"}),
                         ("no pool, closing synchronisation", {"PWICP_POOL_MB": "0", "PWICP_RUN_SYNC": "1"}),
                         ("far queries of every dense search on their own launch", {"PWICP_DENSE_FAR_GROUP": "1"}),
+                        ("... every one of them searched to the end, whatever the selection's bins say already",
+                         {"PWICP_DENSE_FAR_GROUP": "1", "PWICP_DENSE_FAR_EDGE": "0"}),
                         ("far queries inside the search's blocks, 8 lanes per front query", {"PWICP_DENSE_FAR_GROUP": "0", "PWICP_FRONT_QUERY_LANES": "8"}),
                         ("4 lanes per front query", {"PWICP_FRONT_QUERY_LANES": "4"}),
                         ("source patch normals left out", {"PWICP_SOURCE_NORMALS": "0"}),
@@ -506,7 +508,7 @@ def test_scheduling_switches_do_not_change_a_bit(tmp_path):
                         ("inner-ICP batches of small problems in one launch of one workgroup", {"PWICP_ICP_SMALL": "1"})):
         env = dict(os.environ)
         for k in ("PWICP_STAGE_GUARD", "PWICP_SPECULATE_DENSE", "PWICP_FUSED_SELECT", "PWICP_POOL_MB", "PWICP_RUN_SYNC",
-                  "PWICP_DENSE_FAR_GROUP", "PWICP_FRONT_QUERY_LANES", "PWICP_SOURCE_NORMALS", "PWICP_DENSE_QUERY_COPY", "PWICP_DENSE_SIDE_STREAM",
+                  "PWICP_DENSE_FAR_GROUP", "PWICP_DENSE_FAR_EDGE", "PWICP_FRONT_QUERY_LANES", "PWICP_SOURCE_NORMALS", "PWICP_DENSE_QUERY_COPY", "PWICP_DENSE_SIDE_STREAM",
                   "PWICP_DENSE_WIN", "PWICP_ICP_SMALL"):
             env.pop(k, None)
         env.update(extra)

@@ -31,6 +31,8 @@ cd $R
 timeout 600 python bench.py --no-cpu-baseline --series-epochs 0 --pairs-in-flight 0 > $OUT/bench_plain.log 2>/dev/null     # (its in-run duration of the dense launch goes into the summary)
 timeout 600 python bench.py --workload frontend --steps 5 > $OUT/bench_frontend.log 2>&1
 timeout 600 python bench.py --workload series --epochs 4 --points 5000000 > $OUT/bench_series.log 2>&1
+# the front end of one cloud: kernels per cloud, where the stream idles (tools/fe_kstats.sh), wall times (tools/fe_time.py)
+(bash tools/fe_kstats.sh; echo; python tools/fe_time.py 1000000; python tools/fe_time.py real 2; python tools/fe_time.py real 12) > $OUT/frontend_timeline.txt 2>&1
 # the loop on two of the reference's own pairs, with the kernel timeline of their last run
 bash tools/real_pair_trace.sh > $OUT/real_pair_timeline.txt 2>&1
 # the 2-rank / CPU-share rehearsals of the shared-target series

@@ -9,6 +9,7 @@ cp $S/traffic.json $D/${TAG}_traffic.json
 cp $S/traffic.json $D/traffic_latest.json
 cp $S/last_step_timeline.txt $D/${TAG}_last_step_timeline.txt
 cp $S/real_pair_timeline.txt $D/${TAG}_real_pair_timeline.txt
+[ -s $S/frontend_timeline.txt ] && grep -v "^run [0-9]" $S/frontend_timeline.txt > $D/${TAG}_frontend_timeline.txt
 for f in final:bench_line frontend:bench_frontend_line series:bench_series_line gpus2:bench_line_gpus2_single_device; do
   grep '^{' $S/bench_${f%%:*}.log | tail -1 > $D/${TAG}_${f##*:}.json
 done
