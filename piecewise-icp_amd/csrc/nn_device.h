@@ -576,6 +576,9 @@ __device__ __forceinline__ unsigned scan_disc_lean(const GridLevel& g, float qx,
 // walks ITS rows as the per-lane search does (four rows' begin / end words in flight, then their points four at a time) - a wide
 // ball (40 rows, 200 candidates) is 1/G of the rows and candidates per lane, i.e. a chain of ~10 round trips instead of ~90.
 // Same pruning, same float expression per candidate: after the group minimum, the same exact d2.
+#ifndef PW_FAR_ROWS_ABREAST
+#define PW_FAR_ROWS_ABREAST 0       // (measured, round 5: the reference's 19 pairs 11.45 -> 12.25 ms in sum with it; profiles/r05_dense_variants.txt (9))
+#endif
 template <int G>
 __device__ __forceinline__ void scan_disc_group(const GridLevel& g, float qx, float qy, float qz, float rho, int sub, float& best) {
     const bool gy = g.inv_hy != 0.0f, gz = g.inv_hz != 0.0f;
@@ -611,8 +614,26 @@ __device__ __forceinline__ void scan_disc_group(const GridLevel& g, float qx, fl
             lo[k] = g.cell_start[row + x0];
             hi[k] = g.cell_start[row + x1 + 1];
         }
+#if PW_FAR_ROWS_ABREAST
+        // (build variant: the lane's four rows side by side, two points of each per step - eight gathers in flight, the longest row's
+        // half as many steps as one row after the other at four points a step; same candidates, same minimum; slower, see above)
+        const int m4 = max(max(hi[0] - lo[0], hi[1] - lo[1]), max(hi[2] - lo[2], hi[3] - lo[3]));
+        for (int j = 0; j < m4; j += 2) {
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int a = lo[k] + j;
+                const int b = a + 1 < hi[k] ? a + 1 : a;
+                if (a < hi[k]) { v[2 * k] = g.pts[a]; v[2 * k + 1] = g.pts[b]; }
+                else { v[2 * k] = make_float4(1e30f, 1e30f, 1e30f, 0.f); v[2 * k + 1] = v[2 * k]; }       // (d2 = inf: never the minimum)
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) nn_consider_d2<0>(v[u], qx, qy, qz, best);
+        }
+#else
 #pragma unroll
         for (int k = 0; k < 4; ++k) scan_d2x4<0>(g.pts, lo[k], hi[k], qx, qy, qz, best);
+#endif
     }
 #pragma unroll
     for (int o = 1; o < G; o <<= 1) best = fminf(best, __shfl_xor(best, o));
