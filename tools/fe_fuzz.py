@@ -41,6 +41,10 @@ for c in range(cases):
         knobs["PWICP_FUSION_COLOURS"] = str(int(rng.choice([1, 2, 4])))
     if rng.random() < 0.3:
         knobs["PWICP_FUSION_CHUNK_DIV"] = str(int(rng.choice([16, 256, 8192])))
+    if rng.random() < 0.3:
+        knobs["PWICP_FE_PIECES"] = str(int(rng.choice([1, 2, 3, 8])))
+    if rng.random() < 0.15:
+        knobs["PWICP_FE_AHEAD"] = "0"
     out = {}
     for mode in ("host", "device"):
         os.environ["PWICP_FRONTEND"] = mode
