@@ -2044,6 +2044,7 @@ int pw_frontend_segment_device(pwicp_context* ctx, const float* cloud_xyz4, int 
     hipStream_t st = ctx->stream;
     FeTrace tr{ctx};
     FeWorkspace& ws = *workspace_of(ctx);
+    ws.rev0_ready = false; ws.rev0_counted = false;      // (whatever a call that failed half-way left standing)
     DevBuf<float4>& pts = ws.pts;
     HIPCHK(ctx, pts.reserve((size_t)n));
     HIPCHK(ctx, hipMemcpyAsync(pts.p, cloud_xyz4, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, st));
