@@ -1354,6 +1354,12 @@ __global__ void __launch_bounds__(64) k_fe_mail(const unsigned* src, int n, unsi
     if (t == 0) mail_publish(&dst[16], seq);
 }
 
+// two words from two places in one read-back (the counts a round of the fusion hands to the next one)
+__global__ void __launch_bounds__(64) k_fe_gather2(const unsigned* __restrict__ a, const unsigned* __restrict__ b, unsigned* __restrict__ out) {
+    if (threadIdx.x == 0) out[0] = *a;
+    if (threadIdx.x == 1) out[1] = *b;
+}
+
 int fe_read_words(pwicp_context* ctx, FeWorkspace& ws, const void* d_src, int n_words, void* h_out, void* d_clear = nullptr, int n_clear = 0) {
     static const bool use_mail = !(getenv("PWICP_FE_MAILBOX") && atoi(getenv("PWICP_FE_MAILBOX")) == 0);
     if (!use_mail || !ws.mail_h || n_words > 16) {
@@ -1500,8 +1506,7 @@ int refine_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     hipLaunchKernelGGL(k_ref_seed_emit<false>, grid1(n), dim3(256), 0, st, d_nb, k, n, d_lab, key.p, cnt.p, (int*)nullptr);
     PWCHK(pw_exclusive_scan(ctx, cnt.p, (long long)n + 1, &tmp));
     int m = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&m, cnt.p + n, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));
+    PWCHK(fe_read_words(ctx, *workspace_of(ctx), cnt.p + n, 1, &m));
     hipLaunchKernelGGL(k_ref_seed_emit<true>, grid1(n), dim3(256), 0, st, d_nb, k, n, d_lab, key.p, cnt.p, La.p);
     int* L = La.p;
     int* Lnext = Lb.p;
@@ -1604,8 +1609,8 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
         }
         hipLaunchKernelGGL(k_sel_result, dim3(1), dim3(1), 0, st, ws.sel_state.p, (double*)(ws.sel_state.p + 3));
         double median = 0.0;
-        HIPCHK(ctx, hipMemcpyAsync(&median, ws.sel_state.p + 3, sizeof(double), hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
+        HIPCHK(ctx, ws.host_reserve(0));
+        PWCHK(fe_read_words(ctx, ws, ws.sel_state.p + 3, 2, &median));
         lambda = std::max(DBL_EPSILON, median);
         if (trace) fprintf(stderr, "[pwicp front end/dev]   lambda0 = %.17g\n", lambda);
     }
@@ -1633,6 +1638,7 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
     DevBuf<int>* arena_cur = &ws.arenaB;       // (the one arena0 points into from the second round on)
     int nc = n, round = 0;
     bool rev_counted = true;               // (the first round's counts come from k_fus_min_metric, the later ones' from k_fus_next_lists)
+    int list_entries = -1;                 // entries of the round's lists when the host knows them (-1: read back from the index)
     long long count = n;
     HIPCHK(ctx, ws.Pf.reserve(2 * N));
     hipLaunchKernelGGL(k_fus_pack_single, grid1(n), dim3(256), 0, st, dP, n, ws.Pf.p);
@@ -1678,10 +1684,16 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
             hipLaunchKernelGGL(k_fus_reverse<0>, grid1(nc), dim3(256), 0, st, cen, nc, ws.root0.p, len0, off0, arena0, ws.revoff.p, (int*)nullptr);
         }
         PWCHK(pw_exclusive_scan(ctx, ws.revoff.p, (long long)n + 1, &ws.tmp));
-        int n_entries = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&n_entries, ws.revoff.p + n, sizeof(int), hipMemcpyDeviceToHost, st));
+        // (entries of the index = entries of the round's lists: the hand-over of the round before has told the host - no read-back,
+        // and the host goes on enqueuing; the first round's lists are the graph's rows)
+        int n_entries = list_entries;
+        if (n_entries < 0) PWCHK(fe_read_words(ctx, ws, ws.revoff.p + n, 1, &n_entries));
         HIPCHK(ctx, hipMemcpyAsync(ws.cursor.p, ws.revoff.p, sizeof(int) * N, hipMemcpyDeviceToDevice, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
+        // (a block that has to grow goes back to the pool first: not while launches that read it may still be running)
+        {
+            const size_t want = (size_t)std::max(n_entries, 1);
+            if (ws.revown.p && want > ws.revown.n && want * sizeof(int) > ws.revown.cap_bytes) HIPCHK(ctx, hipStreamSynchronize(st));
+        }
         HIPCHK(ctx, ws.revown.reserve((size_t)std::max(n_entries, 1)));
         hipLaunchKernelGGL(k_fus_reverse<1>, grid1(nc), dim3(256), 0, st, cen, nc, ws.root0.p, len0, off0, arena0, ws.cursor.p, ws.revown.p);
         }
@@ -1932,9 +1944,14 @@ int fusion_device(pwicp_context* ctx, const FePt* dP, const int* d_nb, int k, in
         PWCHK(pw_exclusive_scan(ctx, ws.alive.p, (long long)nc + 1, &ws.tmp));
         PWCHK(pw_exclusive_scan(ctx, ws.newlen.p, (long long)nc + 1, &ws.tmp));
         int nc_next = 0, n_list = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&nc_next, ws.alive.p + nc, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipMemcpyAsync(&n_list, ws.newlen.p + nc, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
+        {
+            int two[2] = {0, 0};
+            hipLaunchKernelGGL(k_fe_gather2, dim3(1), dim3(64), 0, st, (const unsigned*)(ws.alive.p + nc), (const unsigned*)(ws.newlen.p + nc),
+                               (unsigned*)(ws.ctr.p + 12));
+            PWCHK(fe_read_words(ctx, ws, ws.ctr.p + 12, 2, two));
+            nc_next = two[0]; n_list = two[1];
+        }
+        list_entries = n_list;
         HIPCHK(ctx, arena_next->reserve((size_t)std::max(n_list, 1)));
         HIPCHK(ctx, hipMemsetAsync(ws.revoff.p, 0, sizeof(int) * (N + 1), st));        // (the closed round's index is no longer read)
         rev_counted = true;
