@@ -159,7 +159,10 @@ typedef struct {
     double t_inner_ms;                    /* HIP-event time of the inner-ICP launches        */
     double dense_kbar;                    /* mean target points examined per dense query     */
     int32_t dense_rows;                   /* 0: disc-pruned dense search (default); 9 / 3: 27-cell stencil on cells / columns */
-    int32_t reserved0;
+    int32_t n_dense_bounded;              /* dense queries (of n_corr_dense) that were NOT searched to the end: their distance was proved to lie
+                                             above the percentile the search feeds (C.cpp:266-281 returns Dist75 only) - far queries of a
+                                             misaligned pair; the value written for them is an upper bound.  n_corr counts the reference-
+                                             defined queries; completed ones = n_corr - n_dense_bounded */
 } pwicp_result;
 
 /* Uploads both clouds and their supervoxel labellings, runs patch selection/statistics and builds
@@ -393,11 +396,6 @@ PWICP_API int  pwicp_comm_rank(const pwicp_comm* comm);
 PWICP_API int  pwicp_comm_world(const pwicp_comm* comm);
 PWICP_API int  pwicp_comm_allgather(pwicp_comm* comm, const void* send, size_t bytes, void* recv /* world * bytes */);
 PWICP_API int  pwicp_comm_broadcast(pwicp_comm* comm, void* buf, size_t bytes, int root);
-/* Test hook of the id file's acceptance rules (no GPU, no RCCL): op 0 writes an id file with this process's job token dated age_s
- * seconds back (returns 1), op 1 reads it as a rank != 0 would: 1 accepted, 0 rejected.  A rank accepts a file only if it carries its
- * launch's token ($PWICP_JOB_ID / $TORCHELASTIC_RUN_ID / MASTER_ADDR / MASTER_PORT / WORLD_SIZE), is younger than 600 s AND was not
- * written more than 30 s before the reading process started (an earlier launch with the same token that was killed). */
-PWICP_API int  pwicp_comm_debug_id_file(const char* path, int op, long age_s);
 /* One rank of PiecewiseICP_4D_call sharded over `world` processes: pair p -> rank p mod world, adaptive pair map from rank 0
  * (broadcast), one all-gather of the 384-byte records, rank 0 writes the files.  Returns the same value on every rank.
  * PiecewiseICP_4D_call takes this path by itself when $PWICP_RCCL=1 and $WORLD_SIZE > 1 (rank / device from $RANK /
@@ -421,23 +419,9 @@ PWICP_API void pwicp_series_release_parked(void);
 enum {
     PWICP_PROF_DENSE = 1,    /* events around every dense 1-NN launch   -> t_dense_nn_ms */
     PWICP_PROF_INNER = 2,    /* events around every inner-ICP batch     -> t_inner_ms */
-    PWICP_PROF_REPLAY = 4    /* keep the stable flags of the first dense launch for pwicp_pair_bench_dense_nn */
+    PWICP_PROF_REPLAY = 4    /* keep the stable flags of the first dense launch (the measurement replay of csrc/pwicp_internal.h) */
 };
 PWICP_API int pwicp_pair_set_profiling(pwicp_pair* pair, int flags);
-
-/* ---- one dense NN launch on resident data, for roofline measurement (bench.py) --------------- */
-/* Runs the dense 1-NN kernel for all source patch points of `pair` against cloud1 `n_launches`
- * times on the pair's stream and returns the mean HIP-event time per launch, the number of queries
- * per launch, and Kbar (mean target points in the 27-cell stencil of a query). */
-PWICP_API int pwicp_pair_bench_dense_nn(pwicp_pair* pair, int n_launches, double* ms_per_launch,
-                                        long long* n_queries, double* kbar, double* cell_edge);
-
-/* The dense 1-NN search of calPercentileDistBetween2PC (CommonFunc.cpp:266-281) by itself: the squared distance of EVERY source
- * patch point (pwicp_pair_num_patch_points: tot2 of them, in the order of the source patch arrays, current positions) to its nearest
- * point of cloud1 - the search the loop runs on the points of its stable patches, here with every patch taken as stable.
- * far_group: 0 / 1 = the far queries inside the search's own launch / on the launch that puts eight lanes on each; -1 = as the loop
- * would choose for a first search.  d2_out: tot2 floats.  (Parity tests compare it with a brute-force search.) */
-PWICP_API int pwicp_pair_dense_distances(pwicp_pair* pair, int far_group, float* d2_out);
 
 #ifdef __cplusplus
 }

@@ -91,7 +91,7 @@ void pwicp_destroy(pwicp_context* ctx) {
 }  // extern "C"
 
 // host/registration.cpp (WorkerParking): what an allocation that is out of device memory may release as its last resort
-bool pw_set_release_parked_hook(bool (*fn)()) { PwPoolRegistry::get().release_parked = fn; return true; }
+bool pw_set_release_parked_hook(bool (*fn)(int)) { PwPoolRegistry::get().release_parked = fn; return true; }
 
 int pw_side_stream(pwicp_context* ctx) {
     if (ctx->side) return PWICP_OK;

@@ -45,7 +45,7 @@ struct PwPoolRegistry {
     // last resort of an allocation that still fails after every cache of the device has been trimmed: frees what closed series /
     // pair calls have left PARKED for the next one - whole contexts with their front-end work spaces, gigabytes that no cache trim
     // reaches (set by host/registration.cpp: WorkerParking; returns whether anything was released)
-    bool (*release_parked)() = nullptr;
+    bool (*release_parked)(int device) = nullptr;    // host/registration.cpp: frees what is parked for THAT device only
 };
 struct PwPool {
     std::mutex mu;
@@ -94,7 +94,12 @@ struct PwPool {
                 e = hipMalloc(out, c);
                 if (e == hipErrorOutOfMemory && PwPoolRegistry::get().release_parked) {     // ... then the parked contexts
                     (void)hipGetLastError();
-                    if (PwPoolRegistry::get().release_parked()) e = hipMalloc(out, c);
+                    // (destroying a parked context selects ITS device: the caller's device is put back before the retry)
+                    int cur = device;
+                    (void)hipGetDevice(&cur);
+                    const bool freed = PwPoolRegistry::get().release_parked(device);
+                    (void)hipSetDevice(cur);
+                    if (freed) e = hipMalloc(out, c);
                 }
             }
         }

@@ -392,6 +392,11 @@ __device__ __forceinline__ int dense_home_cell(int c, int n) {
 #else
 #define PW_DENSE_SGPR_ATTR
 #endif
+// PW_DENSE_FAST (round 6): on a level of columns the ball is ONE flat per-lane loop over a list of ranges in LDS (disc_ranges_columns /
+// scan_ranges_flat, nn_device.h); 0 = every ball through scan_disc_lean's nested row loops (rounds 2 - 5)
+#ifndef PW_DENSE_FAST
+#define PW_DENSE_FAST 1
+#endif
 template <int PERM, bool FARG>
 __global__ void __launch_bounds__(kDenseBlock) PW_DENSE_SGPR_ATTR k_nn_dense_disc(GridLevel dl, GridDesc far, const float4* __restrict__ pat,
                                                           const int* __restrict__ qorder, const int* __restrict__ qpatch,
@@ -399,9 +404,15 @@ __global__ void __launch_bounds__(kDenseBlock) PW_DENSE_SGPR_ATTR k_nn_dense_dis
                                                           float* __restrict__ d2out,
                                                           unsigned long long* __restrict__ examined, int chunk, FusedSelect fs,
                                                           DenseFarList fl, const float4* __restrict__ patq, int sub) {
-    __shared__ unsigned s_hist[kFsBins];    // pass 0 of the percentile selection (select_dev.h), fs.scratch != nullptr only
-    __shared__ float4 s_q[kDenseBlock];          // .w carries the candidate d2 of an unresolved query
-    __shared__ int s_slot[kDenseBlock];
+    // LDS, two lives: while the lanes search, their range lists (PW_DENSE_FAST: kDiscRangesMax x block int2, lane-major); once the
+    // whole block is through (first barrier below), the bins of the percentile selection's pass 0 (select_dev.h, fs.scratch !=
+    // nullptr only) and the compacted far queries (.w carries the candidate d2 of an unresolved query)
+    constexpr int kTailBytes = kFsBins * 4 + kDenseBlock * 16 + kDenseBlock * 4;
+    constexpr int kListBytes = PW_DENSE_FAST ? kDiscRangesMax * kDenseBlock * 8 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kTailBytes > kListBytes ? kTailBytes : kListBytes];
+    float4* const s_q = (float4*)s_raw;
+    unsigned* const s_hist = (unsigned*)(s_raw + kDenseBlock * 16);
+    int* const s_slot = (int*)(s_raw + kDenseBlock * 16 + kFsBins * 4);
     __shared__ int s_wcnt[kDenseBlock / 64];
 #ifdef PW_DENSE_BLOCKTRACE
     if (threadIdx.x == 0 && blockIdx.x < 8192) { pw_dense_bt[8 * blockIdx.x] = __builtin_amdgcn_s_memrealtime(); pw_dense_bt[8 * blockIdx.x + 2] = blockIdx.x % kXcds; }
@@ -421,13 +432,9 @@ __global__ void __launch_bounds__(kDenseBlock) PW_DENSE_SGPR_ATTR k_nn_dense_dis
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = tile * kDenseBlock + tid;
     unsigned cnt = 0;
-    bool unresolved = false;
+    bool unresolved = false, have = false;       // have: `best` is this lane's final value (its bin is counted behind the barriers)
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     float best = INFINITY;
-    if (fs.scratch) {
-        for (int t = tid; t < kFsBins; t += kDenseBlock) s_hist[t] = 0u;
-        __syncthreads();
-    }
     if (i < nq) {
         // patq (the run's first search, on a source that has not moved yet): the queries lie in launch order, so the point comes
         // with the first round trip, and the stable flag of its patch shares the second one with the words of the query's own
@@ -463,10 +470,19 @@ __global__ void __launch_bounds__(kDenseBlock) PW_DENSE_SGPR_ATTR k_nn_dense_dis
             if (best < INFINITY && rho <= kMaxRhoCells * dl.h) {
                 // (a row outside the grid / an empty clipped segment: nothing of the ball has been scanned yet)
                 const bool in = cy >= 0 && cy < dl.ny && cz >= 0 && cz < dl.nz && max(cx - 1, 0) <= min(cx + 1, dl.nx - 1);
+                have = true;
+#if PW_DENSE_FAST
+                const bool gyl = dl.inv_hy != 0.0f, gzl = dl.inv_hz != 0.0f;
+                if (gyl != gzl) {                // a level of columns (wave-uniform): the flat loop
+                    const int n = disc_ranges_columns(dl, ux, uy, uz, rho, in ? (gyl ? cy : cz) : INT_MIN, max(cx - 1, 0), min(cx + 1, dl.nx - 1),
+                                                      loA, hiA, (int2*)s_raw, kDenseBlock, tid, cnt);
+                    if (n >= 0) scan_ranges_flat<PERM>(dl, (const int2*)s_raw, kDenseBlock, tid, n, ux, uy, uz, best);
+                    else { have = false; unresolved = true; }            // (cannot happen below kMaxRhoCells; a far query is always exact)
+                } else
+#endif
                 cnt += scan_disc_lean<PERM, false, true>(dl, ux, uy, uz, rho, in ? cy : INT_MIN, in ? cz : INT_MIN, max(cx - 1, 0),
                                                          min(cx + 1, dl.nx - 1), loA, hiA, best);
-                d2out[i] = best;
-                if (fs.scratch) atomicAdd(&s_hist[__float_as_uint(best) >> 21], 1u);
+                if (have) d2out[i] = best;
             } else {
                 unresolved = true;
             }
@@ -479,7 +495,7 @@ __global__ void __launch_bounds__(kDenseBlock) PW_DENSE_SGPR_ATTR k_nn_dense_dis
     const unsigned long long mask = __ballot(unresolved);
     const int before = __popcll(mask & ((1ull << lane) - 1ull));
     if (lane == 0) s_wcnt[wave] = __popcll(mask);
-    __syncthreads();
+    __syncthreads();                                 // (every lane of the block is through with its range list: the LDS changes hands)
     PW_BT(6);
     int base = 0, total = 0;
 #pragma unroll
@@ -487,11 +503,14 @@ __global__ void __launch_bounds__(kDenseBlock) PW_DENSE_SGPR_ATTR k_nn_dense_dis
         if (w < wave) base += s_wcnt[w];
         total += s_wcnt[w];
     }
+    if (fs.scratch)
+        for (int t = tid; t < kFsBins; t += kDenseBlock) s_hist[t] = 0u;
     if (unresolved) {
         s_q[base + before] = make_float4(q.x, q.y, q.z, best);
         s_slot[base + before] = i;
     }
     __syncthreads();
+    if (have && fs.scratch) atomicAdd(&s_hist[__float_as_uint(best) >> 21], 1u);
     if (FARG) {
         // ... and handed to the launch behind this one (k_nn_dense_far), which puts EIGHT lanes on each: a far query scans ~40
         // rows and ~200 candidates (the first iteration of a real pair: half the queries), and a launch of 10^5 queries is a
@@ -519,6 +538,141 @@ __global__ void __launch_bounds__(kDenseBlock) PW_DENSE_SGPR_ATTR k_nn_dense_dis
     if (threadIdx.x == 0 && blockIdx.x < 8192) pw_dense_bt[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
+
+#ifdef PW_DENSE_SLOTS
+// -DPW_DENSE_SLOTS (tools/dense_slots.py, round 6): what the wave of k_nn_dense_disc EXECUTES against what its lanes NEED.  A lane
+// walks its ball z-slab by z-slab, four rows at a time, row by row in passes of four candidates; the wave runs every one of those
+// loops to its slowest lane's count, i.e. sum over (slab, row slot, piece) of max over lanes of the passes - against the max over
+// lanes of a lane's OWN sum of passes, which is what one flat per-lane loop over all its ranges would execute.  This kernel repeats
+// the search's decisions (same phase A, same ball, same ranges) without scanning the ball and counts both, launch by launch.
+__device__ unsigned long long pw_dense_slots[128];
+extern "C" __attribute__((visibility("default"))) int pwicp_debug_dense_slots(unsigned long long* out, int n, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(pw_dense_slots), sizeof(unsigned long long) * (size_t)n) != hipSuccess) return -1;
+    if (reset) { static unsigned long long z[128]; if (hipMemcpyToSymbol(HIP_SYMBOL(pw_dense_slots), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+__device__ __forceinline__ int slots_wmax(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ unsigned long long slots_wsum(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <int PERM>
+__global__ void __launch_bounds__(kDenseBlock) k_dense_slots(GridLevel dl, const float4* __restrict__ pat, const int* __restrict__ qorder,
+                                                             const int* __restrict__ qpatch, const int* __restrict__ stable, int nq, int chunk,
+                                                             const float4* __restrict__ patq, int sub) {
+    const int xr = (int)(blockIdx.x / kXcds);
+    const int run = xr / sub;
+    const int tile = chunk > 0 ? run * (kXcds * sub) + (int)(blockIdx.x % kXcds) * sub + xr % sub : (int)blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int i = tile * kDenseBlock + tid;
+    int st = 0, loA = 0, hiA = 0, cx = 0, cy = 0, cz = 0;
+    float ux = 0.f, uy = 0.f, uz = 0.f, best = INFINITY;
+    if (i < nq) {
+        const int p = patq ? 0 : qorder[i], pa = qpatch[i];
+        st = (patq || p >= 0) ? stable[pa] : 0;
+        const float4 q = patq ? patq[i] : pat[max(p, 0)];
+        if (st) {
+            ux = PERM == 0 ? q.x : (PERM == 1 ? q.y : q.z); uy = PERM == 0 ? q.y : (PERM == 1 ? q.z : q.x); uz = PERM == 0 ? q.z : (PERM == 1 ? q.x : q.y);
+            cx = dense_home_cell(cell_of(ux, dl.ox, dl.inv_h), dl.nx); cy = dense_home_cell(cell_of(uy, dl.oy, dl.inv_hy), dl.ny);
+            cz = dense_home_cell(cell_of(uz, dl.oz, dl.inv_hz), dl.nz);
+            row_range(dl, cy, cz, cx - 1, cx + 1, loA, hiA);
+            scan_d2_level<PERM>(dl, loA, hiA, ux, uy, uz, best);
+        }
+    }
+    const int pA = st ? (hiA - loA + 3) >> 2 : 0;
+    const float rho = fast_sqrt_up(best) + 2.0f * dl.slack;
+    const bool res = st && best < INFINITY && rho <= kMaxRhoCells * dl.h;
+    // the ball's rows exactly as scan_disc_lean enumerates them, wave-uniformly
+    const GridLevel& g = dl;
+    const bool gy = g.inv_hy != 0.0f, gz = g.inv_hz != 0.0f;
+    const bool in = cy >= 0 && cy < dl.ny && cz >= 0 && cz < dl.nz && max(cx - 1, 0) <= min(cx + 1, dl.nx - 1);
+    const int sy = in ? cy : INT_MIN, sz = in ? cz : INT_MIN, sx0 = max(cx - 1, 0), sx1 = min(cx + 1, dl.nx - 1);
+    const int y0 = gy ? max(icell(uy - rho, g.oy, g.inv_hy), 0) : 0, y1 = gy ? min(icell(uy + rho, g.oy, g.inv_hy), g.ny - 1) : 0;
+    const int z0 = gz ? max(icell(uz - rho, g.oz, g.inv_hz), 0) : 0, z1 = gz ? min(icell(uz + rho, g.oz, g.inv_hz), g.nz - 1) : 0;
+    const float rho2 = rho * rho, slack2 = 2.0f * g.slack;
+    const int nzl = res ? max(z1 - z0 + 1, 0) : 0, nyl = res ? max(y1 - y0 + 1, 0) : 0;
+    const int mz = slots_wmax(nzl), myb = slots_wmax((nyl + 3) >> 2);
+    int eB = 0, lB = 0, cB = 0, nranges = 0, setups = 0;
+    bool fast = res && nzl <= 1 && y0 >= cy - 1 && y1 <= cy + 1 && in;
+    for (int iz = 0; iz < mz; ++iz) {
+        const int z = z0 + iz;
+        bool zin = iz < nzl;
+        float remz = rho2;
+        if (zin && gz) {
+            const float lo = g.oz + (float)z * g.h;
+            const float ez = fmaxf(fmaxf(lo - uz, uz - (lo + g.h)) - slack2, 0.0f);
+            remz = rho2 - ez * ez;
+            if (!(remz > 0.0f)) zin = false;
+        }
+        for (int ib = 0; ib < myb; ++ib) {
+            const bool bin = zin && y0 + 4 * ib <= y1;
+            if (__ballot(bin)) ++setups;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int lo = 0, hi = 0, lo2 = 0, hi2 = 0;
+                const int y = y0 + 4 * ib + k;
+                if (bin && y <= y1) {
+                    float rem = remz;
+                    bool ok = true;
+                    if (gy) {
+                        const float l = g.oy + (float)y * g.h;
+                        const float ey = fmaxf(fmaxf(l - uy, uy - (l + g.h)) - slack2, 0.0f);
+                        rem = remz - ey * ey;
+                        ok = rem > 0.0f;
+                    }
+                    if (ok) {
+                        const float rx = fast_sqrt_up(rem) + slack2;
+                        const int x0 = max(icell(ux - rx, g.ox, g.inv_h), 0), x1 = min(icell(ux + rx, g.ox, g.inv_h), g.nx - 1);
+                        if (x0 <= x1) {
+                            if (x0 < cx - 1 || x1 > cx + 1) fast = false;
+                            const int row = (z * g.ny + y) * g.nx;
+                            if (y == sy && z == sz) {
+                                if (x0 < sx0) { lo = g.cell_start[row + x0]; hi = loA; }
+                                if (x1 > sx1) { lo2 = hiA; hi2 = g.cell_start[row + x1 + 1]; }
+                            } else {
+                                lo = g.cell_start[row + x0];
+                                hi = g.cell_start[row + x1 + 1];
+                            }
+                        }
+                    }
+                }
+                const int p1 = (hi - lo + 3) >> 2, p2 = (hi2 - lo2 + 3) >> 2;
+                eB += slots_wmax(p1) + slots_wmax(p2);
+                lB += p1 + p2;
+                cB += (hi - lo) + (hi2 - lo2);
+                nranges += (p1 > 0) + (p2 > 0);
+            }
+        }
+    }
+    const int eA = slots_wmax(pA), mB = slots_wmax(lB), mAB = slots_wmax(pA + lB);
+    const unsigned long long anyres = __ballot(res);
+    const unsigned long long s_res = slots_wsum(res ? 1 : 0), s_pA = slots_wsum((unsigned long long)pA), s_lB = slots_wsum((unsigned long long)lB),
+                             s_cA = slots_wsum((unsigned long long)(st ? hiA - loA : 0)), s_cB = slots_wsum((unsigned long long)cB),
+                             s_unres = slots_wsum(st && !res ? 1 : 0), s_st = slots_wsum(st ? 1 : 0), s_fast = slots_wsum(fast ? 1 : 0);
+    const bool allfast = __ballot(res && !fast) == 0ull;
+    if (lane == 0 && __ballot(st != 0)) {
+        unsigned long long* S = pw_dense_slots;
+        atomicAdd(&S[0], anyres ? 1ull : 0ull); atomicAdd(&S[1], s_res); atomicAdd(&S[2], (unsigned long long)eA); atomicAdd(&S[3], s_pA);
+        atomicAdd(&S[4], (unsigned long long)eB); atomicAdd(&S[5], s_lB); atomicAdd(&S[6], (unsigned long long)mB);
+        atomicAdd(&S[7], (unsigned long long)mAB); atomicAdd(&S[8], (unsigned long long)setups); atomicAdd(&S[9], s_cA);
+        atomicAdd(&S[10], s_cB); atomicAdd(&S[11], s_unres); atomicAdd(&S[12], s_st); atomicAdd(&S[13], s_fast);
+        atomicAdd(&S[14], anyres && allfast ? 1ull : 0ull); atomicAdd(&S[15], 1ull);
+        atomicAdd(&S[80 + min(eB >> 1, 15)], 1ull);
+        atomicAdd(&S[96 + min(mB, 15)], 1ull);
+    }
+    if (res) {
+        atomicAdd(&pw_dense_slots[16 + min((int)(rho * dl.inv_h * 4.0f), 15)], 1ull);
+        atomicAdd(&pw_dense_slots[32 + min(nranges, 15)], 1ull);
+        atomicAdd(&pw_dense_slots[48 + min(nzl * nyl, 15)], 1ull);
+        atomicAdd(&pw_dense_slots[64 + min(lB, 15)], 1ull);
+    }
+}
+#endif
 
 // ---- the same search with the candidates of a BLOCK staged in LDS (round 5; levels of COLUMNS only) ---------------------------
 // In strip order (tall strips of 16 cells) the 256 queries of a block lie on ~4 consecutive row segments of the searched level, and
@@ -929,7 +1083,8 @@ __device__ float nn_block_shells_d2(const GridLevel& c, float qx, float qy, floa
     return best;
 }
 
-__global__ void __launch_bounds__(kBlock) k_nn_dense_far(GridDesc far, DenseFarList fl, float* __restrict__ d2out, FusedSelect fs) {
+__global__ void __launch_bounds__(kBlock) k_nn_dense_far(GridDesc far, DenseFarList fl, float* __restrict__ d2out, FusedSelect fs,
+                                                         unsigned long long* __restrict__ examined) {
     __shared__ unsigned s_hist[kFsBins];
     __shared__ unsigned s_n, s_last;
     constexpr int kSlowCap = 32;            // queries of this block that need the general search: the whole block takes them at the end
@@ -958,6 +1113,7 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_far(GridDesc far, DenseFarL
         __syncthreads();
     }
     const int sub = tid % kGroup;
+    unsigned n_bounded = 0;         // queries of this group that were NOT searched to the end (proved above the percentile's edge)
     // everything within g of the query examined, best result d: is the query's distance known to lie above the percentile?
     auto above_edge = [&](float d, float g) { return g > 0.0f && fminf(d, g * g * 0.99999f) >= edge; };
     // (entry qi to block qi % #blocks: neighbours on the list are neighbours in space, and the few queries that need the general
@@ -987,13 +1143,15 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_far(GridDesc far, DenseFarL
                 // (a small ball first: three quarters of a real pair's far queries are within a cell of the surface)
                 const float r1 = kFirstBallCells * L.h;
                 scan_disc_group<kGroup>(L, u.x, u.y, u.z, r1, sub, d);
-                done = (d < INFINITY && fast_sqrt_up(d) + sl2 <= r1) || above_edge(d, r1 - sl2);
+                done = d < INFINITY && fast_sqrt_up(d) + sl2 <= r1;
+                if (!done && above_edge(d, r1 - sl2)) { done = true; ++n_bounded; }
                 if (done) FAR_STAT(2 + 3 * lv);
                 if (!done) {
                     const float sq2 = d < INFINITY ? fast_sqrt_up(d) + sl2 : INFINITY;
                     const float r2 = fminf(sq2, lim);                  // the candidate's ball if it fits, else the widest
                     scan_disc_group<kGroup>(L, u.x, u.y, u.z, r2, sub, d);
-                    done = sq2 <= lim || (d < INFINITY && fast_sqrt_up(d) + sl2 <= lim) || above_edge(d, r2 - sl2);
+                    done = sq2 <= lim || (d < INFINITY && fast_sqrt_up(d) + sl2 <= lim);
+                    if (!done && above_edge(d, r2 - sl2)) { done = true; ++n_bounded; }
                     if (done) FAR_STAT(3 + 3 * lv);
                 }
             }
@@ -1027,6 +1185,14 @@ __global__ void __launch_bounds__(kBlock) k_nn_dense_far(GridDesc far, DenseFarL
         }
     }
     if (fs.scratch) fs_pass0_epilogue(s_hist, fs);
+    // honest accounting: a query that was cut short is NOT a completed 1-NN query - counted in bits 40.. of the block's
+    // diagnostic counter (bits 0..39: candidates examined), pwicp_result.n_dense_bounded
+    if (examined) {
+        unsigned long long nb = sub == 0 ? (unsigned long long)n_bounded : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nb += __shfl_xor(nb, o);
+        if ((tid & 63) == 0 && nb) atomicAdd(&examined[(blockIdx.x & 255) * 16], nb << 40);
+    }
     // the block that reads the count last re-arms the list for the next launch
     __syncthreads();
     if (tid == 0) {
@@ -1804,6 +1970,13 @@ int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pa
         }
 #undef PW_DENSE
 #undef PW_DENSE_W
+#ifdef PW_DENSE_SLOTS
+        if (!use_win) {
+            if (dense->perm == 0) hipLaunchKernelGGL((k_dense_slots<0>), dim3(chunk * kXcds), dim3(kDenseBlock), 0, ctx->stream, *dense, d_pat, d_qorder, d_qpatch, d_stable, nq, chunk, d_patq, sub);
+            else if (dense->perm == 1) hipLaunchKernelGGL((k_dense_slots<1>), dim3(chunk * kXcds), dim3(kDenseBlock), 0, ctx->stream, *dense, d_pat, d_qorder, d_qpatch, d_stable, nq, chunk, d_patq, sub);
+            else hipLaunchKernelGGL((k_dense_slots<2>), dim3(chunk * kXcds), dim3(kDenseBlock), 0, ctx->stream, *dense, d_pat, d_qorder, d_qpatch, d_stable, nq, chunk, d_patq, sub);
+        }
+#endif
         if (far_group)
         {
             // blocks per CU: four, each walking its share of the list (measured on the reference's scans, 120 k far queries: loop
@@ -1812,7 +1985,7 @@ int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pa
             static int per_cu = -1;
             if (per_cu < 0) { const char* e = getenv("PWICP_FAR_BLOCKS_PER_CU"); per_cu = e ? std::max(atoi(e), 1) : 4; }
             hipLaunchKernelGGL(k_nn_dense_far, dim3((unsigned)std::min(div_up((long long)nq * kGroup, kBlock), ctx->n_cu * per_cu)), dim3(kBlock), 0,
-                               ctx->stream, g, fl, d_d2, fs ? *fs : none);
+                               ctx->stream, g, fl, d_d2, fs ? *fs : none, d_examined);
         }
         HIPCHK(ctx, hipGetLastError());
         return PWICP_OK;

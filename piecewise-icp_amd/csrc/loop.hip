@@ -15,6 +15,7 @@
 #include "icp.h"
 #include "nn_device.h"
 #include "patch.h"
+#include "pwicp_internal.h"
 #include "select_dev.h"
 #include "stage_dev.h"
 #include "xform_dev.h"
@@ -1142,6 +1143,9 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
             if (e.second == 0) res->t_dense_nn_ms += ms; else res->t_inner_ms += ms;
         }
     }
+    // bits 40..: dense queries that were cut short at the percentile's edge (k_nn_dense_far), bits 0..39: candidates examined
+    res->n_dense_bounded = (int32_t)std::min<unsigned long long>(ex >> 40, 0x7fffffffull);
+    ex &= (1ull << 40) - 1ull;
     res->dense_kbar = res->n_corr_dense > 0 ? (double)ex / (double)res->n_corr_dense : 0.0;
     // 0: disc-pruned search (rows vary with the candidate's distance); 3 / 9: the stencil kernel on columns / cells
     res->dense_rows = pr->dense_lv ? 0 : ((pr->tgt->g_c1.d.fine.ny == 1 || pr->tgt->g_c1.d.fine.nz == 1) ? 3 : 9);
@@ -1310,7 +1314,7 @@ int pwicp_pair_bench_dense_nn(pwicp_pair* pr, int n_launches, double* ms_per_lau
         std::vector<unsigned long long> hx(256 * 16);
         HIPCHK(ctx, hipMemcpyAsync(hx.data(), pr->examined.p, hx.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        for (int i = 0; i < 256; ++i) ex += hx[(size_t)i * 16];
+        for (int i = 0; i < 256; ++i) ex += hx[(size_t)i * 16] & ((1ull << 40) - 1ull);     // (bits 40..: bounded far queries)
     }
     hipEvent_t e0 = pr->event(0), e1 = pr->event(1);
     HIPCHK(ctx, hipEventRecord(e0, ctx->stream));

@@ -572,6 +572,86 @@ __device__ __forceinline__ unsigned scan_disc_lean(const GridLevel& g, float qx,
     return cnt;
 }
 
+// ---- round 6: the ball on a level of COLUMNS as ONE flat loop per lane ---------------------------------------------------------
+// tools/dense_slots.py (profiles/r06_dense_variants.txt): a wave of scan_disc_lean executes, per (z slab, batch of four rows, row,
+// piece), a scan loop that runs to its slowest lane's count - 11.1 passes of four candidates for the ball where the lanes' OWN sums
+// need 7.0 - and ~600 of its ~1 000 vector instructions are the walk around the candidates (a z loop, a y loop, four row slots with
+// two pieces each), not the candidates.  On a level of columns the ball has ONE row axis and at most kDiscRowsMax rows:
+//   1. every row's x-range from scan_disc_lean's own formulas (same floats, same cells), begin / end words of ALL touched rows
+//      requested together (unrolled: one round trip), the own row reduced to the pieces phase A has not scanned;
+//   2. the non-empty ranges written to a per-lane list in LDS (lane-major: conflict-free 8-byte accesses);
+//   3. one loop over the list, four candidates per pass, no tails: the wave runs max over lanes of the lane's SUM of passes.
+// Same candidates as scan_disc_lean visits, same float expression each, and a minimum does not depend on the order: the same d2, bit
+// for bit.  (First tried and measured slower: the two neighbour rows' words preloaded before phase A with the other lanes left to
+// scan_disc_lean, inline - 36.0 us - or compacted behind the block - 32.8 us - against 30.4; profiles/r06_dense_variants.txt.)
+constexpr int kDiscRowsMax = 7;            // rows a ball of at most kMaxRhoCells (2.75) cells can touch: floor(2 * 2.75) + 2
+constexpr int kDiscRangesMax = 8;          // ... plus the second piece of the own row
+// x-range of row `r` of the ball (scan_disc_lean's formulas, one row axis): false = the row is not touched
+__device__ __forceinline__ bool disc_row_cells(const GridLevel& g, float ux, float v, float ov, int r, float rho2, float slack2, int& x0, int& x1) {
+    const float l = ov + (float)r * g.h;
+    const float e = fmaxf(fmaxf(l - v, v - (l + g.h)) - slack2, 0.0f);
+    const float rem = rho2 - e * e;
+    if (!(rem > 0.0f)) return false;
+    const float rx = fast_sqrt_up(rem) + slack2;
+    x0 = max(icell(ux - rx, g.ox, g.inv_h), 0);
+    x1 = min(icell(ux + rx, g.ox, g.inv_h), g.nx - 1);
+    return x0 <= x1;
+}
+// list: kDiscRangesMax rows of `stride` int2 (lane-major), `tid` = this lane's column.  home: the row whose cells sx0 .. sx1 = points
+// [slo, shi) phase A has scanned (INT_MIN: none).  Returns the number of ranges, -1 if the ball has more rows than the list holds.
+__device__ __forceinline__ int disc_ranges_columns(const GridLevel& g, float ux, float uy, float uz, float rho, int home, int sx0, int sx1,
+                                                   int slo, int shi, int2* __restrict__ list, int stride, int tid, unsigned& cnt) {
+    const bool gy = g.inv_hy != 0.0f;
+    const float v = gy ? uy : uz, ov = gy ? g.oy : g.oz, inv_hv = gy ? g.inv_hy : g.inv_hz;
+    const int nv = gy ? g.ny : g.nz;
+    const int v0 = max(icell(v - rho, ov, inv_hv), 0), v1 = min(icell(v + rho, ov, inv_hv), nv - 1);
+    if (v1 - v0 >= kDiscRowsMax) return -1;
+    const float rho2 = rho * rho, slack2 = 2.0f * g.slack;
+    int lo[kDiscRangesMax], hi[kDiscRangesMax];
+#pragma unroll
+    for (int k = 0; k < kDiscRangesMax; ++k) lo[k] = hi[k] = 0;
+#pragma unroll
+    for (int k = 0; k < kDiscRowsMax; ++k) {
+        const int r = v0 + k;
+        int x0, x1;
+        if (r <= v1 && disc_row_cells(g, ux, v, ov, r, rho2, slack2, x0, x1)) {
+            const int* __restrict__ cs = g.cell_start + (size_t)r * g.nx;         // (the other axis has ONE cell: row = r * nx)
+            if (r == home) {
+                if (x0 < sx0) { lo[k] = cs[x0]; hi[k] = slo; }
+                if (x1 > sx1) { lo[kDiscRowsMax] = shi; hi[kDiscRowsMax] = cs[x1 + 1]; }
+            } else {
+                lo[k] = cs[x0];
+                hi[k] = cs[x1 + 1];
+            }
+        }
+    }
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < kDiscRangesMax; ++k)
+        if (hi[k] > lo[k]) {
+            list[n * stride + tid] = make_int2(lo[k], hi[k]);
+            cnt += (unsigned)(hi[k] - lo[k]);
+            ++n;
+        }
+    return n;
+}
+template <int PERM>
+__device__ __forceinline__ void scan_ranges_flat(const GridLevel& g, const int2* __restrict__ list, int stride, int tid, int n, float ux, float uy,
+                                                 float uz, float& best) {
+    const PwXyz3* __restrict__ p3 = (const PwXyz3*)g.pts3;
+    int j = 0, e = 0, k = 0;
+    if (n > 0) { const int2 r = list[tid]; j = r.x; e = r.y; k = 1; }
+    while (j < e) {
+        const PwXyz3 a = p3[j], b = p3[j + 1], c = p3[j + 2], d = p3[j + 3];
+        nn_consider_d2<PERM>(make_float4(a.x, a.y, a.z, 0.f), ux, uy, uz, best);
+        nn_consider_d2<PERM>(make_float4(b.x, b.y, b.z, 0.f), ux, uy, uz, best);
+        nn_consider_d2<PERM>(make_float4(c.x, c.y, c.z, 0.f), ux, uy, uz, best);
+        nn_consider_d2<PERM>(make_float4(d.x, d.y, d.z, 0.f), ux, uy, uz, best);
+        j += 4;
+        if (j >= e && k < n) { const int2 r = list[k * stride + tid]; j = r.x; e = r.y; ++k; }
+    }
+}
+
 // scan_disc_lean shared by a group of G lanes (one query): the rows of the ball are dealt to the lanes round-robin and every lane
 // walks ITS rows as the per-lane search does (four rows' begin / end words in flight, then their points four at a time) - a wide
 // ball (40 rows, 200 candidates) is 1/G of the rows and candidates per lane, i.e. a chain of ~10 round trips instead of ~90.

@@ -109,6 +109,13 @@ __device__ __forceinline__ void fs_pick0(unsigned* h, const FusedSelect& fs, uns
 // are all in the bins): if at least k + 1 of them lie in bins <= b, the k-th smallest of ALL values - the ones still to come only add
 // to the counts - is below the upper edge of bin b.  Returns that edge as float bits ((b + 1) << 21), ~0u when the bins do not decide
 // it yet.  Read-only on the global bins; `h` (kFsBins words of LDS) is scratch and left zeroed; blockDim.x == 256.
+// The edge must be the bit pattern of a finite positive float: bin b holds the values whose bits >> 21 == b, the last finite one
+// is bin 1019 (+inf = 0x7F800000 opens bin 1020), and (b + 1) << 21 with b = 1023 would be 0x80000000 = -0.0f - "above" which every
+// far query lies.  Bins >= 1020 are only reachable with inf / NaN distances (coordinates are checked finite at upload); they decide
+// nothing.  NOTE for every consumer of the dense distances: a value written for a query that was cut short at the edge is an
+// UPPER BOUND of its distance, good for the rank statistics below the edge (the percentile, R.cpp:905) and for nothing else.
+constexpr unsigned kFsLastFiniteEdge = 1020u;
+static_assert((kFsLastFiniteEdge << 21) == 0x7F800000u, "the last edge the selection may report is +inf");
 __device__ __forceinline__ unsigned fs_partial_edge(unsigned* h, const FusedSelect& fs) {
     __shared__ unsigned s_w[4], s_edge;
     const unsigned* g0 = fs.scratch + kFsCtl;
@@ -154,7 +161,7 @@ __device__ __forceinline__ unsigned fs_partial_edge(unsigned* h, const FusedSele
         unsigned run = excl;
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
-            if (k >= run && k < run + c[b]) { const unsigned bin = (unsigned)(t * 8 + b); s_edge = bin + 1u < (unsigned)kFsBins ? (bin + 1u) << 21 : ~0u; }
+            if (k >= run && k < run + c[b]) { const unsigned bin = (unsigned)(t * 8 + b); s_edge = bin + 1u <= kFsLastFiniteEdge ? (bin + 1u) << 21 : ~0u; }
             run += c[b];
         }
     }

@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "pwicp.h"
+#include "../csrc/pwicp_internal.h"
 
 namespace {
 
@@ -88,6 +89,18 @@ constexpr int64_t kIdMaxAgeSeconds = 600;
 // (torchrun's static rendezvous: TORCHELASTIC_RUN_ID "none", default port, same world size, no $PWICP_JOB_ID) and it is younger than
 // kIdMaxAgeSeconds (an earlier launch that was killed a minute ago).
 constexpr int64_t kLauncherStaggerSeconds = 30;
+// How far apart the processes of ONE launch may start: 30 s by default, $PWICP_ID_STAGGER_S for launchers that start ranks minutes
+// apart (srun / mpirun behind container pulls, ranks started by hand).  With $PWICP_JOB_ID set the token is unique per launch by
+// the user's own word, an id file that carries it IS this launch's, and the start-time rule is not applied at all (a
+// rank that started later than the stagger after rank 0's write used to refuse a valid id until the rendezvous timed out).
+int64_t launcher_stagger_seconds() {
+    static const int64_t v = [] {
+        if (std::getenv("PWICP_JOB_ID")) return (int64_t)-1;
+        if (const char* e = std::getenv("PWICP_ID_STAGGER_S")) return (int64_t)std::max(atoll(e), 0ll);
+        return kLauncherStaggerSeconds;
+    }();
+    return v;
+}
 
 // start of this process, seconds since the epoch: /proc/self/stat field 22 (clock ticks since boot) + btime of /proc/stat; without
 // procfs the first call into this file stands in for it
@@ -149,12 +162,13 @@ int read_id_file(const std::string& path, ncclUniqueId* id) {
     }
     if (!ok || f.magic != kIdMagic || f.token != job_token()) return 0;                 // another job's, or a torn write
     if ((int64_t)std::time(nullptr) - f.written_at > kIdMaxAgeSeconds) return 0;        // left behind by an earlier run
-    if (f.written_at < process_start_epoch() - kLauncherStaggerSeconds) {               // ... also one with THIS launch's token
+    if (launcher_stagger_seconds() >= 0 && f.written_at < process_start_epoch() - launcher_stagger_seconds()) {    // ... also one with THIS launch's token
         static bool told_stale = false;
         if (!told_stale) {
             told_stale = true;
             std::cerr << "pwicp: " << path << " was written " << (process_start_epoch() - f.written_at) << " s before this process started: "
-                         "an earlier launch's id (same job token) - waiting for rank 0 to replace it\n";
+                         "an earlier launch's id (same job token) - waiting for rank 0 to replace it ($PWICP_ID_STAGGER_S widens the "
+                         "allowed start-time spread of one launch, $PWICP_JOB_ID switches the rule off)\n";
         }
         return 0;
     }

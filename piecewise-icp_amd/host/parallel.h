@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <deque>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -71,35 +72,46 @@ class Pool {
     template <typename F>
     void run(int n, F fn) {
         if (n <= 1) { if (n == 1) fn(0); return; }
-        struct Job { int left; std::mutex mu; std::condition_variable cv; };      // `left` under `mu`
+        struct Job { int left; std::mutex mu; std::condition_variable cv; std::exception_ptr err; };      // `left` under `mu`
         Job job;
         job.left = n - 1;
         {
             std::lock_guard<std::mutex> g(mu_);
             for (int t = 1; t < n; ++t)
                 q_.emplace_back([&job, &fn, t] {
-                    fn(t);
+                    std::exception_ptr e;
+                    try { fn(t); } catch (...) { e = std::current_exception(); }      // (handed to the caller, who rethrows it)
                     std::lock_guard<std::mutex> g2(job.mu);          // (the unlock is this task's last touch of the Job)
+                    if (e && !job.err) job.err = e;
                     if (--job.left == 0) job.cv.notify_all();
                 });
         }
         cv_.notify_all();
-        fn(0);
+        // The queued tasks hold references to `job` and `fn`, which live on this stack frame: whatever the caller's own share (or a
+        // task it helps out with) throws - std::bad_alloc inside a parallel_for body - the frame must outlive every one of them.
+        // The first exception is kept, all n are waited for, then it is thrown again.
+        std::exception_ptr err;
+        try { fn(0); } catch (...) { err = std::current_exception(); }
         for (;;) {
             {
                 std::lock_guard<std::mutex> g(job.mu);
-                if (job.left == 0) return;
+                if (job.left == 0) break;
             }
             std::function<void()> task;
             {
                 std::lock_guard<std::mutex> g(mu_);
                 if (!q_.empty()) { task = std::move(q_.front()); q_.pop_front(); }
             }
-            if (task) { task(); continue; }
+            if (task) {
+                task();                       // (a task keeps its own exception for ITS caller: nothing escapes here)
+                continue;
+            }
             std::unique_lock<std::mutex> g(job.mu);
             job.cv.wait(g, [&job] { return job.left == 0; });
-            return;
+            break;
         }
+        if (!err) err = job.err;               // (all tasks are done: no lock needed)
+        if (err) std::rethrow_exception(err);
     }
 
   private:

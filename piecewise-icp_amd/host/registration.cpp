@@ -9,6 +9,7 @@
 // calTransToReferenceEpoch Registration.cpp:977-1153, calAbsErrorOfTransPara Registration.cpp:1157-1251.
 // Pipeline per pair: load PCD -> VoxelGrid + SOR -> subtract the target centroid -> supervoxel labels (host front
 // end) -> pwicp_pair_create / pwicp_pair_run (the fine-registration loop on the GPU) -> T_final = S^-1 T S -> files.
+#include <hip/hip_runtime_api.h>      // (hipGetDevice / hipSetDevice around the release of parked contexts only)
 #include <algorithm>
 #include <chrono>
 #include <climits>
@@ -591,7 +592,7 @@ PWICP_API int pwicp_write_trans_matrix_file(const char* path, const float* T16, 
 // takes them over warm: the second PiecewiseICP_4D_call of a process costs what its clouds cost.  One set per device is kept
 // ($PWICP_SERIES_KEEP=0: none) until pwicp_series_release_parked() or the end of the process.
 struct ParkedWorker { pwicp_context* ctx = nullptr; std::unique_ptr<AuxContexts> aux; };
-bool pw_set_release_parked_hook(bool (*fn)());        // csrc/api.hip (library-internal)
+bool pw_set_release_parked_hook(bool (*fn)(int device));        // csrc/api.hip (library-internal)
 
 struct WorkerParking {
     std::mutex mu;
@@ -601,13 +602,28 @@ struct WorkerParking {
     static WorkerParking& get() { static WorkerParking* p = new WorkerParking; return *p; }       // (the object itself is never deleted)
     // destroys what is parked (pwicp_series_release_parked, and once at exit: registered when the first set is parked, i.e. after
     // the HIP runtime has registered its own exit work, so it runs before the runtime goes away)
-    bool release_all() {
+    // `device` >= 0: only what is parked for that device (the out-of-memory hook of PwPool::take - the other devices' sets are
+    // not what the failing allocation competes with).  pwicp_destroy selects the context's device: the caller's is put back.
+    bool release_all(int device = -1) {
         std::map<int, ParkedWorker> take;
         std::map<int, pwicp_context*> take_pair;
-        { std::lock_guard<std::mutex> g(mu); take.swap(by_device); take_pair.swap(pair_by_device); }
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (device < 0) { take.swap(by_device); take_pair.swap(pair_by_device); }
+            else {
+                auto a = by_device.find(device);
+                if (a != by_device.end()) { take[device] = std::move(a->second); by_device.erase(a); }
+                auto b = pair_by_device.find(device);
+                if (b != pair_by_device.end()) { take_pair[device] = b->second; pair_by_device.erase(b); }
+            }
+        }
+        if (take.empty() && take_pair.empty()) return false;
+        int cur = -1;
+        const bool have_cur = hipGetDevice(&cur) == hipSuccess;
         for (auto& kv : take) { kv.second.aux.reset(); if (kv.second.ctx) pwicp_destroy(kv.second.ctx); }
         for (auto& kv : take_pair) if (kv.second) pwicp_destroy(kv.second);
-        return !take.empty() || !take_pair.empty();
+        if (have_cur) (void)hipSetDevice(cur);
+        return true;
     }
     void hook_exit() {          // (call with mu held)
         if (!exit_hook) {
@@ -615,7 +631,7 @@ struct WorkerParking {
             std::atexit([] { (void)WorkerParking::get().release_all(); });
             // an allocation anywhere in the process that runs out of device memory gets the parked sets back before it fails
             // (csrc/common.h PwPool::take: after its own cache and every other cache of the device)
-            pw_set_release_parked_hook([] { return WorkerParking::get().release_all(); });
+            pw_set_release_parked_hook([](int device) { return WorkerParking::get().release_all(device); });
         }
     }
     static bool enabled() { static const bool on = !(std::getenv("PWICP_SERIES_KEEP") && atoi(std::getenv("PWICP_SERIES_KEEP")) == 0); return on; }
@@ -908,10 +924,13 @@ static bool target_labels(pwicp_series* s, int scan, const std::shared_ptr<Prepa
         std::unique_lock<std::mutex> g(lx.mu);
         const bool came = lx.cv.wait_for(g, std::chrono::duration<double>(tmo_s), [&] { return lx.supplied.count(scan) > 0; });
         if (came && lx.supplied[scan].m == t->m && (int)lx.supplied[scan].lab.size() == t->m) {
-            t->lab = std::move(lx.supplied[scan].lab);
+            // COPIED, and kept until the series closes: the exchange supplies a scan once, but it may have several takers in this
+            // process - one worker per device prepares the shared target on ITS device (pwicp_series_set_devices), and a target
+            // dropped after a failed window is prepared again in a later one.  (a second taker used to wait out the
+            // whole time-out, 600 s, for labels the first one had moved away.)
+            t->lab = lx.supplied[scan].lab;
             t->nsv = lx.supplied[scan].nsv;
             t->segmented = true;
-            lx.supplied.erase(scan);
             ++lx.n_received;
             g.unlock();
             timeline("target labels: received", scan);
@@ -920,6 +939,7 @@ static bool target_labels(pwicp_series* s, int scan, const std::shared_ptr<Prepa
         std::cerr << "[pwicp] labels of target scan " << scan << (came ? " do not fit this rank's preprocessed cloud" : " did not arrive")
                   << ": segmenting it here.\n";
         lx.supplied.erase(scan);
+        lx.expected.erase(scan);           // ... and later takers of this process segment it at once instead of waiting again
     }
     const bool ok = prepare_labels(t.get(), aux);
     { std::lock_guard<std::mutex> g(lx.mu); lx.done[scan] = ok ? t : nullptr; if (ok) ++lx.n_segmented; }

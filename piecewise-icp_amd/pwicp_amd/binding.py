@@ -54,7 +54,7 @@ class Result(C.Structure):
                 ("n_corr", C.c_longlong), ("n_corr_dense", C.c_longlong), ("n_inner_total", C.c_longlong),
                 ("t_loop_ms", C.c_double), ("t_dense_nn_ms", C.c_double), ("n_dense_nn_launches", C.c_int),
                 ("t_inner_ms", C.c_double), ("dense_kbar", C.c_double),
-                ("dense_rows", C.c_int32), ("reserved0", C.c_int32)]
+                ("dense_rows", C.c_int32), ("n_dense_bounded", C.c_int32)]
 
 
 class Step(C.Structure):

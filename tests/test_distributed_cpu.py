@@ -234,6 +234,18 @@ def test_rccl_id_file_of_an_earlier_launch_with_the_same_token_is_not_taken(tmp_
     since_start = time.time() - psutil.Process().create_time()
     assert L.pwicp_comm_debug_id_file(path, 0, int(since_start) + 60) == 1
     assert L.pwicp_comm_debug_id_file(path, 1, 0) == 0
+    # ... unless the launcher is known to start its ranks far apart ($PWICP_ID_STAGGER_S), or the launch has a name of its own
+    # ($PWICP_JOB_ID: the token IS unique then and the start-time rule is off) - ADVICE r5.  Same token needed: the reader with
+    # $PWICP_JOB_ID must have written the file itself.
+    rd = ("import ctypes as C, sys; sys.path.insert(0, %r); import pwicp_amd as P; L = P.load_library(); "
+          "L.pwicp_comm_debug_id_file.argtypes = [C.c_char_p, C.c_int, C.c_long]; "
+          % os.path.join(ROOT, "piecewise-icp_amd"))
+    wide = dict(os.environ, PWICP_ID_STAGGER_S="100000")
+    two = ("ok = L.pwicp_comm_debug_id_file(%r, 0, 400) == 1 and L.pwicp_comm_debug_id_file(%r, 1, 0) == %d; sys.exit(0 if ok else 1)")
+    assert subprocess.run([sys.executable, "-c", rd + two % (path + b".w", path + b".w", 1)], env=wide).returncode == 0
+    assert subprocess.run([sys.executable, "-c", rd + two % (path + b".d", path + b".d", 0)], env=dict(os.environ)).returncode == 0
+    named = dict(os.environ, PWICP_JOB_ID="named-launch")
+    assert subprocess.run([sys.executable, "-c", rd + two % (path + b".n", path + b".n", 1)], env=named).returncode == 0
     assert L.pwicp_comm_debug_id_file(path, 0, 700 + int(since_start)) == 1   # older than the age limit
     assert L.pwicp_comm_debug_id_file(path, 1, 0) == 0
     # another launch's token: not taken however fresh (a subprocess with another PWICP_JOB_ID writes, this process reads)
