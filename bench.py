@@ -352,6 +352,15 @@ def series_end_to_end(args, P, rank, world, local_rank, dist, dev, barrier):
         parts = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(parts, t)
         labels_by_rank = [[int(x) for x in p_.tolist()] for p_ in parts]
+    # the stage walls of EVERY rank (the series ends with its slowest rank: that one's stages are what the wall time is made of)
+    stages_by_rank = [dict(stages, rank=rank)]
+    if dist is not None:
+        stages_by_rank = [None] * world
+        dist.all_gather_object(stages_by_rank, dict(stages, rank=rank))
+    if rank == 0:
+        def _busy(st):
+            return sum(v for k, v in st.items() if k.endswith("_ms"))
+        slowest = max(stages_by_rank, key=_busy)
     if rank == 0:
         out = {"metric": "pairs/sec of a WARM process, PCD files -> transforms (Direct2Ref series of %d source epochs x %d pts, pairs dealt over "
                          "the GPUs; cold_value: the first series of the process, what a fresh reference process or rounds 1 - 3 are comparable with)" % (E, n),
@@ -359,6 +368,11 @@ def series_end_to_end(args, P, rank, world, local_rank, dist, dev, barrier):
                "pairs": E, "wall_s": round(tmax, 3), "cold_wall_s": round(tcold, 3), "warm_walls_s": [round(x, 3) for x in walls], "all_pairs_ok": ok,
                "rank0_stage_wall_ms": {k: round(v, 1) for k, v in stages.items() if k.endswith("_ms")},
                "rank0_scan_bytes_to_gpu": stages["scan_bytes"],
+               "frontend_host_takeovers_rank0": P.frontend_fallback_counts(),
+               "slowest_rank": int(slowest["rank"]),
+               "slowest_rank_stage_wall_ms": {k: round(v, 1) for k, v in slowest.items() if k.endswith("_ms")},
+               "stage_wall_ms_by_rank": [{k: (round(v, 1) if k.endswith("_ms") else v) for k, v in st.items() if k.endswith("_ms") or k == "rank"}
+                                         for st in stages_by_rank],
                "target_labels_by_rank": labels_by_rank,
                "target_labels_note": "[taken from rank 0's broadcast, made by the rank's own front end] per rank: the shared target of "
                                      "the series is segmented once, by rank 0 (pwicp_amd.series.run_pairs_sharing_target)",
@@ -427,11 +441,67 @@ def frontend_workload(args, ctx, P, rank, world):
             "config": {"workload": "supervoxel labels of one synthetic %d-pt cloud: k-NN-45 graph + PCA normals + fusion + boundary "
                                    "refinement, host buffer in -> labels out" % n, "points_per_cloud": n, "supervoxels": int(nsv_d)},
             "labels_identical_to_serial_passes": bool(nsv_d == nsv_h and np.array_equal(lab_d, lab_h)),
+            "host_takeovers_in_this_process": P.frontend_fallback_counts(),
             "cpu_baseline": {"value": round(n / t_host, 1), "unit": "points/s", "kind": "port",
                              "sample": "the same cloud through the serial host passes (host/frontend.cpp; k-NN graph still on the "
                                        "device), host threads only for normals / lambda0 / seeds", "ms": round(1e3 * t_host, 3)},
             "cpu_reference": ref}))
     ctx.close()
+
+
+def large_roofline(args, P, ctx):
+    """A second roofline record of the dense 1-NN launch on a `--large-points` pair (BASELINE configs[4]'s point count is 5 M; 4 M by
+    default): at 1 M points the launch is two generations of blocks and its ramp and drain are a third of it.  Same measurement as the
+    main record: HIP events around the launch inside the loop, on untimed steps.  Physical traffic only if profiles/traffic_latest.json
+    holds it for these kernel sources and this size."""
+    n = args.large_points
+    global FRONTEND_S
+    keep = FRONTEND_S                      # (make_pair times the front ends of ITS clouds into the global the main line reports)
+    tgt, l1, n1, src, l2, n2, _ = make_pair(n, epoch=1, ctx=ctx)
+    FRONTEND_S = keep
+    r = R_SPACING
+    pair = P.Pair(ctx, tgt, l1, n1, src, l2, n2, P.Params(r, r, 10 * r, 10 * r, 1, 10 * r, 0.8 * r))
+    try:
+        pair.set_profiling(0)
+        walls = []
+        for _ in range(2):
+            pair.reset(); pair.run()
+        for _ in range(5):
+            pair.reset()
+            t0 = time.perf_counter(); pair.run(); walls.append(time.perf_counter() - t0)
+        pair.set_profiling(1)
+        prof = []
+        for _ in range(max(args.roofline_steps, 1)):
+            pair.reset()
+            prof.append(pair.run())
+        n_launch = sum(rr.n_dense_nn_launches for rr in prof)
+        t_ms = sum(rr.t_dense_nn_ms for rr in prof)
+        if not n_launch or t_ms <= 0:
+            return None
+        nq = sum(rr.n_corr_dense for rr in prof) / n_launch
+        dur_s = t_ms / n_launch * 1e-3
+        kbar = prof[-1].dense_kbar
+        compulsory = (16 + 4) * nq + 12.0 * len(tgt)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+            if tj.get("kernel_source_sha256") == kernel_source_hash() and tj.get("large_points") == n:
+                traffic = tj.get("k_nn_dense_bytes_per_launch_large")
+        except Exception:
+            traffic = None
+        b = traffic if traffic else compulsory
+        return {"bound": "hbm", "kernel": "k_nn_dense_disc", "points_per_cloud": n, "achieved": round(b / dur_s / 1e9, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(b / dur_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_is": ("PMC FETCH_SIZE x correction + WRITE_SIZE per launch" if traffic else
+                               "not measured for these sources / this size: achieved uses the compulsory bytes (lower bound)"),
+                "frac_useful": round(compulsory / dur_s / 1e9 / HBM_PEAK_GBS, 4), "compulsory_bytes_per_launch": int(compulsory),
+                "traffic_over_compulsory": (round(traffic / compulsory, 2) if traffic else None),
+                "queries_per_launch": int(nq), "kbar": round(kbar, 2), "avg_launch_us": round(dur_s * 1e6, 2),
+                "ms_per_step": round(1e3 * sorted(walls)[len(walls) // 2], 4), "outer_iterations": int(prof[-1].n_outer),
+                "correspondences_per_step": int(prof[-1].n_corr),
+                "note": "same pair generator and parameters as the main line at %d points per cloud; not part of `value`" % n}
+    finally:
+        pair.close()
 
 
 def launch_ranks(n):
@@ -468,6 +538,11 @@ def main():
     ap.add_argument("--no-inner-timing", action="store_true",
                     help="skip the two extra untimed steps that time the inner ICP with HIP events (kernel-trace runs: the last "
                          "step of the process is then a step as timed)")
+    ap.add_argument("--roofline-steps", type=int, default=5,
+                    help="extra untimed steps with HIP events around the dense 1-NN launch (the roofline record's duration)")
+    ap.add_argument("--large-points", type=int, default=4000000,
+                    help="a SECOND roofline record (roofline_large) of the dense 1-NN launch on a pair of this many points per cloud, where "
+                         "the launch's fixed part is not the whole story (N=1 only); 0: skip")
     ap.add_argument("--labels", choices=["supervoxel", "grid"], default="supervoxel")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for debugging)")
     ap.add_argument("--workload", choices=["pair", "series", "frontend"], default="pair",
@@ -527,7 +602,8 @@ def main():
     t0 = time.time()
     pair = P.Pair(ctx, tgt, l1, n1, src, l2, n2, prm)
     t_setup = time.time() - t0
-    pair.set_profiling(1)        # HIP events around the dense 1-NN launch in EVERY step (the roofline figure; ~9 us of every step)
+    pair.set_profiling(0)        # the timed steps carry NO event records (round 6; a record is a ~5 us bubble on the stream): the
+                                 # roofline kernel's duration comes from extra, untimed steps behind the timed region
 
     def barrier():
         if dist is not None:
@@ -566,17 +642,40 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     tmax = elapsed
-    corr_local = float(sum(rr.n_corr for rr in results))
-    corr_total = corr_local
+    bounded_local = float(sum(rr.n_dense_bounded for rr in results))
+    corr_ref_local = float(sum(rr.n_corr for rr in results))
+    corr_local = corr_ref_local - bounded_local          # completed 1-NN queries only
+    corr_total, corr_ref_total, bounded_total = corr_local, corr_ref_local, bounded_local
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         tmax = float(t.item())
-        c = torch.tensor([corr_local], dtype=torch.float64, device=dev)
+        c = torch.tensor([corr_local, corr_ref_local, bounded_local], dtype=torch.float64, device=dev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        corr_total = float(c.item())
+        corr_total, corr_ref_total, bounded_total = [float(x) for x in c.tolist()]
 
     res = results[-1]
+    # who took part (the first multi-GPU record must be readable on its own): every rank's device as the runtime sees it, and the size
+    # of the communicator the exchange above went through (backend nccl = RCCL)
+    me = {"rank": rank, "local_rank": local_rank, "pid": os.getpid(), "device": int(torch.cuda.current_device())}
+    try:
+        pr_ = torch.cuda.get_device_properties(me["device"])
+        me.update({"name": pr_.name, "uuid": str(getattr(pr_, "uuid", "")), "pci_bus_id": getattr(pr_, "pci_bus_id", None),
+                   "visible_devices": torch.cuda.device_count()})
+    except Exception:
+        pass
+    ranks_seen = [me]
+    comm_info = {"backend": (args.backend if dist is not None else None), "world_size": (dist.get_world_size() if dist is not None else 1)}
+    if dist is not None:
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, me)
+        if args.backend == "nccl":
+            try:
+                comm_info["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception:
+                pass
+        comm_info["distinct_devices"] = len({(r_.get("uuid") or r_.get("pci_bus_id") or r_["device"]) for r_ in ranks_seen})
+        comm_info["records_gathered_per_timed_region"] = len(recs) * world
     side_by_side = None
     if world == 1 and args.pairs_in_flight > 1:
         try:
@@ -593,7 +692,13 @@ def main():
         else:
             series_line = series_end_to_end(args, P, rank, world, local_rank, dist, dev, barrier)
     # inner-iteration timing needs two more HIP events per ICP call (a ~6 us stream bubble each): measured on two
-    # extra, untimed steps so that the timed region carries only the dense-NN events of the roofline figure
+    # extra, untimed steps
+    roofline_large = None
+    if world == 1 and args.large_points > 0:
+        try:
+            roofline_large = large_roofline(args, P, ctx)
+        except Exception as e:                 # a secondary record must not take the metric line with it
+            roofline_large = {"error": "%s: %s" % (type(e).__name__, e)}
     pair.set_profiling(1 | 2)
     t_inner_ms = n_inner_prof = 0
     for _ in range(0 if args.no_inner_timing else 2):
@@ -601,14 +706,20 @@ def main():
         rp = pair.run()
         t_inner_ms += rp.t_inner_ms
         n_inner_prof += int(rp.n_inner_total)
+    # ---- roofline of the dominant kernel (dense 1-NN, k_nn_dense_disc): HIP events around its launches inside the loop, on
+    # `--roofline-steps` extra UNTIMED steps of the same pair (same launches, same stream; the timed steps stay free of events)
     pair.set_profiling(1)
-    # ---- roofline of the dominant kernel (dense 1-NN, k_nn_dense_disc), measured live with HIP events -------
-    n_launch = sum(rr.n_dense_nn_launches for rr in results)
-    t_dense_ms = sum(rr.t_dense_nn_ms for rr in results)
+    prof = []
+    for _ in range(max(args.roofline_steps, 1)):
+        pair.reset()
+        prof.append(pair.run())
+    pair.set_profiling(0)
+    n_launch = sum(rr.n_dense_nn_launches for rr in prof)
+    t_dense_ms = sum(rr.t_dense_nn_ms for rr in prof)
     roofline = None
     if n_launch > 0 and t_dense_ms > 0:
-        nq = sum(rr.n_corr_dense for rr in results) / n_launch
-        kbar = res.dense_kbar
+        nq = sum(rr.n_corr_dense for rr in prof) / n_launch
+        kbar = prof[-1].dense_kbar
         dur_s = (t_dense_ms / n_launch) * 1e-3
         # SURVEY 8d's ALGORITHMIC stream (every query re-reads its candidates: query 16 + d2 out 4 + ~5 cell rows x (begin,
         # end) 8 + 16 per target point examined, Kbar measured by the kernel): mostly L1/L2 hits -> reported as model_gbs only
@@ -616,18 +727,20 @@ def main():
         model_gbs = b_nn * nq / dur_s / 1e9
         # PHYSICAL bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md
         # prescribes; profiles/traffic_latest.json) — only if they were collected on exactly these kernel sources
-        traffic, pmc, stale = None, {}, None
+        traffic, pmc, stale, tj = None, {}, None, {}
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        sha = kernel_source_hash()
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                if tj.get("kernel_source_sha256") == kernel_source_hash():
+                if tj.get("kernel_source_sha256") == sha:
                     traffic = tj.get("k_nn_dense_bytes_per_launch")
                     pmc = tj.get("dense_sq_counters", {})
                 else:
                     stale = "profiles/traffic_latest.json was collected on other kernel sources: traffic not reported"
+                    tj = {}
             except Exception:
-                traffic = None
+                traffic, tj = None, {}
         # compulsory: every query in (16 B), its d2 out (4 B), the target once (the search reads its packed 12-byte copy)
         compulsory = (16 + 4) * nq + 12.0 * len(tgt)
         hbm_bytes = traffic if traffic else compulsory
@@ -646,15 +759,23 @@ def main():
                     "traffic_over_compulsory": (round(traffic / compulsory, 2) if traffic else None),
                     # the same fraction on the USEFUL bytes only (queries in, d2 out, the target once): what an ideal kernel would move
                     "frac_useful": round(compulsory / dur_s / 1e9 / HBM_PEAK_GBS, 4),
+                    # SURVEY 8d's formula taken literally (B_nn x queries / duration / peak): a CACHE-stream figure - every query
+                    # re-reads its candidates from L1 / L2 - that exceeds 1 and is no HBM fraction; printed so nobody has to recompute it
+                    "frac_survey8d": round(model_gbs / HBM_PEAK_GBS, 3),
+                    "frac_survey8d_is": "L1/L2 stream incl. cache hits (not HBM traffic; earns no roofline credit)",
+                    "duration_source": "HIP events around the launch inside the loop, %d launches on %d extra untimed steps" % (n_launch, len(prof)),
+                    "traffic_source": ({"file": "profiles/traffic_latest.json", "kernel_source_sha256": sha,
+                                        "collected_by": tj.get("source"), "fetch_correction_factor": tj.get("fetch_correction_factor")}
+                                       if traffic else {"file": None, "kernel_source_sha256_now": sha}),
                     "fetch_correction": "FETCH_SIZE x 1.974 (k_transform_all's 16-B stream); holds for this kernel's 12-B gathers: the "
                                         "L2 fetches 128-B lines whatever the load width and the counter tallies 64 B per request "
                                         "(profiles/r05_gather_calibration.txt)",
                     "note": "achieved/frac = PHYSICAL fabric bytes per launch / HIP-event time / 8 TB/s; frac_useful = the compulsory bytes "
                             "over the same time; model_gbs = SURVEY 8d's algorithmic stream (cache hits included) for reference.  The 27 MB "
                             "working set of the pair stays in the 256 MiB Infinity Cache across the timed steps (the counters include its "
-                            "hits), so 'HBM' here is fabric traffic.  The launch is ~19 us of vector-ALU-bound throughput plus ~12 us "
-                            "that do not shrink with the work (one wave's chain of dependent round trips, ramp and drain): "
-                            "profiles/r05_dense_variants.txt (4), DESIGN.md 4.1"}
+                            "hits), so 'HBM' here is fabric traffic.  What bounds the launch is the CU's address / tag pipe and L1 "
+                            "(every query gathers ~27 candidates of 12 B: 0.5 GB per launch through the L1s) together with the vector "
+                            "ALU, not HBM: profiles/r06_dense_variants.txt, DESIGN.md 4.1"}
         if stale:
             roofline["stale_profile"] = stale
 
@@ -673,6 +794,9 @@ def main():
                        "points_per_cloud": args.points, "spacing_m": r, "patches_target_source": list(pair.num_patches()),
                        "outer_iterations": n_outer, "inner_iterations": n_inner,
                        "correspondences_per_step": int(res.n_corr), "parallelism": "pair-per-gpu x%d" % world,
+                       "other_configs": "BASELINE configs[0] (the reference's own scans), [2] and [3] / [4] are parity-test cases "
+                                        "(tests/test_gpu_configs.py); configs[2], the rockfall pair, is NOT in the reference's tree - wherever "
+                                        "this repo says cfg 3 it means a synthetic rockfall-scale stand-in, checked against the oracle only",
                        "segmentation": ("boundary-preserving supervoxels, product front end on the device (csrc/frontend.hip; setup, untimed)"
                                         if args.labels == "supervoxel" else "grid cells (setup, untimed)")},
             "ms_per_outer_iteration": round(res.t_loop_ms / max(n_outer, 1), 4),
@@ -681,8 +805,16 @@ def main():
             # (one after the other here), then upload + patch selection + grids
             "frontend_s": round(FRONTEND_S, 3), "setup_s": round(t_setup, 3),
             "roofline": roofline,
+            "roofline_large": roofline_large,
+            # honest accounting of the metric's unit (one correspondence = one COMPLETED 1-NN query): far queries of a dense
+            # search whose distance was proved to lie above the percentile are cut short (csrc/grid.hip k_nn_dense_far; C.cpp:266-281
+            # returns Dist75 only).  `value` counts completed queries only; value_reference_equivalent counts every query the reference
+            # issues (what rounds 1 - 5 printed as `value`)
+            "queries_bounded_not_completed": int(bounded_total),
+            "value_reference_equivalent": round(corr_ref_total / tmax, 1),
             "series_end_to_end": series_line,
             "pairs_side_by_side": side_by_side,
+            "communicator": comm_info, "ranks": ranks_seen,
         }
         if world == 1 and not args.no_cpu_baseline:
             io, io_mt, mt_cores = cpu_baseline(tgt, l1, n1, src, l2, n2)

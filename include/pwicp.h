@@ -216,6 +216,12 @@ PWICP_API int pwicp_pair_reset(pwicp_pair* pair);
 /* The while-loop of Piecewise_ICP (R.cpp:680-694) = repeated PwICP_singleIteration
  * (R.cpp:704-972; decl R.h:181-188), entirely on the device. */
 PWICP_API int pwicp_pair_run(pwicp_pair* pair, pwicp_result* result);
+/* pwicp_pair_run for n INDEPENDENT pairs side by side - the iterations of the reference's pair loop (R.cpp:89-187) share nothing -
+ * one host thread per pair inside the call; every pair must live on a context of its own (pwicp_pair_create_with_target_on), else
+ * PWICP_E_INVALID.  reset_first != 0: pwicp_pair_reset before each run.  results[k] is bit for bit what pwicp_pair_run(pairs[k])
+ * gives alone; returns the first status that is not PWICP_OK.  One registration is a chain of dependent short launches: four in
+ * flight cost about half the time each (GPU_MAX_HW_QUEUES=8). */
+PWICP_API int pwicp_pairs_run_concurrent(pwicp_pair* const* pairs, int n, pwicp_result* results, int reset_first);
 /* ONE outer iteration: PwICP_singleIteration (R.cpp:704-972; decl R.h:181-188) on the pair's resident data.  The
  * caller owns what the reference keeps between calls: currDT, BBchange_1/2 (reference parameters of R.h:187) and the two
  * stage flags (the reference's module globals g_toStage2 / g_toStage3, R.cpp:11-14), and runs the loop of Piecewise_ICP
@@ -402,6 +408,14 @@ PWICP_API int  pwicp_comm_broadcast(pwicp_comm* comm, void* buf, size_t bytes, i
  * $LOCAL_RANK, id file $PWICP_RCCL_ID_FILE or /tmp/pwicp_rccl_<MASTER_PORT>.id). */
 PWICP_API bool pwicp_series_run_distributed(const char* confile, int startEpoch, int epochNum, int pairMode, float overlapThd,
                                             int rank, int world, int device, const char* id_file);
+
+/* How often, in this process, the serial host passes of the front end (host/frontend.cpp: the order-defining restatement of
+ * supervoxel_segmentation.h:98-236) took over from the device passes - same labels either way, 10 - 20 x the time:
+ * [0] clouds through the device front end, [1] fusions finished on the host because the device pass gave up (queue / arena
+ * overflow, sweep cap), [2] boundary refinements finished on the host, [3] list arenas doubled and the fusion restarted on the
+ * device, [4] fusions / [5] whole front ends run on the host because the environment asked for it ($PWICP_FUSION=host,
+ * $PWICP_FRONTEND=host).  bench.py prints them beside the series' stage walls. */
+PWICP_API int pwicp_frontend_fallback_counts(long long* counts6);
 
 /* Host threads the library's one pool (host/parallel.h) works with in this process: the CPUs it may really use - affinity mask, cut by
  * the cgroup CPU quota, divided by $LOCAL_WORLD_SIZE (the ranks of a node share its CPUs) - at most 32, at least 1;

@@ -24,6 +24,7 @@
 //
 // All decisions use the reference's double arithmetic (no contraction: the library is built with -ffp-contract=off;
 // sqrt and the division are IEEE on gfx950), so labels are identical to the host pipeline's, which the tests assert.
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -1976,6 +1977,11 @@ __global__ void k_fe_assemble(const float4* __restrict__ cloud, const double* __
     P[i] = p;
 }
 
+// How often the serial host passes took over from the device passes in this process (a silent take-over must show up):
+// [0] clouds through the device front end, [1] fusions finished by the serial host pass because the device pass gave up (queue /
+// arena overflow, sweep cap), [2] boundary refinements finished by the host pass, [3] list arenas doubled and the fusion restarted,
+// [4] fusions / [5] refinements run on the host because the environment asked for it ($PWICP_FUSION=host, $PWICP_FRONTEND=host).
+std::atomic<long long> g_fe_counts[6];
 // fusion (device, or the serial host pass when asked for / when the device pass gives up), refinement, relabel, download
 int segment_from_device_graph(pwicp_context* ctx, FeTrace& tr, const float* cloud_xyz4, const FePt* dP, const int* d_nb, int k, int n,
                               double res, int n_sv, int32_t* labels, int* n_supervoxels) {
@@ -1986,17 +1992,22 @@ int segment_from_device_graph(pwicp_context* ctx, FeTrace& tr, const float* clou
     HIPCHK(ctx, d_map.reserve((size_t)n));
     int n_roots = 0;
     bool host_fusion = getenv("PWICP_FUSION") && std::string(getenv("PWICP_FUSION")) == "host";
+    g_fe_counts[0].fetch_add(1, std::memory_order_relaxed);
+    if (host_fusion) g_fe_counts[4].fetch_add(1, std::memory_order_relaxed);
+    const bool fusion_asked_host = host_fusion;
     if (!host_fusion) {
         PWCHK(fusion_device(ctx, dP, d_nb, k, n, res, n_sv, d_lab.p, &d_roots, &n_roots, &host_fusion));
         FeWorkspace& fws = *workspace_of(ctx);
         if (host_fusion && fws.sa_overflow && fws.sa_factor < 6) {       // the list arena was too small for this cloud: once more, doubled
             fws.sa_factor = 6;
+            g_fe_counts[3].fetch_add(1, std::memory_order_relaxed);
             if (getenv("PWICP_TRACE")) fprintf(stderr, "[pwicp front end/dev]   list arena doubled, fusion restarted\n");
             PWCHK(fusion_device(ctx, dP, d_nb, k, n, res, n_sv, d_lab.p, &d_roots, &n_roots, &host_fusion));
         }
         tr.lap("fusion");
     }
     if (host_fusion) {                                  // (serial host pass: $PWICP_FUSION=host, or the device pass gave up)
+        if (!fusion_asked_host) g_fe_counts[1].fetch_add(1, std::memory_order_relaxed);
         std::vector<FePt> P((size_t)n);
         std::vector<int> nb((size_t)n * k), root_of, roots;
         HIPCHK(ctx, hipMemcpyAsync(P.data(), dP, sizeof(FePt) * (size_t)n, hipMemcpyDeviceToHost, st));
@@ -2016,6 +2027,7 @@ int segment_from_device_graph(pwicp_context* ctx, FeTrace& tr, const float* clou
     bool host_refine = false;
     PWCHK(refine_device(ctx, dP, d_nb, k, n, res, d_lab.p, &host_refine));
     if (host_refine) {
+        g_fe_counts[2].fetch_add(1, std::memory_order_relaxed);
         std::vector<FePt> P((size_t)n);
         std::vector<int> nb((size_t)n * k), root_of((size_t)n);
         HIPCHK(ctx, hipMemcpyAsync(P.data(), dP, sizeof(FePt) * (size_t)n, hipMemcpyDeviceToHost, st));
@@ -2038,6 +2050,13 @@ int segment_from_device_graph(pwicp_context* ctx, FeTrace& tr, const float* clou
 }
 
 }  // namespace
+
+extern "C" void pw_frontend_count(int which) { if (which >= 0 && which < 6) g_fe_counts[which].fetch_add(1, std::memory_order_relaxed); }
+extern "C" PWICP_API int pwicp_frontend_fallback_counts(long long* counts6) {
+    if (!counts6) return PWICP_E_INVALID;
+    for (int k = 0; k < 6; ++k) counts6[k] = g_fe_counts[k].load(std::memory_order_relaxed);
+    return PWICP_OK;
+}
 
 void pw_frontend_release_workspace(pwicp_context* ctx) {
     if (!ctx) return;

@@ -397,6 +397,10 @@ __device__ __forceinline__ int dense_home_cell(int c, int n) {
 #ifndef PW_DENSE_FAST
 #define PW_DENSE_FAST 1
 #endif
+// PW_DENSE_A_HEAD: points of the query's own row segment requested at once before the four-per-pass loop (0: the loop from the start)
+#ifndef PW_DENSE_A_HEAD
+#define PW_DENSE_A_HEAD 0
+#endif
 template <int PERM, bool FARG>
 __global__ void __launch_bounds__(kDenseBlock) PW_DENSE_SGPR_ATTR k_nn_dense_disc(GridLevel dl, GridDesc far, const float4* __restrict__ pat,
                                                           const int* __restrict__ qorder, const int* __restrict__ qpatch,
@@ -463,7 +467,11 @@ __global__ void __launch_bounds__(kDenseBlock) PW_DENSE_SGPR_ATTR k_nn_dense_dis
                 row_range(dl, cy, cz, cx - 1, cx + 1, loA, hiA);
             }
             PW_BT(3);
+#if PW_DENSE_A_HEAD > 0
+            scan_d2_head<PERM, PW_DENSE_A_HEAD>(dl, loA, hiA, ux, uy, uz, best);
+#else
             scan_d2_level<PERM>(dl, loA, hiA, ux, uy, uz, best);
+#endif
             PW_BT(4);
             cnt += (unsigned)(hiA - loA);
             const float rho = fast_sqrt_up(best) + 2.0f * dl.slack;

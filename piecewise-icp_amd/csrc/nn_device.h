@@ -446,7 +446,7 @@ __device__ __forceinline__ void scan_d2x4(const float4* __restrict__ pts, int lo
 #ifndef PW_DENSE_SCAN
 #define PW_DENSE_SCAN 1
 #endif
-constexpr int kPts3Pad = 8;            // far-away points behind the last one of a packed copy
+constexpr int kPts3Pad = 20;           // far-away points behind the last one of a packed copy (scan_d2_head reads up to 15 + 3 past a range)
 struct PwXyz3 { float x, y, z; };
 typedef float pw_f2 __attribute__((ext_vector_type(2)));
 template <int PERM = 0>
@@ -635,10 +635,82 @@ __device__ __forceinline__ int disc_ranges_columns(const GridLevel& g, float ux,
         }
     return n;
 }
+// Phase A of the dense search: the first HEAD points of a non-empty range requested at once (one round trip instead of HEAD / 4
+// dependent ones - the own row segment holds 12 +- 2 points on the bench pair), the rest four per pass.  Points past the range's
+// end are real target points of the next cells: harmless for a minimum over all targets (see PW_DENSE_SCAN above).
+template <int PERM, int HEAD>
+__device__ __forceinline__ void scan_d2_head(const GridLevel& g, int lo, int hi, float qx, float qy, float qz, float& best) {
+    if (hi <= lo) return;
+    const PwXyz3* __restrict__ p3 = (const PwXyz3*)g.pts3;
+    PwXyz3 v[HEAD];
+#pragma unroll
+    for (int k = 0; k < HEAD; ++k) v[k] = p3[lo + k];
+#pragma unroll
+    for (int k = 0; k < HEAD; ++k) nn_consider_d2<PERM>(make_float4(v[k].x, v[k].y, v[k].z, 0.f), qx, qy, qz, best);
+    for (int j = lo + HEAD; j < hi; j += 4) {
+        const PwXyz3 a = p3[j], b = p3[j + 1], c = p3[j + 2], d = p3[j + 3];
+        nn_consider_d2<PERM>(make_float4(a.x, a.y, a.z, 0.f), qx, qy, qz, best);
+        nn_consider_d2<PERM>(make_float4(b.x, b.y, b.z, 0.f), qx, qy, qz, best);
+        nn_consider_d2<PERM>(make_float4(c.x, c.y, c.z, 0.f), qx, qy, qz, best);
+        nn_consider_d2<PERM>(make_float4(d.x, d.y, d.z, 0.f), qx, qy, qz, best);
+    }
+}
+
+// PW_FLAT_PREFETCH: the NEXT range of the list is read while the current one is being walked (a range switch then costs two moves, not
+// an LDS round trip in the lane's chain of dependent loads)
+#ifndef PW_FLAT_PREFETCH
+#define PW_FLAT_PREFETCH 1
+#endif
+#ifndef PW_FLAT_PIPE
+#define PW_FLAT_PIPE 0
+#endif
 template <int PERM>
 __device__ __forceinline__ void scan_ranges_flat(const GridLevel& g, const int2* __restrict__ list, int stride, int tid, int n, float ux, float uy,
                                                  float uz, float& best) {
     const PwXyz3* __restrict__ p3 = (const PwXyz3*)g.pts3;
+#if PW_FLAT_PIPE
+    // the four points of the NEXT pass requested before the current four are evaluated (12 more registers)
+    int2 r0 = make_int2(0, 0), r1 = make_int2(0, 0);
+    if (n > 0) r0 = list[tid];
+    if (n > 1) r1 = list[stride + tid];
+    int j = r0.x, e = r0.y, k = 2;
+    PwXyz3 a, b, c, d;
+    if (j < e) { a = p3[j]; b = p3[j + 1]; c = p3[j + 2]; d = p3[j + 3]; }
+    while (j < e) {
+        int jn = j + 4, en = e;
+        if (jn >= e) {
+            jn = r1.x; en = r1.y;
+            r1 = make_int2(0, 0);
+            if (k < n) { r1 = list[k * stride + tid]; ++k; }
+        }
+        PwXyz3 a2 = a, b2 = b, c2 = c, d2_ = d;
+        if (jn < en) { a2 = p3[jn]; b2 = p3[jn + 1]; c2 = p3[jn + 2]; d2_ = p3[jn + 3]; }
+        nn_consider_d2<PERM>(make_float4(a.x, a.y, a.z, 0.f), ux, uy, uz, best);
+        nn_consider_d2<PERM>(make_float4(b.x, b.y, b.z, 0.f), ux, uy, uz, best);
+        nn_consider_d2<PERM>(make_float4(c.x, c.y, c.z, 0.f), ux, uy, uz, best);
+        nn_consider_d2<PERM>(make_float4(d.x, d.y, d.z, 0.f), ux, uy, uz, best);
+        a = a2; b = b2; c = c2; d = d2_;
+        j = jn; e = en;
+    }
+#elif PW_FLAT_PREFETCH
+    int2 r0 = make_int2(0, 0), r1 = make_int2(0, 0);
+    if (n > 0) r0 = list[tid];
+    if (n > 1) r1 = list[stride + tid];
+    int j = r0.x, e = r0.y, k = 2;
+    while (j < e) {
+        const PwXyz3 a = p3[j], b = p3[j + 1], c = p3[j + 2], d = p3[j + 3];
+        nn_consider_d2<PERM>(make_float4(a.x, a.y, a.z, 0.f), ux, uy, uz, best);
+        nn_consider_d2<PERM>(make_float4(b.x, b.y, b.z, 0.f), ux, uy, uz, best);
+        nn_consider_d2<PERM>(make_float4(c.x, c.y, c.z, 0.f), ux, uy, uz, best);
+        nn_consider_d2<PERM>(make_float4(d.x, d.y, d.z, 0.f), ux, uy, uz, best);
+        j += 4;
+        if (j >= e) {
+            j = r1.x; e = r1.y;                          // (empty once the list is used up: the loop ends)
+            r1 = make_int2(0, 0);
+            if (k < n) { r1 = list[k * stride + tid]; ++k; }
+        }
+    }
+#else
     int j = 0, e = 0, k = 0;
     if (n > 0) { const int2 r = list[tid]; j = r.x; e = r.y; k = 1; }
     while (j < e) {
@@ -650,6 +722,7 @@ __device__ __forceinline__ void scan_ranges_flat(const GridLevel& g, const int2*
         j += 4;
         if (j >= e && k < n) { const int2 r = list[k * stride + tid]; j = r.x; e = r.y; ++k; }
     }
+#endif
 }
 
 // scan_disc_lean shared by a group of G lanes (one query): the rows of the ball are dealt to the lanes round-robin and every lane

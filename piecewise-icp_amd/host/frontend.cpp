@@ -544,6 +544,7 @@ PWICP_API int pwicp_frontend_segment(const float* cloud_xyz4, int n, float sv_re
     return segment_from_neighbors(cloud_xyz4, n, nb.data(), knn, sv_resolution, labels, n_supervoxels);
 }
 
+void pw_frontend_count(int which);            // csrc/frontend.hip: the take-over counters of pwicp_frontend_fallback_counts
 // Same result, with the k-NN graph built on the GPU (pwicp_knn): the variant the entry points use.
 PWICP_API int pwicp_frontend_segment_dev(pwicp_context* ctx, const float* cloud_xyz4, int n, float sv_resolution, int knn,
                                          float point_spacing, int32_t* labels, int* n_supervoxels) {
@@ -554,6 +555,7 @@ PWICP_API int pwicp_frontend_segment_dev(pwicp_context* ctx, const float* cloud_
     if (!(e && std::strcmp(e, "host") == 0))
         return pw_frontend_segment_device(ctx, cloud_xyz4, n, knn, cell_edge, sv_resolution, labels, n_supervoxels);
     // $PWICP_FRONTEND=host: k-NN graph on the device, the serial passes on the host (same labels)
+    pw_frontend_count(5);
     pwhost::HostBuf<int32_t> nb;
     if (!nb.reserve((size_t)n * knn)) return PWICP_E_NOMEM;
     const int rc = pwicp_knn(ctx, cloud_xyz4, n, knn, cell_edge, nb.data());

@@ -11,4 +11,4 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from .binding import (PwicpError, Context, Pair, Series, Target, Params, Result, Step, lib_path, load_library,  # noqa: F401
                       device_count, f4, frontend_segment, preprocess, sor_filter, pc_resolution, PiecewiseICP_pair_call,
-                      PiecewiseICP_4D_call, series_run_distributed, series_release_parked)
+                      PiecewiseICP_4D_call, series_run_distributed, series_release_parked, frontend_fallback_counts, run_pairs_concurrent)

@@ -690,3 +690,30 @@ class Pair:
         self._ctx._chk(self._L.pwicp_pair_bench_dense_nn(self._h, n_launches, C.byref(ms), C.byref(nq), C.byref(kb),
                                                          C.byref(edge)))
         return ms.value, nq.value, kb.value, edge.value
+
+
+def frontend_fallback_counts():
+    """pwicp_frontend_fallback_counts: how often the serial host passes of the front end took over in this process -
+    {clouds, fusion_on_host, refinement_on_host, arena_doubled, fusion_host_by_env, frontend_host_by_env}."""
+    L = load_library()
+    v = (C.c_longlong * 6)()
+    L.pwicp_frontend_fallback_counts.argtypes = [C.POINTER(C.c_longlong)]
+    if L.pwicp_frontend_fallback_counts(v) != 0:
+        raise PwicpError(-2, "pwicp_frontend_fallback_counts")
+    names = ("clouds_on_device", "fusion_taken_over_by_host", "refinement_taken_over_by_host", "list_arena_doubled",
+             "fusion_on_host_by_env", "frontend_on_host_by_env")
+    return {k: int(v[i]) for i, k in enumerate(names)}
+
+
+def run_pairs_concurrent(pairs, reset_first=True):
+    """pwicp_pairs_run_concurrent: the registrations of independent pairs (each on a Context of its own) side by side, one host
+    thread per pair inside the library; returns their Results (bit for bit what Pair.run gives for each alone)."""
+    L = load_library()
+    n = len(pairs)
+    hs = (C.c_void_p * n)(*[p._h for p in pairs])
+    res = (Result * n)()
+    L.pwicp_pairs_run_concurrent.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Result), C.c_int]
+    rc = L.pwicp_pairs_run_concurrent(hs, n, res, 1 if reset_first else 0)
+    if rc != 0:
+        raise PwicpError(rc, "pwicp_pairs_run_concurrent")
+    return [res[k] for k in range(n)]

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COMMON = ["--points", "200000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-inner-timing",
-          "--series-epochs", "4", "--pairs-in-flight", "0"]
+          "--series-epochs", "4", "--pairs-in-flight", "0", "--large-points", "0"]
 
 
 def _bench(extra, dump, timeout=900, env_extra=None):

@@ -175,6 +175,52 @@ def test_series_8_pairs_1m_shared_target(tmp_path, ctx, oracle):
         _assert_loop_parity(res, io)
 
 
+def test_two_workers_of_one_process_both_take_the_supplied_target_labels(tmp_path, ctx):
+    """ADVICE r5 (host/registration.cpp target_labels): a rank that EXPECTS the labels of the shared target from another rank and runs
+    two workers (pwicp_series_set_devices: every worker prepares the target on its own device) used to hand the supplied labels to the
+    first worker only - the second waited out $PWICP_LABEL_TIMEOUT_S (600 s) and then segmented the target itself.  Both workers must
+    take them (received == 2, segmented == 0), quickly, and the records must equal the ones of a plain run."""
+    import threading
+    import time
+    import pwicp_amd as P
+    from pwicp_amd import synth
+    from pwicp_amd.pcd import write_pcd_binary
+    n = 120000
+    inp = tmp_path / "scans"
+    inp.mkdir()
+    tgt, _ = synth.make_tile(n, R)
+    write_pcd_binary(str(inp / "Epoch_001.pcd"), tgt)
+    for e in range(1, 5):
+        s, _ = synth.make_source(n, R, epoch=e)
+        write_pcd_binary(str(inp / ("Epoch_%03d.pcd" % (e + 1))), s)
+    cfg = tmp_path / "cfg.txt"
+    _write_series_config(cfg, str(inp), str(tmp_path) + "/res_")
+    with P.Series(str(cfg), 0, 5, 0, 0.75, 0) as plain:
+        want = plain.run_pairs([0, 1, 2, 3])
+    # the labels "another rank" would broadcast: the target preprocessed and segmented the way the series does it
+    p1 = ctx.preprocess(tgt, R, 14, 5.0)
+    r1, _, _ = G.reduce_pair(p1, p1)
+    lab, nsv = ctx.frontend_segment(r1, 10 * R, 45, R)
+    os.environ["PWICP_LABEL_TIMEOUT_S"] = "120"
+    try:
+        with P.Series(str(cfg), 0, 5, 0, 0.75, 0) as series:
+            series.set_devices([0, 0])
+            series.expect_target_labels(0)
+            th = threading.Thread(target=lambda: (time.sleep(0.5), series.supply_target_labels(0, lab, nsv)))
+            th.start()
+            t0 = time.time()
+            recs = series.run_pairs([0, 1, 2, 3])
+            wall = time.time() - t0
+            th.join()
+            received, segmented = series.target_label_counts()
+    finally:
+        os.environ.pop("PWICP_LABEL_TIMEOUT_S", None)
+    assert wall < 60.0, wall                       # (one worker waiting out the time-out would take 120 s)
+    assert (received, segmented) == (2, 0), (received, segmented)
+    assert np.all(recs["status"] == 0)
+    assert recs["T"].tobytes() == want["T"].tobytes() and recs["VCM"].tobytes() == want["VCM"].tobytes()
+
+
 def test_series_4_pairs_5m_streamed(tmp_path, ctx, oracle):
     """BASELINE configs[4] shape on one GPU: what each GPU of the 8-GPU run gets - a reference epoch and 4 source epochs of
     5 M points (L = 11.2 m), Direct2Ref, streamed through pwicp_series_run_pairs two pairs per window ($PWICP_SERIES_WINDOW) so

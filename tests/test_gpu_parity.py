@@ -257,6 +257,16 @@ def test_four_registrations_side_by_side(ctx):
         t.join()
     assert not bad, bad
     assert all(a.status == 0 for a in alone)
+    # the same through the library's own call (pwicp_pairs_run_concurrent: one host thread per pair inside the library)
+    for rep in range(5):
+        got = P.run_pairs_concurrent(pairs)
+        assert [key(g) for g in got] == [key(a) for a in alone], rep
+    with pytest.raises(P.PwicpError):              # two pairs on one context: refused, not raced
+        extra = P.Pair(ctxs[0], None, None, 0, _data.pair(200000, epoch=2)[1], *_labels(_data.pair(200000, epoch=2)[1], "grid"), prm, target=T)
+        try:
+            P.run_pairs_concurrent([pairs[0], extra])
+        finally:
+            extra.close()
     for pr in pairs:
         pr.close()
     T.close()

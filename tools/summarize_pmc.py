@@ -56,5 +56,18 @@ if (dense, "FETCH_SIZE") in mean:
                           "-> FETCH_SIZE x %.3f (MI355X_MICROARCH.md: gfx950 FETCH_SIZE tallies 128-B requests at 64 B for 16-B/lane "
                           "loads); WRITE_SIZE taken as is" % (f_cal, w_cal, factor))
     res["source"] = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 5 --warmup 1 (tools/collect_profiles.sh)"
+# the large pair of bench.py's second roofline record: the same two counters, collected on `--points <large>` runs (pmc_large/)
+accL = defaultdict(lambda: [0.0, 0])
+for f in glob.glob(os.path.join(out, "pmc_large", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = (short(r["Kernel_Name"]), r["Counter_Name"])
+        accL[k][0] += float(r["Counter_Value"]); accL[k][1] += 1
+if (dense, "FETCH_SIZE") in accL and "fetch_correction_factor" in res:
+    fL = accL[(dense, "FETCH_SIZE")][0] / accL[(dense, "FETCH_SIZE")][1]
+    wL = accL[(dense, "WRITE_SIZE")][0] / accL[(dense, "WRITE_SIZE")][1] if (dense, "WRITE_SIZE") in accL else 0.0
+    res["large_points"] = int(open(os.path.join(out, "large_points.txt")).read().split()[0])
+    res["k_nn_dense_bytes_per_launch_large"] = int(round(fL * 1024.0 * res["fetch_correction_factor"] + wL * 1024.0))
+    res["raw_counter_means"].update({"dense_FETCH_SIZE_large": fL, "dense_WRITE_SIZE_large": wL,
+                                     "dense_dispatches_large": accL[(dense, "FETCH_SIZE")][1]})
 json.dump(res, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
