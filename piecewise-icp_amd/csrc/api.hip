@@ -73,9 +73,6 @@ void pwicp_destroy(pwicp_context* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); ctx->side = nullptr; }
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     ctx->scratch.reset();
     if (pw_tls_pool.get() == ctx->pool.get()) pw_tls_pool.reset();
     if (ctx->pool) ctx->pool->trim();           // (the pool itself lives as long as a buffer of this context does)
@@ -92,18 +89,6 @@ void pwicp_destroy(pwicp_context* ctx) {
 
 // host/registration.cpp (WorkerParking): what an allocation that is out of device memory may release as its last resort
 bool pw_set_release_parked_hook(bool (*fn)(int)) { PwPoolRegistry::get().release_parked = fn; return true; }
-
-int pw_side_stream(pwicp_context* ctx) {
-    if (ctx->side) return PWICP_OK;
-    // (of the LOWEST priority: what runs on it is bulk work that must not delay the dispatch of the main stream's small dependent
-    // launches; never taken from / returned to the pool of main streams)
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, least));
-    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    return PWICP_OK;
-}
 
 extern "C" {
 

@@ -128,11 +128,6 @@ inline void PwPoolRegistry::trim_device(int device) {
 struct pwicp_context {
     int device = 0;
     hipStream_t stream = nullptr;
-    // a second stream of the context for work that does not depend on what `stream` is doing (loop.hip: the run's first dense
-    // search beside the inner ICP), forked / joined through the two events; made at the first use (pw_side_stream, api.hip)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool side_open = false;               // work on `side` that `stream` has not yet been made to wait for
     std::shared_ptr<PwPool> pool = std::make_shared<PwPool>();
     std::string err;
     int n_cu = 256;
@@ -147,7 +142,6 @@ struct pwicp_context {
     void set_err(const char* msg) { err = msg; }
 };
 
-int pw_side_stream(pwicp_context* ctx);       // api.hip: makes ctx->side and its events if they are not there yet
 
 #define PW_STR2(x) #x
 #define PW_STR(x) PW_STR2(x)

@@ -384,39 +384,29 @@ __device__ __forceinline__ int dense_home_cell(int c, int n) {
 #endif
 }
 
-#ifndef PW_DENSE_SGPR
-#define PW_DENSE_SGPR 0
-#endif
-#if PW_DENSE_SGPR > 0
-#define PW_DENSE_SGPR_ATTR __attribute__((amdgpu_num_sgpr(PW_DENSE_SGPR)))
-#else
-#define PW_DENSE_SGPR_ATTR
-#endif
 // PW_DENSE_FAST (round 6): on a level of columns the ball is ONE flat per-lane loop over a list of ranges in LDS (disc_ranges_columns /
 // scan_ranges_flat, nn_device.h); 0 = every ball through scan_disc_lean's nested row loops (rounds 2 - 5)
 #ifndef PW_DENSE_FAST
 #define PW_DENSE_FAST 1
 #endif
-// PW_DENSE_A_HEAD: points of the query's own row segment requested at once before the four-per-pass loop (0: the loop from the start)
-#ifndef PW_DENSE_A_HEAD
-#define PW_DENSE_A_HEAD 0
-#endif
 template <int PERM, bool FARG>
-__global__ void __launch_bounds__(kDenseBlock) PW_DENSE_SGPR_ATTR k_nn_dense_disc(GridLevel dl, GridDesc far, const float4* __restrict__ pat,
+__global__ void __launch_bounds__(kDenseBlock) k_nn_dense_disc(GridLevel dl, GridDesc far, const float4* __restrict__ pat,
                                                           const int* __restrict__ qorder, const int* __restrict__ qpatch,
                                                           const int* __restrict__ stable, int nq,
                                                           float* __restrict__ d2out,
                                                           unsigned long long* __restrict__ examined, int chunk, FusedSelect fs,
                                                           DenseFarList fl, const float4* __restrict__ patq, int sub) {
-    // LDS, two lives: while the lanes search, their range lists (PW_DENSE_FAST: kDiscRangesMax x block int2, lane-major); once the
-    // whole block is through (first barrier below), the bins of the percentile selection's pass 0 (select_dev.h, fs.scratch !=
-    // nullptr only) and the compacted far queries (.w carries the candidate d2 of an unresolved query)
-    constexpr int kTailBytes = kFsBins * 4 + kDenseBlock * 16 + kDenseBlock * 4;
+    // LDS: the lanes' range lists (PW_DENSE_FAST: kDiscRangesMax x block int2, lane-major) while they search; once the whole block is
+    // through (first barrier below) the same bytes hold the compacted far queries (.w carries the candidate d2 of an unresolved query).
+    // The bins of the percentile selection's pass 0 (select_dev.h, fs.scratch != nullptr only) have LDS of their own: zeroed at the start
+    // and filled as the lanes finish - sharing the list's bytes put a zeroing pass and a barrier into every block's epilogue (in-loop
+    // launch 29.7 against 28.4 us)
+    constexpr int kTailBytes = kDenseBlock * 16 + kDenseBlock * 4;
     constexpr int kListBytes = PW_DENSE_FAST ? kDiscRangesMax * kDenseBlock * 8 : 0;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[kTailBytes > kListBytes ? kTailBytes : kListBytes];
+    __shared__ unsigned s_hist[kFsBins];
     float4* const s_q = (float4*)s_raw;
-    unsigned* const s_hist = (unsigned*)(s_raw + kDenseBlock * 16);
-    int* const s_slot = (int*)(s_raw + kDenseBlock * 16 + kFsBins * 4);
+    int* const s_slot = (int*)(s_raw + kDenseBlock * 16);
     __shared__ int s_wcnt[kDenseBlock / 64];
 #ifdef PW_DENSE_BLOCKTRACE
     if (threadIdx.x == 0 && blockIdx.x < 8192) { pw_dense_bt[8 * blockIdx.x] = __builtin_amdgcn_s_memrealtime(); pw_dense_bt[8 * blockIdx.x + 2] = blockIdx.x % kXcds; }
@@ -436,9 +426,13 @@ __global__ void __launch_bounds__(kDenseBlock) PW_DENSE_SGPR_ATTR k_nn_dense_dis
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = tile * kDenseBlock + tid;
     unsigned cnt = 0;
-    bool unresolved = false, have = false;       // have: `best` is this lane's final value (its bin is counted behind the barriers)
+    bool unresolved = false, have = false;       // have: `best` is this lane's final value
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     float best = INFINITY;
+    if (fs.scratch) {
+        for (int t = tid; t < kFsBins; t += kDenseBlock) s_hist[t] = 0u;
+        __syncthreads();
+    }
     if (i < nq) {
         // patq (the run's first search, on a source that has not moved yet): the queries lie in launch order, so the point comes
         // with the first round trip, and the stable flag of its patch shares the second one with the words of the query's own
@@ -467,11 +461,7 @@ __global__ void __launch_bounds__(kDenseBlock) PW_DENSE_SGPR_ATTR k_nn_dense_dis
                 row_range(dl, cy, cz, cx - 1, cx + 1, loA, hiA);
             }
             PW_BT(3);
-#if PW_DENSE_A_HEAD > 0
-            scan_d2_head<PERM, PW_DENSE_A_HEAD>(dl, loA, hiA, ux, uy, uz, best);
-#else
             scan_d2_level<PERM>(dl, loA, hiA, ux, uy, uz, best);
-#endif
             PW_BT(4);
             cnt += (unsigned)(hiA - loA);
             const float rho = fast_sqrt_up(best) + 2.0f * dl.slack;
@@ -490,7 +480,10 @@ __global__ void __launch_bounds__(kDenseBlock) PW_DENSE_SGPR_ATTR k_nn_dense_dis
 #endif
                 cnt += scan_disc_lean<PERM, false, true>(dl, ux, uy, uz, rho, in ? cy : INT_MIN, in ? cz : INT_MIN, max(cx - 1, 0),
                                                          min(cx + 1, dl.nx - 1), loA, hiA, best);
-                if (have) d2out[i] = best;
+                if (have) {
+                    d2out[i] = best;
+                    if (fs.scratch) atomicAdd(&s_hist[__float_as_uint(best) >> 21], 1u);
+                }
             } else {
                 unresolved = true;
             }
@@ -511,14 +504,11 @@ __global__ void __launch_bounds__(kDenseBlock) PW_DENSE_SGPR_ATTR k_nn_dense_dis
         if (w < wave) base += s_wcnt[w];
         total += s_wcnt[w];
     }
-    if (fs.scratch)
-        for (int t = tid; t < kFsBins; t += kDenseBlock) s_hist[t] = 0u;
     if (unresolved) {
         s_q[base + before] = make_float4(q.x, q.y, q.z, best);
         s_slot[base + before] = i;
     }
     __syncthreads();
-    if (have && fs.scratch) atomicAdd(&s_hist[__float_as_uint(best) >> 21], 1u);
     if (FARG) {
         // ... and handed to the launch behind this one (k_nn_dense_far), which puts EIGHT lanes on each: a far query scans ~40
         // rows and ~200 candidates (the first iteration of a real pair: half the queries), and a launch of 10^5 queries is a
@@ -682,315 +672,8 @@ __global__ void __launch_bounds__(kDenseBlock) k_dense_slots(GridLevel dl, const
 }
 #endif
 
-// ---- the same search with the candidates of a BLOCK staged in LDS (round 5; levels of COLUMNS only) ---------------------------
-// In strip order (tall strips of 16 cells) the 256 queries of a block lie on ~4 consecutive row segments of the searched level, and
-// everything their balls can touch is a WINDOW of the level: the rows [rmin - 2, rmax + 2] x the cells [xmin - 2, xmax + 2], i.e.
-// ONE contiguous span of points per row (~9 rows x 20 cells, ~700 points, 11 KB).  The block reads the begin / end words of the
-// window's cells (one coalesced load per row) and the spans themselves (coalesced 12-byte loads) into LDS, and every lane runs the
-// disc search of k_nn_dense_disc on the copy: the same rows, the same cells, the same float expression per candidate - but a
-// gather is an LDS read instead of a vector-memory round trip through the address / tag pipe (20 -> 13 cache lines per gather was
-// what rounds 3 - 4 bought; this is ~0.1), and a lane's chain of eight dependent global round trips is three (query, table,
-// points).  A lane whose ball leaves the window (or that finds no candidate) goes to the far path with what it has, as before;
-// a block whose window does not fit (queries that have drifted apart after an update, the end of a strip) runs the search from
-// global memory as k_nn_dense_disc does.  Exact by the same argument: every cell the ball touches is either scanned from the copy
-// or the lane is handed on.
-// (First version, one window per WAVE - 5.5 rows x 19 cells, 418 points, 9.5 KB each: 4 waves per SIMD instead of 7, 51 us against
-// 34 although it spent fewer wave cycles, 73 M against 90 M; profiles/r05_dense_variants.txt.)
-#ifndef PW_WIN_PTS
-#define PW_WIN_PTS 1024
-#endif
-#ifndef PW_WIN_HALO
-#define PW_WIN_HALO 2
-#endif
-#ifndef PW_WIN_WAVES
-#define PW_WIN_WAVES 7       // waves per SIMD the register allocation aims at (71 registers, nothing spilled; 8: 28 bytes of scratch)
-#endif
-constexpr int kWinHalo = PW_WIN_HALO;   // rows / cells kept on either side of the block's queries
-constexpr int kWinRows = 12;            // most rows of a window (three per wave)
-constexpr int kWinCells = 24;           // most cells of a window row
-constexpr int kWinTab = kWinCells + 1;  // begin words of the cells + the end of the last one
-constexpr int kWinPts = PW_WIN_PTS;     // most points of a window (12 bytes each in LDS)
-constexpr int kWinArr = kWinPts + 8;    // a coordinate array of the copy, with the far-away points behind the last one
-
-// [lo, hi) of the copy: x, y and z of the window's points in three arrays, read in PAIRS from the even index at or below `lo`, two
-// pairs per pass (ds_read_b64 / _b128: the cheapest LDS reads per byte) and evaluated two candidates per packed instruction
-// (nn_consider_d2_pair).  A pass may take points beyond `hi` (real target points, they cannot make a minimum wrong); the copy ends
-// in far-away points.
-template <int PERM>
-__device__ __forceinline__ void scan_lds4(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
-                                          int lo, int hi, float qx, float qy, float qz, float& best) {
-    const pw_f2* __restrict__ px = (const pw_f2*)sx;
-    const pw_f2* __restrict__ py = (const pw_f2*)sy;
-    const pw_f2* __restrict__ pz = (const pw_f2*)sz;
-    for (int b = lo >> 1, be = (hi + 1) >> 1; b < be; b += 2) {
-        const pw_f2 x0 = px[b], x1 = px[b + 1], y0 = py[b], y1 = py[b + 1], z0 = pz[b], z1 = pz[b + 1];
-        nn_consider_d2_pair<PERM>(x0, y0, z0, qx, qy, qz, best);
-        nn_consider_d2_pair<PERM>(x1, y1, z1, qx, qy, qz, best);
-    }
-}
-
-#ifdef PW_WIN_STATS
-// -DPW_WIN_STATS (tools/win_stats.py): [0] blocks with a query, [1] blocks whose window fitted, [2] rows of those windows, [3] cells,
-// [4] points, [5] lanes resolved on the window, [6] lanes handed on without a candidate, [7] lanes whose ball left the window,
-// [8] lanes of blocks that searched global memory, [9] lanes outside the grid, [10] windows refused by rows, [11] by cells, [12] by points
-__device__ unsigned long long pw_win_stats[16];
-extern "C" __attribute__((visibility("default"))) int pwicp_debug_win_stats(unsigned long long* out16, int reset) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pw_win_stats), sizeof(pw_win_stats)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(pw_win_stats), z, sizeof(z)); }
-    return 0;
-}
-#define PW_WSTAT(k, v) atomicAdd(&pw_win_stats[k], (unsigned long long)(v))
-#else
-#define PW_WSTAT(k, v)
-#endif
-
-typedef unsigned short pw_u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b) {
-    const pw_u16x2 r = __builtin_elementwise_min(__builtin_bit_cast(pw_u16x2, a), __builtin_bit_cast(pw_u16x2, b));
-    return __builtin_bit_cast(unsigned, r);
-}
-__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
-    const pw_u16x2 r = __builtin_elementwise_max(__builtin_bit_cast(pw_u16x2, a), __builtin_bit_cast(pw_u16x2, b));
-    return __builtin_bit_cast(unsigned, r);
-}
-
-template <int PERM, bool FARG>
-__global__ void __launch_bounds__(kDenseBlock, PW_WIN_WAVES) k_nn_dense_win(GridLevel dl, GridDesc far, const float4* __restrict__ pat,
-                                                         const int* __restrict__ qorder, const int* __restrict__ qpatch,
-                                                         const int* __restrict__ stable, int nq,
-                                                         float* __restrict__ d2out,
-                                                         unsigned long long* __restrict__ examined, int chunk, FusedSelect fs,
-                                                         DenseFarList fl, const float4* __restrict__ patq, int sub) {
-    constexpr int NW = kDenseBlock / 64;
-    constexpr int RPW = (kWinRows + NW - 1) / NW;             // rows of the window a wave loads
-    static_assert(kWinRows <= 64 && kWinTab <= 64, "a window row's table is loaded by one wave, the rows' spans are summed on one");
-    constexpr int kWinBytes = 3 * kWinArr * 4 + kWinRows * kWinTab * 4;
-    constexpr int kTailBytes = kFsBins * 4 + kDenseBlock * 16 + kDenseBlock * 4;
-    // the block's window; once every wave is done with it the same bytes hold the bins of the selection's pass 0 and the block's
-    // list of far queries
-    __shared__ __attribute__((aligned(16))) unsigned char smem[kWinBytes > kTailBytes ? kWinBytes : kTailBytes];
-    __shared__ int s_wcnt[NW];
-    __shared__ unsigned s_box[2 * NW];
-    __shared__ int s_span[2 * kWinRows];                      // begin, end of the rows' spans (indices into the level's points)
-    const int xr = (int)(blockIdx.x / kXcds);
-    const int tile = chunk > 0 ? (xr / sub) * (kXcds * sub) + (int)(blockIdx.x % kXcds) * sub + xr % sub : (int)blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* const s_x = (float*)smem;
-    float* const s_y = s_x + kWinArr;
-    float* const s_z = s_y + kWinArr;
-    int* const s_tab = (int*)(smem + 3 * kWinArr * 4);
-    unsigned* const s_hist = (unsigned*)smem;
-    float4* const s_q = (float4*)(smem + kFsBins * 4);
-    int* const s_slot = (int*)(smem + kFsBins * 4 + kDenseBlock * 16);
-    const int i = tile * kDenseBlock + tid;
-    unsigned cnt = 0;
-    bool unresolved = false, resolved = false;
-    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-    float best = INFINITY;
-    int st = 0;
-    if (i < nq) {
-        const int p = patq ? 0 : qorder[i], pa = qpatch[i];
-        if (patq) { q = patq[i]; st = stable[pa]; }
-        else { st = p >= 0 ? stable[pa] : 0; q = pat[max(p, 0)]; }
-        if (!st) d2out[i] = __uint_as_float(kSentinel);
-    }
-    const float ux = PERM == 0 ? q.x : (PERM == 1 ? q.y : q.z), uy = PERM == 0 ? q.y : (PERM == 1 ? q.z : q.x),
-                uz = PERM == 0 ? q.z : (PERM == 1 ? q.x : q.y);
-    // a level of columns: cells along x, rows along ONE of the other two axes
-    const bool rowz = dl.inv_hy == 0.0f;
-    const float ur = rowz ? uz : uy, orr = rowz ? dl.oz : dl.oy;
-    const int nrow = rowz ? dl.nz : dl.ny;
-    const int cx = cell_of(ux, dl.ox, dl.inv_h), cr = cell_of(ur, orr, dl.inv_h);
-    const bool ing = st && cx >= 0 && cx < dl.nx && cr >= 0 && cr < nrow;
-    // the block's box of cells: packed (row, cell) minima / maxima, wave by wave, then over the waves
-    unsigned kmin = ing ? ((unsigned)cr << 16) | (unsigned)cx : 0xffffffffu, kmax = ing ? ((unsigned)cr << 16) | (unsigned)cx : 0u;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        kmin = pk_min_u16(kmin, (unsigned)__shfl_xor((int)kmin, o));
-        kmax = pk_max_u16(kmax, (unsigned)__shfl_xor((int)kmax, o));
-    }
-    if (lane == 0) { s_box[2 * wave] = kmin; s_box[2 * wave + 1] = kmax; }
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < NW; ++w) { kmin = pk_min_u16(kmin, s_box[2 * w]); kmax = pk_max_u16(kmax, s_box[2 * w + 1]); }
-    kmin = (unsigned)__builtin_amdgcn_readfirstlane((int)kmin);
-    kmax = (unsigned)__builtin_amdgcn_readfirstlane((int)kmax);
-    const bool any = kmin != 0xffffffffu;
-    const int X0 = max((int)(kmin & 0xffffu) - kWinHalo, 0), X1 = min((int)(kmax & 0xffffu) + kWinHalo, dl.nx - 1);
-    const int R0 = max((int)(kmin >> 16) - kWinHalo, 0), R1 = min((int)(kmax >> 16) + kWinHalo, nrow - 1);
-    const int nwc = X1 - X0 + 1, nwr = R1 - R0 + 1;
-    bool win = any && nwc <= kWinCells && nwr <= kWinRows;          // (the same on every thread of the block)
-#ifdef PW_WIN_STATS
-    if (tid == 0 && any) { PW_WSTAT(0, 1); if (nwr > kWinRows) PW_WSTAT(10, 1); else if (nwc > kWinCells) PW_WSTAT(11, 1); }
-#endif
-    if (win) {
-        // begin words of the window's cells: wave w takes the rows w, w + NW, ...; lane = cell
-        int t[RPW];
-#pragma unroll
-        for (int k = 0; k < RPW; ++k) {
-            const int w = wave + k * NW;
-            t[k] = (w < nwr && lane <= nwc) ? dl.cell_start[(R0 + w) * dl.nx + X0 + lane] : 0;
-        }
-#pragma unroll
-        for (int k = 0; k < RPW; ++k) {
-            const int w = wave + k * NW;
-            if (w < nwr) {
-                if (lane == 0) s_span[2 * w] = t[k];
-                if (lane == nwc) s_span[2 * w + 1] = t[k];
-            }
-        }
-        __syncthreads();
-        // where the rows' spans go in the copy: lane w of every wave sums for row w (the same on every wave)
-        const int sb = lane < nwr ? s_span[2 * lane] : 0, se = lane < nwr ? s_span[2 * lane + 1] : 0;
-        int incl = se - sb;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            const int u = __shfl_up(incl, o);
-            if (lane >= o) incl += u;
-        }
-        const int total = __shfl(incl, nwr - 1);
-        const int delta = incl - (se - sb) - sb;                    // copy index = level index + delta (lane = row)
-        win = total <= kWinPts;
-#ifdef PW_WIN_STATS
-        if (tid == 0) { if (win) { PW_WSTAT(1, 1); PW_WSTAT(2, nwr); PW_WSTAT(3, nwc); PW_WSTAT(4, total); } else PW_WSTAT(12, 1); }
-#endif
-        if (win) {
-            const float* __restrict__ p3 = dl.pts3;
-            PwXyz3 a[RPW], b[RPW];
-            int rs[RPW], rl[RPW], rd[RPW];
-#pragma unroll
-            for (int k = 0; k < RPW; ++k) {
-                const int w = min(wave + k * NW, kWinRows - 1);
-                rs[k] = __shfl(sb, w); rl[k] = (wave + k * NW < nwr) ? __shfl(se, w) - rs[k] : 0; rd[k] = __shfl(delta, w);
-                if (lane < rl[k]) a[k] = pts3_point(p3, rs[k] + lane);
-                if (lane + 64 < rl[k]) b[k] = pts3_point(p3, rs[k] + lane + 64);
-            }
-#pragma unroll
-            for (int k = 0; k < RPW; ++k) {
-                const int w = wave + k * NW;
-                if (w < nwr && lane <= nwc) s_tab[w * kWinTab + lane] = t[k] + rd[k];
-                const int o = rs[k] + rd[k];
-                if (lane < rl[k]) { s_x[o + lane] = a[k].x; s_y[o + lane] = a[k].y; s_z[o + lane] = a[k].z; }
-                if (lane + 64 < rl[k]) { s_x[o + lane + 64] = b[k].x; s_y[o + lane + 64] = b[k].y; s_z[o + lane + 64] = b[k].z; }
-                for (int j = lane + 128; j < rl[k]; j += 64) {
-                    const PwXyz3 c = pts3_point(p3, rs[k] + j);
-                    s_x[o + j] = c.x; s_y[o + j] = c.y; s_z[o + j] = c.z;
-                }
-            }
-            if (tid < 8) { s_x[total + tid] = 1.0e18f; s_y[total + tid] = 1.0e18f; s_z[total + tid] = 1.0e18f; }
-        }
-        __syncthreads();
-    }
-    if (st) {
-        if (win && ing) {
-            const float slack2 = 2.0f * dl.slack;
-            const int sx0 = max(cx - 1, 0), sx1 = min(cx + 1, dl.nx - 1);
-            const int tb0 = (cr - R0) * kWinTab - X0;
-            const int a0 = s_tab[tb0 + sx0], a1 = s_tab[tb0 + sx1 + 1];
-            scan_lds4<PERM>(s_x, s_y, s_z, a0, a1, ux, uy, uz, best);
-            cnt += (unsigned)(a1 - a0);
-            if (!(best < INFINITY)) {
-                // nothing in the query's own three cells: the rows above and below before giving up on the window
-#pragma unroll
-                for (int dr = -1; dr <= 1; dr += 2) {
-                    const int r = cr + dr;
-                    if (r >= R0 && r <= R1) {
-                        const int tb = (r - R0) * kWinTab - X0;
-                        const int lo = s_tab[tb + sx0], hi = s_tab[tb + sx1 + 1];
-                        scan_lds4<PERM>(s_x, s_y, s_z, lo, hi, ux, uy, uz, best);
-                        cnt += (unsigned)(hi - lo);
-                    }
-                }
-            }
-            bool done = false;
-            if (best < INFINITY) {
-                const float rho = fast_sqrt_up(best) + slack2;
-                const int r0 = max(icell(ur - rho, orr, dl.inv_h), 0), r1 = min(icell(ur + rho, orr, dl.inv_h), nrow - 1);
-                if (r0 >= R0 && r1 <= R1) {
-                    const float rho2 = rho * rho;
-                    done = true;
-                    for (int r = r0; r <= r1; ++r) {
-                        const float l = orr + (float)r * dl.h;
-                        const float e = fmaxf(fmaxf(l - ur, ur - (l + dl.h)) - slack2, 0.0f);
-                        const float rem = rho2 - e * e;
-                        if (!(rem > 0.0f)) continue;
-                        const float rx = fast_sqrt_up(rem) + slack2;
-                        const int x0 = max(icell(ux - rx, dl.ox, dl.inv_h), 0), x1 = min(icell(ux + rx, dl.ox, dl.inv_h), dl.nx - 1);
-                        if (x0 > x1) continue;
-                        if (x0 < X0 || x1 > X1) { done = false; break; }       // the ball leaves the window: handed on
-                        const int tb = (r - R0) * kWinTab - X0;
-                        if (r == cr) {
-                            if (x0 < sx0) { const int lo = s_tab[tb + x0]; scan_lds4<PERM>(s_x, s_y, s_z, lo, a0, ux, uy, uz, best); cnt += (unsigned)(a0 - lo); }
-                            if (x1 > sx1) { const int hi = s_tab[tb + x1 + 1]; scan_lds4<PERM>(s_x, s_y, s_z, a1, hi, ux, uy, uz, best); cnt += (unsigned)(hi - a1); }
-                        } else {
-                            const int lo = s_tab[tb + x0], hi = s_tab[tb + x1 + 1];
-                            scan_lds4<PERM>(s_x, s_y, s_z, lo, hi, ux, uy, uz, best);
-                            cnt += (unsigned)(hi - lo);
-                        }
-                    }
-                }
-            }
-            if (done) { d2out[i] = best; resolved = true; PW_WSTAT(5, 1); }
-            else { unresolved = true; if (best < INFINITY) PW_WSTAT(7, 1); else PW_WSTAT(6, 1); }
-        } else if (win) {
-            unresolved = true;          // a query outside the level's grid
-            PW_WSTAT(9, 1);
-        } else {
-            PW_WSTAT(8, 1);
-            // the block's window does not fit: the search of k_nn_dense_disc, from global memory
-            const int cy = cell_of(uy, dl.oy, dl.inv_hy), cz = cell_of(uz, dl.oz, dl.inv_hz);
-            int loA, hiA;
-            row_range(dl, cy, cz, cx - 1, cx + 1, loA, hiA);
-            scan_d2_level<PERM>(dl, loA, hiA, ux, uy, uz, best);
-            cnt += (unsigned)(hiA - loA);
-            const float rho = fast_sqrt_up(best) + 2.0f * dl.slack;
-            if (best < INFINITY && rho <= kMaxRhoCells * dl.h) {
-                const bool in = cy >= 0 && cy < dl.ny && cz >= 0 && cz < dl.nz && max(cx - 1, 0) <= min(cx + 1, dl.nx - 1);
-                cnt += scan_disc_lean<PERM, false, true>(dl, ux, uy, uz, rho, in ? cy : INT_MIN, in ? cz : INT_MIN, max(cx - 1, 0),
-                                                         min(cx + 1, dl.nx - 1), loA, hiA, best);
-                d2out[i] = best;
-                resolved = true;
-            } else {
-                unresolved = true;
-            }
-        }
-    }
-    __syncthreads();                       // every wave is done with the window: the bytes change hands
-    if (fs.scratch)
-        for (int t = tid; t < kFsBins; t += kDenseBlock) s_hist[t] = 0u;
-    const unsigned long long mask = __ballot(unresolved);
-    const int before = __popcll(mask & ((1ull << lane) - 1ull));
-    if (lane == 0) s_wcnt[wave] = __popcll(mask);
-    __syncthreads();
-    if (resolved && fs.scratch) atomicAdd(&s_hist[__float_as_uint(best) >> 21], 1u);
-    int bs = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-        if (w < wave) bs += s_wcnt[w];
-        total += s_wcnt[w];
-    }
-    if (unresolved) {
-        s_q[bs + before] = make_float4(q.x, q.y, q.z, best);
-        s_slot[bs + before] = i;
-    }
-    __syncthreads();
-    if (FARG) {
-        __shared__ unsigned s_base;
-        if (tid == 0 && total > 0) s_base = atomicAdd(fl.count, (unsigned)total);
-        __syncthreads();
-        if (tid < total) {
-            fl.q[s_base + tid] = s_q[tid];
-            fl.slot[s_base + tid] = s_slot[tid];
-        }
-    } else if (tid < total) {
-        const float4 u = s_q[tid];
-        const float d = dense_far_path(far, u, u.w, cnt);
-        d2out[s_slot[tid]] = d;
-        if (fs.scratch) atomicAdd(&s_hist[__float_as_uint(d) >> 21], 1u);
-    }
-    add_examined(examined, cnt);
-    if (fs.scratch) fs_pass0_epilogue(s_hist, fs);
-}
+// (Round 5's search on an LDS copy of the block's candidate window - k_nn_dense_win, exact, 37.5 - 51 us against 30 - was removed
+// in round 6; its design and counters are profiles/r05_dense_variants.txt (1), the code is in the history at 195adaa.)
 
 #ifndef PW_FAR_RUN
 #define PW_FAR_RUN 4
@@ -1701,8 +1384,7 @@ int pw_select_kth_launch(pwicp_context* ctx, const float* d_vals, int n, int k, 
                          bool armed, const SelectMail* mail) {
     if (n <= 0) return PWICP_E_INVALID;
     // few blocks: every block ends with one global atomic per non-empty bin, and same-address atomics serialise
-    static int nbl = -1;                 // PWICP_SELECT_BLOCKS: number of blocks (A/B measurements)
-    if (nbl < 0) { const char* e = getenv("PWICP_SELECT_BLOCKS"); nbl = e ? std::max(atoi(e), 1) : ctx->n_cu; }
+    const int nbl = ctx->n_cu;
     int nb = std::min(div_up(n, kBlock), nbl);
     // `armed`: the scratch buffer was zeroed when it was allocated and only ever used by this function (every
     // selection leaves it zeroed again)
@@ -1734,14 +1416,9 @@ namespace {
 __global__ void k_pack_xyz3(const float4* __restrict__ in, int n, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n + kPts3Pad + (n & 1)) return;
-    // (behind the last point: far-away points - a scan may read past the end of its range, nn_device.h PW_DENSE_SCAN)
+    // (behind the last point: far-away points - a scan may read past the end of its range, nn_device.h scan_d2_level)
     const float4 p = i < n ? in[i] : make_float4(1.0e18f, 1.0e18f, 1.0e18f, 0.f);
-#if PW_DENSE_SCAN == 2
-    float* b = out + 6 * (size_t)(i >> 1) + (i & 1);                // pairs: x0, x1, y0, y1, z0, z1
-    b[0] = p.x; b[2] = p.y; b[4] = p.z;
-#else
     out[3 * (size_t)i] = p.x; out[3 * (size_t)i + 1] = p.y; out[3 * (size_t)i + 2] = p.z;
-#endif
 }
 int pack_level(pwicp_context* ctx, GridLevel* lv, DevBuf<float>* buf) {
     HIPCHK(ctx, buf->reserve(((size_t)lv->n + kPts3Pad + 2) * 3));
@@ -1953,33 +1630,14 @@ int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pa
         const int sub = sub_env > 0 ? std::min(sub_env, chunk) : chunk;
         chunk = div_up(chunk, sub) * sub;
         FusedSelect none{};
-        // the window search (k_nn_dense_win) on a level of columns whose cell indices fit 16 bits; PWICP_DENSE_WIN=0: the search
-        // from global memory on every level
-        static int win_env = -1;
-        if (win_env < 0) { const char* e = getenv("PWICP_DENSE_WIN"); win_env = e ? atoi(e) : 0; }
-        // PWICP_DENSE_LDS_PAD: bytes of unused dynamic LDS per block - fewer blocks per CU (A/B of the occupancy, tools/dense_variants.py)
-        static int lds_pad = -1;
-        if (lds_pad < 0) { const char* e = getenv("PWICP_DENSE_LDS_PAD"); lds_pad = e ? std::max(atoi(e), 0) : 0; }
-        const bool columns = (dense->inv_hy == 0.0f) != (dense->inv_hz == 0.0f);
-        const bool use_win = win_env && columns && dense->pts3 && dense->nx < 65535 && std::max(dense->ny, dense->nz) < 65535;
-#define PW_DENSE_W(PERM_, FARG_)                                                                                            \
-    hipLaunchKernelGGL((k_nn_dense_win<PERM_, FARG_>), dim3(chunk * kXcds), dim3(kDenseBlock), 0, ctx->stream, *dense, g, d_pat, d_qorder, \
-                       d_qpatch, d_stable, nq, d_d2, d_examined, chunk, fs ? *fs : none, fl, d_patq, sub)
-        if (use_win) {
-            if (far_group) { if (dense->perm == 0) PW_DENSE_W(0, true); else if (dense->perm == 1) PW_DENSE_W(1, true); else PW_DENSE_W(2, true); }
-            else { if (dense->perm == 0) PW_DENSE_W(0, false); else if (dense->perm == 1) PW_DENSE_W(1, false); else PW_DENSE_W(2, false); }
-        } else
 #define PW_DENSE(PERM_, FARG_)                                                                                              \
-    hipLaunchKernelGGL((k_nn_dense_disc<PERM_, FARG_>), dim3(chunk * kXcds), dim3(kDenseBlock), lds_pad, ctx->stream, *dense, g, d_pat, d_qorder, \
+    hipLaunchKernelGGL((k_nn_dense_disc<PERM_, FARG_>), dim3(chunk * kXcds), dim3(kDenseBlock), 0, ctx->stream, *dense, g, d_pat, d_qorder, \
                        d_qpatch, d_stable, nq, d_d2, d_examined, chunk, fs ? *fs : none, fl, d_patq, sub)
-        {
         if (far_group) { if (dense->perm == 0) PW_DENSE(0, true); else if (dense->perm == 1) PW_DENSE(1, true); else PW_DENSE(2, true); }
         else { if (dense->perm == 0) PW_DENSE(0, false); else if (dense->perm == 1) PW_DENSE(1, false); else PW_DENSE(2, false); }
-        }
 #undef PW_DENSE
-#undef PW_DENSE_W
 #ifdef PW_DENSE_SLOTS
-        if (!use_win) {
+        {
             if (dense->perm == 0) hipLaunchKernelGGL((k_dense_slots<0>), dim3(chunk * kXcds), dim3(kDenseBlock), 0, ctx->stream, *dense, d_pat, d_qorder, d_qpatch, d_stable, nq, chunk, d_patq, sub);
             else if (dense->perm == 1) hipLaunchKernelGGL((k_dense_slots<1>), dim3(chunk * kXcds), dim3(kDenseBlock), 0, ctx->stream, *dense, d_pat, d_qorder, d_qpatch, d_stable, nq, chunk, d_patq, sub);
             else hipLaunchKernelGGL((k_dense_slots<2>), dim3(chunk * kXcds), dim3(kDenseBlock), 0, ctx->stream, *dense, d_pat, d_qorder, d_qpatch, d_stable, nq, chunk, d_patq, sub);
@@ -1989,9 +1647,8 @@ int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pa
         {
             // blocks per CU: four, each walking its share of the list (measured on the reference's scans, 120 k far queries: loop
             // 0.465 / 0.437 / 0.434 / 0.438 / 0.443 / 0.462 / 0.533 ms with 1 / 2 / 3 / 4 / 6 / 8 / 16 - a block's epilogue, the
-            // flush of its selection bins, costs more than a second and third pass over the list; PWICP_FAR_BLOCKS_PER_CU)
-            static int per_cu = -1;
-            if (per_cu < 0) { const char* e = getenv("PWICP_FAR_BLOCKS_PER_CU"); per_cu = e ? std::max(atoi(e), 1) : 4; }
+            // flush of its selection bins, costs more than a second and third pass over the list)
+            constexpr int per_cu = 4;
             hipLaunchKernelGGL(k_nn_dense_far, dim3((unsigned)std::min(div_up((long long)nq * kGroup, kBlock), ctx->n_cu * per_cu)), dim3(kBlock), 0,
                                ctx->stream, g, fl, d_d2, fs ? *fs : none, d_examined);
         }
@@ -2000,10 +1657,8 @@ int pw_nn_dense_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_pa
     }
     // no small-cell level (PWICP_DISC_CELL_FACTOR=0): the 27-cell stencil kernel with (d2, index) keys, kept for A/B runs
     {
-        static int xcd = -1;                 // PWICP_DENSE_XCD=0: plain block order (A/B measurements only)
-        if (xcd < 0) { const char* e = getenv("PWICP_DENSE_XCD"); xcd = e ? atoi(e) : 1; }
         const int tiles = div_up(nq, kBlock);
-        const int chunk = xcd ? div_up(tiles, kXcds) : 0;
+        const int chunk = div_up(tiles, kXcds);
         hipLaunchKernelGGL(k_nn_dense_direct, dim3(chunk ? chunk * kXcds : tiles), dim3(kBlock), 0, ctx->stream, g, d_pat, d_qorder,
                            d_pt_patch, d_stable, nq, d_d2, d_examined, chunk);
     }
@@ -2019,11 +1674,11 @@ int pw_morton_order(pwicp_context* ctx, const GridDesc& g, const float4* d_pts, 
     // In Morton order (round 3) the 64 queries of a wave sit in ~4 x 4 cells of four rows and every gather of the wave touches
     // ~20 cache lines (TCP_TOTAL_CACHE_ACCESSES / SQ_INSTS_VMEM_RD); along a row their windows tile one span of the row's
     // points.  41.3 -> 39.1 us.  PWICP_QUERY_ORDER="xb,rb" (0: Morton order of the fine cells).
-    static int xb = -1, rb = 8, serp = 1;
+    static int xb = -1, rb = 8;
+    const int serp = 1;                     // rows of a block boustrophedon (a wave that crosses a row end stays in one place)
     if (xb < 0) {
         xb = 32;
         if (const char* e = getenv("PWICP_QUERY_ORDER")) { xb = std::max(atoi(e), 0); const char* c = strchr(e, ','); if (!c) c = strchr(e, ':'); if (c) rb = std::max(atoi(c + 1), 1); }
-        if (const char* e = getenv("PWICP_QUERY_SERP")) serp = atoi(e);
     }
     if (xb > 0 && strip_lv && (double)strip_lv->nx * strip_lv->ny * strip_lv->nz * 1.1 + (double)xb * rb * 2 < 4.0e9) {
         DevBuf<unsigned> keys, keys_out;

@@ -278,162 +278,10 @@ __global__ void __launch_bounds__(kAccBlock) k_icp_iter(GridDesc g, const float4
     }
 }
 
-// ---- the same iterations for a SMALL problem, all of a batch in ONE launch of ONE workgroup (round 5; measured, NOT the default) ----
-// VERDICT r4 item 4.  The reference's own scans give ~1.8 k target and <= 1.8 k stable source centroids: 14 blocks of k_icp_iter, and
-// an iteration is 12 us of latency - search 4.4, rows + block sums + store + count 2.8, partial sums 0.8, the 6x6 tail 4 (tools/
-// ktrace.py real 2) - plus a launch, twelve times per registration.  Here one block of 768 threads keeps the target's fine grid level
-// (begin words + points) in LDS (the compiler turns every access of the search into ds_read: no flat loads in the ISA), searches
-// with ONE lane per centroid (exact whichever way it is walked: same (d2, index)) and runs the batch's iterations back to back with
-// block barriers between them: no launch, no cross-block hand-over, no L2 round trips in the search.  The 28 sums are formed in
-// EXACTLY the order of k_icp_iter - eight consecutive points by the tree ((x0+x1)+(x2+x3))+((x4+x5)+(x6+x7)), the sixteen groups of a
-// 128-point block in order, the blocks by tail_sums_block - so T is bit-identical to the multi-launch path
-// (test_scheduling_switches_do_not_change_a_bit runs with PWICP_ICP_SMALL=1).
-// RESULT: 35 - 48 us per iteration instead of 15 (Epoch_002's loop 0.62 instead of 0.43 ms, Epoch_012 0.82 instead of 0.67;
-// profiles/r05_icp_small.txt).  What one CU lacks is not latency but THROUGHPUT: 1 750 exact searches are ~14 k wave instructions
-// at perfect lane efficiency (~40 k with the divergence of per-lane scans) on four SIMDs = 6 - 17 us of issue per iteration, plus
-// seven LDS transposition steps of the row sums per round; k_icp_iter spreads the same instructions over 14 CUs and 224 waves.
-// (First version: the eight-point tree by shuffles - 28 doubles x 3 steps = 168 ds_bpermute per thread on one LDS pipe: the same time.)
-// Kept behind PWICP_ICP_SMALL=1.
+// (Round 5's single-workgroup form of these iterations for small problems - k_icp_small: the target's fine level in LDS, one lane per
+// centroid, a batch's iterations back to back; bit-identical, 35 - 48 us per iteration against 15 - was removed in round 6:
+// profiles/r05_icp_small.txt, the code is in the history at 195adaa.)
 constexpr int kTailSegs = 16;                   // segments of tail_sums_block (below)
-constexpr int kSmallBlock = 768;                // threads: 12 waves = 3 per SIMD = 168 registers (the 6x6 tail wants > 128 inside the loop)
-constexpr int kSmallPts = 3072;                 // most stable centroids (3 per thread) and most target centroids
-constexpr int kSmallCells = 8192;               // most cells of the target's fine level (+ 1 begin word)
-constexpr int kSmallVB = kSmallPts / kAccPts;   // most 128-point blocks
-
-__global__ void __launch_bounds__(kSmallBlock) k_icp_small(GridDesc g, const float4* __restrict__ tgt, const float4* __restrict__ tgt_n,
-                                                         float4* __restrict__ src, float4* __restrict__ srcn, int ns_host,
-                                                         const unsigned* __restrict__ ns_dev, IcpState* st, double mse_rel, int n_iter,
-                                                         IcpMail mail, StageGuard sg) {
-    __shared__ int s_cell[kSmallCells + 1];
-    __shared__ float4 s_pts[kSmallPts];
-    __shared__ double s_grp[kSmallBlock / kGroup][kNSums];        // the sums of a round's 128 groups of eight points
-    __shared__ double s_row[4][kSmallBlock];                      // four of the 28 sums' terms of every point of a round
-    __shared__ double s_part[kSmallVB][kNSums];                   // ... of the 128-point blocks (k_icp_iter's `partials`)
-    __shared__ double s_segs[kTailSegs][32];
-    __shared__ double s_sums[kNSums];
-    __shared__ unsigned s_state[kTailWords];
-    __shared__ float s_T[16];
-    const int tid = threadIdx.x;
-    const int done_in = st->done, iters_in = st->iters;
-    const unsigned ns_in = ns_dev ? *ns_dev : (unsigned)ns_host;
-    if (tid < 16) s_T[tid] = st->T[tid];
-    const int ns = (int)ns_in;
-    if (done_in || ns <= 0) {
-        if (mail.dst) icp_send_mail(mail, st);
-        return;
-    }
-    // the target's fine level into LDS (the coarse level, rarely needed, stays where it is)
-    const int ncell = g.fine.nx * g.fine.ny * g.fine.nz + 1;
-    for (int c = tid; c < ncell; c += kSmallBlock) s_cell[c] = g.fine.cell_start[c];
-    for (int c = tid; c < g.fine.n; c += kSmallBlock) s_pts[c] = g.fine.pts[c];
-    GridDesc gl = g;
-    gl.fine.cell_start = s_cell;
-    gl.fine.pts = s_pts;
-    constexpr int R = kSmallPts / kSmallBlock;
-    const unsigned pre = (mail.dst && mail.na + mail.nb <= 64 && tid < 64) ? mail_prefetch(mail) : 0u;
-    __syncthreads();
-    const int nact = (ns + kAccPts - 1) / kAccPts;
-    int iters = iters_in;
-    bool first_here = true;
-    for (int it = 0; it < n_iter; ++it) {
-        for (int r = 0; r < R; ++r) {
-            if (r * kSmallBlock >= ns) break;
-            const int i = r * kSmallBlock + tid;
-            // the row of the point's match: a, b, c, the normal and d (k_icp_iter's operands), zero for a thread without a point
-            double a = 0.0, bb = 0.0, c = 0.0, d = 0.0, d2 = 0.0;
-            float nx = 0.f, ny = 0.f, nz = 0.f;
-            if (i < ns) {
-                float4 p = src[i], nrm = srcn[i];
-                if (iters > 0) {        // transformPointCloudWithNormals with the previous estimate
-                    float T[16];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) T[e] = s_T[e];
-                    p = xform_point(T, p);
-                    nrm = xform_normal(T, nrm);
-                    src[i] = p; srcn[i] = nrm;
-                }
-                unsigned ex = 0;
-                const NNBest b = nn_query(gl, p.x, p.y, p.z, ex);
-                const int bi = b.idx();
-                const float4 t = tgt[bi], n = tgt_n[bi];
-                const float sx = p.x, sy = p.y, sz = p.z, dx = t.x, dy = t.y, dz = t.z;
-                nx = n.x; ny = n.y; nz = n.z;
-                a = (double)(nz * sy - ny * sz);
-                bb = (double)(nx * sz - nz * sx);
-                c = (double)(ny * sx - nx * sy);
-                d = (double)(nx * dx + ny * dy + nz * dz - nx * sx - ny * sy - nz * sz);
-                d2 = (double)b.d2();
-            }
-            // the 28 sums in k_icp_iter's numbering (sum k lives there on lane k % 8 as its (k / 8)-th value).  Eight consecutive points
-            // are the eight points of a wave of k_icp_iter and are summed by the same tree, ((x0+x1)+(x2+x3))+((x4+x5)+(x6+x7)) - but
-            // not by shuffles: 28 doubles x 3 steps are 168 ds_bpermute per thread, and ONE CU's LDS pipe took ~15 us per iteration
-            // for them (the first version of this kernel: 0.62 instead of 0.44 ms on Epoch_002).  The rows go through LDS four sums
-            // at a time and 96 x 4 threads each add the eight values of one group and sum.
-            const bool has = i < ns;
-            double row[kNSums];
-            row[0] = a * a;    row[1] = a * bb;   row[2] = a * c;    row[3] = a * nx;   row[4] = a * ny;   row[5] = a * nz;   row[6] = bb * bb;
-            row[7] = bb * c;   row[8] = bb * nx;  row[9] = bb * ny;  row[10] = bb * nz; row[11] = c * c;   row[12] = c * nx;  row[13] = c * ny;
-            row[14] = c * nz;  row[15] = (double)(nx * nx); row[16] = (double)(nx * ny); row[17] = (double)(nx * nz); row[18] = (double)(ny * ny);
-            row[19] = (double)(ny * nz); row[20] = (double)(nz * nz);
-            row[21] = a * d;   row[22] = bb * d;  row[23] = c * d;   row[24] = nx * d;  row[25] = ny * d;  row[26] = nz * d;  row[27] = d2;
-#pragma unroll
-            for (int q = 0; q < kNSums / 4; ++q) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) s_row[k][tid] = has ? row[4 * q + k] : 0.0;
-                __syncthreads();
-                if (tid < (kSmallBlock / kGroup) * 4) {
-                    const int grp = tid >> 2, k = tid & 3;
-                    double x[kGroup];
-#pragma unroll
-                    for (int j = 0; j < kGroup; ++j) x[j] = s_row[k][grp * kGroup + j];
-                    s_grp[grp][4 * q + k] = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
-                }
-                __syncthreads();
-            }
-            // the sixteen groups of a 128-point block in order (k_icp_iter: acc = sh[0] + sh[1] + ...)
-            constexpr int BPR = kSmallBlock / kAccPts;                 // 128-point blocks per round
-            if (tid < BPR * kNSums) {
-                const int b = tid / kNSums, k = tid % kNSums, vb = r * BPR + b;
-                if (vb < nact) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int w0 = 0; w0 < kAccPts / kGroup; w0 += 4) {          // (four reads in flight, then the adds in group order)
-                        double g4[4];
-#pragma unroll
-                        for (int w = 0; w < 4; ++w) g4[w] = s_grp[b * (kAccPts / kGroup) + w0 + w][k];
-#pragma unroll
-                        for (int w = 0; w < 4; ++w) acc = (w0 + w == 0) ? g4[w] : acc + g4[w];
-                    }
-                    s_part[vb][k] = acc;
-                }
-            }
-            __syncthreads();
-        }
-        // what a tail needs of the state before this iteration: the launch's first from memory, later ones from the tail's LDS copy
-        TailPrev pv{0.f, 0, 1.7976931348623157e308};
-        if (first_here) pv = tail_prefetch(st, false);
-        else {
-            if (tid < 16) pv.F = __uint_as_float(s_state[16 + tid]);
-            if (tid == 0) { pv.iters = (int)s_state[32]; pv.mse = __hiloint2double((int)s_state[37], (int)s_state[36]); }
-        }
-        first_here = false;
-        tail_sums_block(&s_part[0][0], nact, s_segs, s_sums);
-        if (tid < 64) icp_solve_tail(st, s_sums, ns, mse_rel, false, pv, s_state, sg);
-        __syncthreads();
-        if (tid < 16) s_T[tid] = __uint_as_float(s_state[tid]);
-        iters = (int)s_state[32];
-        const bool done = s_state[33] != 0u;
-        __syncthreads();
-        if (done) break;                                             // converged (or the iteration cap)
-    }
-    if (tid >= 64 || !mail.dst) return;
-    if (mail.na + mail.nb <= 64) icp_send_mail_fast(mail, pre, s_state, sg);
-    else {
-        drain_stores();
-        wave_sync();
-        icp_send_mail(mail, st);
-    }
-}
 
 // value of lane `lane` (wave-uniform index) in every lane: v_readlane, no LDS round trip
 __device__ __forceinline__ double lane_bcast(double v, int lane) {
@@ -1187,20 +1035,6 @@ int pw_icp_enqueue(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt, c
     const int nb = div_up(ns_max, kAccPts);
     IcpMail none{};
     FusedSelect nofs{};
-    // PWICP_ICP_SMALL=1 (measured, slower: see k_icp_small): a small problem's whole batch in one launch of one workgroup; passes 1 / 2
-    // of a percentile selection that would have ridden on the first two launches go out as launches of their own in front of it.
-    static const bool small_on = getenv("PWICP_ICP_SMALL") && atoi(getenv("PWICP_ICP_SMALL")) != 0;
-    if (small_on && n_iter > 0 && ns_max <= kSmallPts && g.fine.n <= kSmallPts &&
-        (long long)g.fine.nx * g.fine.ny * g.fine.nz <= (long long)kSmallCells) {
-        if (fs && fs->scratch && n_iter >= 2) {
-            PWCHK(pw_fs_pass_launch(ctx, 1, *fs));
-            PWCHK(pw_fs_pass_launch(ctx, 2, *fs));
-        }
-        hipLaunchKernelGGL(k_icp_small, dim3(1), dim3(kSmallBlock), 0, ctx->stream, g, d_tgt, d_tgt_n, w->src.p, w->srcn.p, ns_max, ns_dev,
-                           w->state.p, euclid_eps, n_iter, mail ? *mail : none, sg ? *sg : StageGuard{});
-        HIPCHK(ctx, hipGetLastError());
-        return PWICP_OK;
-    }
     for (int k = 0; k < n_iter; ++k) {
         const bool sel = fs && fs->scratch && k < 2;           // passes 1 and 2 on the first two launches (the caller enqueues >= 2)
         hipLaunchKernelGGL(k_icp_iter, dim3(nb + (sel ? fs->nblk : 0)), dim3(kAccBlock), 0, ctx->stream, g, d_tgt, d_tgt_n, w->src.p,
@@ -1250,8 +1084,7 @@ int pw_xf_vcm_launch(pwicp_context* ctx, const GridDesc& g, const float4* d_tgt,
                      int n_pat, unsigned* d_bbox_part, unsigned* d_slot) {
     const int nb_vcm = div_up(std::max(ns_max, 1), kAccPts);
     // (a cloud block ends with the bounding-box fold, ~3 us of dependent atomics: one block per CU, 4 k points each, not two)
-    static const int cloud_mul = getenv("PWICP_XFVCM_CLOUD_MUL") ? atoi(getenv("PWICP_XFVCM_CLOUD_MUL")) : 1;
-    const int nb_cloud = std::min(div_up(n, kVcmBlock), ctx->n_cu * std::max(cloud_mul, 1));
+    const int nb_cloud = std::min(div_up(n, kVcmBlock), ctx->n_cu);
     const int nb_rest = std::min(div_up(n_ctbp + n_pat, kVcmBlock), ctx->n_cu * 2);
     VcmMail none{};
     hipLaunchKernelGGL(k_xf_vcm, dim3(nb_vcm + nb_rest + nb_cloud), dim3(kVcmBlock), 0, ctx->stream, g, d_tgt, d_tgt_n, d_stct,

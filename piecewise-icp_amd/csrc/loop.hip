@@ -862,9 +862,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         if (ahead_of_icp) { *ahead_of_icp = fs; return PWICP_OK; }       // (only taken with `fused`)
         if (!fused) PWCHK(select_p75_enqueue(pr, pr->P2.tot, nsp, &sel_seq));
         // the percentile only steers the threshold: transform and next front go out while it travels
-        static int nb1 = -1;
-        if (nb1 < 0) { const char* e = getenv("PWICP_FS_BLOCKS1"); nb1 = e ? std::max(atoi(e), 1) : 64; }
-        fs.nblk = nb1;
+        fs.nblk = 64;
         if (with_front) PWCHK(enqueue_xf_front(slot, fused ? &fs : nullptr));
         else enqueue_transform(slot, fused ? &fs : nullptr);
         fs.nblk = kFsBlocks;
@@ -884,10 +882,6 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         unsigned* const slot = pr->scal.p + (size_t)kSlot * k;
 
         ht("iteration begins");
-        if (ctx->side_open) {                  // what the second stream was given in the iteration before is ordered before this one's launches
-            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-            ctx->side_open = false;
-        }
         if (!front_ready) { PWCHK(enqueue_front(slot, nullptr, true, k == 0)); ht("front enqueued"); }
         front_ready = false;
         const float4* const ct2 = pr->src_ctbp();
@@ -915,7 +909,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         // this very iteration, its result is simply not used; if the ICP needs more than the first batch, the transform /
         // front that were enqueued were no-ops / premature and are enqueued again.
         const bool spec_dense = speculate && k == 0 && !stage2 && pr->dense_lv && !pr->no_fused_select && !(pr->profiling & PWICP_PROF_REPLAY);
-        bool spec_done = false, spec_xf_valid = false, dense_on_side = false;
+        bool spec_done = false, spec_xf_valid = false;
         // Still Stage 1 after the first iteration: whether THIS iteration ends it (R.cpp:891-894) depends on its transformation.
         // The ICP tail that converges takes that decision itself (stage_dev.h) and the update + next front go out behind the
         // batch, guarded by its flag - a no-op of ~4 us if Stage 1 goes on, instead of a host round trip (~12 us) if it ends.
@@ -960,36 +954,10 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                     // first iteration: the dense search right behind the classification (it needs the stable flags, not the ICP),
                     // passes 1 / 2 of its percentile on the ICP launches (n_iter = 3 here)
                     if (spec_now && n_iter >= 2) {
-                        // PWICP_DENSE_SIDE_STREAM=1 (round 5, measured, NOT the default): when its queries are the copy made at pair
-                        // creation (nothing of what it reads is touched by the update that follows the ICP) the search can run on the
-                        // context's SECOND stream, passes 1 / 2 as launches of their own behind it, BESIDE the ICP launches (3 x 12 -
-                        // 17 us of dependent round trips on a few CUs) instead of in front of them; the main stream waits for that
-                        // stream before the next classification (which rewrites the stable flags the search reads).  Bit-identical
-                        // (test_scheduling_switches_do_not_change_a_bit) and SLOWER: 0.263 - 0.269 ms per step against 0.252 - 0.254,
-                        // also with the second stream at the lowest priority - the search keeps every CU's wave slots filled four at a
-                        // time and a 16-wave ICP block finds room only once the search's grid has been dealt out, so the ICP launches
-                        // end up behind most of the search anyway, plus two event hand-overs (~5 us each).
-                        static const bool side_env = getenv("PWICP_DENSE_SIDE_STREAM") && atoi(getenv("PWICP_DENSE_SIDE_STREAM")) != 0;
-                        static const bool patq_env = !(getenv("PWICP_DENSE_QUERY_COPY") && atoi(getenv("PWICP_DENSE_QUERY_COPY")) == 0);
-                        const bool on_side = side_env && patq_env && (pr->lazy || !pr->dirty) && pw_side_stream(ctx) == PWICP_OK;
-                        if (on_side) {
-                            HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-                            HIPCHK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
-                            hipStream_t const main_stream = ctx->stream;
-                            ctx->stream = ctx->side;
-                            FusedSelect fs_side{};
-                            int rc = enqueue_dense_tail(slot, 0, /*rank_dev*/ true, /*with_front*/ true, &fs_side);
-                            if (rc == PWICP_OK) rc = pw_fs_pass_launch(ctx, 1, fs_side);
-                            if (rc == PWICP_OK) rc = pw_fs_pass_launch(ctx, 2, fs_side);
-                            const hipError_t ej = hipEventRecord(ctx->ev_join, ctx->side);
-                            ctx->stream = main_stream;
-                            ctx->side_open = true;
-                            PWCHK(rc);
-                            HIPCHK(ctx, ej);
-                            dense_on_side = true;
-                        } else {
-                            PWCHK(enqueue_dense_tail(slot, 0, /*rank_dev*/ true, /*with_front*/ true, &fs_icp));
-                        }
+                        // (round 5, measured and removed in round 6: the search on a SECOND stream beside the ICP launches - bit-identical,
+                        // 0.263 against 0.252 ms per step: the search keeps every CU's wave slots filled and a 16-wave ICP block finds
+                        // room only once the search's grid has been dealt out)
+                        PWCHK(enqueue_dense_tail(slot, 0, /*rank_dev*/ true, /*with_front*/ true, &fs_icp));
                     }
                 }
                 if (n_iter > 0)
@@ -1009,7 +977,7 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
                     }
                 }
                 if (spec_now) {
-                    if (fs_icp.scratch || dense_on_side) PWCHK(enqueue_xf_front(slot));          // the search and its selection are already on a stream
+                    if (fs_icp.scratch) PWCHK(enqueue_xf_front(slot));          // the search and its selection are already on a stream
                     else PWCHK(enqueue_dense_tail(slot, 0, /*rank_dev*/ true, /*with_front*/ true));
                     spec_done = true;
                 }
@@ -1137,10 +1105,6 @@ int pwicp_pair_run(pwicp_pair* pr, pwicp_result* res) {
         mat4_mul(Tk, res->T16, res->T16);
         res->n_outer = k + 1;
         res->DTseries[k + 1] = currDT;
-    }
-    if (ctx->side_open) {                      // (a run that ended in the iteration that used the second stream)
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-        ctx->side_open = false;
     }
     // closing message: the VCM (R.cpp:958-961) and the diagnostic counter; its arrival also means the stream is idle
     unsigned long long ex = 0;

@@ -432,56 +432,17 @@ __device__ __forceinline__ void scan_d2x4(const float4* __restrict__ pts, int lo
 }
 
 // the same on a level of the dense search: from the packed 12-byte copy of its points (global_load_dwordx3: 10.7 instead of 8
-// points per 128-byte line - a vector-memory instruction of this search costs by the cache lines it touches: 39.6 -> 38.3 us;
-// -DPW_DENSE_XYZ4: the 16-byte points).
-// Round 5, PW_DENSE_SCAN: how the range [lo, hi) is walked.  The minimum over ALL target points is what the search returns, so a
-// candidate beyond the range's end (a real target point of the next cell) can never make the result wrong - only reading outside
-// the array must not happen, and the packed copy ends in kPts3Pad far-away points.
-//   0  four per pass, then a tail of two and of one (rounds 2 - 4)
-//   1  four per pass, no tails: the last pass reads up to three points past `hi`
-//   2  the packed copy holds the points in PAIRS (x0, x1, y0, y1, z0, z1: 24 bytes per two points), two pairs per pass from the even
-//      index at or below `lo`: the three differences, three squares and two sums of TWO candidates are one v_pk_add_f32 /
-//      v_pk_mul_f32 each (the vector ALU issues a packed instruction in the time of a plain one) and the minimum of both one
-//      v_min3_f32 - 4.5 instead of 6.5 vector instructions per candidate, same float expression per candidate.
-#ifndef PW_DENSE_SCAN
-#define PW_DENSE_SCAN 1
-#endif
-constexpr int kPts3Pad = 20;           // far-away points behind the last one of a packed copy (scan_d2_head reads up to 15 + 3 past a range)
+// points per 128-byte line - a vector-memory instruction of this search costs by the cache lines it touches: 39.6 -> 38.3 us).
+// Four candidates per pass, NO tails (round 5): the minimum over ALL target points is what the search returns, so a candidate beyond
+// the range's end (a real target point of the next cell) can never make the result wrong - only reading outside the array must not
+// happen, and the packed copy ends in kPts3Pad far-away points.  (Measured and not kept, profiles/r05_dense_variants.txt (2): tails
+// of two and one, 33.6 against 32.8 us; the points stored in pairs for v_pk_add_f32 / v_pk_mul_f32, 17 % fewer vector instructions,
+// 34.8 us - the compiler packs what it can of the plain form by itself.)
+constexpr int kPts3Pad = 8;            // far-away points behind the last one of a packed copy
 struct PwXyz3 { float x, y, z; };
-typedef float pw_f2 __attribute__((ext_vector_type(2)));
-template <int PERM = 0>
-__device__ __forceinline__ void nn_consider_d2_pair(const pw_f2 px, const pw_f2 py, const pw_f2 pz, float qx, float qy, float qz, float& best) {
-    const pw_f2 d0 = qx - px, d1 = qy - py, d2_ = qz - pz;
-    const pw_f2 dx = PERM == 0 ? d0 : (PERM == 1 ? d2_ : d1);
-    const pw_f2 dy = PERM == 0 ? d1 : (PERM == 1 ? d0 : d2_);
-    const pw_f2 dz = PERM == 0 ? d2_ : (PERM == 1 ? d1 : d0);
-    pw_f2 s = dx * dx;
-    s = s + dy * dy;
-    s = s + dz * dz;
-    best = fminf(fminf(best, s.x), s.y);
-}
-// point i of a packed copy, whatever its layout (the window search copies spans of it; diagnostics)
-__device__ __forceinline__ PwXyz3 pts3_point(const float* __restrict__ p3, int i) {
-#if PW_DENSE_SCAN == 2
-    const float* b = p3 + 6 * (size_t)(i >> 1) + (i & 1);
-    return PwXyz3{b[0], b[2], b[4]};
-#else
-    const float* b = p3 + 3 * (size_t)i;
-    return PwXyz3{b[0], b[1], b[2]};
-#endif
-}
 template <int PERM = 0, bool P3 = true>
 __device__ __forceinline__ void scan_d2_level(const GridLevel& g, int lo, int hi, float qx, float qy, float qz, float& best) {
-#ifndef PW_DENSE_XYZ4
     if (!P3) { scan_d2x4<PERM>(g.pts, lo, hi, qx, qy, qz, best); return; }      // (a level without the packed copy)
-#if PW_DENSE_SCAN == 2
-    const pw_f2* __restrict__ pp = (const pw_f2*)g.pts3;
-    for (int b = lo >> 1, be = (hi + 1) >> 1; b < be; b += 2) {
-        const pw_f2 x0 = pp[3 * b], y0 = pp[3 * b + 1], z0 = pp[3 * b + 2], x1 = pp[3 * b + 3], y1 = pp[3 * b + 4], z1 = pp[3 * b + 5];
-        nn_consider_d2_pair<PERM>(x0, y0, z0, qx, qy, qz, best);
-        nn_consider_d2_pair<PERM>(x1, y1, z1, qx, qy, qz, best);
-    }
-#elif PW_DENSE_SCAN == 1
     const PwXyz3* __restrict__ p3 = (const PwXyz3*)g.pts3;
     for (int j = lo; j < hi; j += 4) {
         const PwXyz3 a = p3[j], b = p3[j + 1], c = p3[j + 2], d = p3[j + 3];
@@ -490,27 +451,6 @@ __device__ __forceinline__ void scan_d2_level(const GridLevel& g, int lo, int hi
         nn_consider_d2<PERM>(make_float4(c.x, c.y, c.z, 0.f), qx, qy, qz, best);
         nn_consider_d2<PERM>(make_float4(d.x, d.y, d.z, 0.f), qx, qy, qz, best);
     }
-#else
-    const PwXyz3* __restrict__ p3 = (const PwXyz3*)g.pts3;
-    int j = lo;
-    for (; j + 4 <= hi; j += 4) {
-        const PwXyz3 a = p3[j], b = p3[j + 1], c = p3[j + 2], d = p3[j + 3];
-        nn_consider_d2<PERM>(make_float4(a.x, a.y, a.z, 0.f), qx, qy, qz, best);
-        nn_consider_d2<PERM>(make_float4(b.x, b.y, b.z, 0.f), qx, qy, qz, best);
-        nn_consider_d2<PERM>(make_float4(c.x, c.y, c.z, 0.f), qx, qy, qz, best);
-        nn_consider_d2<PERM>(make_float4(d.x, d.y, d.z, 0.f), qx, qy, qz, best);
-    }
-    if (j + 2 <= hi) {
-        const PwXyz3 a = p3[j], b = p3[j + 1];
-        nn_consider_d2<PERM>(make_float4(a.x, a.y, a.z, 0.f), qx, qy, qz, best);
-        nn_consider_d2<PERM>(make_float4(b.x, b.y, b.z, 0.f), qx, qy, qz, best);
-        j += 2;
-    }
-    if (j < hi) { const PwXyz3 a = p3[j]; nn_consider_d2<PERM>(make_float4(a.x, a.y, a.z, 0.f), qx, qy, qz, best); }
-#endif
-#else
-    scan_d2x4<PERM>(g.pts, lo, hi, qx, qy, qz, best);
-#endif
 }
 
 // scan_disc without divisions / exact square roots; rows of one z-slab are taken four at a time (all begin/end words of
@@ -635,64 +575,13 @@ __device__ __forceinline__ int disc_ranges_columns(const GridLevel& g, float ux,
         }
     return n;
 }
-// Phase A of the dense search: the first HEAD points of a non-empty range requested at once (one round trip instead of HEAD / 4
-// dependent ones - the own row segment holds 12 +- 2 points on the bench pair), the rest four per pass.  Points past the range's
-// end are real target points of the next cells: harmless for a minimum over all targets (see PW_DENSE_SCAN above).
-template <int PERM, int HEAD>
-__device__ __forceinline__ void scan_d2_head(const GridLevel& g, int lo, int hi, float qx, float qy, float qz, float& best) {
-    if (hi <= lo) return;
-    const PwXyz3* __restrict__ p3 = (const PwXyz3*)g.pts3;
-    PwXyz3 v[HEAD];
-#pragma unroll
-    for (int k = 0; k < HEAD; ++k) v[k] = p3[lo + k];
-#pragma unroll
-    for (int k = 0; k < HEAD; ++k) nn_consider_d2<PERM>(make_float4(v[k].x, v[k].y, v[k].z, 0.f), qx, qy, qz, best);
-    for (int j = lo + HEAD; j < hi; j += 4) {
-        const PwXyz3 a = p3[j], b = p3[j + 1], c = p3[j + 2], d = p3[j + 3];
-        nn_consider_d2<PERM>(make_float4(a.x, a.y, a.z, 0.f), qx, qy, qz, best);
-        nn_consider_d2<PERM>(make_float4(b.x, b.y, b.z, 0.f), qx, qy, qz, best);
-        nn_consider_d2<PERM>(make_float4(c.x, c.y, c.z, 0.f), qx, qy, qz, best);
-        nn_consider_d2<PERM>(make_float4(d.x, d.y, d.z, 0.f), qx, qy, qz, best);
-    }
-}
-
-// PW_FLAT_PREFETCH: the NEXT range of the list is read while the current one is being walked (a range switch then costs two moves, not
-// an LDS round trip in the lane's chain of dependent loads)
-#ifndef PW_FLAT_PREFETCH
-#define PW_FLAT_PREFETCH 1
-#endif
-#ifndef PW_FLAT_PIPE
-#define PW_FLAT_PIPE 0
-#endif
 template <int PERM>
 __device__ __forceinline__ void scan_ranges_flat(const GridLevel& g, const int2* __restrict__ list, int stride, int tid, int n, float ux, float uy,
                                                  float uz, float& best) {
     const PwXyz3* __restrict__ p3 = (const PwXyz3*)g.pts3;
-#if PW_FLAT_PIPE
-    // the four points of the NEXT pass requested before the current four are evaluated (12 more registers)
-    int2 r0 = make_int2(0, 0), r1 = make_int2(0, 0);
-    if (n > 0) r0 = list[tid];
-    if (n > 1) r1 = list[stride + tid];
-    int j = r0.x, e = r0.y, k = 2;
-    PwXyz3 a, b, c, d;
-    if (j < e) { a = p3[j]; b = p3[j + 1]; c = p3[j + 2]; d = p3[j + 3]; }
-    while (j < e) {
-        int jn = j + 4, en = e;
-        if (jn >= e) {
-            jn = r1.x; en = r1.y;
-            r1 = make_int2(0, 0);
-            if (k < n) { r1 = list[k * stride + tid]; ++k; }
-        }
-        PwXyz3 a2 = a, b2 = b, c2 = c, d2_ = d;
-        if (jn < en) { a2 = p3[jn]; b2 = p3[jn + 1]; c2 = p3[jn + 2]; d2_ = p3[jn + 3]; }
-        nn_consider_d2<PERM>(make_float4(a.x, a.y, a.z, 0.f), ux, uy, uz, best);
-        nn_consider_d2<PERM>(make_float4(b.x, b.y, b.z, 0.f), ux, uy, uz, best);
-        nn_consider_d2<PERM>(make_float4(c.x, c.y, c.z, 0.f), ux, uy, uz, best);
-        nn_consider_d2<PERM>(make_float4(d.x, d.y, d.z, 0.f), ux, uy, uz, best);
-        a = a2; b = b2; c = c2; d = d2_;
-        j = jn; e = en;
-    }
-#elif PW_FLAT_PREFETCH
+    // (the NEXT range is read while the current one is walked: a range switch is two moves, not an LDS round trip in the lane's chain.
+    // Measured and not kept, profiles/r06_dense_variants.txt: the next pass's points requested before the current four are evaluated,
+    // 30.2 against 28.2 us; the first 12 / 16 points of the own row segment requested at once, 27.6 / 28.6.)
     int2 r0 = make_int2(0, 0), r1 = make_int2(0, 0);
     if (n > 0) r0 = list[tid];
     if (n > 1) r1 = list[stride + tid];
@@ -710,28 +599,13 @@ __device__ __forceinline__ void scan_ranges_flat(const GridLevel& g, const int2*
             if (k < n) { r1 = list[k * stride + tid]; ++k; }
         }
     }
-#else
-    int j = 0, e = 0, k = 0;
-    if (n > 0) { const int2 r = list[tid]; j = r.x; e = r.y; k = 1; }
-    while (j < e) {
-        const PwXyz3 a = p3[j], b = p3[j + 1], c = p3[j + 2], d = p3[j + 3];
-        nn_consider_d2<PERM>(make_float4(a.x, a.y, a.z, 0.f), ux, uy, uz, best);
-        nn_consider_d2<PERM>(make_float4(b.x, b.y, b.z, 0.f), ux, uy, uz, best);
-        nn_consider_d2<PERM>(make_float4(c.x, c.y, c.z, 0.f), ux, uy, uz, best);
-        nn_consider_d2<PERM>(make_float4(d.x, d.y, d.z, 0.f), ux, uy, uz, best);
-        j += 4;
-        if (j >= e && k < n) { const int2 r = list[k * stride + tid]; j = r.x; e = r.y; ++k; }
-    }
-#endif
 }
 
 // scan_disc_lean shared by a group of G lanes (one query): the rows of the ball are dealt to the lanes round-robin and every lane
 // walks ITS rows as the per-lane search does (four rows' begin / end words in flight, then their points four at a time) - a wide
 // ball (40 rows, 200 candidates) is 1/G of the rows and candidates per lane, i.e. a chain of ~10 round trips instead of ~90.
 // Same pruning, same float expression per candidate: after the group minimum, the same exact d2.
-#ifndef PW_FAR_ROWS_ABREAST
-#define PW_FAR_ROWS_ABREAST 0       // (measured, round 5: the reference's 19 pairs 11.45 -> 12.25 ms in sum with it; profiles/r05_dense_variants.txt (9))
-#endif
+// (measured and not kept, profiles/r05_dense_variants.txt (9): the lane's four rows side by side, two points of each per step)
 template <int G>
 __device__ __forceinline__ void scan_disc_group(const GridLevel& g, float qx, float qy, float qz, float rho, int sub, float& best) {
     const bool gy = g.inv_hy != 0.0f, gz = g.inv_hz != 0.0f;
@@ -767,26 +641,8 @@ __device__ __forceinline__ void scan_disc_group(const GridLevel& g, float qx, fl
             lo[k] = g.cell_start[row + x0];
             hi[k] = g.cell_start[row + x1 + 1];
         }
-#if PW_FAR_ROWS_ABREAST
-        // (build variant: the lane's four rows side by side, two points of each per step - eight gathers in flight, the longest row's
-        // half as many steps as one row after the other at four points a step; same candidates, same minimum; slower, see above)
-        const int m4 = max(max(hi[0] - lo[0], hi[1] - lo[1]), max(hi[2] - lo[2], hi[3] - lo[3]));
-        for (int j = 0; j < m4; j += 2) {
-            float4 v[8];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int a = lo[k] + j;
-                const int b = a + 1 < hi[k] ? a + 1 : a;
-                if (a < hi[k]) { v[2 * k] = g.pts[a]; v[2 * k + 1] = g.pts[b]; }
-                else { v[2 * k] = make_float4(1e30f, 1e30f, 1e30f, 0.f); v[2 * k + 1] = v[2 * k]; }       // (d2 = inf: never the minimum)
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) nn_consider_d2<0>(v[u], qx, qy, qz, best);
-        }
-#else
 #pragma unroll
         for (int k = 0; k < 4; ++k) scan_d2x4<0>(g.pts, lo[k], hi[k], qx, qy, qz, best);
-#endif
     }
 #pragma unroll
     for (int o = 1; o < G; o <<= 1) best = fminf(best, __shfl_xor(best, o));

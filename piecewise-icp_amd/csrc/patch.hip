@@ -296,7 +296,6 @@ __device__ __forceinline__ void front_init(const FrontInit& in) {
         for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < in.n_zero; i += 16 * (int)blockDim.x) in.zero[i] = 0ull;
 }
 
-__global__ void __launch_bounds__(kFrontBlock) k_front_init_only(FrontInit init) { front_init(init); }
 
 // The "front" of an outer iteration in ONE launch: blocks [0, nb_nrm) compute the source patch normals (R.cpp:824),
 // the remaining blocks the 1-NN of the source centroids and boundary points among the target centroids
@@ -592,15 +591,6 @@ int pw_front_launch(pwicp_context* ctx, const float4* d_pat, const int* d_off, i
     if (m <= 0 || nq <= 0) {
         if (fs && fs->scratch) return pw_fs_pass_launch(ctx, 2, *fs);
         return PWICP_OK;
-    }
-    static int split = -1;               // PWICP_FRONT_SPLIT=1: two launches (A/B measurements only)
-    if (split < 0) { const char* e = getenv("PWICP_FRONT_SPLIT"); split = e ? atoi(e) : 0; }
-    if (split) {
-        // (the merged launch arms the iteration's slot words and, at the start of a run, the counters: here a launch of its own)
-        if (init && (init->slot || init->zero)) hipLaunchKernelGGL(k_front_init_only, dim3(16), dim3(kFrontBlock), 0, ctx->stream, *init);
-        if (fs && fs->scratch) PWCHK(pw_fs_pass_launch(ctx, 2, *fs));
-        if (d_nrm) PWCHK(pw_patch_normals_launch(ctx, d_pat, d_off, m, d_nrm));
-        return pw_nn_launch(ctx, g, d_q, nq, d_idx, d_d2, nullptr);
     }
     const int nb_nrm = d_nrm ? div_up((long long)m * kGroup, kFrontBlock) : 0;      // nullptr: the queries only
     const int qg = front_query_lanes(false, nq);

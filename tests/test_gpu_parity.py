@@ -510,16 +510,10 @@ def test_scheduling_switches_do_not_change_a_bit(tmp_path):
                         ("far queries inside the search's blocks, 8 lanes per front query", {"PWICP_DENSE_FAR_GROUP": "0", "PWICP_FRONT_QUERY_LANES": "8"}),
                         ("4 lanes per front query", {"PWICP_FRONT_QUERY_LANES": "4"}),
                         ("source patch normals left out", {"PWICP_SOURCE_NORMALS": "0"}),
-                        ("dense search gathers its queries through the order array", {"PWICP_DENSE_QUERY_COPY": "0"}),
-                        ("first dense search on the context's second stream, beside the ICP", {"PWICP_DENSE_SIDE_STREAM": "1"}),
-                        ("dense search on the LDS window of its block", {"PWICP_DENSE_WIN": "1"}),
-                        # (the pairs of the worker have <= 3072 patches: their inner-ICP batches as ONE launch of one workgroup,
-                        #  k_icp_small - same sums in the same order as one k_icp_iter launch per iteration)
-                        ("inner-ICP batches of small problems in one launch of one workgroup", {"PWICP_ICP_SMALL": "1"})):
+                        ("dense search gathers its queries through the order array", {"PWICP_DENSE_QUERY_COPY": "0"})):
         env = dict(os.environ)
         for k in ("PWICP_STAGE_GUARD", "PWICP_SPECULATE_DENSE", "PWICP_FUSED_SELECT", "PWICP_POOL_MB", "PWICP_RUN_SYNC",
-                  "PWICP_DENSE_FAR_GROUP", "PWICP_DENSE_FAR_EDGE", "PWICP_FRONT_QUERY_LANES", "PWICP_SOURCE_NORMALS", "PWICP_DENSE_QUERY_COPY", "PWICP_DENSE_SIDE_STREAM",
-                  "PWICP_DENSE_WIN", "PWICP_ICP_SMALL"):
+                  "PWICP_DENSE_FAR_GROUP", "PWICP_DENSE_FAR_EDGE", "PWICP_FRONT_QUERY_LANES", "PWICP_SOURCE_NORMALS", "PWICP_DENSE_QUERY_COPY"):
             env.pop(k, None)
         env.update(extra)
         out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
@@ -698,28 +692,3 @@ def test_dense_search_against_brute_force(ctx, oracle, scene, far_group):
     if scene == "beyond_coverage":
         assert (np.sqrt(d2) > 0.1).sum() > 2000
     pair.close()
-
-
-@pytest.mark.parametrize("name,env,select", [
-    ("dense search on the LDS window of its block (strips of 16 cells)", {"PWICP_DENSE_WIN": "1", "PWICP_QUERY_ORDER": "16:128"},
-     "dense_search_against_brute or cliff or rockfall or (loop_parity_with_oracle and 200000)"),
-    ("inner-ICP batches of small problems in one workgroup", {"PWICP_ICP_SMALL": "1"},
-     "inner_icp or too_few or test_golden_epoch2_through_gpu or (loop_parity_with_oracle and 20000)"),
-    ("first dense search on the second stream", {"PWICP_DENSE_SIDE_STREAM": "1"},
-     "deterministic or single_iteration_steps or (loop_parity_with_oracle and 200000)"),
-], ids=["dense_win", "icp_small", "side_stream"])
-def test_measured_but_not_default_paths_stay_exact(name, env, select):
-    """Round 5's three measured-and-not-kept designs stay in the library behind switches (profiles/r05_dense_variants.txt,
-    r05_icp_small.txt): each must keep passing the parity tests of the stage it replaces - run here in a process of its
-    own, because the switches are read once per process."""
-    import subprocess
-    import sys
-    e = dict(os.environ)
-    e.update(env)
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"),
-                          os.path.join(root, "tests", "test_gpu_configs.py"), "-m", "gpu", "-x", "-q", "-k",
-                          "(%s) and not measured_but_not_default" % select], capture_output=True, text=True, timeout=1200, env=e, cwd=root)
-    tail = (out.stdout + out.stderr)[-1500:]
-    assert out.returncode == 0, name + ": " + tail
-    assert " passed" in out.stdout and "no tests ran" not in out.stdout, name + ": " + tail

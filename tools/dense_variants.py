@@ -61,5 +61,5 @@ if __name__ == "__main__":
         if ref is None:
             ref = r
         same = r["d75"] == ref["d75"] and r["dt"] == ref["dt"]
-        print("%-60s dense %.2f us  kbar %.1f  edge %.4f  nq %d  loop %.3f ms  same=%s" %
-              (" ".join(v), r["ms"] * 1e3, r["kbar"], r["edge"], r["nq"], r["loop_ms"], same))
+        print("%-60s dense %.2f us (in the run, with its event records: %.2f)  kbar %.1f  edge %.4f  nq %d  loop %.3f ms  same=%s" %
+              (" ".join(v), r["ms"] * 1e3, r["dense_in_run_ms"] * 1e3, r["kbar"], r["edge"], r["nq"], r["loop_ms"], same))
