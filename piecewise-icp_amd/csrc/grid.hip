@@ -389,6 +389,11 @@ __device__ __forceinline__ int dense_home_cell(int c, int n) {
 #ifndef PW_DENSE_FAST
 #define PW_DENSE_FAST 1
 #endif
+// PW_DENSE_A_HEAD: points of the query's own row segment requested at once before the four-per-pass loop (scan_d2_head; 0: the loop
+// from the start)
+#ifndef PW_DENSE_A_HEAD
+#define PW_DENSE_A_HEAD 12
+#endif
 template <int PERM, bool FARG>
 __global__ void __launch_bounds__(kDenseBlock) k_nn_dense_disc(GridLevel dl, GridDesc far, const float4* __restrict__ pat,
                                                           const int* __restrict__ qorder, const int* __restrict__ qpatch,
@@ -404,10 +409,14 @@ __global__ void __launch_bounds__(kDenseBlock) k_nn_dense_disc(GridLevel dl, Gri
     constexpr int kTailBytes = kDenseBlock * 16 + kDenseBlock * 4;
     constexpr int kListBytes = PW_DENSE_FAST ? kDiscRangesMax * kDenseBlock * 8 : 0;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[kTailBytes > kListBytes ? kTailBytes : kListBytes];
-    __shared__ unsigned s_hist[kFsBins];
+    // (d2 >= +0: bins 0 .. 1023 only - 4 KB less LDS is a block more per CU, and a block per CU is worth 2 us of the launch INSIDE the
+    // loop, where it finds the L2 cold (tools/inloop_dense.sh): 4 / 5 / 6 / 7 blocks per CU 35.1 / 31.3 / 29.0 / 27.2 us; an eighth -
+    // the block's bookkeeping words squeezed into the bins of NaN patterns, 20 KB exactly - brings nothing more: 27.7)
+    __shared__ unsigned s_hist[kFsPosBins];
+    constexpr int kHistBins = kFsPosBins;
+    __shared__ int s_wcnt[kDenseBlock / 64];
     float4* const s_q = (float4*)s_raw;
     int* const s_slot = (int*)(s_raw + kDenseBlock * 16);
-    __shared__ int s_wcnt[kDenseBlock / 64];
 #ifdef PW_DENSE_BLOCKTRACE
     if (threadIdx.x == 0 && blockIdx.x < 8192) { pw_dense_bt[8 * blockIdx.x] = __builtin_amdgcn_s_memrealtime(); pw_dense_bt[8 * blockIdx.x + 2] = blockIdx.x % kXcds; }
 #define PW_BT(k_) do { if (threadIdx.x == 0 && blockIdx.x < 8192) pw_dense_bt[8 * blockIdx.x + (k_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -430,7 +439,7 @@ __global__ void __launch_bounds__(kDenseBlock) k_nn_dense_disc(GridLevel dl, Gri
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     float best = INFINITY;
     if (fs.scratch) {
-        for (int t = tid; t < kFsBins; t += kDenseBlock) s_hist[t] = 0u;
+        for (int t = tid; t < kHistBins; t += kDenseBlock) s_hist[t] = 0u;
         __syncthreads();
     }
     if (i < nq) {
@@ -461,7 +470,11 @@ __global__ void __launch_bounds__(kDenseBlock) k_nn_dense_disc(GridLevel dl, Gri
                 row_range(dl, cy, cz, cx - 1, cx + 1, loA, hiA);
             }
             PW_BT(3);
+#if PW_DENSE_A_HEAD > 0
+            scan_d2_head<PERM, PW_DENSE_A_HEAD>(dl, loA, hiA, ux, uy, uz, best);
+#else
             scan_d2_level<PERM>(dl, loA, hiA, ux, uy, uz, best);
+#endif
             PW_BT(4);
             cnt += (unsigned)(hiA - loA);
             const float rho = fast_sqrt_up(best) + 2.0f * dl.slack;
@@ -530,7 +543,7 @@ __global__ void __launch_bounds__(kDenseBlock) k_nn_dense_disc(GridLevel dl, Gri
     }
     PW_BT(7);
     add_examined(examined, cnt);
-    if (fs.scratch) fs_pass0_epilogue(s_hist, fs);
+    if (fs.scratch) fs_pass0_epilogue(s_hist, fs, kHistBins);
 #ifdef PW_DENSE_BLOCKTRACE
     __syncthreads();
     if (threadIdx.x == 0 && blockIdx.x < 8192) pw_dense_bt[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();

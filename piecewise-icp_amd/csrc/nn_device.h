@@ -438,7 +438,7 @@ __device__ __forceinline__ void scan_d2x4(const float4* __restrict__ pts, int lo
 // happen, and the packed copy ends in kPts3Pad far-away points.  (Measured and not kept, profiles/r05_dense_variants.txt (2): tails
 // of two and one, 33.6 against 32.8 us; the points stored in pairs for v_pk_add_f32 / v_pk_mul_f32, 17 % fewer vector instructions,
 // 34.8 us - the compiler packs what it can of the plain form by itself.)
-constexpr int kPts3Pad = 8;            // far-away points behind the last one of a packed copy
+constexpr int kPts3Pad = 20;           // far-away points behind the last one of a packed copy
 struct PwXyz3 { float x, y, z; };
 template <int PERM = 0, bool P3 = true>
 __device__ __forceinline__ void scan_d2_level(const GridLevel& g, int lo, int hi, float qx, float qy, float qz, float& best) {
@@ -575,13 +575,36 @@ __device__ __forceinline__ int disc_ranges_columns(const GridLevel& g, float ux,
         }
     return n;
 }
+// Phase A of the dense search: the first HEAD points of a non-empty range requested at once (one round trip instead of HEAD / 4
+// dependent ones - the own row segment holds 12 +- 2 points on the bench pair), the rest four per pass.  Points past the range's
+// end are real target points of the next cells: harmless for a minimum over all targets (see scan_d2_level).  Measured INSIDE the
+// loop (tools/inloop_dense.sh: rocprofv3 kernel trace of bench.py's steps), where the launch finds the L2 cold: HEAD = 8 / 12:
+// 29.3 / 28.8 us against 29.7; replayed back to back it is worth 0.3 us and 16 points are slower.
+template <int PERM, int HEAD>
+__device__ __forceinline__ void scan_d2_head(const GridLevel& g, int lo, int hi, float qx, float qy, float qz, float& best) {
+    if (hi <= lo) return;
+    const PwXyz3* __restrict__ p3 = (const PwXyz3*)g.pts3;
+    PwXyz3 v[HEAD];
+#pragma unroll
+    for (int k = 0; k < HEAD; ++k) v[k] = p3[lo + k];
+#pragma unroll
+    for (int k = 0; k < HEAD; ++k) nn_consider_d2<PERM>(make_float4(v[k].x, v[k].y, v[k].z, 0.f), qx, qy, qz, best);
+    for (int j = lo + HEAD; j < hi; j += 4) {
+        const PwXyz3 a = p3[j], b = p3[j + 1], c = p3[j + 2], d = p3[j + 3];
+        nn_consider_d2<PERM>(make_float4(a.x, a.y, a.z, 0.f), qx, qy, qz, best);
+        nn_consider_d2<PERM>(make_float4(b.x, b.y, b.z, 0.f), qx, qy, qz, best);
+        nn_consider_d2<PERM>(make_float4(c.x, c.y, c.z, 0.f), qx, qy, qz, best);
+        nn_consider_d2<PERM>(make_float4(d.x, d.y, d.z, 0.f), qx, qy, qz, best);
+    }
+}
+
 template <int PERM>
 __device__ __forceinline__ void scan_ranges_flat(const GridLevel& g, const int2* __restrict__ list, int stride, int tid, int n, float ux, float uy,
                                                  float uz, float& best) {
     const PwXyz3* __restrict__ p3 = (const PwXyz3*)g.pts3;
     // (the NEXT range is read while the current one is walked: a range switch is two moves, not an LDS round trip in the lane's chain.
     // Measured and not kept, profiles/r06_dense_variants.txt: the next pass's points requested before the current four are evaluated,
-    // 30.2 against 28.2 us; the first 12 / 16 points of the own row segment requested at once, 27.6 / 28.6.)
+    // 30.2 against 28.2 us replayed, 32.0 against 29.7 inside the loop.)
     int2 r0 = make_int2(0, 0), r1 = make_int2(0, 0);
     if (n > 0) r0 = list[tid];
     if (n > 1) r1 = list[stride + tid];

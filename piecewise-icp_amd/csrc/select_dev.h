@@ -40,10 +40,13 @@ __device__ __forceinline__ int fs_word(int bin) { return (bin & 63) * 32 + (bin 
 // ---- pass 0, called by EVERY block of the dense kernel once its lanes have added their values to the LDS bins `h` ----------
 // Fire-and-forget atomics into one of kFsRep replicas: no completion count, no pick here — a block of the dense kernel
 // retires without waiting for anything; the kernel boundary orders the bins before pass 1, whose blocks pick for themselves.
-__device__ __forceinline__ void fs_pass0_epilogue(unsigned* h, const FusedSelect& fs) {
+// nbins: the bins `h` holds (squared distances are >= +0: their bit patterns end at bin 1023, so a kernel that only ever adds such
+// values keeps half the array - kFsPosBins words)
+constexpr int kFsPosBins = kFsBins / 2;
+__device__ __forceinline__ void fs_pass0_epilogue(unsigned* h, const FusedSelect& fs, int nbins = kFsBins) {
     __syncthreads();
     unsigned* g0 = fs.scratch + kFsCtl + (int)(blockIdx.x & (kFsRep - 1)) * kFsBins;
-    for (int t = threadIdx.x; t < kFsBins; t += blockDim.x) {
+    for (int t = threadIdx.x; t < nbins; t += blockDim.x) {
         const unsigned v = h[t];
         if (v) atomicAdd(&g0[fs_word(t)], v);
     }
