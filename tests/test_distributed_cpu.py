@@ -54,7 +54,8 @@ WORKER = textwrap.dedent('''
     from pwicp_amd import fourd
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    pairs = fourd.pair_schedule(0, 6, 0)                      # 5 pairs over 2 ranks
+    n_pairs = int(os.environ.get("PWICP_TEST_PAIRS", "5"))
+    pairs = fourd.pair_schedule(0, n_pairs + 1, 0)            # 5 pairs over 2 ranks; 8 over 8 (BASELINE configs[3]: an epoch per GPU)
     mine = fourd.shard(pairs, rank, world)
     recs = []
     for pid, (t, s) in mine:                                  # stand-in registrar: deterministic function of the pair
@@ -62,7 +63,8 @@ WORKER = textwrap.dedent('''
         V = np.full((6, 6), float(pid))
         recs.append(fourd.pack_record(pid, 0, 3 + pid, 7, T, V, 1000 * pid))
     table = fourd.gather_records(recs, len(pairs), world, dist=dist)
-    assert sorted(table) == list(range(5)), sorted(table)
+    assert sorted(table) == list(range(n_pairs)), sorted(table)
+    assert [pid for pid, _ in mine] == [p for p in range(n_pairs) if p %% world == rank]      # pair p -> rank p mod G
     for pid, (t, s) in enumerate(pairs):
         r = table[pid]
         assert r["n_outer"] == 3 + pid and r["n_corr"] == 1000 * pid and abs(r["T"][3] - (0.5 * s + t)) < 1e-6
@@ -81,6 +83,20 @@ def test_shard_and_gather_world2_gloo(tmp_path):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "GATHER_OK" in out.stdout
+
+
+def test_shard_and_gather_world8_gloo(tmp_path):
+    """The shape the 8-GPU node will run (BASELINE configs[3]: 8 source epochs, one pair per rank; R.cpp:89-187's iterations are
+    independent): pair p -> rank p mod 8, ONE all-gather of the 384-byte records, every rank holding the whole table afterwards.
+    Eight gloo ranks on the CPU."""
+    script = tmp_path / "worker8.py"
+    script.write_text(WORKER % ROOT)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         capture_output=True, text=True, timeout=600, env=dict(os.environ, PWICP_TEST_PAIRS="8", OMP_NUM_THREADS="1"))
     assert out.returncode == 0, out.stdout + out.stderr
     assert "GATHER_OK" in out.stdout
 
@@ -302,7 +318,7 @@ LABEL_WORKER = textwrap.dedent('''
         mine = [p for p in range(3) if p %% world == rank]
         recs = run_pairs_sharing_target(s, mine, 0, rank, world, dist, dev)
         assert list(recs["pair"]) == mine
-        if rank != 0:
+        if rank != 0 and mine:                                        # (a rank without pairs prepares no target: nothing to receive into)
             if fail:
                 assert s.got is None                                   # rank 0 failed on the target: this rank segments for itself
             else:
@@ -332,6 +348,18 @@ def test_shared_target_labels_travel_from_rank0_world2_gloo(tmp_path):
     res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "LABELS_OK" in res.stdout
+
+
+def test_shared_target_labels_travel_from_rank0_world8_gloo(tmp_path):
+    """The same hand-over with eight ranks (three pairs: five ranks have none and still take part in every collective)."""
+    script = tmp_path / "labels8.py"
+    script.write_text(LABEL_WORKER % {"root": ROOT})
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert res.returncode == 0, res.stdout + res.stderr
     assert "LABELS_OK" in res.stdout
 
