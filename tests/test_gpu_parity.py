@@ -432,6 +432,9 @@ def test_golden_epoch2_through_gpu(ctx, oracle):
     V = np.array(res.VCM).reshape(6, 6)
     mine = np.concatenate([1000 * 63.6619772368 * np.sqrt(np.diag(V)[:3]), 1000 * np.sqrt(np.diag(V)[3:])])
     assert np.allclose(mine, stds, rtol=5e-3)
+    # honest accounting (round 6): far queries of a dense search that were cut short at the percentile's edge are counted, never more
+    # than the dense queries there were, and the reference-defined query count is untouched by the count
+    assert 0 <= res.n_dense_bounded <= res.n_corr_dense <= res.n_corr
     pair.close()
 
 
