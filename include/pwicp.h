@@ -216,11 +216,13 @@ PWICP_API int pwicp_pair_reset(pwicp_pair* pair);
 /* The while-loop of Piecewise_ICP (R.cpp:680-694) = repeated PwICP_singleIteration
  * (R.cpp:704-972; decl R.h:181-188), entirely on the device. */
 PWICP_API int pwicp_pair_run(pwicp_pair* pair, pwicp_result* result);
-/* pwicp_pair_run for n INDEPENDENT pairs side by side - the iterations of the reference's pair loop (R.cpp:89-187) share nothing -
- * one host thread per pair inside the call; every pair must live on a context of its own (pwicp_pair_create_with_target_on), else
- * PWICP_E_INVALID.  reset_first != 0: pwicp_pair_reset before each run.  results[k] is bit for bit what pwicp_pair_run(pairs[k])
- * gives alone; returns the first status that is not PWICP_OK.  One registration is a chain of dependent short launches: four in
- * flight cost about half the time each (GPU_MAX_HW_QUEUES=8). */
+/* pwicp_pair_run for n INDEPENDENT pairs side by side - the iterations of the reference's pair loop (R.cpp:89-187) share nothing:
+ * one host thread per CONTEXT among the pairs inside the call, the pairs of one context one after the other on its thread, in the
+ * order given (so K contexts - pwicp_pair_create_with_target_on - and any number of pairs dealt to them are K registrations in flight
+ * with no barrier between them).  reset_first != 0: pwicp_pair_reset before each run.  results[k] is bit for bit what
+ * pwicp_pair_run(pairs[k]) gives alone; returns the first status that is not PWICP_OK; the same pair twice is PWICP_E_INVALID.
+ * One registration is a chain of dependent short launches: four in flight cost about half the time each (GPU_MAX_HW_QUEUES=8,
+ * INTEGRATION.md). */
 PWICP_API int pwicp_pairs_run_concurrent(pwicp_pair* const* pairs, int n, pwicp_result* results, int reset_first);
 /* ONE outer iteration: PwICP_singleIteration (R.cpp:704-972; decl R.h:181-188) on the pair's resident data.  The
  * caller owns what the reference keeps between calls: currDT, BBchange_1/2 (reference parameters of R.h:187) and the two

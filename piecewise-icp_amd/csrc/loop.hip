@@ -589,33 +589,41 @@ int pwicp_pair_reset(pwicp_pair* pr) {
 }
 
 // Registrations of INDEPENDENT pairs side by side (the pair loop of R.cpp:89-187: no state flows between its iterations): one host
-// thread per pair, every pair on a context (= stream, pool, mailbox) of its own.  A registration is a chain of ~14 dependent short
-// launches that leaves most of the chip idle; four chains in flight cost 0.13 ms each instead of 0.24 (bench.py pairs_side_by_side).
-// Each result is bit for bit what pwicp_pair_run gives for that pair alone (tests/test_gpu_parity.py).
+// thread per CONTEXT (= stream, pool, mailbox) among the pairs; the pairs of one context run one after the other on its thread, in
+// the order given.  A registration is a chain of ~14 dependent short launches that leaves most of the chip idle; four chains in flight
+// cost 0.13 ms each instead of 0.24 (bench.py pairs_side_by_side), the reference's own 19 pairs on four contexts 4.3 ms instead of
+// 11.8 (tools/real_pairs_concurrent.py).  Each result is bit for bit what pwicp_pair_run gives for that pair alone
+// (tests/test_gpu_parity.py).
 int pwicp_pairs_run_concurrent(pwicp_pair* const* pairs, int n, pwicp_result* results, int reset_first) {
     if (!pairs || !results || n <= 0) return PWICP_E_INVALID;
+    std::vector<pwicp_context*> ctxs;                 // distinct contexts, in order of first appearance
+    std::vector<std::vector<int>> mine;               // pairs of each
     for (int a = 0; a < n; ++a) {
         if (!pairs[a]) return PWICP_E_INVALID;
         for (int b = 0; b < a; ++b)
-            if (pairs[a] == pairs[b] || pairs[a]->ctx == pairs[b]->ctx) {        // (a context is one stream and one error slot)
-                pairs[a]->ctx->set_err("pwicp_pairs_run_concurrent: every pair needs a context of its own (pwicp_pair_create_with_target_on)");
-                return PWICP_E_INVALID;
-            }
+            if (pairs[a] == pairs[b]) { pairs[a]->ctx->set_err("pwicp_pairs_run_concurrent: the same pair twice"); return PWICP_E_INVALID; }
+        size_t c = 0;
+        while (c < ctxs.size() && ctxs[c] != pairs[a]->ctx) ++c;
+        if (c == ctxs.size()) { ctxs.push_back(pairs[a]->ctx); mine.emplace_back(); }
+        mine[c].push_back(a);
     }
     std::vector<int> rc((size_t)n, PWICP_OK);
-    auto one = [&](int k) {
-        int r = reset_first ? pwicp_pair_reset(pairs[k]) : PWICP_OK;
-        if (r == PWICP_OK) r = pwicp_pair_run(pairs[k], &results[k]);
-        rc[(size_t)k] = r;
+    auto one = [&](size_t c) {
+        for (int k : mine[c]) {
+            int r = reset_first ? pwicp_pair_reset(pairs[k]) : PWICP_OK;
+            if (r == PWICP_OK) r = pwicp_pair_run(pairs[k], &results[k]);
+            rc[(size_t)k] = r;
+        }
     };
     std::vector<std::thread> th;
-    th.reserve((size_t)n);
+    th.reserve(ctxs.size());
+    size_t started = 1;
     try {
-        for (int k = 1; k < n; ++k) th.emplace_back(one, k);
-    } catch (...) {                                                               // (no thread to be had: the rest one after the other)
-        for (int k = (int)th.size() + 1; k < n; ++k) one(k);
+        for (; started < ctxs.size(); ++started) th.emplace_back(one, started);
+    } catch (...) {                                   // (no thread to be had: the remaining contexts on this one, afterwards)
     }
     one(0);
+    for (size_t c = started; c < ctxs.size(); ++c) one(c);
     for (auto& t : th) t.join();
     for (int k = 0; k < n; ++k) if (rc[(size_t)k] != PWICP_OK) return rc[(size_t)k];
     return PWICP_OK;

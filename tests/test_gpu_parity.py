@@ -261,12 +261,16 @@ def test_four_registrations_side_by_side(ctx):
     for rep in range(5):
         got = P.run_pairs_concurrent(pairs)
         assert [key(g) for g in got] == [key(a) for a in alone], rep
-    with pytest.raises(P.PwicpError):              # two pairs on one context: refused, not raced
-        extra = P.Pair(ctxs[0], None, None, 0, _data.pair(200000, epoch=2)[1], *_labels(_data.pair(200000, epoch=2)[1], "grid"), prm, target=T)
-        try:
-            P.run_pairs_concurrent([pairs[0], extra])
-        finally:
-            extra.close()
+    # pairs that share a context run one after the other on that context's thread, beside the other contexts' pairs: same results
+    s2 = _data.pair(200000, epoch=2)[1]
+    extra = P.Pair(ctxs[0], None, None, 0, s2, *_labels(s2, "grid"), prm, target=T)
+    try:
+        got = P.run_pairs_concurrent(pairs + [extra])
+        assert [key(g) for g in got[:K]] == [key(a) for a in alone] and key(got[K]) == key(alone[1])
+        with pytest.raises(P.PwicpError):          # the same pair twice: refused
+            P.run_pairs_concurrent([pairs[0], pairs[0]])
+    finally:
+        extra.close()
     for pr in pairs:
         pr.close()
     T.close()
